@@ -1,0 +1,154 @@
+"""Pin the numpy oracle (oracle/aki_oracle.py) to golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, load_golden
+from golden import gen
+import aki_oracle as O
+
+
+def _shapes(g):
+    return [(k, tuple(s)) for k, s in json.loads(str(g["shapes"]))]
+
+
+def test_mask_bit_exact_vs_reference():
+    g = load_golden("mask_cases.npz")
+    n_cases = int(g["n_cases"])
+    assert n_cases >= 20
+    cases = gen.mask_cases()
+    assert len(cases) == n_cases
+    for i, (am, s, t, e) in enumerate(cases):
+        assert np.array_equal(g[f"am_{i}"].astype(np.int64), am)
+        assert list(g[f"args_{i}"]) == [s, t, e]
+        n = len(am)
+        want = gen.unpack_mask_bits(g[f"bits_{i}"], (1, n, n))
+        got = O.make_modality_mutual_mask(am, s, t, e)
+        assert got.dtype == np.int64 and np.array_equal(got, want), f"dense restatement, case {i}"
+        got2 = O.mask_from_spans(am, [O.clamp_span(n, s, t, e)])
+        assert np.array_equal(got2, want), f"closed form / spans, case {i}"
+
+
+def test_decoupled_embedding_and_linear():
+    g = load_golden("decoupled.npz")
+    V = int(g["V"])
+    e = O.decoupled_embedding(g["ids"], g["W"], g["Wadd"], V - 1)
+    assert np.array_equal(e, g["emb"])
+    y = O.decoupled_linear(g["x"], g["W"], None, g["Wl"], None, V - 1)
+    assert y.shape == g["y"].shape
+    np.testing.assert_allclose(y, g["y"], atol=2e-6, rtol=1e-6)
+
+
+def test_longrope_tables():
+    g = load_golden("rope_longrope.npz")
+    sc = float(g["attention_scaling"])
+    assert abs(sc - O.longrope_attention_scaling(131072, 4096)) < 1e-6
+    # fp32 pow() differs by an ulp between numpy and torch; the angle error grows with the position
+    for pos, fac, cw, sw in ((g["pos_s"], g["short"], g["cos_s"], g["sin_s"]), (g["pos_l"], g["long"], g["cos_l"], g["sin_l"])):
+        c, s = O.rope_cos_sin(pos, 96, 10000.0, fac, sc)
+        tol = (2e-6 + 4e-7 * pos.astype(np.float64))[..., None]
+        assert np.all(np.abs(c - cw) <= tol) and np.all(np.abs(s - sw) <= tol)
+
+
+@pytest.mark.parametrize("tag", ["small", "mid"])
+def test_phi3_attention_block(tag):
+    g = load_golden(f"attn_block_{tag}.npz")
+    p = gen.fill_params(_shapes(g), 31)
+    B, L = g["am"].shape
+    d = p["qkv_proj.weight"].shape[1]
+    H = d // 96
+    x = gen.rng_for("attn_block_" + tag).standard_normal((B, L, d), dtype=np.float32)
+    m4 = gen.unpack_mask_bits(g["mask_bits"], tuple(g["mask_shape"]))
+    # dense mask == span restatement
+    rects = [[O.clamp_span(L, *map(int, g["spans"][b]))] for b in range(B)]
+    for b in range(B):
+        assert np.array_equal(O.mask_from_spans(g["am"][b], rects[b]), m4[b])
+    cos, sin = O.rope_cos_sin(np.arange(L)[None], 96)
+    tol = (2e-6 + 4e-7 * np.arange(L, dtype=np.float64))[None, :, None]
+    assert np.all(np.abs(cos - g["cos"]) <= tol) and np.all(np.abs(sin - g["sin"]) <= tol)
+    cos, sin = g["cos"], g["sin"]          # tables are inputs of the attention block; use the reference's
+    y = O.phi3_attention(x, p["qkv_proj.weight"], p["o_proj.weight"], cos, sin, O.invert_mask_441(m4), H)
+    np.testing.assert_allclose(y, g["y32"], atol=1e-5, rtol=1e-5)
+    # span-driven core (what the kernel computes) equals the dense-mask core on every row
+    qkv = x @ p["qkv_proj.weight"].T
+    hd = lambda t: t.reshape(B, L, H, 96).transpose(0, 2, 1, 3)
+    q, k = O.apply_rope(hd(qkv[..., :d]), hd(qkv[..., d:2 * d]), cos, sin)
+    v = hd(qkv[..., 2 * d:])
+    o_dense = O.mma_attention_core(q, k, v, O.invert_mask_441(m4), 96 ** -0.5)
+    o_span = O.mma_attention_core_spans(q, k, v, g["am"], rects, 96 ** -0.5)
+    np.testing.assert_allclose(o_span, o_dense, atol=2e-6, rtol=1e-5)
+    # bf16 eager emulation tracks the reference's bf16 eager output to bf16 resolution
+    xb = O.bf16_round(x)
+    pb = {k_: O.bf16_round(v_) for k_, v_ in p.items()}
+    y16 = O.phi3_attention(xb, pb["qkv_proj.weight"], pb["o_proj.weight"], cos, sin,
+                           O.invert_mask_441(m4, O.BF16_MIN), H, emulate_bf16=True)
+    err = np.abs(y16 - g["y16"])
+    scale = np.abs(g["y16"]).max()
+    assert err.max() <= 2 ** -6 * scale and err.mean() <= 2e-3 * scale
+
+
+def test_perceiver_small_and_full():
+    g = load_golden("perceiver_small.npz")
+    p = gen.fill_params(_shapes(g), 21)
+    x = gen.rng_for("perceiver_small").standard_normal((2, 1, 1, 16, 64), dtype=np.float32)
+    y = O.perceiver_resampler(x, p)
+    np.testing.assert_allclose(y, g["y"], atol=2e-5, rtol=1e-4)
+    g = load_golden("perceiver_full.npz")
+    p = gen.fill_params(_shapes(g), 22)
+    x = gen.rng_for("perceiver_full").standard_normal((1, 1, 1, 729, 1152), dtype=np.float32)
+    y = O.perceiver_resampler(x, p)
+    np.testing.assert_allclose(y[0, 0, g["rows"]], g["y_rows"], atol=5e-4, rtol=1e-3)
+    assert abs(float(np.abs(y.astype(np.float64)).sum()) - float(g["y_abs"])) <= 1e-4 * float(g["y_abs"])
+
+
+def test_patch_embed_full_dims():
+    g = load_golden("patch_embed_full.npz")
+    p = gen.fill_params(_shapes(g), 41)
+    x = gen.rng_for("patch_embed").random((2, 3, 384, 384), dtype=np.float32) * 2 - 1
+    y = O.siglip_patch_embed(x, p["patch_embedding.weight"], p["patch_embedding.bias"], p["position_embedding.weight"])
+    assert y.shape == (2, 729, 1152)
+    np.testing.assert_allclose(y[:, g["rows"]], g["y_rows"], atol=2e-5, rtol=1e-5)
+    assert abs(float(np.abs(y.astype(np.float64)).sum()) - float(g["y_abs"])) <= 1e-5 * float(g["y_abs"])
+
+
+def tiny_cfg():
+    T = gen.TINY
+    return dict(vis_layers=T["vis_layers"], vis_heads=T["vis_heads"], lm_layers=T["lm_layers"], lm_heads=T["lm_heads"],
+                max_original_id=T["vocab"] - 1, media_token_id=T["media_token_id"], pad_token_id=T["pad_token_id"],
+                num_vision_tokens=T["num_vision_tokens"])
+
+
+def test_tiny_aki_end_to_end():
+    g = load_golden("tiny_e2e.npz")
+    p = gen.fill_params(_shapes(g), 11)
+    rng = gen.rng_for("tiny_batch")
+    B = g["lang_x"].shape[0]
+    vision_x = rng.standard_normal((B, 1, 1, 3, gen.TINY["image"], gen.TINY["image"]), dtype=np.float32)
+    out = O.aki_forward(p, tiny_cfg(), vision_x, g["lang_x"], g["attention_mask"], g["labels"])
+    prep = out["prep"]
+    np.testing.assert_allclose(prep["inputs_embeds"], g["inputs_embeds"], atol=2e-5, rtol=1e-4)
+    assert np.array_equal(prep["attention_mask"], gen.unpack_mask_bits(g["mask_bits"], tuple(g["mask_shape"])))
+    assert np.array_equal(prep["labels"], g["new_labels"])
+    np.testing.assert_allclose(out["logits"][:, :, g["logit_cols"]], g["logits"], atol=2e-4, rtol=1e-3)
+    assert abs(out["loss"] - float(g["loss"])) < 1e-4
+    # pad rows of inputs_embeds carry the scalar pad_token_id (src/vlm.py:584-588)
+    L0 = prep["lengths"][1]
+    assert np.all(prep["inputs_embeds"][1, L0:] == float(gen.TINY["pad_token_id"]))
+
+
+def test_multi_image_raises_like_reference():
+    T = gen.TINY
+    lang_x = np.array([[1, T["media_token_id"], 5, T["media_token_id"], 6, 32001, 7]])
+    emb = np.zeros((1, 7, 4), dtype=np.float32)
+    vt = np.zeros((1, 2, 8, 4), dtype=np.float32)
+    with pytest.raises(RuntimeError):
+        O.prepare_inputs_for_forward(vt, lang_x, np.ones_like(lang_x), None, emb, T["media_token_id"], T["pad_token_id"], 8)
+
+
+def test_fixture_files_are_data_only():
+    for f in os.listdir(GOLDEN_DIR):
+        if f.endswith(".npz"):
+            assert os.path.getsize(os.path.join(GOLDEN_DIR, f)) < 2 * 1024 * 1024
