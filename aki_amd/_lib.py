@@ -1,0 +1,117 @@
+"""ctypes binding of libaki_mi355x.so (include/aki_mi355x.h).  The product path has no CPU fallback:
+if the library is missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaki_mi355x.so")
+
+AKI_DT_BF16, AKI_DT_F32 = 0, 1
+AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
+AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
+AKI_MAX_RECTS = 8
+AKI_PLAN_STRIDE = 12
+AKI_ABI_VERSION = 1
+
+
+class AkiError(RuntimeError):
+    pass
+
+
+class MmaRect(C.Structure):
+    _fields_ = [("row_lo", C.c_int32), ("row_hi", C.c_int32), ("col_lo", C.c_int32), ("col_hi", C.c_int32)]
+
+
+class MmaAttnCoreArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+                ("rects", C.c_void_p), ("col_valid_bits", C.c_void_p), ("seq_lens", C.c_void_p),
+                ("max_rects", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("Dh", C.c_int32),
+                ("scale", C.c_float), ("dtype", C.c_int32), ("dead_rows", C.c_int32)]
+
+
+class MmaAttnArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w_qkv", C.c_void_p), ("cos", C.c_void_p), ("sin", C.c_void_p),
+                ("position_ids", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p), ("rects", C.c_void_p),
+                ("col_valid_bits", C.c_void_p), ("seq_lens", C.c_void_p), ("max_rects", C.c_int32),
+                ("B", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("Dh", C.c_int32), ("d_model", C.c_int32),
+                ("ldx", C.c_int32), ("ldw", C.c_int32), ("pos_rows", C.c_int32), ("scale", C.c_float),
+                ("dtype", C.c_int32), ("dead_rows", C.c_int32)]
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldx", C.c_int32), ("ldw", C.c_int32),
+                ("ldy", C.c_int32), ("ldr", C.c_int32), ("res_row_mod", C.c_int32), ("act", C.c_int32),
+                ("dtype", C.c_int32)]
+
+
+class SpliceArgs(C.Structure):
+    _fields_ = [("lang_x", C.c_void_p), ("attention_mask", C.c_void_p), ("labels", C.c_void_p),
+                ("embed_weight", C.c_void_p), ("embed_additional", C.c_void_p), ("vision_tokens", C.c_void_p),
+                ("plan", C.c_void_p), ("inputs_embeds", C.c_void_p), ("labels_out", C.c_void_p),
+                ("mask_1d_out", C.c_void_p), ("rects", C.c_void_p), ("col_valid_bits", C.c_void_p),
+                ("seq_lens", C.c_void_p), ("max_original_id", C.c_int64), ("media_token_id", C.c_int64),
+                ("pad_token_id", C.c_int64), ("B", C.c_int32), ("T", C.c_int32), ("T_img", C.c_int32),
+                ("Nv", C.c_int32), ("d", C.c_int32), ("L_out", C.c_int32), ("max_rects", C.c_int32),
+                ("padding_side", C.c_int32), ("dtype", C.c_int32)]
+
+
+# name -> (restype, argtypes); also the list of symbols include/aki_mi355x.h declares
+SIGNATURES = {
+    "aki_strerror": (C.c_char_p, [C.c_int]),
+    "aki_abi_version": (C.c_int, []),
+    "aki_mma_attn_core_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
+    "aki_mma_attn_core_fwd": (C.c_int, [C.POINTER(MmaAttnCoreArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aki_mma_attn_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
+    "aki_mma_attn_fwd": (C.c_int, [C.POINTER(MmaAttnArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aki_qkv_rope_fwd": (C.c_int, [C.POINTER(MmaAttnArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aki_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    "aki_rmsnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_float, C.c_int32, C.c_void_p]),
+    "aki_layernorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "aki_patch_embed_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
+    "aki_patch_embed_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aki_connector_mlp_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
+    "aki_connector_mlp_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
+                                                                            C.c_void_p]),
+    "aki_connector_proj_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
+                                                                             C.c_void_p]),
+    "aki_splice_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "aki_splice_fwd": (C.c_int, [C.POINTER(SpliceArgs), C.c_void_p]),
+    "aki_mma_mask_dense": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises AkiError (never falls back) when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AkiError(f"{LIB_PATH} not found: build it with `python -m aki_amd.build` (hipcc, gfx950). "
+                       "There is no CPU fallback for the AKI MMA path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise AkiError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.aki_abi_version() != AKI_ABI_VERSION:
+        raise AkiError("libaki_mi355x.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().aki_strerror(rc).decode()
+        raise AkiError(f"{what or 'aki call'} failed: {msg} (status {rc})")

@@ -1,0 +1,79 @@
+// aki_device.h - shared device helpers for the gfx950 (CDNA4 / MI355X) kernels.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "aki_mi355x.h"
+
+namespace aki {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+typedef uint16_t bf16_t;  // storage type on the host side of the ABI
+
+#define AKI_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define AKI_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// two f32 -> packed bf16x2 (RNE, NaN preserving: lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  bf16x2 p;
+  p[0] = (__bf16)lo;
+  p[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ float round_bf16(float x) { return (float)((__bf16)x); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float c = 0.79788456080286535588f;
+  return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// max over the two 32-lane halves (lanes l and l^32), result in every lane.
+__device__ __forceinline__ float halves_max(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float halves_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
+// Bijective XCD-aware block remap (cdna_hip_programming.md T1): blocks that share an XCD (bid % 8)
+// get a contiguous chunk of the logical tile sequence, so neighbouring tiles hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+}  // namespace aki
+
+// ---- host side helpers (api translation units) -------------------------------------------------
+#define AKI_CHECK_ARG(cond) \
+  do {                      \
+    if (!(cond)) return AKI_ERR_INVALID_ARG; \
+  } while (0)
+#define AKI_CHECK_ALIGN16(p) \
+  do {                       \
+    if (((uintptr_t)(p)) & 15) return AKI_ERR_ALIGNMENT; \
+  } while (0)
+#define AKI_LAUNCH_CHECK() \
+  do {                     \
+    if (hipGetLastError() != hipSuccess) return AKI_ERR_LAUNCH; \
+  } while (0)
+
+static inline size_t aki_elt_size(int dtype) { return dtype == AKI_DT_BF16 ? 2 : 4; }
+static inline size_t aki_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -1,0 +1,219 @@
+// api.hip - extern "C" entry points of libaki_mi355x.so (include/aki_mi355x.h).
+// Host-side validation only; every launch goes to the stream the caller passes.
+#include "aki_device.h"
+
+namespace aki {
+int linear_bf16(const aki_linear_args* a, hipStream_t stream);
+int linear_f32(const aki_linear_args* a, hipStream_t stream);
+int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStream_t stream);
+int qkv_rope_f32(const aki_mma_attn_args* a, void* q, void* k, void* v, float* tmp, hipStream_t stream);
+int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream);
+int attn_core_f32(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream, int causal);
+int norm_launch(bool rms, const void* x, const void* w, const void* b, void* y, int rows, int cols, int ldx, int ldy,
+                float eps, int dtype, hipStream_t stream);
+int splice_plan_launch(const int64_t* lang_x, int B, int T, int64_t media, int64_t assistant, int Nv, int* plan, hipStream_t s);
+int splice_launch(const aki_splice_args* a, hipStream_t s);
+int mask_dense_launch(const aki_mma_rect* rects, int max_rects, const uint64_t* vbits, const int* seq_lens, int B, int L,
+                      int64_t* out, hipStream_t s);
+int im2col_launch(const void* pix, void* out, int N, int S, int P, int Kp, int dtype, hipStream_t s);
+}  // namespace aki
+
+using namespace aki;
+
+static inline bool dtype_ok(int dt) { return dt == AKI_DT_BF16 || dt == AKI_DT_F32; }
+
+extern "C" {
+
+const char* aki_strerror(int status) {
+  switch (status) {
+    case AKI_OK: return "ok";
+    case AKI_ERR_INVALID_ARG: return "invalid argument (null pointer, non-positive size or inconsistent shapes)";
+    case AKI_ERR_UNSUPPORTED: return "unsupported dtype / head_dim / size for the gfx950 kernels";
+    case AKI_ERR_ALIGNMENT: return "pointer or leading dimension is not 16-byte aligned";
+    case AKI_ERR_WORKSPACE: return "workspace missing or too small";
+    case AKI_ERR_LAUNCH: return "HIP kernel launch failed";
+    default: return "unknown aki status";
+  }
+}
+
+int aki_abi_version(void) { return AKI_ABI_VERSION; }
+
+// ---- attention core --------------------------------------------------------------------------------
+size_t aki_mma_attn_core_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype) {
+  (void)L; (void)dtype;
+  return aki_align_up((size_t)B * H * Dh * sizeof(float), 256);
+}
+
+int aki_mma_attn_core_fwd(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, void* stream) {
+  AKI_CHECK_ARG(a && a->q && a->k && a->v && a->o);
+  AKI_CHECK_ARG(a->B > 0 && a->H > 0 && a->L > 0 && a->Dh > 0 && a->scale > 0.f);
+  AKI_CHECK_ARG(dtype_ok(a->dtype));
+  AKI_CHECK_ARG(a->max_rects >= 0 && (a->max_rects == 0 || a->rects));
+  if (a->dtype == AKI_DT_BF16) return attn_core_bf16(a, ws, ws_bytes, (hipStream_t)stream);
+  return attn_core_f32(a, ws, ws_bytes, (hipStream_t)stream, 1);
+}
+
+// ---- fused MMA op ------------------------------------------------------------------------------------
+static size_t qkv_bytes(int B, int H, int L, int Dh, int dtype) {
+  return aki_align_up((size_t)B * H * L * Dh * aki_elt_size(dtype), 256);
+}
+
+size_t aki_mma_attn_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype) {
+  size_t n = 3 * qkv_bytes(B, H, L, Dh, dtype) + aki_mma_attn_core_workspace_bytes(B, H, L, Dh, dtype);
+  if (dtype == AKI_DT_F32) n += 3 * qkv_bytes(B, H, L, Dh, dtype);  // un-rotated qkv scratch
+  return n;
+}
+
+static int check_fused(const aki_mma_attn_args* a) {
+  AKI_CHECK_ARG(a && a->x && a->w_qkv && a->cos && a->sin);
+  AKI_CHECK_ARG(a->B > 0 && a->H > 0 && a->L > 0 && a->Dh > 0 && a->d_model > 0);
+  AKI_CHECK_ARG(a->ldx >= a->d_model && a->ldw >= a->d_model && a->pos_rows > 0);
+  AKI_CHECK_ARG(a->position_ids || a->pos_rows >= a->L);
+  AKI_CHECK_ARG(dtype_ok(a->dtype));
+  return AKI_OK;
+}
+
+int aki_qkv_rope_fwd(const aki_mma_attn_args* a, void* q, void* k, void* v, void* stream) {
+  int rc = check_fused(a);
+  if (rc) return rc;
+  AKI_CHECK_ARG(q && k && v);
+  if (a->dtype == AKI_DT_BF16) return qkv_rope_bf16(a, q, k, v, (hipStream_t)stream);
+  return AKI_ERR_UNSUPPORTED;  // the f32 path needs scratch: use aki_mma_attn_fwd
+}
+
+int aki_mma_attn_fwd(const aki_mma_attn_args* a, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_fused(a);
+  if (rc) return rc;
+  AKI_CHECK_ARG(a->o && a->scale > 0.f);
+  AKI_CHECK_ARG(a->max_rects >= 0 && (a->max_rects == 0 || a->rects));
+  if (!ws || ws_bytes < aki_mma_attn_workspace_bytes(a->B, a->H, a->L, a->Dh, a->dtype)) return AKI_ERR_WORKSPACE;
+  AKI_CHECK_ALIGN16(ws);
+  const size_t qb = qkv_bytes(a->B, a->H, a->L, a->Dh, a->dtype);
+  char* w = (char*)ws;
+  void* q = w; void* k = w + qb; void* v = w + 2 * qb;
+  char* rest = w + 3 * qb;
+  if (a->dtype == AKI_DT_BF16) {
+    rc = qkv_rope_bf16(a, q, k, v, (hipStream_t)stream);
+  } else {
+    rc = qkv_rope_f32(a, q, k, v, (float*)rest, (hipStream_t)stream);
+    rest += 3 * qb;
+  }
+  if (rc) return rc;
+  aki_mma_attn_core_args c = {};
+  c.q = q; c.k = k; c.v = v; c.o = a->o; c.lse = a->lse; c.rects = a->rects; c.col_valid_bits = a->col_valid_bits;
+  c.seq_lens = a->seq_lens; c.max_rects = a->max_rects; c.B = a->B; c.H = a->H; c.L = a->L; c.Dh = a->Dh;
+  c.scale = a->scale; c.dtype = a->dtype; c.dead_rows = a->dead_rows;
+  return aki_mma_attn_core_fwd(&c, rest, aki_mma_attn_core_workspace_bytes(a->B, a->H, a->L, a->Dh, a->dtype), stream);
+}
+
+// ---- linear ------------------------------------------------------------------------------------------
+int aki_linear_fwd(const aki_linear_args* a, void* stream) {
+  AKI_CHECK_ARG(a && a->x && a->w && a->y);
+  AKI_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0);
+  AKI_CHECK_ARG(dtype_ok(a->dtype));
+  AKI_CHECK_ARG(a->act >= AKI_ACT_NONE && a->act <= AKI_ACT_SWIGLU);
+  const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
+  AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));
+  if (a->dtype == AKI_DT_BF16) return linear_bf16(a, (hipStream_t)stream);
+  return linear_f32(a, (hipStream_t)stream);
+}
+
+// ---- norms -------------------------------------------------------------------------------------------
+int aki_rmsnorm_fwd(const void* x, const void* w, void* y, int32_t rows, int32_t cols, int32_t ldx, int32_t ldy, float eps,
+                    int32_t dtype, void* stream) {
+  AKI_CHECK_ARG(x && w && y && dtype_ok(dtype) && ldx >= cols && ldy >= cols);
+  return norm_launch(true, x, w, nullptr, y, rows, cols, ldx, ldy, eps, dtype, (hipStream_t)stream);
+}
+
+int aki_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int32_t rows, int32_t cols, int32_t ldx,
+                      int32_t ldy, float eps, int32_t dtype, void* stream) {
+  AKI_CHECK_ARG(x && w && y && dtype_ok(dtype) && ldx >= cols && ldy >= cols);
+  return norm_launch(false, x, w, b, y, rows, cols, ldx, ldy, eps, dtype, (hipStream_t)stream);
+}
+
+// ---- patch embed -------------------------------------------------------------------------------------
+size_t aki_patch_embed_workspace_bytes(int32_t N, int32_t S, int32_t P, int32_t dtype) {
+  const int G = S / P;
+  const size_t Kp = aki_align_up((size_t)3 * P * P, 64);
+  return aki_align_up((size_t)N * G * G * Kp * aki_elt_size(dtype), 256);
+}
+
+int aki_patch_embed_fwd(const void* pixels, const void* w, const void* bias, const void* pos, void* out, int32_t N, int32_t S,
+                        int32_t P, int32_t E, int32_t Kp, int32_t dtype, void* ws, size_t ws_bytes, void* stream) {
+  AKI_CHECK_ARG(pixels && w && out && N > 0 && S > 0 && P > 0 && E > 0 && dtype_ok(dtype));
+  AKI_CHECK_ARG(S >= P && Kp == (int)aki_align_up((size_t)3 * P * P, 64));
+  if (!ws || ws_bytes < aki_patch_embed_workspace_bytes(N, S, P, dtype)) return AKI_ERR_WORKSPACE;
+  const int G = S / P;
+  int rc = im2col_launch(pixels, ws, N, S, P, Kp, dtype, (hipStream_t)stream);
+  if (rc) return rc;
+  aki_linear_args g = {};
+  g.x = ws; g.w = w; g.bias = bias; g.residual = pos; g.y = out;
+  g.M = N * G * G; g.N = E; g.K = Kp; g.ldx = Kp; g.ldw = Kp; g.ldy = E; g.ldr = E;
+  g.res_row_mod = pos ? G * G : 0; g.act = AKI_ACT_NONE; g.dtype = dtype;
+  return aki_linear_fwd(&g, stream);
+}
+
+// ---- connector ---------------------------------------------------------------------------------------
+size_t aki_connector_mlp_workspace_bytes(int32_t rows, int32_t d, int32_t d_inner, int32_t dtype) {
+  return aki_align_up((size_t)rows * d * aki_elt_size(dtype), 256) + aki_align_up((size_t)rows * d_inner * aki_elt_size(dtype), 256);
+}
+
+int aki_connector_mlp_fwd(const void* x, const void* ln_w, const void* ln_b, const void* w1, const void* w2, void* out,
+                          int32_t rows, int32_t d, int32_t d_inner, float eps, int32_t dtype, void* ws, size_t ws_bytes,
+                          void* stream) {
+  AKI_CHECK_ARG(x && ln_w && w1 && w2 && out && rows > 0 && d > 0 && d_inner > 0 && dtype_ok(dtype));
+  if (!ws || ws_bytes < aki_connector_mlp_workspace_bytes(rows, d, d_inner, dtype)) return AKI_ERR_WORKSPACE;
+  char* normed = (char*)ws;
+  char* hidden = normed + aki_align_up((size_t)rows * d * aki_elt_size(dtype), 256);
+  int rc = aki_layernorm_fwd(x, ln_w, ln_b, normed, rows, d, d, d, eps, dtype, stream);
+  if (rc) return rc;
+  aki_linear_args g = {};
+  g.x = normed; g.w = w1; g.y = hidden; g.M = rows; g.N = d_inner; g.K = d; g.ldx = d; g.ldw = d; g.ldy = d_inner;
+  g.act = AKI_ACT_GELU_ERF; g.dtype = dtype;
+  rc = aki_linear_fwd(&g, stream);
+  if (rc) return rc;
+  aki_linear_args g2 = {};
+  g2.x = hidden; g2.w = w2; g2.y = out; g2.residual = x; g2.M = rows; g2.N = d; g2.K = d_inner; g2.ldx = d_inner; g2.ldw = d_inner;
+  g2.ldy = d; g2.ldr = d; g2.act = AKI_ACT_NONE; g2.dtype = dtype;
+  return aki_linear_fwd(&g2, stream);
+}
+
+int aki_connector_proj_fwd(const void* x, const void* ln_w, const void* ln_b, const void* w, const void* b, void* out,
+                           int32_t rows, int32_t d, int32_t d_out, float eps, int32_t dtype, void* ws, size_t ws_bytes,
+                           void* stream) {
+  AKI_CHECK_ARG(x && ln_w && w && out && rows > 0 && d > 0 && d_out > 0 && dtype_ok(dtype));
+  if (!ws || ws_bytes < aki_align_up((size_t)rows * d * aki_elt_size(dtype), 256)) return AKI_ERR_WORKSPACE;
+  int rc = aki_layernorm_fwd(x, ln_w, ln_b, ws, rows, d, d, d, eps, dtype, stream);
+  if (rc) return rc;
+  aki_linear_args g = {};
+  g.x = ws; g.w = w; g.bias = b; g.y = out; g.M = rows; g.N = d_out; g.K = d; g.ldx = d; g.ldw = d; g.ldy = d_out;
+  g.act = AKI_ACT_NONE; g.dtype = dtype;
+  return aki_linear_fwd(&g, stream);
+}
+
+// ---- splice / mask -------------------------------------------------------------------------------------
+int aki_splice_plan(const int64_t* lang_x, int32_t B, int32_t T, int64_t media_token_id, int64_t assistant_token_id,
+                    int32_t Nv, int32_t* plan, void* stream) {
+  AKI_CHECK_ARG(lang_x && plan && B > 0 && T > 0 && Nv > 0);
+  return splice_plan_launch(lang_x, B, T, media_token_id, assistant_token_id, Nv, plan, (hipStream_t)stream);
+}
+
+int aki_splice_fwd(const aki_splice_args* a, void* stream) {
+  AKI_CHECK_ARG(a && a->lang_x && a->embed_weight && a->plan && a->inputs_embeds);
+  AKI_CHECK_ARG(a->B > 0 && a->T > 0 && a->Nv > 0 && a->d > 0 && a->L_out > 0 && dtype_ok(a->dtype));
+  AKI_CHECK_ARG(a->T_img == 0 || a->vision_tokens);
+  AKI_CHECK_ARG(a->max_rects >= 0 && a->max_rects <= AKI_MAX_RECTS);
+  AKI_CHECK_ARG(a->padding_side == 0 || a->padding_side == 1);
+  if (((size_t)a->d * aki_elt_size(a->dtype)) % 16) return AKI_ERR_ALIGNMENT;
+  AKI_CHECK_ALIGN16(a->embed_weight); AKI_CHECK_ALIGN16(a->embed_additional); AKI_CHECK_ALIGN16(a->vision_tokens);
+  AKI_CHECK_ALIGN16(a->inputs_embeds);
+  return splice_launch(a, (hipStream_t)stream);
+}
+
+int aki_mma_mask_dense(const aki_mma_rect* rects, int32_t max_rects, const uint64_t* col_valid_bits, const int32_t* seq_lens,
+                       int32_t B, int32_t L, int64_t* out, void* stream) {
+  AKI_CHECK_ARG(out && B > 0 && L > 0 && max_rects >= 0 && max_rects <= AKI_MAX_RECTS && (max_rects == 0 || rects));
+  return mask_dense_launch(rects, max_rects, col_valid_bits, seq_lens, B, L, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

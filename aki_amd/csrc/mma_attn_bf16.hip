@@ -1,0 +1,304 @@
+// mma_attn_bf16.hip - span-driven modality-mutual attention core, bf16 / head_dim 96, CDNA4 MFMA.
+//
+// Replaces the eager path HF:phi3/modeling_phi3.py:145-167 under the reference's dense
+// (B,1,L,L) mask (src/vlm.py:410-443) without ever forming an L x L tensor:
+//   visible(r,c) = valid(c) && r < seq_len && ( c <= r || r in rect rows && c in rect cols )
+// Tiles are classified FULL / EMPTY / PARTIAL per wave from the rectangle table; only PARTIAL tiles
+// pay for the per-element predicate.
+//
+// Work decomposition.  Workgroup = NW waves = NW*32 query rows of one (batch, head); KV tiles of 64
+// keys are staged through registers into a double-buffered LDS image (K rows padded to 208 B so the
+// ds_read_b128 fragment reads are conflict-free; V rows 192 B, conflict-free for the transposed read).
+// Per wave and KV tile:
+//   S^T = K Q^T      12 x v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = Q kept in 24 VGPRs)
+//                    -> lane (q = lane&31) holds 32 of the 64 scores of ITS OWN row: the row max /
+//                    row sum are in-register reductions plus one v_permlane32_swap across halves.
+//   online softmax in f32 (log2 domain: p = exp2(s*c - m)), masked scores = -inf
+//   O^T += V^T P     12 MFMAs; P goes from the S^T accumulators to the B operand with no lane
+//                    movement (cdna_hip_programming.md section 3, "accumulator tile as the next MFMA's
+//                    operand": element j of lane-half h <-> key 16s + 8(j>>2) + 4h + (j&3)); the
+//                    matching V^T A-operand comes from two ds_read_b64_tr_b16 per fragment.
+// O^T keeps the query on the lane, so the rescale factor and the final 1/l are lane-local.
+#include "aki_device.h"
+
+namespace aki {
+
+struct AttnParams {
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* v;
+  bf16_t* o;
+  float* lse;
+  const aki_mma_rect* rects;
+  const uint64_t* vbits;
+  const int* seq_lens;
+  const float* vmean;  // [B,H,96] f32: column mean of V (uniform softmax of rows with no visible column)
+  int max_rects;
+  int B, H, L;
+  int nqt, nwords;
+  float scale_log2;  // scale * log2(e)
+  int dead_uniform;
+};
+
+constexpr int KROW = 208;  // padded K row pitch in LDS (bytes)
+constexpr int VROW = 192;
+constexpr int KTILE = 64 * KROW;
+constexpr int VTILE = 64 * VROW;
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnParams p) {
+  constexpr int BQ = NW * 32;
+  constexpr int NT = NW * 64;
+  constexpr int NCH = (64 * 12 + NT - 1) / NT;  // 16-B chunks per thread per tile (K and V each)
+  __shared__ __attribute__((aligned(16))) char smem[2 * KTILE + 2 * VTILE + AKI_MAX_RECTS * 16];
+  char* const sK = smem;
+  char* const sV = smem + 2 * KTILE;
+  const aki_mma_rect* sR = (const aki_mma_rect*)(smem + 2 * KTILE + 2 * VTILE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = t / p.nqt;
+  const int qt = p.nqt - 1 - (t - bh * p.nqt);  // late (heavy) query tiles first
+  const int b = bh / p.H, head = bh - b * p.H;
+  const int L = p.L;
+  const int q0 = qt * BQ;
+  const int wq0 = q0 + wave * 32;
+  const int row = wq0 + l31;
+  const int Lb = p.seq_lens ? min(p.seq_lens[b], L) : L;
+
+  if (tid < AKI_MAX_RECTS) {
+    u32x4 r = {0u, 0u, 0u, 0u};
+    if (tid < p.max_rects) r = ((const u32x4*)p.rects)[(size_t)b * p.max_rects + tid];
+    ((u32x4*)sR)[tid] = r;
+  }
+  __syncthreads();
+
+  // ---- column extent of the workgroup, per-wave rectangle summary, per-lane unlock range ---------
+  int hi_col = min(q0 + BQ, L);
+  int touch_lo = 0x7fffffff, touch_hi = 0, full_lo = 0, full_hi = 0;
+  int rc0 = 0, rc1 = 0;
+#pragma unroll
+  for (int i = 0; i < AKI_MAX_RECTS; ++i) {
+    const aki_mma_rect r = sR[i];
+    if (r.row_hi > r.row_lo && r.col_hi > r.col_lo) {
+      if (r.row_lo < q0 + BQ && r.row_hi > q0) hi_col = max(hi_col, min(r.col_hi, L));
+      if (r.row_lo < wq0 + 32 && r.row_hi > wq0) {
+        touch_lo = min(touch_lo, r.col_lo);
+        touch_hi = max(touch_hi, r.col_hi);
+        if (r.row_lo <= wq0 && r.row_hi >= wq0 + 32) { full_lo = r.col_lo; full_hi = r.col_hi; }
+      }
+      if (row >= r.row_lo && row < r.row_hi) { rc0 = r.col_lo; rc1 = r.col_hi; }
+    }
+  }
+  const int jend = (hi_col + 63) >> 6;
+  const bool wave_alive = wq0 < Lb;            // wave-uniform
+  const bool wave_has_dead = wq0 + 32 > Lb;    // some rows of the wave are beyond seq_len
+  const bool row_alive = row < Lb;
+
+  const bf16_t* qb = p.q + ((size_t)bh * L) * 96;
+  const char* kb = (const char*)(p.k + ((size_t)bh * L) * 96);
+  const char* vb_ = (const char*)(p.v + ((size_t)bh * L) * 96);
+
+  // Q fragments (B operand of S^T = K Q^T): lane (q=l31, h) holds Q[q][16ks + 8h .. +7]
+  bf16x8 qf[6];
+  {
+    const bf16_t* qrow = qb + (size_t)min(row, L - 1) * 96 + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
+  }
+
+  f32x16 o[3];
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1e30f, l_part = 0.f;
+
+  u32x4 kreg[NCH], vreg[NCH];
+  auto load_tile = [&](int j) {
+    const int c0 = j * 64;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * NT;
+      if (NCH * NT == 768 || c < 768) {
+        const int kr = c / 12, kc = c - kr * 12;
+        const size_t off = (size_t)min(c0 + kr, L - 1) * 192 + kc * 16;
+        kreg[i] = *(const u32x4*)(kb + off);
+        vreg[i] = *(const u32x4*)(vb_ + off);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * NT;
+      if (NCH * NT == 768 || c < 768) {
+        const int kr = c / 12, kc = c - kr * 12;
+        *(u32x4*)(sK + buf * KTILE + kr * KROW + kc * 16) = kreg[i];
+        *(u32x4*)(sV + buf * VTILE + c * 16) = vreg[i];
+      }
+    }
+  };
+
+  // per-lane LDS offsets
+  const int koff = l31 * KROW + h * 16;                                   // + 32*KROW (2nd key block) + ks*32
+  const int voff = (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+  if (jend > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int j = 0; j < jend; ++j) {
+    if (j + 1 < jend) load_tile(j + 1);
+    const int c0 = j * 64;
+    unsigned long long vb;
+    if (p.vbits) vb = p.vbits[(size_t)b * p.nwords + j];
+    else vb = (c0 + 64 <= L) ? ~0ull : ((1ull << (L - c0)) - 1ull);
+    const bool causal_full = (c0 + 63 <= wq0);
+    const bool causal_none = (c0 > wq0 + 31);
+    const bool rect_full = (c0 >= full_lo && c0 + 64 <= full_hi);
+    const bool rect_touch = (c0 < touch_hi && c0 + 64 > touch_lo);
+    const bool skip = !wave_alive || vb == 0ull || (causal_none && !rect_touch);
+    if (!skip) {
+      const char* Kb = sK + (j & 1) * KTILE;
+      const char* Vb = sV + (j & 1) * VTILE;
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        const bf16x8 a0 = *(const bf16x8*)(Kb + koff + ks * 32);
+        const bf16x8 a1 = *(const bf16x8*)(Kb + koff + 32 * KROW + ks * 32);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
+      }
+      const bool full = (vb == ~0ull) && (causal_full || rect_full) && !wave_has_dead;
+      if (!full) {
+        const unsigned long long vbh = vb >> (4 * h);
+        const int ck = c0 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          {
+            const int c = ck + cr;
+            bool vis = (c <= row) | ((c >= rc0) & (c < rc1));
+            vis = vis & (((vbh >> cr) & 1ull) != 0ull) & row_alive;
+            s0[r] = vis ? s0[r] : -INFINITY;
+          }
+          {
+            const int c = ck + cr + 32;
+            bool vis = (c <= row) | ((c >= rc0) & (c < rc1));
+            vis = vis & (((vbh >> (cr + 32)) & 1ull) != 0ull) & row_alive;
+            s1[r] = vis ? s1[r] : -INFINITY;
+          }
+        }
+      }
+      float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+      mx = halves_max(mx) * p.scale_log2;
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2, -m_new));
+        s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2, -m_new));
+        ps += s0[r] + s1[r];
+      }
+      l_part = l_part * alpha + ps;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+#pragma unroll
+      for (int ks4 = 0; ks4 < 4; ++ks4) {
+        bf16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (__bf16)((ks4 < 2) ? s0[8 * (ks4 & 1) + e] : s1[8 * (ks4 & 1) + e]);
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+          const char* va = Vb + voff + ks4 * 16 * VROW + dt * 64;
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + 8 * VROW));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (j + 1 < jend) store_tile((j + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: O = O^T / l, rows with no visible column -> uniform softmax (mean of V) or zero ----
+  const float l_tot = halves_sum(l_part);
+  if (row < L) {
+    const bool dead = !(l_tot > 0.f);
+    const float inv = dead ? 0.f : 1.0f / l_tot;
+    bf16_t* orow = p.o + ((size_t)(b * L + row) * p.H + head) * 96 + 4 * h;
+    const float* vm = p.vmean + (size_t)bh * 96 + 4 * h;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[dt][4 * q4 + e] * inv;
+        if (dead && p.dead_uniform) {
+          const f32x4 mv = *(const f32x4*)(vm + dt * 32 + q4 * 8);
+          v[0] = mv[0]; v[1] = mv[1]; v[2] = mv[2]; v[3] = mv[3];
+        }
+        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *(u32x2*)(orow + dt * 32 + q4 * 8) = pk;
+      }
+    if (p.lse && h == 0) p.lse[(size_t)bh * L + row] = dead ? -INFINITY : (m_run + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
+  }
+}
+
+// column mean of V over all L rows, f32 [B,H,96]
+__global__ void vmean_bf16_kernel(const bf16_t* v, float* out, int L) {
+  __shared__ float red[4][96];
+  const int bh = blockIdx.x, d = threadIdx.x % 96, part = threadIdx.x / 96;  // 384 threads
+  const bf16_t* base = v + (size_t)bh * L * 96;
+  float s = 0.f;
+  for (int t = part; t < L; t += 4) s += bf16_bits_to_f32(base[(size_t)t * 96 + d]);
+  red[part][d] = s;
+  __syncthreads();
+  if (part == 0) out[(size_t)bh * 96 + d] = (red[0][d] + red[1][d] + red[2][d] + red[3][d]) / (float)L;
+}
+
+int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (a->Dh != 96) return AKI_ERR_UNSUPPORTED;
+  if (a->max_rects < 0 || a->max_rects > AKI_MAX_RECTS) return AKI_ERR_INVALID_ARG;
+  AKI_CHECK_ALIGN16(a->q); AKI_CHECK_ALIGN16(a->k); AKI_CHECK_ALIGN16(a->v); AKI_CHECK_ALIGN16(a->o);
+  const size_t need = (size_t)a->B * a->H * 96 * sizeof(float);
+  if (!ws || ws_bytes < need) return AKI_ERR_WORKSPACE;
+  AKI_CHECK_ALIGN16(ws);
+  constexpr int NW = 4;
+  AttnParams p = {};
+  p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.o = (bf16_t*)a->o; p.lse = a->lse;
+  p.rects = a->rects; p.vbits = a->col_valid_bits; p.seq_lens = a->seq_lens; p.vmean = (const float*)ws;
+  p.max_rects = a->rects ? a->max_rects : 0;
+  p.B = a->B; p.H = a->H; p.L = a->L;
+  p.nqt = (a->L + NW * 32 - 1) / (NW * 32);
+  p.nwords = (a->L + 63) / 64;
+  p.scale_log2 = a->scale * 1.44269504088896340736f;
+  p.dead_uniform = a->dead_rows == AKI_DEAD_ROWS_UNIFORM;
+  if (p.dead_uniform) {
+    hipLaunchKernelGGL(vmean_bf16_kernel, dim3(a->B * a->H), dim3(384), 0, stream, p.v, (float*)ws, a->L);
+    AKI_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL((mma_attn_bf16_kernel<NW>), dim3(a->B * a->H * p.nqt), dim3(NW * 64), 0, stream, p);
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
+}
+
+}  // namespace aki

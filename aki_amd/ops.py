@@ -1,0 +1,312 @@
+"""Torch-tensor front end of the C ABI (include/aki_mi355x.h).
+
+PyTorch is plumbing here: device memory, the current HIP stream and autograd bookkeeping.  Every
+function below hands raw device pointers to libaki_mi355x.so; there is NO eager/CPU fallback -
+CPU tensors or a missing library raise :class:`aki_amd._lib.AkiError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import AkiError
+
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SWIGLU = L.AKI_ACT_NONE, L.AKI_ACT_GELU_ERF, L.AKI_ACT_GELU_TANH, L.AKI_ACT_SWIGLU
+DEAD_ROWS_ZERO, DEAD_ROWS_UNIFORM = L.AKI_DEAD_ROWS_ZERO, L.AKI_DEAD_ROWS_UNIFORM
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return L.AKI_DT_BF16
+    if t.dtype == torch.float32:
+        return L.AKI_DT_F32
+    raise AkiError(f"unsupported dtype {t.dtype}: the AKI HIP path computes in bf16 or f32")
+
+
+def _dev(*ts: Optional[torch.Tensor]) -> torch.device:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise AkiError("the AKI MMA path runs on MI355X only: got a CPU tensor and there is no CPU fallback")
+        dev = dev or t.device
+        if t.device != dev:
+            raise AkiError("tensors on different devices")
+    return dev
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows2d(t: torch.Tensor) -> torch.Tensor:
+    """View as [rows, cols] with unit inner stride (copy only if the layout forces it)."""
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.stride(-1) != 1 or (t2.shape[0] > 1 and t2.stride(0) < t2.shape[1]):
+        t2 = t2.contiguous()
+    return t2
+
+
+def _ws(nbytes: int, dev) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class MaskTable:
+    """Device-resident description of the modality-mutual mask (what replaces the dense (B,1,L,L) tensor)."""
+    rects: Optional[torch.Tensor]          # int32 [B, max_rects, 4]
+    col_valid_bits: Optional[torch.Tensor]  # int64 (bit pattern of uint64) [B, ceil(L/64)]
+    seq_lens: Optional[torch.Tensor]       # int32 [B]
+    L: int
+    mask_1d: Optional[torch.Tensor] = None  # int64 [B, L] spliced 1-D mask (for callers that want it)
+
+    @property
+    def max_rects(self) -> int:
+        return 0 if self.rects is None else int(self.rects.shape[1])
+
+    @staticmethod
+    def causal(B: int, Lq: int, device) -> "MaskTable":
+        return MaskTable(None, None, None, Lq)
+
+    @staticmethod
+    def from_host(rects, mask_1d, seq_lens, device) -> "MaskTable":
+        """rects: [B][k] of (row_lo,row_hi,col_lo,col_hi); mask_1d: bool/int [B,L]; seq_lens: [B] or None."""
+        import numpy as np
+        m = np.asarray(mask_1d).astype(bool)
+        B, Lq = m.shape
+        k = max(1, max(len(r) for r in rects))
+        ra = np.zeros((B, k, 4), dtype=np.int32)
+        for b, rs in enumerate(rects):
+            for i, r in enumerate(rs):
+                ra[b, i] = r
+        nw = (Lq + 63) // 64
+        pad = np.zeros((B, nw * 64), dtype=bool)
+        pad[:, :Lq] = m
+        bits = np.packbits(pad.reshape(B, nw, 64), axis=-1, bitorder="little").view(np.uint64).reshape(B, nw)
+        t = MaskTable(torch.from_numpy(ra).to(device), torch.from_numpy(bits.view(np.int64).copy()).to(device),
+                      None if seq_lens is None else torch.tensor(list(seq_lens), dtype=torch.int32, device=device), Lq,
+                      torch.from_numpy(m.astype(np.int64)).to(device))
+        return t
+
+
+# ------------------------------------------------------------------------------------------------
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           act: int = ACT_NONE, res_row_mod: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act(x W^T + bias) [+ residual]; W is an nn.Linear weight [N,K] (K a multiple of 64 for bf16)."""
+    dev = _dev(x, w, bias, residual, out)
+    lib = L.load()
+    x2 = _rows2d(x)
+    M, K = x2.shape
+    N = w.shape[0]
+    if w.shape[1] != K or w.stride(1) != 1:
+        raise AkiError(f"linear: weight {tuple(w.shape)} does not match input K={K}")
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    if out is None:
+        out = torch.empty((*x.shape[:-1], n_out), dtype=x.dtype, device=dev)
+    o2 = out.view(-1, out.shape[-1])
+    if o2.shape != (M, n_out) or o2.stride(1) != 1:
+        raise AkiError("linear: bad output buffer")
+    r2 = None
+    if residual is not None:
+        r2 = _rows2d(residual)
+    a = L.LinearArgs(_ptr(x2), _ptr(w), _ptr(bias), _ptr(r2), _ptr(o2), M, N, K, x2.stride(0), w.stride(0), o2.stride(0),
+                     0 if r2 is None else r2.stride(0), res_row_mod, act, _dt(x))
+    L.check(lib.aki_linear_fwd(C.byref(a), _stream()), "aki_linear_fwd")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    dev = _dev(x, w)
+    x2 = _rows2d(x)
+    y = torch.empty_like(x2)
+    L.check(L.load().aki_rmsnorm_fwd(_ptr(x2), _ptr(w), _ptr(y), x2.shape[0], x2.shape[1], x2.stride(0), y.stride(0),
+                                     float(eps), _dt(x), _stream()), "aki_rmsnorm_fwd")
+    return y.reshape(x.shape)
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: float) -> torch.Tensor:
+    dev = _dev(x, w, b)
+    x2 = _rows2d(x)
+    y = torch.empty_like(x2)
+    L.check(L.load().aki_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), x2.shape[0], x2.shape[1], x2.stride(0),
+                                       y.stride(0), float(eps), _dt(x), _stream()), "aki_layernorm_fwd")
+    return y.reshape(x.shape)
+
+
+def mma_attn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: MaskTable, scale: float,
+                  dead_rows: int = DEAD_ROWS_UNIFORM, return_lse: bool = False):
+    """q,k,v [B,H,L,Dh] (contiguous) -> o [B,L,H*Dh]."""
+    dev = _dev(q, k, v)
+    B, H, Lq, Dh = q.shape
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    o = torch.empty((B, Lq, H * Dh), dtype=q.dtype, device=dev)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=dev) if return_lse else None
+    lib = L.load()
+    ws = _ws(lib.aki_mma_attn_core_workspace_bytes(B, H, Lq, Dh, _dt(q)), dev)
+    a = L.MmaAttnCoreArgs(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(table.rects), _ptr(table.col_valid_bits),
+                          _ptr(table.seq_lens), table.max_rects, B, H, Lq, Dh, float(scale), _dt(q), dead_rows)
+    L.check(lib.aki_mma_attn_core_fwd(C.byref(a), _ptr(ws), ws.numel(), _stream()), "aki_mma_attn_core_fwd")
+    return (o, lse) if return_lse else o
+
+
+def _fused_args(x2, w_qkv, cos, sin, position_ids, o, lse, table, B, H, Lq, Dh, scale, dead_rows):
+    return L.MmaAttnArgs(_ptr(x2), _ptr(w_qkv), _ptr(cos), _ptr(sin), _ptr(position_ids), _ptr(o), _ptr(lse),
+                         _ptr(table.rects), _ptr(table.col_valid_bits), _ptr(table.seq_lens), table.max_rects,
+                         B, H, Lq, Dh, x2.shape[1], x2.stride(0), w_qkv.stride(0), cos.shape[0], float(scale),
+                         _dt(x2), dead_rows)
+
+
+def mma_attn(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, table: MaskTable, num_heads: int,
+             scale: Optional[float] = None, position_ids: Optional[torch.Tensor] = None,
+             dead_rows: int = DEAD_ROWS_UNIFORM) -> torch.Tensor:
+    """Fused QKV projection + RoPE + span-driven attention.  x [B,L,d] -> o [B,L,H*Dh] (before o_proj).
+    cos/sin: f32 [pos_rows, Dh]."""
+    dev = _dev(x, w_qkv, cos, sin, position_ids)
+    B, Lq, d = x.shape
+    Dh = w_qkv.shape[0] // (3 * num_heads)
+    x2 = _rows2d(x)
+    cos = cos.to(torch.float32).reshape(-1, Dh).contiguous()
+    sin = sin.to(torch.float32).reshape(-1, Dh).contiguous()
+    if position_ids is not None:
+        position_ids = position_ids.to(torch.int32).expand(B, Lq).contiguous()
+    o = torch.empty((B, Lq, num_heads * Dh), dtype=x.dtype, device=dev)
+    lib = L.load()
+    ws = _ws(lib.aki_mma_attn_workspace_bytes(B, num_heads, Lq, Dh, _dt(x)), dev)
+    a = _fused_args(x2, w_qkv, cos, sin, position_ids, o, None, table, B, num_heads, Lq, Dh,
+                    scale if scale is not None else Dh ** -0.5, dead_rows)
+    L.check(lib.aki_mma_attn_fwd(C.byref(a), _ptr(ws), ws.numel(), _stream()), "aki_mma_attn_fwd")
+    return o
+
+
+def qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, num_heads: int,
+             position_ids: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Stage 1 of the fused op (bf16 only): rotated q,k and v, each [B,H,L,Dh]."""
+    dev = _dev(x, w_qkv, cos, sin)
+    B, Lq, d = x.shape
+    Dh = w_qkv.shape[0] // (3 * num_heads)
+    x2 = _rows2d(x)
+    cos = cos.to(torch.float32).reshape(-1, Dh).contiguous()
+    sin = sin.to(torch.float32).reshape(-1, Dh).contiguous()
+    if position_ids is not None:
+        position_ids = position_ids.to(torch.int32).expand(B, Lq).contiguous()
+    q, k, v = (torch.empty((B, num_heads, Lq, Dh), dtype=x.dtype, device=dev) for _ in range(3))
+    a = _fused_args(x2, w_qkv, cos, sin, position_ids, None, None, MaskTable(None, None, None, Lq), B, num_heads, Lq, Dh,
+                    Dh ** -0.5, 0)
+    L.check(L.load().aki_qkv_rope_fwd(C.byref(a), _ptr(q), _ptr(k), _ptr(v), _stream()), "aki_qkv_rope_fwd")
+    return q, k, v
+
+
+def pad_k(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
+    """Zero-pad the K (last) dimension of a weight to a multiple of `mult` (one-time host-side prep)."""
+    K = w.shape[-1]
+    Kp = (K + mult - 1) // mult * mult
+    if Kp == K:
+        return w.contiguous()
+    out = torch.zeros(*w.shape[:-1], Kp, dtype=w.dtype, device=w.device)
+    out[..., :K] = w
+    return out
+
+
+def patch_embed(pixels: torch.Tensor, w_padded: torch.Tensor, bias: Optional[torch.Tensor], pos: Optional[torch.Tensor],
+                patch: int) -> torch.Tensor:
+    """pixels [N,3,S,S]; w_padded [E,Kp] = pad_k(conv_weight.reshape(E,-1)); pos [G*G,E] -> [N,G*G,E]."""
+    dev = _dev(pixels, w_padded, bias, pos)
+    N, _, S, _ = pixels.shape
+    E, Kp = w_padded.shape
+    G = S // patch
+    pixels = pixels.contiguous()
+    out = torch.empty((N, G * G, E), dtype=pixels.dtype, device=dev)
+    lib = L.load()
+    ws = _ws(lib.aki_patch_embed_workspace_bytes(N, S, patch, _dt(pixels)), dev)
+    L.check(lib.aki_patch_embed_fwd(_ptr(pixels), _ptr(w_padded), _ptr(bias), _ptr(pos), _ptr(out), N, S, patch, E, Kp,
+                                    _dt(pixels), _ptr(ws), ws.numel(), _stream()), "aki_patch_embed_fwd")
+    return out
+
+
+def connector_mlp(x: torch.Tensor, ln_w, ln_b, w1, w2, eps: float = 1e-5) -> torch.Tensor:
+    """out = x + W2 gelu(W1 LN(x)) - the Perceiver FeedForward block with its residual (src/helpers.py:32-39,194)."""
+    dev = _dev(x, ln_w, ln_b, w1, w2)
+    x2 = _rows2d(x).contiguous()
+    rows, d = x2.shape
+    d_inner = w1.shape[0]
+    out = torch.empty_like(x2)
+    lib = L.load()
+    ws = _ws(lib.aki_connector_mlp_workspace_bytes(rows, d, d_inner, _dt(x)), dev)
+    L.check(lib.aki_connector_mlp_fwd(_ptr(x2), _ptr(ln_w), _ptr(ln_b), _ptr(w1), _ptr(w2), _ptr(out), rows, d, d_inner,
+                                      float(eps), _dt(x), _ptr(ws), ws.numel(), _stream()), "aki_connector_mlp_fwd")
+    return out.reshape(x.shape)
+
+
+def connector_proj(x: torch.Tensor, ln_w, ln_b, w, b, eps: float = 1e-5) -> torch.Tensor:
+    """out = Wp LN(x) + bp (src/helpers.py:196-197)."""
+    dev = _dev(x, ln_w, ln_b, w, b)
+    x2 = _rows2d(x).contiguous()
+    rows, d = x2.shape
+    d_out = w.shape[0]
+    out = torch.empty((rows, d_out), dtype=x.dtype, device=dev)
+    lib = L.load()
+    ws = _ws(rows * d * x.element_size() + 256, dev)
+    L.check(lib.aki_connector_proj_fwd(_ptr(x2), _ptr(ln_w), _ptr(ln_b), _ptr(w), _ptr(b), _ptr(out), rows, d, d_out,
+                                       float(eps), _dt(x), _ptr(ws), ws.numel(), _stream()), "aki_connector_proj_fwd")
+    return out.reshape(*x.shape[:-1], d_out)
+
+
+def splice(lang_x: torch.Tensor, attention_mask: Optional[torch.Tensor], labels: Optional[torch.Tensor],
+           embed_weight: torch.Tensor, embed_additional: Optional[torch.Tensor], max_original_id: int,
+           vision_tokens: torch.Tensor, media_token_id: int, pad_token_id: int, assistant_token_id: int = 32001,
+           padding_side: str = "right", max_rects: int = 1):
+    """Language-stream fusion (src/vlm.py:445-603).  Returns (inputs_embeds, labels_out, MaskTable, plan_host).
+    One small device->host copy (the per-sample plan) is needed to size the outputs."""
+    dev = _dev(lang_x, attention_mask, labels, embed_weight, embed_additional, vision_tokens)
+    lib = L.load()
+    B, T = lang_x.shape
+    lang_x = lang_x.to(torch.int64).contiguous()
+    if attention_mask is not None:
+        attention_mask = attention_mask.to(torch.int64).contiguous()
+    if labels is not None:
+        labels = labels.to(torch.int64).contiguous()
+    vision_tokens = vision_tokens.to(embed_weight.dtype).contiguous()
+    _, T_img, Nv, d = vision_tokens.shape
+    plan = torch.empty((B, L.AKI_PLAN_STRIDE), dtype=torch.int32, device=dev)
+    L.check(lib.aki_splice_plan(_ptr(lang_x), B, T, media_token_id, assistant_token_id, Nv, _ptr(plan), _stream()),
+            "aki_splice_plan")
+    plan_h = plan.cpu()
+    n_img = plan_h[:, 0]
+    if int(n_img.max()) > T_img:
+        raise AkiError(f"a sample has {int(n_img.max())} <image> placeholders but vision_x carries only {T_img} images")
+    if int(n_img.max()) > max_rects:
+        raise AkiError(f"{int(n_img.max())} images in one sample but max_rects={max_rects}")
+    L_out = int(plan_h[:, 2].max())
+    dt = embed_weight.dtype
+    embeds = torch.empty((B, L_out, d), dtype=dt, device=dev)
+    labels_out = torch.empty((B, L_out), dtype=torch.int64, device=dev) if labels is not None else None
+    mask_1d = torch.empty((B, L_out), dtype=torch.int64, device=dev)
+    rects = torch.empty((B, max_rects, 4), dtype=torch.int32, device=dev)
+    nw = (L_out + 63) // 64
+    bits = torch.empty((B, nw), dtype=torch.int64, device=dev)
+    seq_lens = torch.empty((B,), dtype=torch.int32, device=dev)
+    a = L.SpliceArgs(_ptr(lang_x), _ptr(attention_mask), _ptr(labels), _ptr(embed_weight), _ptr(embed_additional),
+                     _ptr(vision_tokens), _ptr(plan), _ptr(embeds), _ptr(labels_out), _ptr(mask_1d), _ptr(rects),
+                     _ptr(bits), _ptr(seq_lens), max_original_id, media_token_id, pad_token_id, B, T, T_img, Nv, d, L_out,
+                     max_rects, 1 if padding_side == "left" else 0, _dt(embeds))
+    L.check(lib.aki_splice_fwd(C.byref(a), _stream()), "aki_splice_fwd")
+    return embeds, labels_out, MaskTable(rects, bits, seq_lens, L_out, mask_1d), plan_h
+
+
+def mask_dense(table: MaskTable, B: int) -> torch.Tensor:
+    """The reference's (B,1,L,L) int64 0/1 mask, materialised from the table (bit-exact)."""
+    dev = table.rects.device if table.rects is not None else table.col_valid_bits.device
+    out = torch.empty((B, 1, table.L, table.L), dtype=torch.int64, device=dev)
+    L.check(L.load().aki_mma_mask_dense(_ptr(table.rects), table.max_rects, _ptr(table.col_valid_bits), _ptr(table.seq_lens),
+                                        B, table.L, _ptr(out), _stream()), "aki_mma_mask_dense")
+    return out

@@ -1,0 +1,248 @@
+/* aki_mi355x.h - C ABI of the MI355X-native AKI modality-mutual-attention (MMA) forward path.
+ *
+ * The reference (sony/aki) has no FFI layer: its boundary is Python object protocol
+ * (SURVEY.md section 8(b)).  Each entry point below names the reference function whose work it
+ * replaces (paths relative to /root/reference/codes/open_flamingo/, "HF:" = the transformers
+ * dependency the reference delegates to).  INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *  - Plain C: raw DEVICE pointers, sizes and strides in ELEMENTS, no torch/HIP types.
+ *    `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - Ownership: the caller owns every buffer, including workspaces.  Kernels allocate nothing,
+ *    keep no state between calls, never synchronise the host and are graph-capturable.
+ *  - Errors: int return, 0 = AKI_OK, < 0 = aki_status code; never throws or aborts.  Shapes and
+ *    alignment are validated on the host before anything is launched.
+ *  - Threading: re-entrant; ordering only through `stream`.
+ *  - dtype: AKI_DT_BF16 (MFMA path, fp32 accumulate/softmax) or AKI_DT_F32 (exact-f32 parity path).
+ */
+#ifndef AKI_MI355X_H
+#define AKI_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AKI_ABI_VERSION 1
+
+typedef enum {
+  AKI_OK = 0,
+  AKI_ERR_INVALID_ARG = -1,  /* null pointer, non-positive size, inconsistent shapes           */
+  AKI_ERR_UNSUPPORTED = -2,  /* dtype / head_dim / size outside what the kernels are built for  */
+  AKI_ERR_ALIGNMENT = -3,    /* pointer or leading dimension not 16-byte aligned                */
+  AKI_ERR_WORKSPACE = -4,    /* workspace missing or too small                                  */
+  AKI_ERR_LAUNCH = -5        /* hipGetLastError() after launch was not hipSuccess               */
+} aki_status;
+
+typedef enum { AKI_DT_BF16 = 0, AKI_DT_F32 = 1 } aki_dtype;
+
+/* Activation fused into aki_linear_fwd. */
+typedef enum {
+  AKI_ACT_NONE = 0,
+  AKI_ACT_GELU_ERF = 1,  /* torch.nn.GELU()            - src/helpers.py:37                    */
+  AKI_ACT_GELU_TANH = 2, /* gelu_pytorch_tanh          - HF:siglip MLP                        */
+  AKI_ACT_SWIGLU = 3     /* out = up * silu(gate), W = [gate; up] - HF:phi3/modeling_phi3.py:49-64 */
+} aki_act;
+
+const char* aki_strerror(int status);
+int aki_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mask description.  The reference materialises a dense (B,1,L,L) int64 0/1 tensor
+ * (src/vlm.py:410-443 `_make_modality_mutual_mask`, stacked by src/utils.py:99-108).  Here the
+ * same information travels as a tiny table:
+ *   visible(r,c) = valid(c) && ( c <= r || exists k: row_lo_k <= r < row_hi_k && col_lo_k <= c < col_hi_k )
+ * `rects` is [B][max_rects]; unused entries are all-zero.  Row ranges of one sample's rectangles
+ * must not overlap.  One rectangle per sample reproduces the reference; more are build-defined.
+ * `col_valid_bits` is [B][ceil(L/64)] uint64, bit (c & 63) of word (c >> 6) = attention mask of
+ * column c (bits at c >= L must be 0); NULL = every column < L valid.
+ * `seq_lens` is [B] int32: rows r >= seq_lens[b] are the all-zero rows that batch stacking adds at
+ * the bottom of a shorter sample's mask (src/utils.py:99-108) and are treated as rows with no
+ * visible column; NULL = L for every sample.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t row_lo, row_hi, col_lo, col_hi;
+} aki_mma_rect;
+
+#define AKI_MAX_RECTS 8
+#define AKI_PLAN_STRIDE 12 /* int32 per sample in the splice plan */
+
+/* Rows with no visible column: the reference's additive finfo.min mask (transformers==4.41.2
+ * `_prepare_4d_causal_attention_mask`, implicit at src/aki.py:125) yields a uniform softmax over
+ * all L columns.  AKI_DEAD_ROWS_UNIFORM reproduces that; AKI_DEAD_ROWS_ZERO writes zeros. */
+typedef enum { AKI_DEAD_ROWS_ZERO = 0, AKI_DEAD_ROWS_UNIFORM = 1 } aki_dead_rows;
+
+/* ------------------------------------------------------------------------------------------------
+ * aki_mma_attn_core_fwd - span-driven block-sparse softmax(QK^T * scale + mask) V.
+ * Replaces: HF:phi3/modeling_phi3.py:145-167 `eager_attention_forward` as called from
+ * `Phi3Attention.forward` (:218-263) under the reference's mask (src/vlm.py:556-564), plus the
+ * 4-D mask inversion of transformers==4.41.2.  No L x L tensor is ever formed.
+ *   q,k,v : [B,H,L,Dh] contiguous (k already rotated);  o : [B,L,H*Dh];  lse : [B,H,L] f32 or NULL
+ *   workspace: aki_mma_attn_core_workspace_bytes() bytes, 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* lse;
+  const aki_mma_rect* rects;
+  const uint64_t* col_valid_bits;
+  const int32_t* seq_lens;
+  int32_t max_rects;
+  int32_t B, H, L, Dh;
+  float scale;
+  int32_t dtype;     /* aki_dtype */
+  int32_t dead_rows; /* aki_dead_rows */
+} aki_mma_attn_core_args;
+
+size_t aki_mma_attn_core_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype);
+int aki_mma_attn_core_fwd(const aki_mma_attn_core_args* args, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * aki_mma_attn_fwd - the fused MMA op: QKV projection + RoPE + span-driven attention.
+ * Replaces: `Phi3Attention.forward` up to (not including) o_proj, HF:phi3/modeling_phi3.py:218-258:
+ *   qkv = x W_qkv^T ; split ; rotate-half RoPE with (cos,sin) ; attention core as above.
+ *   x      : [B*L, d_model] (the RMS-normed hidden states), ldx elements between rows
+ *   w_qkv  : [3*H*Dh, d_model] = `self_attn.qkv_proj.weight`, row-major, ldw
+ *   cos,sin: f32 [pos_rows, Dh] tables (HF `Phi3RotaryEmbedding`; default or LongRoPE computed by the host)
+ *   position_ids: int32 [B*L] row index into cos/sin per token, or NULL for (token index mod L)
+ *   o      : [B, L, H*Dh]
+ * Two stream-ordered launches inside one call (projection+RoPE epilogue, then attention); the
+ * rotated Q/K and V live in the caller-owned workspace in head-major [B,H,L,Dh] order.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;
+  const void* w_qkv;
+  const float* cos;
+  const float* sin;
+  const int32_t* position_ids;
+  void* o;
+  float* lse;
+  const aki_mma_rect* rects;
+  const uint64_t* col_valid_bits;
+  const int32_t* seq_lens;
+  int32_t max_rects;
+  int32_t B, H, L, Dh, d_model;
+  int32_t ldx, ldw;
+  int32_t pos_rows;
+  float scale;
+  int32_t dtype;
+  int32_t dead_rows;
+} aki_mma_attn_args;
+
+size_t aki_mma_attn_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype);
+int aki_mma_attn_fwd(const aki_mma_attn_args* args, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Stage 1 of the fused op on its own (used by the KV-cache prefill and by tests). q/k/v out: [B,H,L,Dh]. */
+int aki_qkv_rope_fwd(const aki_mma_attn_args* args, void* q_out, void* k_out, void* v_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * aki_linear_fwd - y = act(x W^T + bias) [+ residual]   (torch.nn.functional.linear semantics)
+ * Replaces: every nn.Linear on the path - o_proj / gate_up_proj / down_proj
+ * (HF:phi3/modeling_phi3.py:49-64,215-216), Perceiver to_q/to_kv/to_out and FeedForward linears
+ * (src/helpers.py:32-39,72-74), projection (src/helpers.py:147), DecoupledLinear pieces (src/helpers.py:594-603).
+ *   x [M,K] ldx ; w [N,K] ldw ; y [M,N_out] ldy (N_out = N/2 for AKI_ACT_SWIGLU, else N)
+ *   bias [N] or NULL ; residual [res_rows? , N_out] ldr or NULL, row index = m % res_row_mod when res_row_mod > 0
+ *   K must be a multiple of 64 (bf16) ; N_out a multiple of 4.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;
+  const void* w;
+  const void* bias;
+  const void* residual;
+  void* y;
+  int32_t M, N, K;
+  int32_t ldx, ldw, ldy, ldr;
+  int32_t res_row_mod;
+  int32_t act;   /* aki_act */
+  int32_t dtype; /* aki_dtype */
+} aki_linear_args;
+
+int aki_linear_fwd(const aki_linear_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation.  rmsnorm: HF:phi3/modeling_phi3.py:266-284 (fp32 statistics, result cast to the
+ * input dtype BEFORE the gain multiply).  layernorm: torch.nn.LayerNorm (src/helpers.py:35,69-70,168).
+ * ---------------------------------------------------------------------------------------------- */
+int aki_rmsnorm_fwd(const void* x, const void* weight, void* y, int32_t rows, int32_t cols, int32_t ldx, int32_t ldy,
+                    float eps, int32_t dtype, void* stream);
+int aki_layernorm_fwd(const void* x, const void* weight, const void* bias, void* y, int32_t rows, int32_t cols,
+                      int32_t ldx, int32_t ldy, float eps, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * aki_patch_embed_fwd - SigLIP patch embedding: Conv2d(3->E, k=P, s=P, valid) + flatten + pos-emb.
+ * Replaces: `SiglipVisionEmbeddings.forward`, HF:siglip/modeling_siglip.py:175-185 (call site src/vlm.py:202-203).
+ *   pixels [N,3,S,S] ; w [E, Kp] = conv weight flattened to [E,3*P*P] and zero-padded to Kp = roundup(3*P*P,64)
+ *   bias [E] ; pos [G*G,E] (G = S/P) ; out [N,G*G,E] ; workspace = aki_patch_embed_workspace_bytes().
+ * ---------------------------------------------------------------------------------------------- */
+size_t aki_patch_embed_workspace_bytes(int32_t N, int32_t S, int32_t P, int32_t dtype);
+int aki_patch_embed_fwd(const void* pixels, const void* w, const void* bias, const void* pos, void* out, int32_t N,
+                        int32_t S, int32_t P, int32_t E, int32_t Kp, int32_t dtype, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Connector MLP (the Perceiver FeedForward block and the final projection).
+ * aki_connector_mlp_fwd : out = x + W2 gelu(W1 LN(x))          - src/helpers.py:32-39,194
+ * aki_connector_proj_fwd: out = Wp LN(x) + bp                   - src/helpers.py:196-197
+ *   x [rows,d] ; w1 [4d,d] ; w2 [d,4d] ; workspace rows*(d+4d) elements.
+ * ---------------------------------------------------------------------------------------------- */
+size_t aki_connector_mlp_workspace_bytes(int32_t rows, int32_t d, int32_t d_inner, int32_t dtype);
+int aki_connector_mlp_fwd(const void* x, const void* ln_w, const void* ln_b, const void* w1, const void* w2, void* out,
+                          int32_t rows, int32_t d, int32_t d_inner, float eps, int32_t dtype, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int aki_connector_proj_fwd(const void* x, const void* ln_w, const void* ln_b, const void* w, const void* b, void* out,
+                           int32_t rows, int32_t d, int32_t d_out, float eps, int32_t dtype, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Language-stream fusion (integer / byte work).
+ * aki_splice_plan : per sample, count <image> placeholders, find the first id == assistant_token_id
+ *                   and the expanded length L_i = T - n_img + Nv*n_img   (src/vlm.py:488-496)
+ *                   plan [B][AKI_PLAN_STRIDE] int32 = {n_img, q_idx, L_i, 0, t_0 .. t_7} with t_k the
+ *                   index of the k-th placeholder (more than AKI_MAX_RECTS images per sample: unsupported)
+ * aki_splice_fwd  : DecoupledEmbedding gather (src/helpers.py:445-484) + vision-token splice
+ *                   (src/vlm.py:539-577) + padding with the scalar pad_token_id / -100
+ *                   (src/vlm.py:584-598, src/utils.py:62-96) + the mask table (rects, valid bits).
+ *   lang_x/attention_mask/labels int64 [B,T] ; embed_weight [V,d] ; embed_additional [n_add,d] or NULL
+ *   vision_tokens [B,T_img,Nv,d] ; outputs sized for L_out = max_i L_i (right or left padding).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const int64_t* lang_x;
+  const int64_t* attention_mask; /* NULL = all ones */
+  const int64_t* labels;         /* NULL = no labels */
+  const void* embed_weight;
+  const void* embed_additional;
+  const void* vision_tokens;
+  const int32_t* plan; /* from aki_splice_plan */
+  void* inputs_embeds; /* [B,L_out,d] */
+  int64_t* labels_out; /* [B,L_out] or NULL */
+  int64_t* mask_1d_out;/* [B,L_out] spliced 1-D mask, zero padded (always right-aligned like the reference's 2-D masks) */
+  aki_mma_rect* rects; /* [B][max_rects] */
+  uint64_t* col_valid_bits; /* [B][ceil(L_out/64)] */
+  int32_t* seq_lens;        /* [B] = L_i */
+  int64_t max_original_id;
+  int64_t media_token_id;
+  int64_t pad_token_id;
+  int32_t B, T, T_img, Nv, d, L_out;
+  int32_t max_rects;
+  int32_t padding_side; /* 0 = right, 1 = left (embeds/labels only, src/utils.py:88-92) */
+  int32_t dtype;
+} aki_splice_args;
+
+int aki_splice_plan(const int64_t* lang_x, int32_t B, int32_t T, int64_t media_token_id, int64_t assistant_token_id,
+                    int32_t Nv, int32_t* plan, void* stream);
+int aki_splice_fwd(const aki_splice_args* args, void* stream);
+
+/* aki_mma_mask_dense - materialise the reference's (B,1,L,L) int64 0/1 mask from the table, for
+ * callers that still want it (bit-exact vs src/vlm.py:410-443 + src/utils.py:99-108). */
+int aki_mma_mask_dense(const aki_mma_rect* rects, int32_t max_rects, const uint64_t* col_valid_bits,
+                       const int32_t* seq_lens, int32_t B, int32_t L, int64_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AKI_MI355X_H */
