@@ -94,6 +94,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: torch ships its own libamdhip64.so.7 and the same SONAME is what this
+    # library needs.  Import torch FIRST so both resolve to torch's copy; loading ours first would map
+    # /opt/rocm's runtime and leave torch's bundled ROCm stack half-mismatched (launches then fail).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise AkiError(f"{LIB_PATH} not found: build it with `python -m aki_amd.build` (hipcc, gfx950). "
                        "There is no CPU fallback for the AKI MMA path.")

@@ -41,14 +41,28 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
-// max over the two 32-lane halves (lanes l and l^32), result in every lane.
+// Exchange across the two 32-lane halves with v_permlane32_swap: after swap(a = x, b = x),
+// a = [x_lo, x_lo] and b = [x_hi, x_hi] (row = 32 lanes).  Inline asm on purpose: with the builtin
+// (__builtin_amdgcn_permlane32_swap) hipcc / ROCm 7.2 -O3 folds the SECOND result into the first
+// (extractvalue 1 -> extractvalue 0 in the optimised IR), which silently turns the cross-half
+// reduction into a lane-local one.  "s_nop 1" = the 2 wait states a VALU write of either operand needs
+// before v_permlane*_swap reads it (cdna_hip_programming.md T21 / section 5.7 item 2).
+__device__ __forceinline__ void halves_pair(float x, float& lo, float& hi) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  lo = a;
+  hi = b;
+}
+// max / sum over lanes l and l^32, result in every lane.
 __device__ __forceinline__ float halves_max(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  float lo, hi;
+  halves_pair(x, lo, hi);
+  return fmaxf(lo, hi);
 }
 __device__ __forceinline__ float halves_sum(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  float lo, hi;
+  halves_pair(x, lo, hi);
+  return lo + hi;
 }
 
 // Bijective XCD-aware block remap (cdna_hip_programming.md T1): blocks that share an XCD (bid % 8)
@@ -70,6 +84,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   do {                       \
     if (((uintptr_t)(p)) & 15) return AKI_ERR_ALIGNMENT; \
   } while (0)
+// hipGetLastError() is sticky per thread: clear whatever an earlier (unrelated) HIP call left behind
+// before launching, then read the launch's own status.
+#define AKI_CLEAR_ERR() ((void)hipGetLastError())
 #define AKI_LAUNCH_CHECK() \
   do {                     \
     if (hipGetLastError() != hipSuccess) return AKI_ERR_LAUNCH; \

@@ -40,11 +40,13 @@ int aki_abi_version(void) { return AKI_ABI_VERSION; }
 
 // ---- attention core --------------------------------------------------------------------------------
 size_t aki_mma_attn_core_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype) {
+  AKI_CLEAR_ERR();
   (void)L; (void)dtype;
   return aki_align_up((size_t)B * H * Dh * sizeof(float), 256);
 }
 
 int aki_mma_attn_core_fwd(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, void* stream) {
+  AKI_CLEAR_ERR();
   AKI_CHECK_ARG(a && a->q && a->k && a->v && a->o);
   AKI_CHECK_ARG(a->B > 0 && a->H > 0 && a->L > 0 && a->Dh > 0 && a->scale > 0.f);
   AKI_CHECK_ARG(dtype_ok(a->dtype));
@@ -74,6 +76,7 @@ static int check_fused(const aki_mma_attn_args* a) {
 }
 
 int aki_qkv_rope_fwd(const aki_mma_attn_args* a, void* q, void* k, void* v, void* stream) {
+  AKI_CLEAR_ERR();
   int rc = check_fused(a);
   if (rc) return rc;
   AKI_CHECK_ARG(q && k && v);
@@ -82,6 +85,7 @@ int aki_qkv_rope_fwd(const aki_mma_attn_args* a, void* q, void* k, void* v, void
 }
 
 int aki_mma_attn_fwd(const aki_mma_attn_args* a, void* ws, size_t ws_bytes, void* stream) {
+  AKI_CLEAR_ERR();
   int rc = check_fused(a);
   if (rc) return rc;
   AKI_CHECK_ARG(a->o && a->scale > 0.f);
@@ -108,6 +112,7 @@ int aki_mma_attn_fwd(const aki_mma_attn_args* a, void* ws, size_t ws_bytes, void
 
 // ---- linear ------------------------------------------------------------------------------------------
 int aki_linear_fwd(const aki_linear_args* a, void* stream) {
+  AKI_CLEAR_ERR();
   AKI_CHECK_ARG(a && a->x && a->w && a->y);
   AKI_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0);
   AKI_CHECK_ARG(dtype_ok(a->dtype));
@@ -121,12 +126,14 @@ int aki_linear_fwd(const aki_linear_args* a, void* stream) {
 // ---- norms -------------------------------------------------------------------------------------------
 int aki_rmsnorm_fwd(const void* x, const void* w, void* y, int32_t rows, int32_t cols, int32_t ldx, int32_t ldy, float eps,
                     int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
   AKI_CHECK_ARG(x && w && y && dtype_ok(dtype) && ldx >= cols && ldy >= cols);
   return norm_launch(true, x, w, nullptr, y, rows, cols, ldx, ldy, eps, dtype, (hipStream_t)stream);
 }
 
 int aki_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int32_t rows, int32_t cols, int32_t ldx,
                       int32_t ldy, float eps, int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
   AKI_CHECK_ARG(x && w && y && dtype_ok(dtype) && ldx >= cols && ldy >= cols);
   return norm_launch(false, x, w, b, y, rows, cols, ldx, ldy, eps, dtype, (hipStream_t)stream);
 }
@@ -140,6 +147,7 @@ size_t aki_patch_embed_workspace_bytes(int32_t N, int32_t S, int32_t P, int32_t 
 
 int aki_patch_embed_fwd(const void* pixels, const void* w, const void* bias, const void* pos, void* out, int32_t N, int32_t S,
                         int32_t P, int32_t E, int32_t Kp, int32_t dtype, void* ws, size_t ws_bytes, void* stream) {
+  AKI_CLEAR_ERR();
   AKI_CHECK_ARG(pixels && w && out && N > 0 && S > 0 && P > 0 && E > 0 && dtype_ok(dtype));
   AKI_CHECK_ARG(S >= P && Kp == (int)aki_align_up((size_t)3 * P * P, 64));
   if (!ws || ws_bytes < aki_patch_embed_workspace_bytes(N, S, P, dtype)) return AKI_ERR_WORKSPACE;
@@ -161,6 +169,7 @@ size_t aki_connector_mlp_workspace_bytes(int32_t rows, int32_t d, int32_t d_inne
 int aki_connector_mlp_fwd(const void* x, const void* ln_w, const void* ln_b, const void* w1, const void* w2, void* out,
                           int32_t rows, int32_t d, int32_t d_inner, float eps, int32_t dtype, void* ws, size_t ws_bytes,
                           void* stream) {
+  AKI_CLEAR_ERR();
   AKI_CHECK_ARG(x && ln_w && w1 && w2 && out && rows > 0 && d > 0 && d_inner > 0 && dtype_ok(dtype));
   if (!ws || ws_bytes < aki_connector_mlp_workspace_bytes(rows, d, d_inner, dtype)) return AKI_ERR_WORKSPACE;
   char* normed = (char*)ws;
@@ -181,6 +190,7 @@ int aki_connector_mlp_fwd(const void* x, const void* ln_w, const void* ln_b, con
 int aki_connector_proj_fwd(const void* x, const void* ln_w, const void* ln_b, const void* w, const void* b, void* out,
                            int32_t rows, int32_t d, int32_t d_out, float eps, int32_t dtype, void* ws, size_t ws_bytes,
                            void* stream) {
+  AKI_CLEAR_ERR();
   AKI_CHECK_ARG(x && ln_w && w && out && rows > 0 && d > 0 && d_out > 0 && dtype_ok(dtype));
   if (!ws || ws_bytes < aki_align_up((size_t)rows * d * aki_elt_size(dtype), 256)) return AKI_ERR_WORKSPACE;
   int rc = aki_layernorm_fwd(x, ln_w, ln_b, ws, rows, d, d, d, eps, dtype, stream);
@@ -194,11 +204,13 @@ int aki_connector_proj_fwd(const void* x, const void* ln_w, const void* ln_b, co
 // ---- splice / mask -------------------------------------------------------------------------------------
 int aki_splice_plan(const int64_t* lang_x, int32_t B, int32_t T, int64_t media_token_id, int64_t assistant_token_id,
                     int32_t Nv, int32_t* plan, void* stream) {
+  AKI_CLEAR_ERR();
   AKI_CHECK_ARG(lang_x && plan && B > 0 && T > 0 && Nv > 0);
   return splice_plan_launch(lang_x, B, T, media_token_id, assistant_token_id, Nv, plan, (hipStream_t)stream);
 }
 
 int aki_splice_fwd(const aki_splice_args* a, void* stream) {
+  AKI_CLEAR_ERR();
   AKI_CHECK_ARG(a && a->lang_x && a->embed_weight && a->plan && a->inputs_embeds);
   AKI_CHECK_ARG(a->B > 0 && a->T > 0 && a->Nv > 0 && a->d > 0 && a->L_out > 0 && dtype_ok(a->dtype));
   AKI_CHECK_ARG(a->T_img == 0 || a->vision_tokens);
@@ -212,6 +224,7 @@ int aki_splice_fwd(const aki_splice_args* a, void* stream) {
 
 int aki_mma_mask_dense(const aki_mma_rect* rects, int32_t max_rects, const uint64_t* col_valid_bits, const int32_t* seq_lens,
                        int32_t B, int32_t L, int64_t* out, void* stream) {
+  AKI_CLEAR_ERR();
   AKI_CHECK_ARG(out && B > 0 && L > 0 && max_rects >= 0 && max_rects <= AKI_MAX_RECTS && (max_rects == 0 || rects));
   return mask_dense_launch(rects, max_rects, col_valid_bits, seq_lens, B, L, out, (hipStream_t)stream);
 }

@@ -315,6 +315,7 @@ __global__ void im2col_kernel(const T* pix, T* out, int N, int S, int P, int G, 
 }
 
 int splice_plan_launch(const int64_t* lang_x, int B, int T, int64_t media, int64_t assistant, int Nv, int* plan, hipStream_t s) {
+  AKI_CLEAR_ERR();
   hipLaunchKernelGGL(splice_plan_kernel, dim3(B), dim3(64), 0, s, lang_x, T, media, assistant, Nv, plan);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
@@ -326,6 +327,7 @@ int splice_launch(const aki_splice_args* a, hipStream_t s) {
   else hipLaunchKernelGGL(splice_kernel<float>, grid, dim3(256), 0, s, *a);
   AKI_LAUNCH_CHECK();
   if (a->rects && a->col_valid_bits && a->seq_lens) {
+    AKI_CLEAR_ERR();
     hipLaunchKernelGGL(splice_table_kernel, dim3(a->B), dim3(64), 0, s, *a);
     AKI_LAUNCH_CHECK();
   }
@@ -334,6 +336,7 @@ int splice_launch(const aki_splice_args* a, hipStream_t s) {
 
 int mask_dense_launch(const aki_mma_rect* rects, int max_rects, const uint64_t* vbits, const int* seq_lens, int B, int L,
                       int64_t* out, hipStream_t s) {
+  AKI_CLEAR_ERR();
   hipLaunchKernelGGL(mask_dense_kernel, dim3(L, B), dim3(256), 0, s, rects, rects ? max_rects : 0, vbits, seq_lens, L, out);
   AKI_LAUNCH_CHECK();
   return AKI_OK;

@@ -250,6 +250,7 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   const int bn_out = (EPI == EPI_SWIGLU) ? BN / 2 : BN;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (n_out + bn_out - 1) / bn_out;
+  AKI_CLEAR_ERR();
   hipLaunchKernelGGL((gemm_bf16_kernel<TN, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(512), SMEM, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;

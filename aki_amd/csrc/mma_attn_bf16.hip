@@ -293,9 +293,11 @@ int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, h
   p.scale_log2 = a->scale * 1.44269504088896340736f;
   p.dead_uniform = a->dead_rows == AKI_DEAD_ROWS_UNIFORM;
   if (p.dead_uniform) {
+    AKI_CLEAR_ERR();
     hipLaunchKernelGGL(vmean_bf16_kernel, dim3(a->B * a->H), dim3(384), 0, stream, p.v, (float*)ws, a->L);
     AKI_LAUNCH_CHECK();
   }
+  AKI_CLEAR_ERR();
   hipLaunchKernelGGL((mma_attn_bf16_kernel<NW>), dim3(a->B * a->H * p.nqt), dim3(NW * 64), 0, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;

@@ -81,8 +81,10 @@ int linear_f32(const aki_linear_args* a, hipStream_t stream) {
   dim3 grid((n_out + 63) / 64, (a->M + 63) / 64);
   if (a->act == AKI_ACT_SWIGLU) {
     if (a->bias || (a->N & 1)) return AKI_ERR_UNSUPPORTED;
+    AKI_CLEAR_ERR();
     hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, stream, p);
   } else {
+    AKI_CLEAR_ERR();
     hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, stream, p);
   }
   AKI_LAUNCH_CHECK();
@@ -219,6 +221,7 @@ int attn_core_f32(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hi
                      a->rects ? a->max_rects : 0, a->B, a->H, a->L, a->Dh, (a->L + 63) / 64,
                      a->scale, a->dead_rows == AKI_DEAD_ROWS_UNIFORM, causal};
   if (p.dead_uniform) {
+    AKI_CLEAR_ERR();
     hipLaunchKernelGGL(vmean_f32_kernel, dim3(a->B * a->H), dim3(128), 0, stream, p.v, (float*)ws, a->L, a->Dh);
     AKI_LAUNCH_CHECK();
   }
@@ -243,6 +246,7 @@ int qkv_rope_f32(const aki_mma_attn_args* a, void* q, void* k, void* v, float* t
   int rc = linear_f32(&g, stream);
   if (rc) return rc;
   const size_t total = (size_t)g.M * g.N;
+  AKI_CLEAR_ERR();
   hipLaunchKernelGGL(rope_split_f32_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, tmp, a->cos, a->sin,
                      a->position_ids, (float*)q, (float*)k, (float*)v, g.M, a->H, a->L, a->Dh);
   AKI_LAUNCH_CHECK();
