@@ -1,0 +1,246 @@
+"""Connector + embedding helpers: the host-side mirror of src/helpers.py (same class names, constructor
+arguments, parameter names and therefore state-dict keys), with the arithmetic done by the HIP kernels.
+
+Reference: /root/reference/codes/open_flamingo/src/helpers.py
+  FeedForward :32-39 | PerceiverAttention :62-102 | PerceiverResampler :105-199
+  DecoupledEmbedding :350-492 | DecoupledLinear :495-613 | VLMOutputWithPast :16-25
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+try:  # the HF output container the reference returns (src/helpers.py:11,16)
+    from transformers.modeling_outputs import CausalLMOutputWithPast
+except Exception:  # pragma: no cover - transformers is present in this image
+    @dataclass
+    class CausalLMOutputWithPast:  # type: ignore
+        loss: Optional[torch.Tensor] = None
+        logits: Optional[torch.Tensor] = None
+        past_key_values: Optional[object] = None
+        hidden_states: Optional[object] = None
+        attentions: Optional[object] = None
+
+        def __getitem__(self, i):
+            return [v for v in (self.loss, self.logits, self.past_key_values) if v is not None][i]
+
+
+@dataclass
+class VLMOutputWithPast(CausalLMOutputWithPast):
+    past_media_locations: Optional[torch.Tensor] = None
+    past_vision_tokens: Optional[torch.Tensor] = None
+
+
+def exists(val):
+    return val is not None
+
+
+def FeedForward(dim, mult=4):
+    """Same container layout as the reference (indices 0,1,3 carry parameters); the forward pass of the
+    block is executed by ``ops.connector_mlp`` in :class:`PerceiverResampler`."""
+    inner_dim = int(dim * mult)
+    return nn.Sequential(
+        nn.LayerNorm(dim),
+        nn.Linear(dim, inner_dim, bias=False),
+        nn.GELU(),
+        nn.Linear(inner_dim, dim, bias=False),
+    )
+
+
+class VisionTokenizer(nn.Module):
+    def __init__(self, dim_media, num_tokens_per_media):
+        super().__init__()
+        self.dim_media = dim_media
+        self.num_tokens_per_media = num_tokens_per_media
+
+
+class PerceiverAttention(nn.Module):
+    def __init__(self, *, dim, dim_head=64, heads=8):
+        super().__init__()
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.dim_head = dim_head
+        inner_dim = dim_head * heads
+        self.norm_media = nn.LayerNorm(dim)
+        self.norm_latents = nn.LayerNorm(dim)
+        self.to_q = nn.Linear(dim, inner_dim, bias=False)
+        self.to_kv = nn.Linear(dim, inner_dim * 2, bias=False)
+        self.to_out = nn.Linear(inner_dim, dim, bias=False)
+
+    def forward(self, x, latents):
+        """x (b,T,n1,D), latents (b,T,n2,D) -> to_out(attn) + latents  (the residual of src/helpers.py:193 is
+        fused into the output projection's epilogue)."""
+        b, T, n1, D = x.shape
+        n2 = latents.shape[2]
+        h, dh = self.heads, self.dim_head
+        xn = ops.layernorm(x, self.norm_media.weight, self.norm_media.bias, self.norm_media.eps)
+        ln = ops.layernorm(latents, self.norm_latents.weight, self.norm_latents.bias, self.norm_latents.eps)
+        q = ops.linear(ln, self.to_q.weight)
+        kv = ops.linear(torch.cat((xn, ln), dim=-2), self.to_kv.weight)
+        k, v = kv.chunk(2, dim=-1)
+        q = q.view(b * T, n2, h, dh).transpose(1, 2)
+        k = k.reshape(b * T, n1 + n2, h, dh).transpose(1, 2)
+        v = v.reshape(b * T, n1 + n2, h, dh).transpose(1, 2)
+        # 8 x 64 heads, 873 keys, no mask: stock attention (SURVEY 8(f) #2 lists a fused kernel as "next")
+        out = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
+        out = out.transpose(1, 2).reshape(b, T, n2, h * dh)
+        return ops.linear(out, self.to_out.weight, residual=latents)
+
+
+class PerceiverResampler(VisionTokenizer):
+    def __init__(self, *, dim, dim_inner=None, depth=6, dim_head=64, heads=8, num_latents=64, max_num_media=None,
+                 max_num_frames=None, ff_mult=4):
+        if dim_inner is not None:
+            projection = nn.Linear(dim, dim_inner)
+        else:
+            projection = None
+            dim_inner = dim
+        super().__init__(dim_media=dim, num_tokens_per_media=num_latents)
+        self.projection = projection
+        self.latents = nn.Parameter(torch.randn(num_latents, dim))
+        self.frame_embs = nn.Parameter(torch.randn(max_num_frames, dim)) if exists(max_num_frames) else None
+        self.media_time_embs = nn.Parameter(torch.randn(max_num_media, 1, dim)) if exists(max_num_media) else None
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([PerceiverAttention(dim=dim, dim_head=dim_head, heads=heads),
+                                              FeedForward(dim=dim, mult=ff_mult)]))
+        self.norm = nn.LayerNorm(dim)
+
+    def forward(self, x):
+        """x (b,T,F,v,D) -> (b,T,n,dim_inner)   (src/helpers.py:170-199)."""
+        b, T, Fr, v = x.shape[:4]
+        if exists(self.frame_embs):
+            x = x + self.frame_embs[:Fr][None, None, :, None, :]
+        x = x.reshape(b, T, Fr * v, x.shape[-1])
+        if exists(self.media_time_embs):
+            x = x + self.media_time_embs[:T]
+        latents = self.latents.to(x.dtype)[None, None].expand(b, T, -1, -1).contiguous()
+        for attn, ff in self.layers:
+            latents = attn(x, latents)                                     # attention + residual
+            latents = ops.connector_mlp(latents, ff[0].weight, ff[0].bias, ff[1].weight, ff[3].weight, ff[0].eps)
+        if exists(self.projection):
+            return ops.connector_proj(latents, self.norm.weight, self.norm.bias, self.projection.weight,
+                                      self.projection.bias, self.norm.eps)
+        return ops.layernorm(latents, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class DecoupledEmbedding(nn.Embedding):
+    """src/helpers.py:350-492.  The lookup itself happens inside the splice kernel (aki_splice_fwd); this
+    module keeps the parameters (``weight``, ``additional_embedding.weight``) and a standalone forward."""
+
+    def __init__(self, max_original_id: int, num_additional_embeddings: int = 0, _weight: torch.Tensor = None,
+                 num_original_embeddings: int = None, embedding_dim: int = None, partially_freeze=True, device=None,
+                 dtype=None, pad_token_id=None) -> None:
+        if pad_token_id is not None and pad_token_id > max_original_id:
+            raise ValueError(f"pad_token_id must be <= max_original_id. Got {pad_token_id} and {max_original_id}."
+                             + "If the original tokenizer does not have a pad_token_id, use pad_token_id=None.")
+        if _weight is not None:
+            assert (num_original_embeddings is None) or (_weight.shape[0] == num_original_embeddings)
+            assert (embedding_dim is None) or (_weight.shape[1] == embedding_dim)
+            num_original_embeddings, embedding_dim = _weight.shape
+        else:
+            assert num_original_embeddings is not None, "num_original_embeddings must be provided if _weight is not provided"
+            assert embedding_dim is not None, "embedding_dim must be provided if _weight is not provided"
+        super().__init__(num_embeddings=num_original_embeddings, embedding_dim=embedding_dim, device=device, dtype=dtype,
+                         padding_idx=pad_token_id, _weight=_weight)
+        self.max_original_id = max_original_id
+        self.padding_idx = pad_token_id
+        self.num_additional_embeddings = num_additional_embeddings
+        if self.num_additional_embeddings > 0:
+            self.additional_embedding = nn.Embedding(num_embeddings=self.num_additional_embeddings,
+                                                     embedding_dim=embedding_dim, device=device, dtype=dtype)
+        self.set_requires_grad(require_regular_grad=not partially_freeze, require_additional_grad=True)
+
+    def set_requires_grad(self, require_regular_grad, require_additional_grad):
+        self.weight.requires_grad_(require_regular_grad)
+        self.additional_embedding.requires_grad_(require_additional_grad)
+
+    def forward(self, input_ids):
+        if self.num_additional_embeddings == 0:
+            return F.embedding(input_ids, self.weight)
+        hi = input_ids > self.max_original_id
+        low = torch.where(hi, torch.zeros_like(input_ids), input_ids)
+        full = F.embedding(low, self.weight)
+        add = self.additional_embedding(torch.where(hi, input_ids - self.max_original_id - 1, torch.zeros_like(input_ids)))
+        return torch.where(hi[..., None], add, full)
+
+    def extra_repr(self) -> str:
+        return "num_original_embeddings={}, num_additional_embeddings={}, embedding_dim={}, partially_freeze={}".format(
+            self.max_original_id + 1, self.num_additional_embeddings, self.embedding_dim, (not self.weight.requires_grad))
+
+
+class DecoupledLinear(nn.Linear):
+    """src/helpers.py:495-613: logits = (x W^T)[..., :max_original_id+1] ++ x W_add^T.  Executed as ONE HIP
+    GEMM over the row-concatenated weight (rebuilt only when a parameter changes)."""
+
+    def __init__(self, max_original_id: int, additional_out_features: int = 0, _weight: torch.Tensor = None,
+                 _bias: torch.Tensor = None, in_features: int = None, original_out_features: int = None, bias: bool = True,
+                 partially_freeze: bool = True, device=None, dtype=None) -> None:
+        if _weight is not None:
+            assert (_weight.shape[0] == original_out_features) or (original_out_features is None)
+            assert (_weight.shape[1] == in_features) or (in_features is None)
+            in_features = _weight.shape[1]
+            original_out_features = _weight.shape[0]
+        else:
+            assert in_features is not None, "in_features must be provided if _weight is not provided"
+            assert original_out_features is not None, "original_out_features must be provided if _weight is not provided"
+        if _bias is not None:
+            assert bias is True, "bias must be True if _bias is provided"
+        super().__init__(in_features, original_out_features, bias, device, dtype)
+        if _weight is not None:
+            self.weight = nn.Parameter(_weight)
+        if _bias is not None:
+            self.bias = nn.Parameter(_bias)
+        self.in_features = in_features
+        self.original_out_features = original_out_features
+        self.max_original_id = max_original_id
+        self.additional_out_features = additional_out_features
+        self.has_bias = bias
+        if additional_out_features > 0:
+            self.additional_fc = nn.Linear(in_features=in_features, out_features=additional_out_features, bias=self.has_bias,
+                                           device=device, dtype=dtype)
+        self.set_requires_grad(require_regular_grad=not partially_freeze, require_additional_grad=True)
+        self._fused = None
+
+    def set_requires_grad(self, require_regular_grad, require_additional_grad):
+        self.weight.requires_grad_(require_regular_grad)
+        if self.has_bias:
+            self.bias.requires_grad_(require_regular_grad)
+        self.additional_fc.requires_grad_(require_additional_grad)
+
+    def _fused_weight(self):
+        n0 = self.max_original_id + 1
+        extra = self.additional_out_features
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.dtype, self.weight.device,
+               self.additional_fc.weight._version if extra else 0, self.additional_fc.weight.data_ptr() if extra else 0)
+        if self._fused is None or self._fused[0] != key:
+            n = n0 + extra
+            npad = (n + 3) // 4 * 4
+            w = torch.zeros((npad, self.in_features), dtype=self.weight.dtype, device=self.weight.device)
+            w[:n0] = self.weight.detach()[:n0]
+            b = None
+            if self.has_bias and self.bias is not None:
+                b = torch.zeros((npad,), dtype=self.weight.dtype, device=self.weight.device)
+                b[:n0] = self.bias.detach()[:n0]
+            if extra:
+                w[n0:n] = self.additional_fc.weight.detach()
+                if b is not None and self.additional_fc.bias is not None:
+                    b[n0:n] = self.additional_fc.bias.detach()
+            self._fused = (key, w, b, n)
+        return self._fused[1], self._fused[2], self._fused[3]
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        w, b, n = self._fused_weight()
+        out = ops.linear(input, w, bias=b)
+        return out[..., :n]
+
+    def extra_repr(self) -> str:
+        return "in_features={}, out_features={}, additional_out_features={}, bias={}, partially_freeze={}".format(
+            self.in_features, self.max_original_id + 1, self.additional_out_features, self.bias is not None,
+            (not self.weight.requires_grad or not self.bias.requires_grad))

@@ -60,6 +60,37 @@ def _ws(nbytes: int, dev) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
 
 
+class EventTap:
+    """Optional per-kernel timing with HIP events on the stream the kernels are launched on (torch's current
+    stream).  bench.py installs one for the timed region; when no tap is installed the cost is one `is None` test."""
+
+    def __init__(self, tags=None):
+        self.tags = tags          # None = every tagged launch
+        self.events = {}
+
+    def want(self, tag) -> bool:
+        return self.tags is None or tag[0] in self.tags
+
+    def begin(self, tag):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        self.events.setdefault(tag, []).append((a, b))
+        a.record()
+        return b
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {tag: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / len(ev)) for tag, ev in self.events.items()}
+
+
+_TAP: Optional[EventTap] = None
+
+
+def set_event_tap(tap: Optional[EventTap]) -> None:
+    global _TAP
+    _TAP = tap
+
+
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class MaskTable:
@@ -121,7 +152,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         r2 = _rows2d(residual)
     a = L.LinearArgs(_ptr(x2), _ptr(w), _ptr(bias), _ptr(r2), _ptr(o2), M, N, K, x2.stride(0), w.stride(0), o2.stride(0),
                      0 if r2 is None else r2.stride(0), res_row_mod, act, _dt(x))
+    end = _TAP.begin(("linear", M, N, K, act)) if (_TAP is not None and _TAP.want(("linear",))) else None
     L.check(lib.aki_linear_fwd(C.byref(a), _stream()), "aki_linear_fwd")
+    if end is not None:
+        end.record()
     return out
 
 
@@ -155,7 +189,10 @@ def mma_attn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: Mask
     ws = _ws(lib.aki_mma_attn_core_workspace_bytes(B, H, Lq, Dh, _dt(q)), dev)
     a = L.MmaAttnCoreArgs(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(table.rects), _ptr(table.col_valid_bits),
                           _ptr(table.seq_lens), table.max_rects, B, H, Lq, Dh, float(scale), _dt(q), dead_rows)
+    end = _TAP.begin(("mma_attn_core", B, H, Lq, Dh)) if (_TAP is not None and _TAP.want(("mma_attn_core",))) else None
     L.check(lib.aki_mma_attn_core_fwd(C.byref(a), _ptr(ws), ws.numel(), _stream()), "aki_mma_attn_core_fwd")
+    if end is not None:
+        end.record()
     return (o, lse) if return_lse else o
 
 
@@ -184,7 +221,10 @@ def mma_attn(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch
     ws = _ws(lib.aki_mma_attn_workspace_bytes(B, num_heads, Lq, Dh, _dt(x)), dev)
     a = _fused_args(x2, w_qkv, cos, sin, position_ids, o, None, table, B, num_heads, Lq, Dh,
                     scale if scale is not None else Dh ** -0.5, dead_rows)
+    end = _TAP.begin(("mma_attn", B, num_heads, Lq, Dh)) if (_TAP is not None and _TAP.want(("mma_attn",))) else None
     L.check(lib.aki_mma_attn_fwd(C.byref(a), _ptr(ws), ws.numel(), _stream()), "aki_mma_attn_fwd")
+    if end is not None:
+        end.record()
     return o
 
 

@@ -1,0 +1,208 @@
+"""MI355X-native Phi-3 decoder (the language model of AKI-4B).
+
+Same module tree / parameter names as ``Phi3ForCausalLM`` (HF:phi3/modeling_phi3.py), so reference
+checkpoints (``lang_model.model.layers.N.self_attn.qkv_proj.weight`` ...) load unchanged, but a decoder
+layer is six HIP launches:
+    rmsnorm -> [QKV projection + RoPE epilogue] -> span-driven MMA attention -> o_proj (+residual)
+            -> rmsnorm -> gate_up (+SwiGLU epilogue) -> down (+residual)
+The modality-mutual mask arrives as an ``ops.MaskTable`` (rectangles + valid bits), never as (B,1,L,L).
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .helpers import CausalLMOutputWithPast
+
+
+def make_phi3_config(**kw):
+    """A Phi3Config (HF) when transformers is importable, else a plain namespace with the same fields."""
+    defaults = dict(vocab_size=32064, hidden_size=3072, intermediate_size=8192, num_hidden_layers=32,
+                    num_attention_heads=32, num_key_value_heads=32, rms_norm_eps=1e-5, rope_theta=10000.0,
+                    max_position_embeddings=4096, original_max_position_embeddings=4096, initializer_range=0.02,
+                    pad_token_id=32000, rope_scaling=None)
+    defaults.update(kw)
+    return SimpleNamespace(**defaults)
+
+
+def _cfg_get(cfg, name, default=None):
+    v = getattr(cfg, name, None)
+    if v is None and hasattr(cfg, "rope_parameters") and isinstance(getattr(cfg, "rope_parameters"), dict):
+        v = cfg.rope_parameters.get(name)
+    return default if v is None else v
+
+
+class Phi3RotaryTables(nn.Module):
+    """cos/sin tables (f32) computed on the host side of the ABI, HF:phi3/modeling_phi3.py:67-124.
+    Supports default RoPE and LongRoPE (short/long factors + attention scaling, as Phi-3.5 ships)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.head_dim = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
+        self.theta = float(_cfg_get(config, "rope_theta", 10000.0))
+        rs = getattr(config, "rope_scaling", None) or (getattr(config, "rope_parameters", None)
+                                                       if isinstance(getattr(config, "rope_parameters", None), dict) else None)
+        self.short = self.long = None
+        self.orig_max = int(_cfg_get(config, "original_max_position_embeddings", config.max_position_embeddings))
+        self.max_pos = int(config.max_position_embeddings)
+        if rs and rs.get("rope_type", rs.get("type")) == "longrope":
+            self.short = torch.tensor(rs["short_factor"], dtype=torch.float32)
+            self.long = torch.tensor(rs["long_factor"], dtype=torch.float32)
+        f = self.max_pos / self.orig_max
+        self.attention_scaling = 1.0 if (self.short is None or f <= 1.0) else math.sqrt(1 + math.log(f) / math.log(self.orig_max))
+        self._cache = {}
+
+    @torch.no_grad()
+    def tables(self, n_pos: int, device):
+        """(cos, sin) f32 [n_pos, head_dim] for positions 0..n_pos-1."""
+        key = (n_pos, str(device))
+        if key not in self._cache:
+            d = self.head_dim
+            base = self.theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d)
+            if self.short is not None:
+                base = (self.long if n_pos > self.orig_max else self.short) * base
+            inv = (1.0 / base).to(device)
+            freqs = torch.arange(n_pos, dtype=torch.float32, device=device)[:, None] * inv[None, :]
+            emb = torch.cat((freqs, freqs), dim=-1)
+            self._cache = {key: ((emb.cos() * self.attention_scaling).contiguous(), (emb.sin() * self.attention_scaling).contiguous())}
+        return self._cache[key]
+
+
+class Phi3RMSNorm(nn.Module):
+    def __init__(self, hidden_size, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        return ops.rmsnorm(x, self.weight, self.variance_epsilon)
+
+
+class Phi3Attention(nn.Module):
+    def __init__(self, config, layer_idx=None):
+        super().__init__()
+        self.layer_idx = layer_idx
+        self.num_heads = config.num_attention_heads
+        self.head_dim = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
+        if getattr(config, "num_key_value_heads", self.num_heads) != self.num_heads:
+            raise NotImplementedError("AKI-4B's Phi-3.5-mini is MHA (32 kv heads); GQA is not on this path")
+        self.scaling = self.head_dim ** -0.5
+        op_size = 3 * self.num_heads * self.head_dim
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, config.hidden_size, bias=False)
+        self.qkv_proj = nn.Linear(config.hidden_size, op_size, bias=False)
+
+    def forward(self, hidden_states, cos, sin, table, residual, position_ids=None):
+        o = ops.mma_attn(hidden_states, self.qkv_proj.weight, cos, sin, table, self.num_heads, self.scaling, position_ids)
+        return ops.linear(o, self.o_proj.weight, residual=residual)
+
+
+class Phi3MLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.gate_up_proj = nn.Linear(config.hidden_size, 2 * config.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(config.intermediate_size, config.hidden_size, bias=False)
+
+    def forward(self, x, residual):
+        a = ops.linear(x, self.gate_up_proj.weight, act=ops.ACT_SWIGLU)
+        return ops.linear(a, self.down_proj.weight, residual=residual)
+
+
+class Phi3DecoderLayer(nn.Module):
+    def __init__(self, config, layer_idx):
+        super().__init__()
+        self.self_attn = Phi3Attention(config, layer_idx)
+        self.mlp = Phi3MLP(config)
+        self.input_layernorm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, h, cos, sin, table, position_ids=None):
+        h = self.self_attn(self.input_layernorm(h), cos, sin, table, h, position_ids)
+        return self.mlp(self.post_attention_layernorm(h), h)
+
+
+class Phi3Model(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.padding_idx = getattr(config, "pad_token_id", None)
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, self.padding_idx)
+        self.layers = nn.ModuleList([Phi3DecoderLayer(config, i) for i in range(config.num_hidden_layers)])
+        self.norm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.rotary_emb = Phi3RotaryTables(config)
+
+    def forward(self, inputs_embeds, table, position_ids=None):
+        B, L, _ = inputs_embeds.shape
+        n_pos = L if position_ids is None else int(position_ids.max()) + 1
+        cos, sin = self.rotary_emb.tables(n_pos, inputs_embeds.device)
+        h = inputs_embeds
+        for layer in self.layers:
+            h = layer(h, cos, sin, table, position_ids)
+        return self.norm(h)
+
+
+class Phi3ForCausalLM(nn.Module):
+    """Drop-in for the HF class on the AKI path: ``lang_model(inputs_embeds=..., attention_mask=<MaskTable>, labels=...)``."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.model = Phi3Model(config)
+        self.vocab_size = config.vocab_size
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+
+    # --- the accessors src/vlm.py:48,80-99 relies on -----------------------------------------------------
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def set_input_embeddings(self, value):
+        self.model.embed_tokens = value
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def set_output_embeddings(self, new_embeddings):
+        self.lm_head = new_embeddings
+
+    def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, labels=None, position_ids=None,
+                use_cache=False, past_key_values=None, **kwargs):
+        if past_key_values is not None or use_cache:
+            raise NotImplementedError("KV-cache decode is SURVEY 8(f) item 1 (next); this build covers the forward/prefill pass")
+        if inputs_embeds is None:
+            inputs_embeds = self.model.embed_tokens(input_ids)
+        B, L, _ = inputs_embeds.shape
+        table = attention_mask
+        if table is None:
+            table = ops.MaskTable.causal(B, L, inputs_embeds.device)
+        elif isinstance(table, torch.Tensor):
+            table = mask_table_from_tensor(table, L)
+        h = self.model(inputs_embeds, table, position_ids)
+        if type(self.lm_head) is nn.Linear:
+            logits = ops.linear(h, self.lm_head.weight, bias=self.lm_head.bias)
+        else:  # DecoupledLinear (src/vlm.py:88-99): its forward is one HIP GEMM over the fused weight
+            logits = self.lm_head(h)
+        loss = None
+        if labels is not None:
+            loss = causal_lm_loss(logits, labels)
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None)
+
+
+def causal_lm_loss(logits, labels, ignore_index=-100):
+    """HF ForCausalLMLoss: shift by one, mean cross entropy over non-ignored targets, computed in f32."""
+    lg = logits[:, :-1].float()
+    tg = labels[:, 1:].to(lg.device)
+    return F.cross_entropy(lg.reshape(-1, lg.shape[-1]), tg.reshape(-1), ignore_index=ignore_index)
+
+
+def mask_table_from_tensor(mask: torch.Tensor, L: int) -> ops.MaskTable:
+    """Accept what a reference caller would pass: a 2-D (B,L) 0/1 padding mask becomes causal + valid bits.
+    A dense 4-D (B,1,L,L) mask is refused: the whole point of this path is that it is never materialised -
+    pass the ``MaskTable`` produced by ``_prepare_inputs_for_forward`` instead."""
+    if mask.dim() == 2:
+        return ops.MaskTable.from_host([[(0, 0, 0, 0)]] * mask.shape[0], mask.detach().cpu().numpy(), None, mask.device)
+    raise ValueError("dense 4-D attention masks are not accepted by the MI355X path; pass an ops.MaskTable")

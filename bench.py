@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py - image+text tokens/s of the AKI-4B forward pass on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one forward pass of the whole AKI-4B model (SigLIP tower -> Perceiver connector -> splice ->
+32 Phi-3.5-mini decoder layers with the fused MMA attention -> lm_head) over one batch of synthetic inputs that are
+already resident in HBM: BASELINE.json configs[1], batch 8 per GPU, one 336x336 image + a 512-token chat prompt
+per sample (LM-stream length L = 512 - 1 + 144 = 655 tokens/sample).  Random-init weights of the true architecture,
+bf16.  Data parallel = independent replicas, batch sharded over ranks, no data-path collective (weak scaling);
+the only collectives are the timing barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0) with the contract's fields plus
+  "roofline"     for the dominant kernel (by time in the timed region), timed live with HIP events on the launch stream
+  "mma_kernel"   the same object for the north-star's MMA op (QKV projection + RoPE + span-driven attention)
+  "cpu_baseline" the oracle (numpy port of the reference's eager path) timed on this box's host cores (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+N_TXT, NV, IMG_PX, BATCH = 512, 144, 336, 8
+
+
+def synth_batch(B, device, dtype, media_id, seed):
+    """[BOS, 5 system tokens, <image>, text ~U[3,31999], <|end|>=32007, <|assistant|>=32001 at N_txt-17,
+    16 answer ids, EOS], no padding; images uniform[0,1) normalised to [-1,1)."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ids = torch.randint(3, 32000, (B, N_TXT), generator=g)
+    ids[:, 0] = 1
+    ids[:, 6] = media_id
+    ids[:, N_TXT - 18] = 32007
+    ids[:, N_TXT - 17] = 32001
+    ids[:, N_TXT - 1] = 2
+    img = (torch.rand((B, 1, 1, 3, IMG_PX, IMG_PX), generator=g) - 0.5) / 0.5
+    return img.to(device=device, dtype=dtype), ids.to(device), torch.ones_like(ids).to(device)
+
+
+def cpu_baseline(budget_s=25.0):
+    """The oracle's numpy port of the reference eager forward on the host cores, bounded sample: ONE sample of the
+    benchmark workload (L = 655), 2 of 32 decoder layers and 2 of 27 SigLIP layers timed and scaled by layer count
+    (the layers are identical), Perceiver connector, splice/mask and lm_head timed in full."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import aki_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    rng = np.random.Generator(np.random.PCG64(0))
+    f = lambda *s: (rng.standard_normal(s, dtype=np.float32) * np.float32(0.02))
+    d, H, F, V = 3072, 32, 8192, 32064
+    L = N_TXT - 1 + NV
+    t = {}
+    # --- SigLIP: patch embed + 2 layers --------------------------------------------------------------
+    E, P, G = 1152, 14, IMG_PX // 14
+    px = rng.random((1, 3, IMG_PX, IMG_PX), dtype=np.float32) * 2 - 1
+    t0 = time.perf_counter()
+    h = O.siglip_patch_embed(px, f(E, 3, P, P), f(E), f(G * G, E))
+    t["patch_embed"] = time.perf_counter() - t0
+    lp = {"layer_norm1.weight": np.ones(E, np.float32), "layer_norm1.bias": np.zeros(E, np.float32),
+          "layer_norm2.weight": np.ones(E, np.float32), "layer_norm2.bias": np.zeros(E, np.float32),
+          "mlp.fc1.weight": f(4304, E), "mlp.fc1.bias": f(4304), "mlp.fc2.weight": f(E, 4304), "mlp.fc2.bias": f(E)}
+    for n_ in ("q", "k", "v", "out"):
+        lp[f"self_attn.{n_}_proj.weight"] = f(E, E)
+        lp[f"self_attn.{n_}_proj.bias"] = f(E)
+    O.siglip_encoder_layer(h, lp, 16)            # warm-up (BLAS thread pool)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        h = O.siglip_encoder_layer(h, lp, 16)
+    t["siglip_layer"] = (time.perf_counter() - t0) / 2
+    # --- Perceiver connector (full) --------------------------------------------------------------------
+    pp = {"latents": rng.standard_normal((NV, E), dtype=np.float32), "norm.weight": np.ones(E, np.float32),
+          "norm.bias": np.zeros(E, np.float32), "projection.weight": f(d, E), "projection.bias": f(d)}
+    for l in range(6):
+        for nm in ("norm_media", "norm_latents"):
+            pp[f"layers.{l}.0.{nm}.weight"] = np.ones(E, np.float32)
+            pp[f"layers.{l}.0.{nm}.bias"] = np.zeros(E, np.float32)
+        pp[f"layers.{l}.0.to_q.weight"] = f(512, E)
+        pp[f"layers.{l}.0.to_kv.weight"] = f(1024, E)
+        pp[f"layers.{l}.0.to_out.weight"] = f(E, 512)
+        pp[f"layers.{l}.1.0.weight"] = np.ones(E, np.float32)
+        pp[f"layers.{l}.1.0.bias"] = np.zeros(E, np.float32)
+        pp[f"layers.{l}.1.1.weight"] = f(4 * E, E)
+        pp[f"layers.{l}.1.3.weight"] = f(E, 4 * E)
+    t0 = time.perf_counter()
+    vt = O.perceiver_resampler(h[None, :, None], pp)
+    t["perceiver"] = time.perf_counter() - t0
+    # --- splice + dense MMA mask (the reference materialises it) ------------------------------------------
+    ids = rng.integers(3, 32000, size=(1, N_TXT)).astype(np.int64)
+    ids[0, 6] = 32011
+    ids[0, N_TXT - 17] = 32001
+    emb = f(1, N_TXT, d)
+    t0 = time.perf_counter()
+    prep = O.prepare_inputs_for_forward(vt.reshape(1, 1, NV, d), ids, np.ones_like(ids), None, emb, 32011, 32000, NV)
+    add = O.invert_mask_441(prep["attention_mask"])
+    t["splice_mask"] = time.perf_counter() - t0
+    # --- 2 decoder layers -----------------------------------------------------------------------------------
+    dp = {"input_layernorm.weight": np.ones(d, np.float32), "post_attention_layernorm.weight": np.ones(d, np.float32),
+          "self_attn.qkv_proj.weight": f(3 * d, d), "self_attn.o_proj.weight": f(d, d),
+          "mlp.gate_up_proj.weight": f(2 * F, d), "mlp.down_proj.weight": f(d, F)}
+    cos, sin = O.rope_cos_sin(np.arange(L)[None], 96)
+    x = prep["inputs_embeds"]
+    O.phi3_decoder_layer(x, dp, cos, sin, add, H)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        x = O.phi3_decoder_layer(x, dp, cos, sin, add, H)
+    t["decoder_layer"] = (time.perf_counter() - t0) / 2
+    # --- final norm + lm_head ---------------------------------------------------------------------------------
+    W = f(V, d)
+    t0 = time.perf_counter()
+    O.decoupled_linear(O.rms_norm(x, np.ones(d, np.float32)), W, None, f(2, d), None, 32010)
+    t["lm_head"] = time.perf_counter() - t0
+    total = t["patch_embed"] + 27 * t["siglip_layer"] + t["perceiver"] + t["splice_mask"] + 32 * t["decoder_layer"] + t["lm_head"]
+    return {"value": round(L / total, 2), "unit": "tokens/s", "cores": int(cores), "kind": "port",
+            "sample": "1 sample of the benchmark workload (336px image + 512-token prompt, L=655), numpy fp32 oracle: "
+                      "2/32 decoder layers and 2/27 SigLIP layers timed and scaled by layer count, connector, splice+dense "
+                      "mask and lm_head timed in full",
+            "seconds_per_forward_est": round(total, 3), "parts_s": {k: round(v, 4) for k, v in t.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE configs[1]: 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel timing table to stderr")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from aki_amd import ops
+    from aki_amd.factory import build_aki
+    B = args.batch
+    model = build_aki(dtype=torch.bfloat16, device=dev, seed=rank)
+    model.eval()
+    vx, ids, am = synth_batch(B, dev, torch.bfloat16, model.media_token_id, seed=1000 + rank)
+    L = N_TXT - 1 + NV
+
+    def step():
+        with torch.no_grad():
+            return model(vx, ids, attention_mask=am)
+
+    for _ in range(args.warmup):
+        out = step()
+    assert out.logits.shape[:2] == (B, L)
+    torch.cuda.synchronize()
+    tap = ops.EventTap(tags={"linear", "mma_attn"})
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.set_event_tap(tap)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.set_event_tap(None)
+    if world > 1:
+        dist.barrier()
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out.logits.float()).all()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        tokens = B * world * L
+        value = tokens * args.steps / elapsed
+        summ = tap.summary()
+        rows = []
+        for tag, (n_calls, avg_ms) in summ.items():
+            if tag[0] == "linear":
+                _, M, N, K, act = tag
+                fl = 2.0 * M * N * K
+                name = f"gemm_bf16 M{M} N{N} K{K}" + (" +swiglu" if act == 3 else "")
+            else:
+                _, b_, h_, l_, dh = tag
+                pairs = l_ * (l_ + 1) // 2 + NV * max(0, (N_TXT - 17 + NV) - (6 + NV))
+                fl = 2.0 * b_ * l_ * 3 * h_ * dh * (h_ * dh) + 4.0 * h_ * dh * pairs * b_
+                name = f"mma_attn (qkv+rope+attention) B{b_} H{h_} L{l_}"
+            rows.append(dict(kernel=name, tag=tag[0], calls_per_step=n_calls / args.steps, avg_ms=avg_ms,
+                             total_ms_per_step=avg_ms * n_calls / args.steps, tflops=fl / avg_ms / 1e9, flops=fl))
+        rows.sort(key=lambda r: -r["total_ms_per_step"])
+        if args.kernel_table:
+            for r in rows:
+                print(f"  {r['kernel']:<48s} x{r['calls_per_step']:5.1f}/step  {r['avg_ms']:8.4f} ms  {r['tflops']:7.1f} TF/s  "
+                      f"{r['total_ms_per_step']:8.3f} ms/step", file=sys.stderr)
+        dom = rows[0]
+        mk = lambda r: {"kernel": r["kernel"], "bound": "mfma", "achieved": round(r["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(r["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "avg_launch_ms": round(r["avg_ms"], 4), "algorithmic_flops_per_launch": r["flops"]}
+        res = {
+            "metric": "image+text tokens/sec forward, AKI-4B, 336px img + 512 txt",
+            "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "AKI-4B (Phi-3.5-mini + SigLIP-so400m/14 + Perceiver) forward, bf16, 1x336px image + "
+                                   "512-token chat prompt per sample, batch 8 per GPU (BASELINE configs[1]); random-init weights",
+                       "global_batch": B * world, "seq_len": L, "tokens_per_sample": L, "patch_plus_text_tokens": 576 + N_TXT,
+                       "parallelism": f"dp{world}"},
+            "roofline": mk(dom),
+        }
+        mma = [r for r in rows if r["tag"] == "mma_attn"]
+        if mma:
+            res["mma_kernel"] = mk(mma[0])
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"]["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

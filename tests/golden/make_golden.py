@@ -119,6 +119,10 @@ def g_tiny_e2e(ref):
                                              padding_side="right")
     out = model(tv, tl, attention_mask=ta, labels=tlab)
     cols = np.unique(np.concatenate((np.arange(0, 32013, 997), [1, 2, 32000, 32001, 32007, 32010, 32011, 32012])))
+    # the reference's own bf16 eager run of the same model (a yardstick for the bf16 HIP path's end-to-end error)
+    import copy
+    m16 = copy.deepcopy(model).to(torch.bfloat16)
+    out16 = m16(tv.to(torch.bfloat16), tl, attention_mask=ta, labels=tlab)
     save("tiny_e2e.npz",
          shapes=np.array(json.dumps(shapes)),
          lang_x=lang_x, attention_mask=am, labels=labels,
@@ -127,7 +131,8 @@ def g_tiny_e2e(ref):
          mask_bits=gen.pack_mask_bits(prep["attention_mask"].numpy()),
          mask_shape=np.array(prep["attention_mask"].shape),
          new_labels=prep["labels"].numpy(),
-         logit_cols=cols, logits=out.logits[:, :, cols].numpy(), loss=np.array(float(out.loss)))
+         logit_cols=cols, logits=out.logits[:, :, cols].numpy(), loss=np.array(float(out.loss)),
+         logits16=out16.logits[:, :, cols].float().numpy(), loss16=np.array(float(out16.loss)))
     # left-padded variant used by generate() (src/aki.py:171)
     prep_l = model._prepare_inputs_for_forward(vision_tokens=vtok, lang_x=tl, attention_mask=ta, padding_side="left")
     save("tiny_splice_left.npz", inputs_embeds=prep_l["inputs_embeds"].numpy(),
