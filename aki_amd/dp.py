@@ -1,0 +1,111 @@
+"""Data-parallel support for the AKI path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI
+on MI355X; "gloo" in the CPU tests).
+
+Forward metric: samples are independent, so the batch is sharded over ranks and there is NO data-path collective
+(`shard_batch`).  Training step (BASELINE configs[2]; reference: DDP at train/train.py:311-312, backward at
+train/train_utils.py:252): the one real exchange is the gradient all-reduce, done here by `GradAllReducer`:
+  * gradients are packed into a few LARGE flat buckets (default 512 MiB - xGMI is point-to-point, 7 links x ~153 GB/s
+    per GPU, so ring collectives are per-link bound and want few, large messages rather than DDP's 25 MiB),
+  * a bucket's all-reduce is launched asynchronously the moment its last gradient is produced by autograd
+    (post-accumulate-grad hooks), overlapping the rest of the backward pass,
+  * `finish()` waits, averages and leaves the result in every `p.grad`.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(t: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = None) -> torch.Tensor:
+    """Contiguous batch shard of this rank (dim 0); the remainder goes to the first ranks."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    n = t.shape[0]
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return t[lo: lo + base + (1 if rank < rem else 0)]
+
+
+class _Bucket:
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.pending = len(params)
+        self.flat: Optional[torch.Tensor] = None
+        self.work = None
+
+
+class GradAllReducer:
+    """Bucketed, backward-overlapped gradient averaging for a replica of the model.
+
+        reducer = GradAllReducer(model.parameters())
+        loss.backward()          # buckets are all-reduced as they fill
+        reducer.finish()         # p.grad now holds the average over ranks
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 512 << 20, group=None,
+                 reduce_dtype: Optional[torch.dtype] = None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.reduce_dtype = reduce_dtype
+        ps = [p for p in params if p.requires_grad]
+        ps.reverse()  # autograd produces gradients roughly in reverse registration order
+        self.buckets: List[_Bucket] = []
+        cur, cur_bytes, key = [], 0, None
+        for p in ps:
+            k = (p.dtype, p.device)
+            nbytes = p.numel() * p.element_size()
+            if cur and (k != key or cur_bytes + nbytes > bucket_bytes):
+                self.buckets.append(_Bucket(cur))
+                cur, cur_bytes = [], 0
+            key = k
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(_Bucket(cur))
+        self._owner = {}
+        self._hooks = []
+        for b in self.buckets:
+            for p in b.params:
+                self._owner[p] = b
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _on_grad(self, p: torch.nn.Parameter):
+        b = self._owner[p]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _launch(self, b: _Bucket):
+        if self.world == 1:
+            return
+        dt = self.reduce_dtype or b.params[0].dtype
+        b.flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt) for p in b.params])
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        for b in self.buckets:
+            if self.world > 1:
+                if b.work is None:       # a parameter got no gradient this step: reduce what we have
+                    self._launch(b)
+                b.work.wait()
+                b.flat.div_(self.world)
+                off = 0
+                for p in b.params:
+                    n = p.numel()
+                    g = b.flat[off: off + n].view_as(p).to(p.dtype)
+                    if p.grad is None:
+                        p.grad = g.clone()
+                    else:
+                        p.grad.copy_(g)
+                    off += n
+            b.pending = len(b.params)
+            b.flat = None
+            b.work = None
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

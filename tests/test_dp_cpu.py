@@ -1,0 +1,73 @@
+"""2-rank gloo tests of the data-parallel helpers (aki_amd/dp.py): batch sharding and the bucketed, backward-overlapped
+gradient all-reduce against a single-process reference on the full batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.GELU(), torch.nn.Linear(32, 32, bias=False),
+                               torch.nn.LayerNorm(32), torch.nn.Linear(32, 4))
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aki_amd.dp import GradAllReducer, shard_batch
+    m = _model()
+    m[2].weight.requires_grad_(False)                      # a frozen parameter, like the vision tower
+    red = GradAllReducer(m.parameters(), bucket_bytes=600)   # tiny buckets -> several async all-reduces
+    assert len(red.buckets) >= 3
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(10, 16, generator=g)
+    y = torch.randn(10, 4, generator=g)
+    for step in range(2):                                  # two steps: bucket state must reset
+        for p in m.parameters():
+            p.grad = None
+        xs, ys = shard_batch(x, rank, world), shard_batch(y, rank, world)
+        loss = ((m(xs) - ys) ** 2).sum() / 10 * world      # so that the rank-average equals the full-batch gradient
+        loss.backward()
+        red.finish()
+    ret[rank] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_batch_covers_everything():
+    from aki_amd.dp import shard_batch
+    x = torch.arange(11)
+    parts = [shard_batch(x, r, 4) for r in range(4)]
+    assert torch.equal(torch.cat(parts), x) and [len(p) for p in parts] == [3, 3, 3, 2]
+
+
+@pytest.mark.timeout(120)
+def test_grad_all_reduce_world2_matches_full_batch():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    m = _model()
+    m[2].weight.requires_grad_(False)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(10, 16, generator=g)
+    y = torch.randn(10, 4, generator=g)
+    (((m(x) - y) ** 2).sum() / 10).backward()
+    want = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    for r in range(world):
+        assert set(ret[r].keys()) == set(want.keys())
+        for n in want:
+            torch.testing.assert_close(ret[r][n], want[n], atol=1e-6, rtol=1e-5)
