@@ -63,6 +63,7 @@ class SpliceArgs(C.Structure):
 SIGNATURES = {
     "aki_strerror": (C.c_char_p, [C.c_int]),
     "aki_abi_version": (C.c_int, []),
+    "aki_debug_set_gemm_tile": (None, [C.c_int]),
     "aki_mma_attn_core_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
     "aki_mma_attn_core_fwd": (C.c_int, [C.POINTER(MmaAttnCoreArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_mma_attn_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),

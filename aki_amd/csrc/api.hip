@@ -16,6 +16,7 @@ int splice_launch(const aki_splice_args* a, hipStream_t s);
 int mask_dense_launch(const aki_mma_rect* rects, int max_rects, const uint64_t* vbits, const int* seq_lens, int B, int L,
                       int64_t* out, hipStream_t s);
 int im2col_launch(const void* pix, void* out, int N, int S, int P, int Kp, int dtype, hipStream_t s);
+extern int g_force_tile;
 }  // namespace aki
 
 using namespace aki;
@@ -37,6 +38,8 @@ const char* aki_strerror(int status) {
 }
 
 int aki_abi_version(void) { return AKI_ABI_VERSION; }
+
+void aki_debug_set_gemm_tile(int mode) { aki::g_force_tile = (mode == 1 || mode == 2) ? mode : 0; }
 
 // ---- attention core --------------------------------------------------------------------------------
 size_t aki_mma_attn_core_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype) {

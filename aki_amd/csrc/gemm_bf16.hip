@@ -5,19 +5,27 @@
 //
 // Orientation.  Both operands are K-contiguous ([M,K] activations, [N,K] nn.Linear weights), so both
 // MFMA fragments are one 16-byte LDS read.  The product is computed "swapped": A-operand = W rows
-// (features), B-operand = x rows (tokens), i.e. the accumulator tile is C^T[feature][token] with
-//   token   = lane & 31                      (on the lanes)
-//   feature = (reg&3) + 8*(reg>>2) + 4*(lane>>5)   (in the 16 accumulator registers)
-// Every lane therefore owns runs of 4 consecutive features of ONE token: row-major bf16 stores are
-// 8 bytes wide, per-token epilogues (RoPE with cos/sin[pos(token)], residual add, SwiGLU pairs) are
-// lane-local, and rotate-half partners d <-> d+48 (48 = 6*8) sit in the same lane.
+// (features), B-operand = x rows (tokens), i.e. each 16x16 accumulator block is C^T[feature][token] with
+//   token   = lane & 15                 (on the lanes)
+//   feature = 4*(lane>>4) + reg         (4 consecutive features per lane)
+// so per-token epilogues are lane-local: RoPE (partner d+48 = 3 blocks further, same lane and register),
+// residual add, SwiGLU (gate/up blocks of the same features are staged into the same wave), and one
+// v_permlane16_swap per dword turns two blocks' 8-byte runs into 16-byte row-major stores.
 //
-// Tile: 8 waves = 2 (features) x 4 (tokens); wave tile = TN*32 features x 64 tokens; BK = 64.
-//   TN = 4: 256 x 256 block tile (generic);  TN = 3: 192 x 256 (two 96-wide heads, QKV+RoPE).
-// LDS: 2 stages x (BN + 256) rows x 128 B.  Staging is global_load_lds (16 B/lane, 1 KiB/wave-
-// instruction = 8 rows); the LDS image is lane-linear and the bank-conflict swizzle
-// (chunk ^= (row>>1)&7) is applied on the SOURCE address and again on the ds_read_b128 address
-// (cdna_hip_programming.md rule 21).  One barrier per K-step; tile k+1 streams in under tile k's MFMAs.
+// MFMA shape: v_mfma_f32_16x16x32_bf16.  Measured on this MI355X (tools/mfma_peak.hip, 2 waves/SIMD, one
+// barrier per K-step, random operands): 2.16 PFLOP/s vs 1.77 for 32x32x16 - the chip holds a higher clock on
+// the 16x16 shape (cdna guide rule 28); in this kernel the switch was worth +8..19 %, the 16-byte stores +3..6 %.
+//
+// Tiles (waves = WN x WM, wave tile = NF*16 features x NT*16 tokens, BK = 64):
+//   BIG   2x4 waves, 8x4 blocks -> 256 x 256     generic large GEMMs
+//   QKV   2x4 waves, 6x4 blocks -> 192 x 256     one 96-wide head per wave (QKV + RoPE epilogue)
+//   SMALL 2x2 waves, 4x4 blocks -> 128 x 128     shapes whose 256^2 tiling cannot fill 256 CUs (2 WGs/CU)
+// LDS: 2 stages x (BN + BM) rows x 128 B filled by global_load_lds (16 B/lane; 1 KiB per wave-instruction =
+// 8 rows).  The LDS image is lane-linear; the bank-conflict swizzle (chunk ^= (row>>1)&7) is applied on the
+// SOURCE address and again on the ds_read_b128 address (guide rule 21); conflict-free for both the 32x32 and
+// the 16x16 fragment read groups.  One vmcnt(0)+barrier per K-step; tile k+1 streams in under tile k's MFMAs.
+// (tools/gemm_lab.hip: a deeper BK=32 x 4-stage counted-vmcnt ring, interleaved LDS-DMA issue, fragment
+// double-buffering, setprio and wave staggering were all measured and bought nothing on this structure.)
 #include "aki_device.h"
 
 namespace aki {
@@ -35,6 +43,7 @@ struct GemmParams {
   int res_row_mod;
   int act;
   int tiles_m, tiles_n;
+  int wide;  // 16-byte stores allowed (n_out % 8 == 0, ldy % 8 == 0, y 16-B aligned)
   // QKV + RoPE
   bf16_t* q_out;
   bf16_t* k_out;
@@ -45,24 +54,34 @@ struct GemmParams {
   int H, L;
 };
 
-template <int TN, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const GemmParams p) {
-  constexpr int TM = 2, BK = 64;
-  constexpr int WROWS = TN * 32;     // features per wave
-  constexpr int BN = 2 * WROWS;      // features per block tile
-  constexpr int BM = 4 * TM * 32;    // tokens per block tile (256)
+// Two feature blocks (P = block n, Q = block n+1), each 4 consecutive features per lane as 2 packed dwords.
+// After the swaps lane row r = lane>>4 owns 8 consecutive features of block n + (r&1), starting at 8*(r>>1).
+__device__ __forceinline__ u32x4 pair_to_wide(unsigned p0, unsigned p1, unsigned q0, unsigned q1) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(p0), "+v"(q0), "+v"(p1), "+v"(q1));
+  u32x4 o = {p0, p1, q0, q1};
+  return o;
+}
+
+template <int NF, int NT, int WN, int WM, int EPI>
+__global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
+  constexpr int BK = 64, NWAVES = WN * WM;
+  constexpr int WROWS = NF * 16;      // features per wave
+  constexpr int BN = WN * WROWS;      // features per block tile
+  constexpr int WTOK = NT * 16;       // tokens per wave
+  constexpr int BM = WM * WTOK;       // tokens per block tile
   constexpr int ROWS = BN + BM;
   constexpr int STAGE_BYTES = ROWS * 128;
-  constexpr int NLD = ROWS / 64;     // global_load_lds per thread per stage
+  constexpr int NLD = ROWS / 8 / NWAVES;  // global_load_lds per thread per stage
+  static_assert(ROWS % (8 * NWAVES) == 0 && NF % 2 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave & 1, wm = wave >> 1;
-  const int l31 = lane & 31, h = lane >> 5;
+  const int wn = wave % WN, wm = wave / WN;
+  const int l15 = lane & 15, kg = lane >> 4;
 
-  // ---- tile id: XCD-contiguous chunks, grouped so 32 concurrent tiles of an XCD share operands ----
+  // ---- tile id: XCD-contiguous chunks, grouped so concurrently running tiles of an XCD share operand panels ----
   const int t = xcd_remap(blockIdx.x, gridDim.x);
   constexpr int GM = 8;
   const int per_group = GM * p.tiles_n;
@@ -75,19 +94,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const GemmParams p) {
   const int n0 = (EPI == EPI_SWIGLU) ? tn * (BN / 2) : tn * BN;  // first output feature of the tile
   const int n_out = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
 
-  // ---- per-thread staging sources --------------------------------------------------------------
+  // ---- per-thread staging sources ----------------------------------------------------------------------------
   const char* src[NLD];
 #pragma unroll
   for (int j = 0; j < NLD; ++j) {
-    const int rowgroup = j * 8 + wave;
+    const int rowgroup = j * NWAVES + wave;
     const int row = rowgroup * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     if (rowgroup * 8 < BN) {
       int wrow;
-      if (EPI == EPI_SWIGLU) {
-        const int w_ = row / WROWS, within = row % WROWS, nb = within >> 5, i = within & 31;
-        const int f = n0 + w_ * (WROWS / 2) + (nb % (TN / 2 > 0 ? TN / 2 : 1)) * 32 + i;
-        wrow = (nb < TN / 2) ? min(f, n_out - 1) : n_out + min(f, n_out - 1);
+      if (EPI == EPI_SWIGLU) {  // wave-local blocks [0,NF/2) = gate rows, [NF/2,NF) = up rows of the same features
+        const int w_ = row / WROWS, within = row % WROWS, nb = within >> 4, i = within & 15;
+        const int f = min(n0 + w_ * (WROWS / 2) + (nb % (NF / 2)) * 16 + i, n_out - 1);
+        wrow = (nb < NF / 2) ? f : n_out + f;
       } else {
         wrow = min(n0 + row, p.N - 1);
       }
@@ -101,23 +120,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const GemmParams p) {
   auto stage = [&](int s, int kt) {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      char* dst = smem + s * STAGE_BYTES + (j * 8 + wave) * 1024;
+      char* dst = smem + s * STAGE_BYTES + (j * NWAVES + wave) * 1024;
       __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[j] + (size_t)kt * (BK * 2)), AKI_LDS_PTR(dst), 16, 0, 0);
     }
   };
 
-  f32x16 acc[TN][TM];
+  f32x4 acc[NF][NT];
 #pragma unroll
-  for (int n = 0; n < TN; ++n)
+  for (int n = 0; n < NF; ++n)
 #pragma unroll
-    for (int m = 0; m < TM; ++m)
+    for (int m = 0; m < NT; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[n][m][r] = 0.f;
 
-  // per-lane fragment addressing: row byte offset + swizzled 16-B chunk for each k-step
-  const int swz = (lane >> 1) & 7;  // == (row>>1)&7 because every block row base is a multiple of 32
-  const int wbase = (wn * WROWS + l31) * 128;
-  const int xbase = BN * 128 + (wm * TM * 32 + l31) * 128;
+  const int swz = (l15 >> 1) & 7;  // == (row>>1)&7: every block row base is a multiple of 16
+  const int wbase = (wn * WROWS + l15) * 128;
+  const int xbase = BN * 128 + (wm * WTOK + l15) * 128;
 
   const int nk = p.K / BK;
   stage(0, 0);
@@ -126,123 +144,135 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const GemmParams p) {
     if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
     const char* sb = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int coff = ((2 * ks + h) ^ swz) << 4;
-      bf16x8 a[TN], b[TM];
+    for (int ks = 0; ks < 2; ++ks) {  // two k32 steps per BK
+      const int coff = ((4 * ks + kg) ^ swz) << 4;
+      bf16x8 a[NF], b[NT];
 #pragma unroll
-      for (int n = 0; n < TN; ++n) a[n] = *(const bf16x8*)(sb + wbase + n * 4096 + coff);
+      for (int n = 0; n < NF; ++n) a[n] = *(const bf16x8*)(sb + wbase + n * 2048 + coff);
 #pragma unroll
-      for (int m = 0; m < TM; ++m) b[m] = *(const bf16x8*)(sb + xbase + m * 4096 + coff);
+      for (int m = 0; m < NT; ++m) b[m] = *(const bf16x8*)(sb + xbase + m * 2048 + coff);
 #pragma unroll
-      for (int n = 0; n < TN; ++n)
+      for (int n = 0; n < NF; ++n)
 #pragma unroll
-        for (int m = 0; m < TM; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[n], b[m], acc[n][m], 0, 0, 0);
+        for (int m = 0; m < NT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], b[m], acc[n][m], 0, 0, 0);
     }
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------------
+  // ---- epilogue: lane (token = l15 of block m, row group kg) owns features 4kg..4kg+3 of every feature block ----
   if (EPI == EPI_QKV_ROPE) {
-    // wave = one 96-wide head slot of q|k|v
-    const int hs = (n0 + wn * WROWS) / 96;
+    const int hs = (n0 + wn * WROWS) / 96;  // head slot of q|k|v handled by this wave (NF = 6)
     if (hs >= 3 * p.H) return;
     const int which = hs / p.H, head = hs % p.H;
     bf16_t* outp = which == 0 ? p.q_out : (which == 1 ? p.k_out : p.v_out);
 #pragma unroll
-    for (int m = 0; m < TM; ++m) {
-      const int mrow = m0 + wm * TM * 32 + m * 32 + l31;
-      if (mrow >= p.M) continue;
-      const int b = mrow / p.L, tt = mrow - b * p.L;
-      bf16_t* dst = outp + ((size_t)(b * p.H + head) * p.L + tt) * 96 + 4 * h;
+    for (int m = 0; m < NT; ++m) {
+      const int mrow = m0 + wm * WTOK + m * 16 + l15;
+      const bool ok = mrow < p.M;
+      const int mr = min(mrow, p.M - 1);
+      const int b = mr / p.L, tt = mr - b * p.L;
+      float v[NF][4];
       if (which < 2) {
-        const int pos = p.position_ids ? p.position_ids[mrow] : tt;
-        const float* cp = p.cos + (size_t)pos * 96 + 4 * h;
-        const float* sp = p.sin + (size_t)pos * 96 + 4 * h;
+        const int pos = p.position_ids ? p.position_ids[mr] : tt;
+        const float* cp = p.cos + (size_t)pos * 96 + 4 * kg;
+        const float* sp = p.sin + (size_t)pos * 96 + 4 * kg;
 #pragma unroll
-        for (int idx = 0; idx < 6; ++idx) {  // feature run d = idx*8 + 4h + e and its partner d + 48
-          const f32x4 c4 = *(const f32x4*)(cp + idx * 8);
-          const f32x4 s4 = *(const f32x4*)(sp + idx * 8);
-          float lo[4], hi[4];
+        for (int n = 0; n < 3; ++n) {  // d = 16n + 4kg + r and its rotate-half partner d + 48 (block n + 3)
+          const f32x4 c4 = *(const f32x4*)(cp + n * 16);
+          const f32x4 s4 = *(const f32x4*)(sp + n * 16);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x1 = acc[idx / 4][m][4 * (idx % 4) + e];
-            const float x2 = acc[(idx + 6) / 4][m][4 * ((idx + 6) % 4) + e];
-            lo[e] = x1 * c4[e] - x2 * s4[e];
-            hi[e] = x2 * c4[e] + x1 * s4[e];
+          for (int r = 0; r < 4; ++r) {
+            const float x1 = acc[n][m][r], x2 = acc[n + 3][m][r];
+            v[n][r] = x1 * c4[r] - x2 * s4[r];
+            v[n + 3][r] = x2 * c4[r] + x1 * s4[r];
           }
-          u32x2 vlo = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3])};
-          u32x2 vhi = {pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
-          *(u32x2*)(dst + idx * 8) = vlo;
-          *(u32x2*)(dst + idx * 8 + 48) = vhi;
         }
       } else {
 #pragma unroll
-        for (int idx = 0; idx < 12; ++idx) {
-          const float* a4 = nullptr;
-          (void)a4;
-          u32x2 v = {pack_bf16x2(acc[idx / 4][m][4 * (idx % 4) + 0], acc[idx / 4][m][4 * (idx % 4) + 1]),
-                     pack_bf16x2(acc[idx / 4][m][4 * (idx % 4) + 2], acc[idx / 4][m][4 * (idx % 4) + 3])};
-          *(u32x2*)(dst + idx * 8) = v;
-        }
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[n][r] = acc[n][m][r];
+      }
+      bf16_t* dst = outp + ((size_t)(b * p.H + head) * p.L + tt) * 96;
+#pragma unroll
+      for (int n = 0; n < NF; n += 2) {
+        const u32x4 o = pair_to_wide(pack_bf16x2(v[n][0], v[n][1]), pack_bf16x2(v[n][2], v[n][3]),
+                                     pack_bf16x2(v[n + 1][0], v[n + 1][1]), pack_bf16x2(v[n + 1][2], v[n + 1][3]));
+        if (ok) *(u32x4*)(dst + (n + (kg & 1)) * 16 + 8 * (kg >> 1)) = o;
       }
     }
     return;
   }
 
-  constexpr int NOUT_BLOCKS = (EPI == EPI_SWIGLU) ? TN / 2 : TN;
+  constexpr int NOUT = (EPI == EPI_SWIGLU) ? NF / 2 : NF;     // output feature blocks per wave
+  const int fwave = n0 + wn * (EPI == EPI_SWIGLU ? WROWS / 2 : WROWS);
 #pragma unroll
-  for (int m = 0; m < TM; ++m) {
-    const int mrow = m0 + wm * TM * 32 + m * 32 + l31;
-    if (mrow >= p.M) continue;
-    bf16_t* yrow = p.y + (size_t)mrow * p.ldy;
+  for (int m = 0; m < NT; ++m) {
+    const int mrow = m0 + wm * WTOK + m * 16 + l15;
+    const bool ok = mrow < p.M;
+    const int mr = min(mrow, p.M - 1);
+    bf16_t* yrow = p.y + (size_t)mr * p.ldy;
     const bf16_t* rrow = nullptr;
-    if (p.residual) rrow = p.residual + (size_t)(p.res_row_mod > 0 ? mrow % p.res_row_mod : mrow) * p.ldr;
+    if (p.residual) rrow = p.residual + (size_t)(p.res_row_mod > 0 ? mr % p.res_row_mod : mr) * p.ldr;
+    float v[NOUT][4];
 #pragma unroll
-    for (int n = 0; n < NOUT_BLOCKS; ++n) {
+    for (int n = 0; n < NOUT; ++n) {
+      const int f = fwave + n * 16 + 4 * kg;       // this lane's 4 features of block n
+      const bool fin = f < n_out;
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int f = n0 + wn * (EPI == EPI_SWIGLU ? WROWS / 2 : WROWS) + n * 32 + q4 * 8 + 4 * h;
-        if (f >= n_out) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (EPI == EPI_SWIGLU) {
-            const float g = acc[n][m][4 * q4 + e], u = acc[n + TN / 2][m][4 * q4 + e];
-            v[e] = u * silu(g);
-          } else {
-            v[e] = acc[n][m][4 * q4 + e];
-          }
+      for (int r = 0; r < 4; ++r) {
+        if (EPI == EPI_SWIGLU) {
+          const float g = acc[n][m][r], u = acc[n + NF / 2][m][r];
+          v[n][r] = u * silu(g);
+        } else {
+          v[n][r] = acc[n][m][r];
         }
-        if (EPI == EPI_PLAIN) {
-          if (p.bias) {
-            const u32x2 bb = *(const u32x2*)(p.bias + f);
-            v[0] += bf16_lo(bb[0]); v[1] += bf16_hi(bb[0]); v[2] += bf16_lo(bb[1]); v[3] += bf16_hi(bb[1]);
-          }
-          if (p.act == AKI_ACT_GELU_ERF) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-          } else if (p.act == AKI_ACT_GELU_TANH) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-          }
+      }
+      if (EPI == EPI_PLAIN) {
+        if (p.bias && fin) {
+          const u32x2 bb = *(const u32x2*)(p.bias + f);
+          v[n][0] += bf16_lo(bb[0]); v[n][1] += bf16_hi(bb[0]); v[n][2] += bf16_lo(bb[1]); v[n][3] += bf16_hi(bb[1]);
         }
-        if (rrow) {
-          const u32x2 rr = *(const u32x2*)(rrow + f);
-          v[0] += bf16_lo(rr[0]); v[1] += bf16_hi(rr[0]); v[2] += bf16_lo(rr[1]); v[3] += bf16_hi(rr[1]);
+        if (p.act == AKI_ACT_GELU_ERF) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[n][r] = gelu_erf(v[n][r]);
+        } else if (p.act == AKI_ACT_GELU_TANH) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[n][r] = gelu_tanh(v[n][r]);
         }
-        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        *(u32x2*)(yrow + f) = o;
+      }
+      if (rrow && fin) {
+        const u32x2 rr = *(const u32x2*)(rrow + f);
+        v[n][0] += bf16_lo(rr[0]); v[n][1] += bf16_hi(rr[0]); v[n][2] += bf16_lo(rr[1]); v[n][3] += bf16_hi(rr[1]);
+      }
+    }
+    if (p.wide) {
+#pragma unroll
+      for (int n = 0; n < NOUT; n += 2) {
+        const u32x4 o = pair_to_wide(pack_bf16x2(v[n][0], v[n][1]), pack_bf16x2(v[n][2], v[n][3]),
+                                     pack_bf16x2(v[n + 1][0], v[n + 1][1]), pack_bf16x2(v[n + 1][2], v[n + 1][3]));
+        const int f = fwave + (n + (kg & 1)) * 16 + 8 * (kg >> 1);
+        if (ok && f < n_out) *(u32x4*)(yrow + f) = o;
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NOUT; ++n) {
+        const int f = fwave + n * 16 + 4 * kg;
+        if (ok && f < n_out) {
+          u32x2 o = {pack_bf16x2(v[n][0], v[n][1]), pack_bf16x2(v[n][2], v[n][3])};
+          *(u32x2*)(yrow + f) = o;
+        }
       }
     }
   }
 }
 
-template <int TN, int EPI>
+template <int NF, int NT, int WN, int WM, int EPI>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
-  constexpr int BN = 2 * TN * 32, BM = 256;
+  constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
   constexpr int SMEM = 2 * (BN + BM) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<TN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return AKI_ERR_LAUNCH;
     attr_set = true;
   }
@@ -251,9 +281,21 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (n_out + bn_out - 1) / bn_out;
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL((gemm_bf16_kernel<TN, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(512), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
+}
+
+int g_force_tile = 0;  // test hook (aki_debug_set_gemm_tile): 0 = heuristic, 1 = 256^2, 2 = 128^2
+
+// 256^2 tiles run one workgroup per CU; 128^2 tiles two (half speed each, ~25 % less operand reuse).
+static bool prefer_small_tiles(int M, int n_out, int bn_big, int bn_small) {
+  if (g_force_tile) return g_force_tile == 2;
+  const long tb = (long)((M + 255) / 256) * ((n_out + bn_big - 1) / bn_big);
+  const long ts = (long)((M + 127) / 128) * ((n_out + bn_small - 1) / bn_small);
+  const double big = (double)((tb + 255) / 256);
+  const double small = (double)((ts + 511) / 512) * (0.5 / 0.75);
+  return small < big;
 }
 
 int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
@@ -269,11 +311,14 @@ int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
   p.residual = (const bf16_t*)a->residual; p.y = (bf16_t*)a->y;
   p.M = a->M; p.N = a->N; p.K = a->K; p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr;
   p.res_row_mod = a->res_row_mod; p.act = a->act;
+  p.wide = (n_out % 8 == 0) && (a->ldy % 8 == 0) && (((uintptr_t)a->y & 15) == 0);
   if (a->act == AKI_ACT_SWIGLU) {
     if (a->bias) return AKI_ERR_UNSUPPORTED;
-    return launch_gemm<4, EPI_SWIGLU>(p, stream);
+    if (prefer_small_tiles(a->M, n_out, 128, 64)) return launch_gemm<4, 4, 2, 2, EPI_SWIGLU>(p, stream);
+    return launch_gemm<8, 4, 2, 4, EPI_SWIGLU>(p, stream);
   }
-  return launch_gemm<4, EPI_PLAIN>(p, stream);
+  if (prefer_small_tiles(a->M, n_out, 256, 128)) return launch_gemm<4, 4, 2, 2, EPI_PLAIN>(p, stream);
+  return launch_gemm<8, 4, 2, 4, EPI_PLAIN>(p, stream);
 }
 
 int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStream_t stream) {
@@ -287,7 +332,7 @@ int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStre
   p.M = a->B * a->L; p.N = 3 * a->H * a->Dh; p.K = a->d_model; p.ldx = a->ldx; p.ldw = a->ldw;
   p.q_out = (bf16_t*)q; p.k_out = (bf16_t*)k; p.v_out = (bf16_t*)v;
   p.cos = a->cos; p.sin = a->sin; p.position_ids = a->position_ids; p.H = a->H; p.L = a->L;
-  return launch_gemm<3, EPI_QKV_ROPE>(p, stream);
+  return launch_gemm<6, 4, 2, 4, EPI_QKV_ROPE>(p, stream);
 }
 
 }  // namespace aki

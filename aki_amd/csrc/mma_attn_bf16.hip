@@ -32,7 +32,6 @@ struct AttnParams {
   const aki_mma_rect* rects;
   const uint64_t* vbits;
   const int* seq_lens;
-  const float* vmean;  // [B,H,96] f32: column mean of V (uniform softmax of rows with no visible column)
   int max_rects;
   int B, H, L;
   int nqt, nwords;
@@ -93,10 +92,16 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
       if (row >= r.row_lo && row < r.row_hi) { rc0 = r.col_lo; rc1 = r.col_hi; }
     }
   }
+  // Rows >= seq_len are the all-zero mask rows of batch stacking: under the reference's finfo.min hand-off they
+  // get a UNIFORM softmax over all L columns.  They run through the normal MFMA path as "every column visible,
+  // score 0"; a workgroup that owns such rows therefore walks all KV tiles.
+  if (p.dead_uniform && q0 + BQ > Lb) hi_col = L;
   const int jend = (hi_col + 63) >> 6;
   const bool wave_alive = wq0 < Lb;            // wave-uniform
   const bool wave_has_dead = wq0 + 32 > Lb;    // some rows of the wave are beyond seq_len
   const bool row_alive = row < Lb;
+  const bool has_uniform = p.dead_uniform && wave_has_dead;   // wave-uniform
+  const bool row_uniform = p.dead_uniform && !row_alive;
 
   const bf16_t* qb = p.q + ((size_t)bh * L) * 96;
   const char* kb = (const char*)(p.k + ((size_t)bh * L) * 96);
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     const bool causal_none = (c0 > wq0 + 31);
     const bool rect_full = (c0 >= full_lo && c0 + 64 <= full_hi);
     const bool rect_touch = (c0 < touch_hi && c0 + 64 > touch_lo);
-    const bool skip = !wave_alive || vb == 0ull || (causal_none && !rect_touch);
+    const bool skip = !has_uniform && (!wave_alive || vb == 0ull || (causal_none && !rect_touch));
     if (!skip) {
       const char* Kb = sK + (j & 1) * KTILE;
       const char* Vb = sV + (j & 1) * VTILE;
@@ -188,13 +193,15 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
             const int c = ck + cr;
             bool vis = (c <= row) | ((c >= rc0) & (c < rc1));
             vis = vis & (((vbh >> cr) & 1ull) != 0ull) & row_alive;
-            s0[r] = vis ? s0[r] : -INFINITY;
+            vis = vis | (row_uniform & (c < L));
+            s0[r] = vis ? (row_uniform ? 0.f : s0[r]) : -INFINITY;
           }
           {
             const int c = ck + cr + 32;
             bool vis = (c <= row) | ((c >= rc0) & (c < rc1));
             vis = vis & (((vbh >> (cr + 32)) & 1ull) != 0ull) & row_alive;
-            s1[r] = vis ? s1[r] : -INFINITY;
+            vis = vis | (row_uniform & (c < L));
+            s1[r] = vis ? (row_uniform ? 0.f : s1[r]) : -INFINITY;
           }
         }
       }
@@ -238,13 +245,13 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     __syncthreads();
   }
 
-  // ---- epilogue: O = O^T / l, rows with no visible column -> uniform softmax (mean of V) or zero ----
+  // ---- epilogue: O = O^T / l.  A row that is inside seq_len but saw no visible column at all (e.g. left padding)
+  // is rare: under AKI_DEAD_ROWS_UNIFORM its lanes average V themselves; otherwise it is written as zeros. ----
   const float l_tot = halves_sum(l_part);
   if (row < L) {
     const bool dead = !(l_tot > 0.f);
     const float inv = dead ? 0.f : 1.0f / l_tot;
     bf16_t* orow = p.o + ((size_t)(b * L + row) * p.H + head) * 96 + 4 * h;
-    const float* vm = p.vmean + (size_t)bh * 96 + 4 * h;
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
@@ -253,8 +260,14 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = o[dt][4 * q4 + e] * inv;
         if (dead && p.dead_uniform) {
-          const f32x4 mv = *(const f32x4*)(vm + dt * 32 + q4 * 8);
-          v[0] = mv[0]; v[1] = mv[1]; v[2] = mv[2]; v[3] = mv[3];
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+          const char* vp = vb_ + (dt * 32 + q4 * 8 + 4 * h) * 2;
+          for (int t2 = 0; t2 < L; ++t2) {
+            const u32x2 w2 = *(const u32x2*)(vp + (size_t)t2 * 192);
+            a0 += bf16_lo(w2[0]); a1 += bf16_hi(w2[0]); a2 += bf16_lo(w2[1]); a3 += bf16_hi(w2[1]);
+          }
+          const float il = 1.0f / (float)L;
+          v[0] = a0 * il; v[1] = a1 * il; v[2] = a2 * il; v[3] = a3 * il;
         }
         u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         *(u32x2*)(orow + dt * 32 + q4 * 8) = pk;
@@ -263,40 +276,21 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   }
 }
 
-// column mean of V over all L rows, f32 [B,H,96]
-__global__ void vmean_bf16_kernel(const bf16_t* v, float* out, int L) {
-  __shared__ float red[4][96];
-  const int bh = blockIdx.x, d = threadIdx.x % 96, part = threadIdx.x / 96;  // 384 threads
-  const bf16_t* base = v + (size_t)bh * L * 96;
-  float s = 0.f;
-  for (int t = part; t < L; t += 4) s += bf16_bits_to_f32(base[(size_t)t * 96 + d]);
-  red[part][d] = s;
-  __syncthreads();
-  if (part == 0) out[(size_t)bh * 96 + d] = (red[0][d] + red[1][d] + red[2][d] + red[3][d]) / (float)L;
-}
-
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (a->Dh != 96) return AKI_ERR_UNSUPPORTED;
   if (a->max_rects < 0 || a->max_rects > AKI_MAX_RECTS) return AKI_ERR_INVALID_ARG;
   AKI_CHECK_ALIGN16(a->q); AKI_CHECK_ALIGN16(a->k); AKI_CHECK_ALIGN16(a->v); AKI_CHECK_ALIGN16(a->o);
-  const size_t need = (size_t)a->B * a->H * 96 * sizeof(float);
-  if (!ws || ws_bytes < need) return AKI_ERR_WORKSPACE;
-  AKI_CHECK_ALIGN16(ws);
+  (void)ws; (void)ws_bytes;  // the bf16 path needs no scratch (kept in the signature for the f32 path)
   constexpr int NW = 4;
   AttnParams p = {};
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.o = (bf16_t*)a->o; p.lse = a->lse;
-  p.rects = a->rects; p.vbits = a->col_valid_bits; p.seq_lens = a->seq_lens; p.vmean = (const float*)ws;
+  p.rects = a->rects; p.vbits = a->col_valid_bits; p.seq_lens = a->seq_lens;
   p.max_rects = a->rects ? a->max_rects : 0;
   p.B = a->B; p.H = a->H; p.L = a->L;
   p.nqt = (a->L + NW * 32 - 1) / (NW * 32);
   p.nwords = (a->L + 63) / 64;
   p.scale_log2 = a->scale * 1.44269504088896340736f;
   p.dead_uniform = a->dead_rows == AKI_DEAD_ROWS_UNIFORM;
-  if (p.dead_uniform) {
-    AKI_CLEAR_ERR();
-    hipLaunchKernelGGL(vmean_bf16_kernel, dim3(a->B * a->H), dim3(384), 0, stream, p.v, (float*)ws, a->L);
-    AKI_LAUNCH_CHECK();
-  }
   AKI_CLEAR_ERR();
   hipLaunchKernelGGL((mma_attn_bf16_kernel<NW>), dim3(a->B * a->H * p.nqt), dim3(NW * 64), 0, stream, p);
   AKI_LAUNCH_CHECK();

@@ -49,6 +49,8 @@ typedef enum {
 
 const char* aki_strerror(int status);
 int aki_abi_version(void);
+/* Test hook: force the bf16 GEMM tile configuration (0 = heuristic, 1 = 256x256, 2 = 128x128).  Not thread safe. */
+void aki_debug_set_gemm_tile(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * Mask description.  The reference materialises a dense (B,1,L,L) int64 0/1 tensor

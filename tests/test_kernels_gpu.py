@@ -65,10 +65,22 @@ DTYPES = [torch.bfloat16, torch.float32]
 # ------------------------------------------------------------------------------------------------
 # linear
 # ------------------------------------------------------------------------------------------------
+@pytest.fixture(params=[0, 1, 2], ids=["tile-auto", "tile-256", "tile-128"])
+def gemm_tile(request):
+    """Run the bf16 GEMM tests under the heuristic and with each tile configuration forced."""
+    from aki_amd import _lib
+    lib = _lib.load()
+    lib.aki_debug_set_gemm_tile(request.param)
+    yield request.param
+    lib.aki_debug_set_gemm_tile(0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(300, 512, 256), (256, 256, 64), (1, 768, 128), (700, 1152, 640), (513, 36, 192)])
-def test_linear_plain_bias_act_residual(dtype, M, N, K):
+def test_linear_plain_bias_act_residual(dtype, M, N, K, gemm_tile):
     ops = _ops()
+    if dtype == torch.float32 and gemm_tile:
+        pytest.skip("tile configuration only affects the bf16 kernel")
     rng = gen.rng_for(f"lin{M}{N}{K}")
     x = rng.standard_normal((M, K), dtype=np.float32)
     w = rng.standard_normal((N, K), dtype=np.float32) * 0.05
@@ -93,8 +105,10 @@ def test_linear_plain_bias_act_residual(dtype, M, N, K):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,Nout,K", [(300, 256, 128), (130, 320, 64), (515, 128, 192)])
-def test_linear_swiglu(dtype, M, Nout, K):
+def test_linear_swiglu(dtype, M, Nout, K, gemm_tile):
     ops = _ops()
+    if dtype == torch.float32 and gemm_tile:
+        pytest.skip("tile configuration only affects the bf16 kernel")
     rng = gen.rng_for(f"swiglu{M}{Nout}{K}")
     x = rng.standard_normal((M, K), dtype=np.float32)
     w = rng.standard_normal((2 * Nout, K), dtype=np.float32) * 0.08
@@ -105,7 +119,7 @@ def test_linear_swiglu(dtype, M, Nout, K):
     check(n(y), want, dtype, "swiglu")
 
 
-def test_linear_identity_layout_bf16():
+def test_linear_identity_layout_bf16(gemm_tile):
     """A = I against an asymmetric W: catches a transposed or permuted accumulator map (cdna guide section 3)."""
     ops = _ops()
     K = N = 256
@@ -221,6 +235,27 @@ def test_mma_attn_core_no_table_is_causal(dtype):
     want = O.mma_attention_core_spans(rnd(q, dtype), rnd(k, dtype), rnd(v, dtype), np.ones((B, L), dtype=np.int64),
                                       [[(0, 0, 0, 0)]] * B, 96 ** -0.5)
     check(n(o), want, dtype, "causal")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dead_rows", [1, 0])
+def test_mma_attn_core_left_padding_dead_rows(dtype, dead_rows):
+    """Left padding: the first rows are inside seq_len but see no valid column -> uniform softmax over all L columns
+    (reference convention, AKI_DEAD_ROWS_UNIFORM) or zeros (AKI_DEAD_ROWS_ZERO)."""
+    ops = _ops()
+    B, H, L = 2, 2, 100
+    q, k, v, _, _, _ = _attn_case("leftpad", B, H, L, dtype, pad=False, dead=False)
+    am = np.ones((B, L), dtype=np.int64)
+    am[0, :7] = 0
+    am[1, :40] = 0
+    rects = [[(10, 30, 30, 80)], [(0, 0, 0, 0)]]
+    table = ops.MaskTable.from_host(rects, am, None, DEV)
+    o = ops.mma_attn_core(t(q, dtype), t(k, dtype), t(v, dtype), table, 96 ** -0.5, dead_rows=dead_rows)
+    want = O.mma_attention_core_spans(rnd(q, dtype), rnd(k, dtype), rnd(v, dtype), am, rects, 96 ** -0.5)
+    if not dead_rows:
+        want[0, :7] = 0
+        want[1, :40] = 0
+    check(n(o), want, dtype, f"left padding, dead_rows={dead_rows}")
 
 
 def test_mma_attn_core_online_softmax_rescale_forced_bf16():

@@ -8,15 +8,22 @@ from aki_amd import ops
 dev = "cuda"
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=20, warm=3, rounds=3):
+    """Back-to-back launches between one event pair (the GPU stays busy; CPU launch overhead is hidden for kernels
+    longer than ~30 us).  Returns (median, min) ms per call over `rounds` rounds."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for a, b in ev:
-        a.record(); fn(); b.record()
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    ts = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / iters)
+    ts.sort()
     return ts[len(ts) // 2], ts[0]
 
 
