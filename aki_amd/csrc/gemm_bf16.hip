@@ -41,6 +41,7 @@ struct GemmParams {
   int M, N, K;  // N = weight rows
   int ldx, ldw, ldy, ldr;
   int res_row_mod;
+  int m_offset;  // global index of row 0 (tail launches): residual row = (m + m_offset) % res_row_mod, token index for QKV
   int act;
   int tiles_m, tiles_n;
   int wide;  // 16-byte stores allowed (n_out % 8 == 0, ldy % 8 == 0, y 16-B aligned)
@@ -62,7 +63,10 @@ __device__ __forceinline__ u32x4 pair_to_wide(unsigned p0, unsigned p1, unsigned
   return o;
 }
 
-template <int NF, int NT, int WN, int WM, int EPI>
+// ACT is a template parameter on purpose: with a runtime switch the 32-fold unrolled epilogue inlines 32 copies of
+// erff/tanhf; even when never executed they bloat the code enough to cost 13 % on the large GEMMs (I-cache misses
+// once per tile; measured in tools/gemm_lab.hip against the identical kernel without them).
+template <int NF, int NT, int WN, int WM, int EPI, int ACT>
 __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int BK = 64, NWAVES = WN * WM;
   constexpr int WROWS = NF * 16;      // features per wave
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     for (int m = 0; m < NT; ++m) {
       const int mrow = m0 + wm * WTOK + m * 16 + l15;
       const bool ok = mrow < p.M;
-      const int mr = min(mrow, p.M - 1);
+      const int mr = min(mrow, p.M - 1) + p.m_offset;   // global token index
       const int b = mr / p.L, tt = mr - b * p.L;
       float v[NF][4];
       if (which < 2) {
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     const int mr = min(mrow, p.M - 1);
     bf16_t* yrow = p.y + (size_t)mr * p.ldy;
     const bf16_t* rrow = nullptr;
-    if (p.residual) rrow = p.residual + (size_t)(p.res_row_mod > 0 ? mr % p.res_row_mod : mr) * p.ldr;
+    if (p.residual) rrow = p.residual + (size_t)(p.res_row_mod > 0 ? (mr + p.m_offset) % p.res_row_mod : mr) * p.ldr;
     float v[NOUT][4];
 #pragma unroll
     for (int n = 0; n < NOUT; ++n) {
@@ -232,10 +236,10 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
           const u32x2 bb = *(const u32x2*)(p.bias + f);
           v[n][0] += bf16_lo(bb[0]); v[n][1] += bf16_hi(bb[0]); v[n][2] += bf16_lo(bb[1]); v[n][3] += bf16_hi(bb[1]);
         }
-        if (p.act == AKI_ACT_GELU_ERF) {
+        if (ACT == AKI_ACT_GELU_ERF) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[n][r] = gelu_erf(v[n][r]);
-        } else if (p.act == AKI_ACT_GELU_TANH) {
+        } else if (ACT == AKI_ACT_GELU_TANH) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[n][r] = gelu_tanh(v[n][r]);
         }
@@ -266,13 +270,13 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   }
 }
 
-template <int NF, int NT, int WN, int WM, int EPI>
+template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
   constexpr int SMEM = 2 * (BN + BM) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return AKI_ERR_LAUNCH;
     attr_set = true;
   }
@@ -281,21 +285,48 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (n_out + bn_out - 1) / bn_out;
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }
 
 int g_force_tile = 0;  // test hook (aki_debug_set_gemm_tile): 0 = heuristic, 1 = 256^2, 2 = 128^2
 
-// 256^2 tiles run one workgroup per CU; 128^2 tiles two (half speed each, ~25 % less operand reuse).
-static bool prefer_small_tiles(int M, int n_out, int bn_big, int bn_small) {
-  if (g_force_tile) return g_force_tile == 2;
-  const long tb = (long)((M + 255) / 256) * ((n_out + bn_big - 1) / bn_big);
-  const long ts = (long)((M + 127) / 128) * ((n_out + bn_small - 1) / bn_small);
-  const double big = (double)((tb + 255) / 256);
-  const double small = (double)((ts + 511) / 512) * (0.5 / 0.75);
-  return small < big;
+// Cost model in units of one 256x256 tile's run time.  256^2 tiles: one workgroup per CU.  128-token tiles do a
+// quarter of the work at ~75 % of the efficiency; up to 256 of them run one per CU, beyond that two share a CU.
+static double cost_big(long tiles) { return (double)((tiles + 255) / 256); }
+static double cost_small(long tiles) { return tiles <= 256 ? (tiles ? 0.25 / 0.75 : 0.0) : (double)((tiles + 511) / 512) * (0.5 / 0.75); }
+
+// plan: 0 = all big, 1 = all small, 2 = big on the first floor(M/256)*256 rows + small tiles on the M tail
+// (removes the wave-quantisation loss of a last, mostly idle round: 1344 tiles on 256 CUs = 5.25 rounds).
+static int plan_tiles(int M, int n_out, int bn_big, int bn_small) {
+  if (g_force_tile) return g_force_tile == 2 ? 1 : 0;
+  const long nb = (n_out + bn_big - 1) / bn_big, ns = (n_out + bn_small - 1) / bn_small;
+  const double all_big = cost_big((long)((M + 255) / 256) * nb);
+  const double all_small = cost_small((long)((M + 127) / 128) * ns);
+  const int m_main = M / 256 * 256, tail = M - m_main;
+  double split = 1e30;
+  if (m_main > 0 && tail > 0) split = cost_big((long)(m_main / 256) * nb) + cost_small((long)((tail + 127) / 128) * ns);
+  if (all_small < all_big && all_small <= split) return 1;
+  if (split < all_big) return 2;
+  return 0;
+}
+
+template <int EPI, int ACT>
+static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
+  if (plan == 1) return launch_gemm<4, 4, 2, 2, EPI, ACT>(p, stream);
+  if (plan == 0) return launch_gemm<8, 4, 2, 4, EPI, ACT>(p, stream);
+  const int m_main = p.M / 256 * 256;
+  GemmParams a = p, b = p;
+  a.M = m_main;
+  int rc = launch_gemm<8, 4, 2, 4, EPI, ACT>(a, stream);
+  if (rc) return rc;
+  b.M = p.M - m_main;
+  b.m_offset = p.m_offset + m_main;
+  b.x = p.x + (size_t)m_main * p.ldx;
+  b.y = p.y + (size_t)m_main * p.ldy;
+  if (p.residual && p.res_row_mod <= 0) b.residual = p.residual + (size_t)m_main * p.ldr;
+  return launch_gemm<4, 4, 2, 2, EPI, ACT>(b, stream);
 }
 
 int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
@@ -314,11 +345,14 @@ int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
   p.wide = (n_out % 8 == 0) && (a->ldy % 8 == 0) && (((uintptr_t)a->y & 15) == 0);
   if (a->act == AKI_ACT_SWIGLU) {
     if (a->bias) return AKI_ERR_UNSUPPORTED;
-    if (prefer_small_tiles(a->M, n_out, 128, 64)) return launch_gemm<4, 4, 2, 2, EPI_SWIGLU>(p, stream);
-    return launch_gemm<8, 4, 2, 4, EPI_SWIGLU>(p, stream);
+    return run_planned<EPI_SWIGLU, 0>(p, plan_tiles(a->M, n_out, 128, 64), stream);
   }
-  if (prefer_small_tiles(a->M, n_out, 256, 128)) return launch_gemm<4, 4, 2, 2, EPI_PLAIN>(p, stream);
-  return launch_gemm<8, 4, 2, 4, EPI_PLAIN>(p, stream);
+  const int plan = plan_tiles(a->M, n_out, 256, 128);
+  switch (a->act) {
+    case AKI_ACT_GELU_ERF: return run_planned<EPI_PLAIN, AKI_ACT_GELU_ERF>(p, plan, stream);
+    case AKI_ACT_GELU_TANH: return run_planned<EPI_PLAIN, AKI_ACT_GELU_TANH>(p, plan, stream);
+    default: return run_planned<EPI_PLAIN, 0>(p, plan, stream);
+  }
 }
 
 int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStream_t stream) {
@@ -332,7 +366,19 @@ int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStre
   p.M = a->B * a->L; p.N = 3 * a->H * a->Dh; p.K = a->d_model; p.ldx = a->ldx; p.ldw = a->ldw;
   p.q_out = (bf16_t*)q; p.k_out = (bf16_t*)k; p.v_out = (bf16_t*)v;
   p.cos = a->cos; p.sin = a->sin; p.position_ids = a->position_ids; p.H = a->H; p.L = a->L;
-  return launch_gemm<6, 4, 2, 4, EPI_QKV_ROPE>(p, stream);
+  // same planning for the 192-feature QKV tiles (small = 192 x 128, 4 waves)
+  const int plan = plan_tiles(p.M, p.N, 192, 192);
+  if (plan == 1) return launch_gemm<6, 4, 2, 2, EPI_QKV_ROPE>(p, stream);
+  if (plan == 0) return launch_gemm<6, 4, 2, 4, EPI_QKV_ROPE>(p, stream);
+  const int m_main = p.M / 256 * 256;
+  GemmParams a1 = p, b1 = p;
+  a1.M = m_main;
+  int rc = launch_gemm<6, 4, 2, 4, EPI_QKV_ROPE>(a1, stream);
+  if (rc) return rc;
+  b1.M = p.M - m_main;
+  b1.m_offset = m_main;
+  b1.x = p.x + (size_t)m_main * p.ldx;
+  return launch_gemm<6, 4, 2, 2, EPI_QKV_ROPE>(b1, stream);
 }
 
 }  // namespace aki

@@ -328,6 +328,42 @@ def test_qkv_rope_stage_bf16():
     check(n(v), hd(qkv[..., 2 * d:]), torch.bfloat16, "v")
 
 
+def test_qkv_rope_full_width_with_m_tail_split_bf16():
+    """AKI-4B width (d=3072, 32 heads) at M = 1380 = 5*256 + 100: exercises the big-tile + M-tail launch pair of the
+    QKV kernel (token index / position ids must stay global in the tail launch)."""
+    ops = _ops()
+    B, L, H = 2, 690, 32
+    d = 96 * H
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(B, L, d, generator=g).to(torch.bfloat16)
+    w = (torch.randn(3 * d, d, generator=g) * 0.02).to(torch.bfloat16)
+    cos, sin = O.rope_cos_sin(np.arange(L)[None], 96)
+    q, k, v = ops.qkv_rope(x.to(DEV), w.to(DEV), torch.from_numpy(cos[0]).to(DEV), torch.from_numpy(sin[0]).to(DEV), H)
+    qkv = x.float().numpy().reshape(B * L, d) @ w.float().numpy().T
+    qkv = qkv.reshape(B, L, 3 * d)
+    hd = lambda a: a.reshape(B, L, H, 96).transpose(0, 2, 1, 3)
+    qw, kw = O.apply_rope(hd(qkv[..., :d]), hd(qkv[..., d:2 * d]), cos, sin)
+    check(n(q), qw, torch.bfloat16, "q rope (tail split)")
+    check(n(k), kw, torch.bfloat16, "k rope (tail split)")
+    check(n(v), hd(qkv[..., 2 * d:]), torch.bfloat16, "v (tail split)")
+
+
+def test_linear_m_tail_split_with_row_mod_residual_bf16():
+    """Split launch + residual row-modulo (position-embedding style): the modulo must use the global row index."""
+    ops = _ops()
+    M, N, K, mod = 1380, 16384, 256, 729
+    g = torch.Generator(device="cpu").manual_seed(6)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    r = torch.randn(mod, N, generator=g).to(torch.bfloat16)
+    b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)
+    y = ops.linear(x.to(DEV), w.to(DEV), bias=b.to(DEV), residual=r.to(DEV), res_row_mod=mod)
+    want = x.float().numpy() @ w.float().numpy().T + b.float().numpy() + r.float().numpy()[np.arange(M) % mod]
+    check(n(y), want, torch.bfloat16, "tail split + row-mod residual")
+    y2 = ops.linear(x.to(DEV), w.to(DEV), residual=y)
+    check(n(y2), x.float().numpy() @ w.float().numpy().T + n(y), torch.bfloat16, "tail split + plain residual")
+
+
 def test_attention_full_size_bf16_vs_f32_kernel_and_oracle_heads():
     """Config 2 of BASELINE.json (B=8, H=32, L=655): bf16 MFMA kernel vs the exact-f32 kernel on all heads, and
     both vs the oracle on two (batch, head) pairs; plus the permutation property of softmax(V)."""

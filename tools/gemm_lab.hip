@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "aki_device.h"
+#include "aki_mi355x.h"
 
 using namespace aki;
 
@@ -398,6 +399,18 @@ static float run_k16(P p, int iters, hipStream_t s) {
 static inline float bf2f(bf16_t b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
 static inline bf16_t f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (bf16_t)(u >> 16); }
 
+static float run_product(P p, int iters, hipStream_t s, int act) {
+  aki_linear_args a = {};
+  a.x = p.x; a.w = p.w; a.y = p.y; a.M = p.M; a.N = p.N; a.K = p.K; a.ldx = p.K; a.ldw = p.K; a.ldy = act == 3 ? p.N / 2 : p.N;
+  a.act = act; a.dtype = AKI_DT_BF16;
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  CHECK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) { int rc = aki_linear_fwd(&a, s); if (rc) { printf("aki_linear_fwd rc=%d\n", rc); exit(1); } }
+  CHECK(hipEventRecord(e1, s)); CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / iters;
+}
+
 template <int VAR, int ABL>
 static float run(P p, int iters, hipStream_t s) {
   constexpr int SMEM = 2 * 512 * 128;
@@ -433,8 +446,8 @@ int main() {
       t = run<0, 0>(p, 10, s); best[0] = fminf(best[0], t);
       t = run_k16<0>(p, 10, s); best[1] = fminf(best[1], t);
       t = run_k16<1>(p, 10, s); best[2] = fminf(best[2], t);
-      t = run<7, 0>(p, 10, s); best[3] = fminf(best[3], t);
-      t = run<7, 3>(p, 10, s); best[4] = fminf(best[4], t);
+      t = run_product(p, 10, s, 0); best[3] = fminf(best[3], t);
+      t = run_product(p, 10, s, 3); best[4] = fminf(best[4], t);
       t = run<0, 1>(p, 10, s); best[5] = fminf(best[5], t);
       t = run<0, 2>(p, 10, s); best[6] = fminf(best[6], t);
       t = run<0, 3>(p, 10, s); best[7] = fminf(best[7], t);
@@ -443,7 +456,7 @@ int main() {
     double maxerr[5] = {0};
     for (int v = 0; v < 5; ++v) {
       CHECK(hipMemset(dy, 0, ny * 2));
-      if (v == 0) run<0, 0>(p, 1, s); if (v == 1) run_k16<0>(p, 1, s); if (v == 2) run_k16<1>(p, 1, s); if (v == 3) run<7, 0>(p, 1, s); if (v == 4) continue;
+      if (v == 0) run<0, 0>(p, 1, s); if (v == 1) run_k16<0>(p, 1, s); if (v == 2) run_k16<1>(p, 1, s); if (v == 3) run_product(p, 1, s, 0); if (v == 4) continue;
       CHECK(hipStreamSynchronize(s));
       int rows[3] = {0, sh.M / 2 + 1, sh.M - 1};
       for (int r : rows) {
@@ -456,7 +469,7 @@ int main() {
         }
       }
     }
-    const char* names[8] = {"baseline", "16x16x32", "16x16x32 wide stores", "V7 +wide stores", "V7 no-store", "ABL no-glds", "ABL no-ds_read", "ABL no-store"};
+    const char* names[8] = {"baseline", "16x16x32", "16x16x32 wide stores", "PRODUCT aki_linear_fwd plain", "PRODUCT aki_linear_fwd swiglu", "ABL no-glds", "ABL no-ds_read", "ABL no-store"};
     printf("== %s M=%d N=%d K=%d\n", sh.name, sh.M, sh.N, sh.K);
     for (int i = 0; i < 8; ++i) printf("   %-20s %8.4f ms  %7.1f TF/s%s\n", names[i], best[i], fl / best[i] / 1e9, i < 5 ? (maxerr[i] < 2e-2 ? "  ok" : "  WRONG") : "");
     CHECK(hipFree(dx)); CHECK(hipFree(dw)); CHECK(hipFree(dy));
