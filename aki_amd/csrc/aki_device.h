@@ -41,6 +41,27 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
+// Fast forms for the bf16 MFMA epilogues (v_exp_f32 + v_rcp_f32, a handful of FMAs).  Absolute errors are below
+// 1e-6 relative to |x| - three orders of magnitude under the bf16 output resolution; the f32 parity path keeps the
+// library erff/tanhf.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+}
+__device__ __forceinline__ float silu_fast(float x) { return x * fast_sigmoid(x); }
+// 0.5 (1 + tanh u) == sigmoid(2u)
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+  const float u = 0.79788456080286535588f * (x + 0.044715f * x * x * x);
+  return x * fast_sigmoid(2.0f * u);
+}
+// erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erfz = 1.0f - poly * __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+  return 0.5f * x * (1.0f + copysignf(erfz, x));
+}
+
 // Exchange across the two 32-lane halves with v_permlane32_swap: after swap(a = x, b = x),
 // a = [x_lo, x_lo] and b = [x_hi, x_hi] (row = 32 lanes).  Inline asm on purpose: with the builtin
 // (__builtin_amdgcn_permlane32_swap) hipcc / ROCm 7.2 -O3 folds the SECOND result into the first

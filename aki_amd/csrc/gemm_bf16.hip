@@ -226,7 +226,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
       for (int r = 0; r < 4; ++r) {
         if (EPI == EPI_SWIGLU) {
           const float g = acc[n][m][r], u = acc[n + NF / 2][m][r];
-          v[n][r] = u * silu(g);
+          v[n][r] = u * silu_fast(g);
         } else {
           v[n][r] = acc[n][m][r];
         }
@@ -238,10 +238,10 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
         }
         if (ACT == AKI_ACT_GELU_ERF) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[n][r] = gelu_erf(v[n][r]);
+          for (int r = 0; r < 4; ++r) v[n][r] = gelu_erf_fast(v[n][r]);
         } else if (ACT == AKI_ACT_GELU_TANH) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[n][r] = gelu_tanh(v[n][r]);
+          for (int r = 0; r < 4; ++r) v[n][r] = gelu_tanh_fast(v[n][r]);
         }
       }
       if (rrow && fin) {

@@ -44,15 +44,33 @@ constexpr int VROW = 192;
 constexpr int KTILE = 64 * KROW;
 constexpr int VTILE = 64 * VROW;
 
+constexpr int MAX_VB_WORDS = 256;  // L <= 16384
+
+// v_max3_f32 without the canonicalising v_max hipcc inserts in front of fmaxf on MFMA results
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// A lane's 32 score columns of a 64-key tile, in register order i = 16*kb + r, are
+//   col(i) = c0 + 4h + (i&3) + 8*((i&15)>>2) + 32*(i>>4)      (strictly increasing in i)
+// so "col <= y" is a PREFIX of the register order.  count_le(x) = number of i with col(i) - (c0+4h) <= x.
+__device__ __forceinline__ int count_le(int x) {
+  const int n = 4 * (x >> 3) + min((x & 7) + 1, 4);
+  return x < 0 ? 0 : min(n, 32);
+}
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnParams p) {
   constexpr int BQ = NW * 32;
   constexpr int NT = NW * 64;
   constexpr int NCH = (64 * 12 + NT - 1) / NT;  // 16-B chunks per thread per tile (K and V each)
-  __shared__ __attribute__((aligned(16))) char smem[2 * KTILE + 2 * VTILE + AKI_MAX_RECTS * 16];
+  __shared__ __attribute__((aligned(16))) char smem[2 * KTILE + 2 * VTILE + AKI_MAX_RECTS * 16 + MAX_VB_WORDS * 8];
   char* const sK = smem;
   char* const sV = smem + 2 * KTILE;
   const aki_mma_rect* sR = (const aki_mma_rect*)(smem + 2 * KTILE + 2 * VTILE);
+  unsigned long long* const sVB = (unsigned long long*)(smem + 2 * KTILE + 2 * VTILE + AKI_MAX_RECTS * 16);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,6 +90,14 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     u32x4 r = {0u, 0u, 0u, 0u};
     if (tid < p.max_rects) r = ((const u32x4*)p.rects)[(size_t)b * p.max_rects + tid];
     ((u32x4*)sR)[tid] = r;
+  }
+  // Valid-column words of this sample go to LDS once: a per-tile global load would share the vmcnt queue with the
+  // K/V prefetch and its wait would drain the prefetch before the tile's compute (measured: 3x slower loop).
+  for (int w = tid; w < p.nwords; w += NT) {
+    unsigned long long vbw;
+    if (p.vbits) vbw = p.vbits[(size_t)b * p.nwords + w];
+    else vbw = (w * 64 + 64 <= L) ? ~0ull : ((1ull << (L - w * 64)) - 1ull);
+    sVB[w] = vbw;
   }
   __syncthreads();
 
@@ -152,18 +178,24 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   const int koff = l31 * KROW + h * 16;                                   // + 32*KROW (2nd key block) + ks*32
   const int voff = (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
-  if (jend > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
+  // jend >= 1 always (q0 < L).  The first tile's wait also retires the Q-fragment loads; the explicit vmcnt(0) below
+  // (a builtin, so hipcc's wait-count model sees it) guarantees nothing is pending at loop entry - otherwise the
+  // compiler protects the Q registers with vmcnt(N) waits INSIDE the loop, which there stall on the K/V prefetch
+  // of the next tile instead (measured: the loop ran at load latency).
+  load_tile(0);
+  store_tile(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
 
   for (int j = 0; j < jend; ++j) {
     if (j + 1 < jend) load_tile(j + 1);
     const int c0 = j * 64;
     unsigned long long vb;
-    if (p.vbits) vb = p.vbits[(size_t)b * p.nwords + j];
-    else vb = (c0 + 64 <= L) ? ~0ull : ((1ull << (L - c0)) - 1ull);
+    {
+      const unsigned long long vbv = sVB[j];
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)vbv), hi = __builtin_amdgcn_readfirstlane((unsigned)(vbv >> 32));
+      vb = ((unsigned long long)hi << 32) | lo;
+    }
     const bool causal_full = (c0 + 63 <= wq0);
     const bool causal_none = (c0 > wq0 + 31);
     const bool rect_full = (c0 >= full_lo && c0 + 64 <= full_hi);
@@ -184,32 +216,44 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
       }
       const bool full = (vb == ~0ull) && (causal_full || rect_full) && !wave_has_dead;
       if (!full) {
+        // visibility as prefix / interval tests in register order (see count_le); valid bits that form a prefix
+        // (right padding, the usual case) fold into the same thresholds, anything else takes the per-bit path.
+        const int base = c0 + 4 * h;
+        const bool vprefix = (vb & (vb + 1ull)) == 0ull;                      // wave-uniform
+        const int nvalid = vprefix ? count_le(c0 + (int)__builtin_popcountll(vb) - 1 - base) : 32;
+        int n_c = min(count_le(row - base), nvalid);                          // causal prefix
+        int i0 = count_le(rc0 - 1 - base), i1 = min(count_le(rc1 - 1 - base), nvalid);  // unlock interval [i0, i1)
+        if (!row_alive) { n_c = 0; i0 = 0; i1 = row_uniform ? count_le(L - 1 - base) : 0; }   // uniform rows: every column < L
         const unsigned long long vbh = vb >> (4 * h);
-        const int ck = c0 + 4 * h;
+        if (vprefix) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cr = (r & 3) + 8 * (r >> 2);
-          {
-            const int c = ck + cr;
-            bool vis = (c <= row) | ((c >= rc0) & (c < rc1));
-            vis = vis & (((vbh >> cr) & 1ull) != 0ull) & row_alive;
-            vis = vis | (row_uniform & (c < L));
-            s0[r] = vis ? (row_uniform ? 0.f : s0[r]) : -INFINITY;
+          for (int r = 0; r < 16; ++r) {
+            const bool v0 = (r < n_c) | ((r >= i0) & (r < i1));
+            const bool v1 = (r + 16 < n_c) | ((r + 16 >= i0) & (r + 16 < i1));
+            s0[r] = v0 ? (row_uniform ? 0.f : s0[r]) : -INFINITY;
+            s1[r] = v1 ? (row_uniform ? 0.f : s1[r]) : -INFINITY;
           }
-          {
-            const int c = ck + cr + 32;
-            bool vis = (c <= row) | ((c >= rc0) & (c < rc1));
-            vis = vis & (((vbh >> (cr + 32)) & 1ull) != 0ull) & row_alive;
-            vis = vis | (row_uniform & (c < L));
-            s1[r] = vis ? (row_uniform ? 0.f : s1[r]) : -INFINITY;
+        } else {   // holes in the 1-D mask: per-bit test (rare)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int cr = (r & 3) + 8 * (r >> 2);
+            bool v0 = (r < n_c) | ((r >= i0) & (r < i1));
+            bool v1 = (r + 16 < n_c) | ((r + 16 >= i0) & (r + 16 < i1));
+            v0 = v0 & ((((vbh >> cr) & 1ull) != 0ull) | row_uniform);
+            v1 = v1 & ((((vbh >> (cr + 32)) & 1ull) != 0ull) | row_uniform);
+            s0[r] = v0 ? (row_uniform ? 0.f : s0[r]) : -INFINITY;
+            s1[r] = v1 ? (row_uniform ? 0.f : s1[r]) : -INFINITY;
           }
         }
       }
-      float mx = fmaxf(s0[0], s1[0]);
+      float mx = max3(s0[0], s0[1], s1[0]);
+      mx = max3(mx, s1[1], s0[2]);
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+      for (int r = 3; r < 16; r += 1) mx = max3(mx, s0[r], s1[r - 1]);
+      mx = fmaxf(mx, s1[15]);
       mx = halves_max(mx) * p.scale_log2;
       const float m_new = fmaxf(m_run, mx);
+      const bool moved = m_new != m_run;
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
       float ps = 0.f;
@@ -220,10 +264,12 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
         ps += s0[r] + s1[r];
       }
       l_part = l_part * alpha + ps;
+      if (__any(moved)) {   // after the first tiles the running max rarely moves: skip the 48-register rescale
 #pragma unroll
-      for (int dt = 0; dt < 3; ++dt)
+        for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
 
 #pragma unroll
       for (int ks4 = 0; ks4 < 4; ++ks4) {
@@ -279,6 +325,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (a->Dh != 96) return AKI_ERR_UNSUPPORTED;
   if (a->max_rects < 0 || a->max_rects > AKI_MAX_RECTS) return AKI_ERR_INVALID_ARG;
+  if ((a->L + 63) / 64 > MAX_VB_WORDS) return AKI_ERR_UNSUPPORTED;
   AKI_CHECK_ALIGN16(a->q); AKI_CHECK_ALIGN16(a->k); AKI_CHECK_ALIGN16(a->v); AKI_CHECK_ALIGN16(a->o);
   (void)ws; (void)ws_bytes;  // the bf16 path needs no scratch (kept in the signature for the f32 path)
   constexpr int NW = 4;
