@@ -41,6 +41,15 @@ class MmaAttnArgs(C.Structure):
                 ("dtype", C.c_int32), ("dead_rows", C.c_int32)]
 
 
+class AttnArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
+                ("q_stride_b", C.c_int64), ("q_stride_h", C.c_int64), ("q_stride_t", C.c_int64),
+                ("k_stride_b", C.c_int64), ("k_stride_h", C.c_int64), ("k_stride_t", C.c_int64),
+                ("v_stride_b", C.c_int64), ("v_stride_h", C.c_int64), ("v_stride_t", C.c_int64),
+                ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32), ("Dh", C.c_int32),
+                ("scale", C.c_float), ("dtype", C.c_int32)]
+
+
 class LinearArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldx", C.c_int32), ("ldw", C.c_int32),
@@ -69,6 +78,7 @@ SIGNATURES = {
     "aki_mma_attn_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
     "aki_mma_attn_fwd": (C.c_int, [C.POINTER(MmaAttnArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_qkv_rope_fwd": (C.c_int, [C.POINTER(MmaAttnArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aki_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "aki_rmsnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_float, C.c_int32, C.c_void_p]),

@@ -9,6 +9,7 @@ int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStre
 int qkv_rope_f32(const aki_mma_attn_args* a, void* q, void* k, void* v, float* tmp, hipStream_t stream);
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream);
 int attn_core_f32(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream, int causal);
+int attn_nc_bf16(const aki_attn_args* a, hipStream_t stream);
 int norm_launch(bool rms, const void* x, const void* w, const void* b, void* y, int rows, int cols, int ldx, int ldy,
                 float eps, int dtype, hipStream_t stream);
 int splice_plan_launch(const int64_t* lang_x, int B, int T, int64_t media, int64_t assistant, int Nv, int* plan, hipStream_t s);
@@ -56,6 +57,23 @@ int aki_mma_attn_core_fwd(const aki_mma_attn_core_args* a, void* ws, size_t ws_b
   AKI_CHECK_ARG(a->max_rects >= 0 && (a->max_rects == 0 || a->rects));
   if (a->dtype == AKI_DT_BF16) return attn_core_bf16(a, ws, ws_bytes, (hipStream_t)stream);
   return attn_core_f32(a, ws, ws_bytes, (hipStream_t)stream, 1);
+}
+
+// ---- plain attention (vision side) ---------------------------------------------------------------------
+int aki_attn_fwd(const aki_attn_args* a, void* ws, size_t ws_bytes, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(a && a->q && a->k && a->v && a->o);
+  AKI_CHECK_ARG(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0 && a->Dh > 0 && a->scale > 0.f && dtype_ok(a->dtype));
+  if (a->dtype == AKI_DT_BF16) return attn_nc_bf16(a, (hipStream_t)stream);
+  // f32 parity path: the simple kernel wants contiguous head-major tensors and equal q/kv lengths are not required
+  const int64_t Dh = a->Dh;
+  if (a->q_stride_t != Dh || a->k_stride_t != Dh || a->v_stride_t != Dh || a->q_stride_h != (int64_t)a->Lq * Dh ||
+      a->k_stride_h != (int64_t)a->Lk * Dh || a->v_stride_h != (int64_t)a->Lk * Dh || a->Lq != a->Lk)
+    return AKI_ERR_UNSUPPORTED;
+  aki_mma_attn_core_args c = {};
+  c.q = a->q; c.k = a->k; c.v = a->v; c.o = a->o; c.B = a->B; c.H = a->H; c.L = a->Lq; c.Dh = a->Dh; c.scale = a->scale;
+  c.dtype = AKI_DT_F32; c.dead_rows = AKI_DEAD_ROWS_ZERO;
+  return attn_core_f32(&c, ws, ws_bytes, (hipStream_t)stream, 0);
 }
 
 // ---- fused MMA op ------------------------------------------------------------------------------------

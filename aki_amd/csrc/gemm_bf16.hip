@@ -295,18 +295,21 @@ int g_force_tile = 0;  // test hook (aki_debug_set_gemm_tile): 0 = heuristic, 1 
 // Cost model in units of one 256x256 tile's run time.  256^2 tiles: one workgroup per CU.  128-token tiles do a
 // quarter of the work at ~75 % of the efficiency; up to 256 of them run one per CU, beyond that two share a CU.
 static double cost_big(long tiles) { return (double)((tiles + 255) / 256); }
-static double cost_small(long tiles) { return tiles <= 256 ? (tiles ? 0.25 / 0.75 : 0.0) : (double)((tiles + 511) / 512) * (0.5 / 0.75); }
+// `work` = small-tile work relative to the big tile (0.25 for 128x128 vs 256x256, 0.5 for the 192x128 QKV tile).
+static double cost_small(long tiles, double work) {
+  return tiles <= 256 ? (tiles ? work / 0.75 : 0.0) : (double)((tiles + 511) / 512) * (2.0 * work / 0.75);
+}
 
 // plan: 0 = all big, 1 = all small, 2 = big on the first floor(M/256)*256 rows + small tiles on the M tail
 // (removes the wave-quantisation loss of a last, mostly idle round: 1344 tiles on 256 CUs = 5.25 rounds).
-static int plan_tiles(int M, int n_out, int bn_big, int bn_small) {
+static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_work = 0.25) {
   if (g_force_tile) return g_force_tile == 2 ? 1 : 0;
   const long nb = (n_out + bn_big - 1) / bn_big, ns = (n_out + bn_small - 1) / bn_small;
   const double all_big = cost_big((long)((M + 255) / 256) * nb);
-  const double all_small = cost_small((long)((M + 127) / 128) * ns);
+  const double all_small = cost_small((long)((M + 127) / 128) * ns, small_work);
   const int m_main = M / 256 * 256, tail = M - m_main;
   double split = 1e30;
-  if (m_main > 0 && tail > 0) split = cost_big((long)(m_main / 256) * nb) + cost_small((long)((tail + 127) / 128) * ns);
+  if (m_main > 0 && tail > 0) split = cost_big((long)(m_main / 256) * nb) + cost_small((long)((tail + 127) / 128) * ns, small_work);
   if (all_small < all_big && all_small <= split) return 1;
   if (split < all_big) return 2;
   return 0;
@@ -367,7 +370,7 @@ int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStre
   p.q_out = (bf16_t*)q; p.k_out = (bf16_t*)k; p.v_out = (bf16_t*)v;
   p.cos = a->cos; p.sin = a->sin; p.position_ids = a->position_ids; p.H = a->H; p.L = a->L;
   // same planning for the 192-feature QKV tiles (small = 192 x 128, 4 waves)
-  const int plan = plan_tiles(p.M, p.N, 192, 192);
+  const int plan = plan_tiles(p.M, p.N, 192, 192, 0.5);
   if (plan == 1) return launch_gemm<6, 4, 2, 2, EPI_QKV_ROPE>(p, stream);
   if (plan == 0) return launch_gemm<6, 4, 2, 4, EPI_QKV_ROPE>(p, stream);
   const int m_main = p.M / 256 * 256;

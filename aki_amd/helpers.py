@@ -83,14 +83,11 @@ class PerceiverAttention(nn.Module):
         ln = ops.layernorm(latents, self.norm_latents.weight, self.norm_latents.bias, self.norm_latents.eps)
         q = ops.linear(ln, self.to_q.weight)
         kv = ops.linear(torch.cat((xn, ln), dim=-2), self.to_kv.weight)
-        k, v = kv.chunk(2, dim=-1)
-        q = q.view(b * T, n2, h, dh).transpose(1, 2)
-        k = k.reshape(b * T, n1 + n2, h, dh).transpose(1, 2)
-        v = v.reshape(b * T, n1 + n2, h, dh).transpose(1, 2)
-        # 8 x 64 heads, 873 keys, no mask: stock attention (SURVEY 8(f) #2 lists a fused kernel as "next")
-        out = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
-        out = out.transpose(1, 2).reshape(b, T, n2, h * dh)
-        return ops.linear(out, self.to_out.weight, residual=latents)
+        kv = kv.view(b * T, n1 + n2, 2, h, dh)
+        # 8 x 64 heads, 144 queries over 873 keys: HIP attention reading k / v in place from the fused kv projection
+        # (q * scale then softmax(sim - max) of the reference == softmax(scale * q k^T))
+        out = ops.attention(q.view(b * T, n2, h, dh), kv[:, :, 0], kv[:, :, 1], self.scale)
+        return ops.linear(out.view(b, T, n2, h * dh), self.to_out.weight, residual=latents)
 
 
 class PerceiverResampler(VisionTokenizer):

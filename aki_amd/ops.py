@@ -196,6 +196,36 @@ def mma_attn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: Mask
     return (o, lse) if return_lse else o
 
 
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+    """Plain multi-head attention for the vision side.  q [B,Lq,H,Dh], k/v [B,Lk,H,Dh] as (possibly strided) VIEWS of
+    the projection outputs (channel stride 1) -> o [B,Lq,H*Dh].  bf16 reads the views in place; f32 (parity path)
+    gathers them into contiguous head-major tensors first."""
+    dev = _dev(q, k, v)
+    B, Lq, H, Dh = q.shape
+    Lk = k.shape[1]
+    o = torch.empty((B, Lq, H * Dh), dtype=q.dtype, device=dev)
+    lib = L.load()
+    if q.dtype == torch.float32:
+        if Lq != Lk:  # the f32 parity kernel is square: pad the queries (extra rows are discarded)
+            qp = torch.zeros((B, Lk, H, Dh), dtype=q.dtype, device=dev)
+            qp[:, :Lq] = q
+            return attention(qp, k, v, scale)[:, :Lq].contiguous()
+        q, k, v = (t_.permute(0, 2, 1, 3).contiguous() for t_ in (q, k, v))     # [B,H,L,Dh]
+        st = lambda t_: (t_.stride(0), t_.stride(1), t_.stride(2))
+    else:
+        for t_ in (q, k, v):
+            if t_.stride(3) != 1:
+                raise AkiError("attention: channel stride must be 1")
+        st = lambda t_: (t_.stride(0), t_.stride(2), t_.stride(1))               # (batch, head, token)
+    ws = _ws(B * H * Dh * 4 + 256, dev)
+    a = L.AttnArgs(_ptr(q), _ptr(k), _ptr(v), _ptr(o), *st(q), *st(k), *st(v), B, H, Lq, Lk, Dh, float(scale), _dt(q))
+    end = _TAP.begin(("attention", B, H, Lq, Lk, Dh)) if (_TAP is not None and _TAP.want(("attention",))) else None
+    L.check(lib.aki_attn_fwd(C.byref(a), _ptr(ws), ws.numel(), _stream()), "aki_attn_fwd")
+    if end is not None:
+        end.record()
+    return o
+
+
 def _fused_args(x2, w_qkv, cos, sin, position_ids, o, lse, table, B, H, Lq, Dh, scale, dead_rows):
     return L.MmaAttnArgs(_ptr(x2), _ptr(w_qkv), _ptr(cos), _ptr(sin), _ptr(position_ids), _ptr(o), _ptr(lse),
                          _ptr(table.rects), _ptr(table.col_valid_bits), _ptr(table.seq_lens), table.max_rects,

@@ -4,7 +4,8 @@
 
 Patch embedding = the HIP patch-embed kernel (im2col + MFMA GEMM with bias and position-embedding epilogue).
 Encoder layers: LayerNorm, fused QKV / out / MLP projections on the HIP GEMM (bias, GELU-tanh and residual
-epilogues); the 16 x 72 non-causal attention itself is stock SDPA for now ("next").
+epilogues) and the 16 x 72 attention on the HIP non-causal attention kernel (aki_attn_fwd), which reads q/k/v in
+place from the fused QKV output.
 """
 from __future__ import annotations
 
@@ -94,9 +95,7 @@ class SiglipAttention(nn.Module):
         wqkv, bqkv = self._prep.get("qkv", ps, lambda: (torch.cat([p.detach() for p in ps[:3]], 0).contiguous(),
                                                         torch.cat([p.detach() for p in ps[3:]], 0).contiguous()))
         qkv = ops.linear(x, wqkv, bias=bqkv).view(N, L, 3, self.num_heads, self.head_dim)
-        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
-        a = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
-        a = a.transpose(1, 2).reshape(N, L, E)
+        a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], self.scale)   # strided views, no copies
         return ops.linear(a, self.out_proj.weight, bias=self.out_proj.bias, residual=residual)
 
 

@@ -143,6 +143,30 @@ int aki_mma_attn_fwd(const aki_mma_attn_args* args, void* workspace, size_t work
 int aki_qkv_rope_fwd(const aki_mma_attn_args* args, void* q_out, void* k_out, void* v_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * aki_attn_fwd - plain (unmasked) multi-head attention softmax(Q K^T * scale) V for the vision side.
+ * Replaces: SigLIP `eager_attention_forward` (HF:siglip/modeling_siglip.py:226-247, 16 heads x 72; call site
+ * src/vlm.py:202-203) and the softmax attention of `PerceiverAttention.forward` (src/helpers.py:93-100, 8 x 64,
+ * 144 latent queries over 729+144 keys).
+ *   q/k/v are read in place through ELEMENT strides (batch, head, token; channel stride 1), so the fused QKV / KV
+ *   projection outputs need no transposition;  o : [B, Lq, H*Dh] contiguous.  Dh in {32, 64, 72, 96}.
+ *   AKI_DT_F32 needs contiguous head-major [B,H,L,Dh] inputs and a workspace of B*H*Dh floats.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  int64_t q_stride_b, q_stride_h, q_stride_t;
+  int64_t k_stride_b, k_stride_h, k_stride_t;
+  int64_t v_stride_b, v_stride_h, v_stride_t;
+  int32_t B, H, Lq, Lk, Dh;
+  float scale;
+  int32_t dtype;
+} aki_attn_args;
+
+int aki_attn_fwd(const aki_attn_args* args, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * aki_linear_fwd - y = act(x W^T + bias) [+ residual]   (torch.nn.functional.linear semantics)
  * Replaces: every nn.Linear on the path - o_proj / gate_up_proj / down_proj
  * (HF:phi3/modeling_phi3.py:49-64,215-216), Perceiver to_q/to_kv/to_out and FeedForward linears

@@ -396,6 +396,33 @@ def test_attention_full_size_bf16_vs_f32_kernel_and_oracle_heads():
     assert bool(((o >= vmin[:, :, None] - 2e-2) & (o <= vmax[:, :, None] + 2e-2)).all())
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Lq,Lk,Dh", [(2, 16, 576, 576, 72), (3, 8, 144, 873, 64), (2, 2, 16, 16, 32), (1, 4, 100, 333, 96),
+                                          (2, 16, 729, 729, 72)])
+def test_plain_attention_vision_side(dtype, B, H, Lq, Lk, Dh):
+    """aki_attn_fwd (SigLIP 16x72, Perceiver 8x64 with 144 queries over 873 keys) on strided views of fused projections."""
+    ops = _ops()
+    rng = gen.rng_for(f"ncattn{B}{H}{Lq}{Lk}{Dh}")
+    if Lq == Lk:   # SigLIP style: one fused [B, L, 3, H, Dh] projection output
+        qkv = rng.standard_normal((B, Lq, 3, H, Dh), dtype=np.float32)
+        tq = t(qkv, dtype)
+        q_, k_, v_ = tq[:, :, 0], tq[:, :, 1], tq[:, :, 2]
+        qn, kn, vn = (rnd(qkv[:, :, i], dtype) for i in range(3))
+    else:          # Perceiver style: q from the latents, k/v from one fused [B, Lk, 2, H, Dh] projection
+        q = rng.standard_normal((B, Lq, H, Dh), dtype=np.float32)
+        kv = rng.standard_normal((B, Lk, 2, H, Dh), dtype=np.float32)
+        tkv = t(kv, dtype)
+        q_, k_, v_ = t(q, dtype), tkv[:, :, 0], tkv[:, :, 1]
+        qn, kn, vn = rnd(q, dtype), rnd(kv[:, :, 0], dtype), rnd(kv[:, :, 1], dtype)
+    o = ops.attention(q_, k_, v_, Dh ** -0.5)
+    s = np.einsum("bqhd,bkhd->bhqk", qn, kn) * np.float32(Dh ** -0.5)
+    want = np.einsum("bhqk,bkhd->bqhd", O.softmax(s, -1), vn).reshape(B, Lq, H * Dh)
+    # P = softmax(...) is rounded to bf16 before P.V exactly like the reference's eager path (`.to(query.dtype)`,
+    # HF:siglip 241): each weight carries 2^-9 relative error, which does not average out over a handful of keys,
+    # so the absolute term is 2e-3 here.
+    check(n(o), want, dtype, f"plain attention Dh={Dh} Lq={Lq} Lk={Lk}", scale_atol=2.0)
+
+
 # ------------------------------------------------------------------------------------------------
 # splice + dense mask vs the reference's own outputs
 # ------------------------------------------------------------------------------------------------
