@@ -133,13 +133,34 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_nc_bf16_kernel(const AttnNcPa
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    // All K fragments of the tile are fetched before the first MFMA (one LDS wait instead of one in front of every
+    // MFMA pair: with 2 waves per SIMD that ~128-cycle LDS latency, 24 times per tile, was the dominant stall).
+    bf16x8 ka[KS], kc[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 a0 = *(const bf16x8*)(Kb + koff + ks * 32);
-      const bf16x8 a1 = *(const bf16x8*)(Kb + koff + 32 * KROW + ks * 32);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
+      ka[ks] = *(const bf16x8*)(Kb + koff + ks * 32);
+      kc[ks] = *(const bf16x8*)(Kb + koff + 32 * KROW + ks * 32);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[ks], s1, 0, 0, 0);
+    }
+    // The V^T fragments do not depend on the softmax: issue their transposed reads now, they land under the VALU work.
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 vfr[4][DT];
+#pragma unroll
+    for (int ks4 = 0; ks4 < 4; ++ks4)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const char* va = Vb + voff + ks4 * 16 * VROW + dt * 64;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + 8 * VROW));
+        const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        vfr[ks4][dt] = vv;
+      }
+    __builtin_amdgcn_sched_barrier(0);
     if (c0 + 64 > Lk) {   // last tile: keys >= Lk are masked (prefix in register order, see mma_attn_bf16.hip count_le)
       const int x = Lk - 1 - c0 - 4 * h;
       const int nv = x < 0 ? 0 : min(4 * (x >> 3) + min((x & 7) + 1, 4), 32);
@@ -179,14 +200,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_nc_bf16_kernel(const AttnNcPa
 #pragma unroll
       for (int e = 0; e < 8; ++e) pf[e] = (__bf16)((ks4 < 2) ? s0[8 * (ks4 & 1) + e] : s1[8 * (ks4 & 1) + e]);
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const char* va = Vb + voff + ks4 * 16 * VROW + dt * 64;
-        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + 8 * VROW));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
-      }
+      for (int dt = 0; dt < DT; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr[ks4][dt]), pf, o[dt], 0, 0, 0);
     }
     if (j + 1 < jend) store_tile((j + 1) & 1);
     __syncthreads();

@@ -19,6 +19,8 @@
 //                    operand": element j of lane-half h <-> key 16s + 8(j>>2) + 4h + (j&3)); the
 //                    matching V^T A-operand comes from two ds_read_b64_tr_b16 per fragment.
 // O^T keeps the query on the lane, so the rescale factor and the final 1/l are lane-local.
+#include <type_traits>
+
 #include "aki_device.h"
 
 namespace aki {
@@ -39,10 +41,11 @@ struct AttnParams {
   int dead_uniform;
 };
 
-constexpr int KROW = 208;  // padded K row pitch in LDS (bytes)
+constexpr int KROW = 192;   // K rows unpadded: bank conflicts are removed by chunk ^= (row>>2)&3 (low 2 bits of the 16-B chunk)
 constexpr int VROW = 192;
 constexpr int KTILE = 64 * KROW;
 constexpr int VTILE = 64 * VROW;
+constexpr int NSTAGE = 3;   // LDS ring: tile j computing, j+1 landed or landing, j+2 being issued
 
 constexpr int MAX_VB_WORDS = 256;  // L <= 16384
 
@@ -61,16 +64,35 @@ __device__ __forceinline__ int count_le(int x) {
   return x < 0 ? 0 : min(n, 32);
 }
 
+// compile-time loop (the tr-read offsets below must be immediates of an inline-asm statement)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// ds_read_b64_tr_b16 through inline asm: the builtin form is treated by hipcc as "may alias any LDS-DMA in flight" and
+// gets an s_waitcnt vmcnt(0) in front, which would drain the K/V ring.  The asm form is invisible to that analysis
+// (and to the compiler's lgkmcnt bookkeeping: the data is only touched after wait_tr_reads below; cdna guide 5.7).
+template <int OFF>
+__device__ __forceinline__ u32x2 ds_read_tr(unsigned lds_addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+  return r;
+}
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnParams p) {
   constexpr int BQ = NW * 32;
   constexpr int NT = NW * 64;
   constexpr int NCH = (64 * 12 + NT - 1) / NT;  // 16-B chunks per thread per tile (K and V each)
-  __shared__ __attribute__((aligned(16))) char smem[2 * KTILE + 2 * VTILE + AKI_MAX_RECTS * 16 + MAX_VB_WORDS * 8];
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * KTILE + NSTAGE * VTILE + AKI_MAX_RECTS * 16 + MAX_VB_WORDS * 8];
   char* const sK = smem;
-  char* const sV = smem + 2 * KTILE;
-  const aki_mma_rect* sR = (const aki_mma_rect*)(smem + 2 * KTILE + 2 * VTILE);
-  unsigned long long* const sVB = (unsigned long long*)(smem + 2 * KTILE + 2 * VTILE + AKI_MAX_RECTS * 16);
+  char* const sV = smem + NSTAGE * KTILE;
+  const aki_mma_rect* sR = (const aki_mma_rect*)(smem + NSTAGE * KTILE + NSTAGE * VTILE);
+  unsigned long long* const sVB = (unsigned long long*)(smem + NSTAGE * KTILE + NSTAGE * VTILE + AKI_MAX_RECTS * 16);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,47 +170,40 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1e30f, l_part = 0.f;
 
-  u32x4 kreg[NCH], vreg[NCH];
-  auto load_tile = [&](int j) {
+  // K/V tiles go global -> LDS directly (global_load_lds, 16 B/lane): the LDS image is lane-linear, i.e. exactly the
+  // contiguous 12 KiB tile of the head-major layout; the K swizzle is applied on the per-lane SOURCE address.
+  auto issue_tile = [&](int j, int stage) {
     const int c0 = j * 64;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * NT;
-      if (NCH * NT == 768 || c < 768) {
-        const int kr = c / 12, kc = c - kr * 12;
-        const size_t off = (size_t)min(c0 + kr, L - 1) * 192 + kc * 16;
-        kreg[i] = *(const u32x4*)(kb + off);
-        vreg[i] = *(const u32x4*)(vb_ + off);
-      }
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * NT;
-      if (NCH * NT == 768 || c < 768) {
-        const int kr = c / 12, kc = c - kr * 12;
-        *(u32x4*)(sK + buf * KTILE + kr * KROW + kc * 16) = kreg[i];
-        *(u32x4*)(sV + buf * VTILE + c * 16) = vreg[i];
-      }
+      const int g = i * NT + tid;                 // 16-B chunk index inside the tile image
+      const int kr = g / 12, pos = g - kr * 12;
+      const size_t rowoff = (size_t)min(c0 + kr, L - 1) * 192;
+      const int srcchunk = pos ^ ((kr >> 2) & 3);
+      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(kb + rowoff + srcchunk * 16), AKI_LDS_PTR(sK + stage * KTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(vb_ + rowoff + pos * 16), AKI_LDS_PTR(sV + stage * VTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
 
   // per-lane LDS offsets
-  const int koff = l31 * KROW + h * 16;                                   // + 32*KROW (2nd key block) + ks*32
+  const int kswz = (l31 >> 2) & 3;   // (row>>2)&3 for row = 32*blk + l31
+  const int krow = l31 * KROW;
   const int voff = (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
-  // jend >= 1 always (q0 < L).  The first tile's wait also retires the Q-fragment loads; the explicit vmcnt(0) below
-  // (a builtin, so hipcc's wait-count model sees it) guarantees nothing is pending at loop entry - otherwise the
-  // compiler protects the Q registers with vmcnt(N) waits INSIDE the loop, which there stall on the K/V prefetch
-  // of the next tile instead (measured: the loop ran at load latency).
-  load_tile(0);
-  store_tile(0);
+  // Retire the Q-fragment loads with a wait hipcc can see (builtin), BEFORE the ring is primed: otherwise the compiler
+  // guards the Q registers with its own vmcnt(0) in front of the first MFMA of every iteration, which drains the
+  // LDS-DMA prefetch (its model does not see the inline-asm counted waits below).
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  __syncthreads();
+  issue_tile(0, 0);
+  if (jend > 1) issue_tile(1, 1);
 
+  int stage = 0;
   for (int j = 0; j < jend; ++j) {
-    if (j + 1 < jend) load_tile(j + 1);
+    // tile j's pieces are older than tile j+1's 2*NCH: wait for them, then make it a workgroup-wide fact
+    if (j + 1 < jend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (j + 2 < jend) issue_tile(j + 2, stage >= 1 ? stage - 1 : NSTAGE - 1);   // the stage read in iteration j-1
     const int c0 = j * 64;
     unsigned long long vb;
     {
@@ -202,18 +217,39 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     const bool rect_touch = (c0 < touch_hi && c0 + 64 > touch_lo);
     const bool skip = !has_uniform && (!wave_alive || vb == 0ull || (causal_none && !rect_touch));
     if (!skip) {
-      const char* Kb = sK + (j & 1) * KTILE;
-      const char* Vb = sV + (j & 1) * VTILE;
+      const char* Kb = sK + stage * KTILE;
+      const char* Vb = sV + stage * VTILE;
       f32x16 s0, s1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      // All K fragments of the tile are fetched before the first MFMA (one LDS wait instead of one in front of every
+      // MFMA pair: with 2 waves per SIMD that ~128-cycle LDS latency, 24 times per tile, was the dominant stall).
+      bf16x8 ka[6], kc[6];
 #pragma unroll
       for (int ks = 0; ks < 6; ++ks) {
-        const bf16x8 a0 = *(const bf16x8*)(Kb + koff + ks * 32);
-        const bf16x8 a1 = *(const bf16x8*)(Kb + koff + 32 * KROW + ks * 32);
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
+        const int coff = ((2 * ks + h) ^ kswz) << 4;
+        ka[ks] = *(const bf16x8*)(Kb + krow + coff);
+        kc[ks] = *(const bf16x8*)(Kb + krow + 32 * KROW + coff);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[ks], s1, 0, 0, 0);
+      }
+      // The V^T fragments do not depend on the softmax: issue their transposed reads now, they land under the VALU work.
+      u32x2 vlo[4][3], vhi[4][3];
+      {
+        const unsigned vaddr = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)sV) + stage * VTILE + voff;
+        static_for<4>([&](auto ks4) {
+          static_for<3>([&](auto dt) {
+            constexpr int off = ks4 * 16 * VROW + dt * 64;
+            vlo[ks4][dt] = ds_read_tr<off>(vaddr);
+            vhi[ks4][dt] = ds_read_tr<off + 8 * VROW>(vaddr);
+          });
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
       const bool full = (vb == ~0ull) && (causal_full || rect_full) && !wave_has_dead;
       if (!full) {
         // visibility as prefix / interval tests in register order (see count_le); valid bits that form a prefix
@@ -271,6 +307,13 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       }
 
+      // every transposed read has to be back before its registers are touched: one wait naming all destinations
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]), "+v"(vlo[0][2]), "+v"(vhi[0][2]),
+                     "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]), "+v"(vlo[1][2]), "+v"(vhi[1][2]),
+                     "+v"(vlo[2][0]), "+v"(vhi[2][0]), "+v"(vlo[2][1]), "+v"(vhi[2][1]), "+v"(vlo[2][2]), "+v"(vhi[2][2]),
+                     "+v"(vlo[3][0]), "+v"(vhi[3][0]), "+v"(vlo[3][1]), "+v"(vhi[3][1]), "+v"(vlo[3][2]), "+v"(vhi[3][2]));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks4 = 0; ks4 < 4; ++ks4) {
         bf16x8 pf;
@@ -278,17 +321,12 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
         for (int e = 0; e < 8; ++e) pf[e] = (__bf16)((ks4 < 2) ? s0[8 * (ks4 & 1) + e] : s1[8 * (ks4 & 1) + e]);
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt) {
-          const char* va = Vb + voff + ks4 * 16 * VROW + dt * 64;
-          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va));
-          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + 8 * VROW));
-          typedef __attribute__((ext_vector_type(8))) short s16x8;
-          const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          const u32x4 vv = {vlo[ks4][dt][0], vlo[ks4][dt][1], vhi[ks4][dt][0], vhi[ks4][dt][1]};
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
         }
       }
     }
-    if (j + 1 < jend) store_tile((j + 1) & 1);
-    __syncthreads();
+    if (++stage == NSTAGE) stage = 0;
   }
 
   // ---- epilogue: O = O^T / l.  A row that is inside seq_len but saw no visible column at all (e.g. left padding)
