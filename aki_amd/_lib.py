@@ -14,7 +14,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 1
+AKI_ABI_VERSION = 2
 
 
 class AkiError(RuntimeError):
@@ -29,7 +29,7 @@ class MmaAttnCoreArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
                 ("rects", C.c_void_p), ("col_valid_bits", C.c_void_p), ("seq_lens", C.c_void_p),
                 ("max_rects", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("Dh", C.c_int32),
-                ("scale", C.c_float), ("dtype", C.c_int32), ("dead_rows", C.c_int32)]
+                ("scale", C.c_float), ("dtype", C.c_int32), ("dead_rows", C.c_int32), ("kv_capacity", C.c_int32)]
 
 
 class MmaAttnArgs(C.Structure):
@@ -38,7 +38,7 @@ class MmaAttnArgs(C.Structure):
                 ("col_valid_bits", C.c_void_p), ("seq_lens", C.c_void_p), ("max_rects", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("Dh", C.c_int32), ("d_model", C.c_int32),
                 ("ldx", C.c_int32), ("ldw", C.c_int32), ("pos_rows", C.c_int32), ("scale", C.c_float),
-                ("dtype", C.c_int32), ("dead_rows", C.c_int32)]
+                ("dtype", C.c_int32), ("dead_rows", C.c_int32), ("kv_capacity", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -77,7 +77,7 @@ SIGNATURES = {
     "aki_mma_attn_core_fwd": (C.c_int, [C.POINTER(MmaAttnCoreArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_mma_attn_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
     "aki_mma_attn_fwd": (C.c_int, [C.POINTER(MmaAttnArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
-    "aki_qkv_rope_fwd": (C.c_int, [C.POINTER(MmaAttnArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aki_qkv_rope_fwd": (C.c_int, [C.POINTER(MmaAttnArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "aki_rmsnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -91,6 +91,8 @@ SIGNATURES = {
                                                                             C.c_void_p]),
     "aki_connector_proj_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
                                                                              C.c_void_p]),
+    "aki_rope_append_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 5 + [C.c_void_p]),
+    "aki_decode_attn_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 5 + [C.c_float, C.c_int32, C.c_void_p]),
     "aki_splice_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "aki_splice_fwd": (C.c_int, [C.POINTER(SpliceArgs), C.c_void_p]),
     "aki_mma_mask_dense": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,

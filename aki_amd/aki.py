@@ -55,6 +55,48 @@ class AKI(VLMWithLanguageStream):
         self._post_forward_hook()
         return output
 
+    @torch.no_grad()
     def generate(self, vision_x, lang_x, image_size=None, attention_mask=None, past_key_values=None,
                  past_media_locations=None, past_vision_tokens=None, **kwargs):
-        raise NotImplementedError("generate() needs the KV-cache decode path: SURVEY 8(f) item 1, next after the forward pass")
+        """Greedy generation (src/aki.py:136-209 + src/aki_generation.py:36-86 as used by local_demo.py / eval.py with
+        do_sample=False): MMA prefill into a KV cache, then one HIP decode step per token.  Like HF `generate` called with
+        `inputs_embeds` only, the return value holds just the NEW tokens [B, <= max_new_tokens]; finished rows are padded
+        with pad_token_id.  Differences from the reference, both only visible for B > 1 (where the reference is
+        inconsistent): the prompt batch is right-padded and every sample continues from its own length."""
+        if kwargs.pop("num_beams", 1) != 1 or kwargs.pop("do_sample", False):
+            raise NotImplementedError("only greedy decoding (num_beams=1, do_sample=False) is implemented on the MI355X path")
+        if past_key_values is not None:
+            raise NotImplementedError("generate() starts from a fresh prefill")
+        max_new_tokens = int(kwargs.pop("max_new_tokens", kwargs.pop("max_length", 20)))
+        eos = kwargs.pop("eos_token_id", None)
+        eos_ids = set([eos] if isinstance(eos, int) else (eos or []))
+        pad_id = kwargs.pop("pad_token_id", self.pad_token_id)
+        vision_tokens = self.vision_tokenizer(self._encode_vision_x(vision_x=vision_x)) if vision_x is not None else None
+        if vision_tokens is None:
+            raise NotImplementedError("text-only generation is outside the AKI hot path")
+        new_inputs = self._prepare_inputs_for_forward(vision_tokens=vision_tokens, lang_x=lang_x, attention_mask=attention_mask,
+                                                      padding_side="right")
+        table = new_inputs["attention_mask"]
+        L = new_inputs["inputs_embeds"].shape[1]
+        out = self.lang_model(inputs_embeds=new_inputs["inputs_embeds"], attention_mask=table, use_cache=True,
+                              cache_capacity=L + max_new_tokens)
+        cache = out.past_key_values
+        B = lang_x.shape[0]
+        last = (cache.cache_len.long() - 1).clamp_(min=0)
+        logits = out.logits[torch.arange(B, device=lang_x.device), last]          # logits of each sample's last real token
+        tokens = torch.full((B, max_new_tokens), pad_id, dtype=torch.long, device=lang_x.device)
+        done = torch.zeros(B, dtype=torch.bool, device=lang_x.device)
+        eos_t = torch.tensor(sorted(eos_ids), dtype=torch.long, device=lang_x.device) if eos_ids else None
+        for t in range(max_new_tokens):
+            nxt = logits.float().argmax(dim=-1)
+            nxt = torch.where(done, torch.full_like(nxt, pad_id), nxt)
+            tokens[:, t] = nxt
+            if eos_t is not None:
+                done = done | (nxt[:, None] == eos_t[None, :]).any(-1)
+                if bool(done.all()):
+                    tokens = tokens[:, : t + 1]
+                    break
+            if t + 1 < max_new_tokens:
+                logits = self.lang_model.decode_step(input_ids=nxt, past_key_values=cache)
+        self._post_forward_hook()
+        return tokens

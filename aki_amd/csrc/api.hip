@@ -10,6 +10,11 @@ int qkv_rope_f32(const aki_mma_attn_args* a, void* q, void* k, void* v, float* t
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream);
 int attn_core_f32(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream, int causal);
 int attn_nc_bf16(const aki_attn_args* a, hipStream_t stream);
+int gemv_bf16(const aki_linear_args* a, hipStream_t stream);
+int rope_append_launch(const void* qkv, const float* cos, const float* sin, const int* pos, const int* cache_len, void* q_out,
+                       void* k_cache, void* v_cache, int B, int H, int Dh, int cap, int dtype, hipStream_t s);
+int decode_attn_launch(const void* q, const void* kc, const void* vc, void* o, const int* n_keys, const uint64_t* vbits, int nwords,
+                       int B, int H, int Dh, int cap, float scale, int dtype, hipStream_t s);
 int norm_launch(bool rms, const void* x, const void* w, const void* b, void* y, int rows, int cols, int ldx, int ldy,
                 float eps, int dtype, hipStream_t stream);
 int splice_plan_launch(const int64_t* lang_x, int B, int T, int64_t media, int64_t assistant, int Nv, int* plan, hipStream_t s);
@@ -96,13 +101,16 @@ static int check_fused(const aki_mma_attn_args* a) {
   return AKI_OK;
 }
 
-int aki_qkv_rope_fwd(const aki_mma_attn_args* a, void* q, void* k, void* v, void* stream) {
+int aki_qkv_rope_fwd(const aki_mma_attn_args* a, void* q, void* k, void* v, void* ws, size_t ws_bytes, void* stream) {
   AKI_CLEAR_ERR();
   int rc = check_fused(a);
   if (rc) return rc;
   AKI_CHECK_ARG(q && k && v);
+  AKI_CHECK_ARG(a->kv_capacity == 0 || a->kv_capacity >= a->L);
   if (a->dtype == AKI_DT_BF16) return qkv_rope_bf16(a, q, k, v, (hipStream_t)stream);
-  return AKI_ERR_UNSUPPORTED;  // the f32 path needs scratch: use aki_mma_attn_fwd
+  // f32 parity path: scratch for the un-rotated projection
+  if (!ws || ws_bytes < (size_t)a->B * a->L * 3 * a->H * a->Dh * sizeof(float)) return AKI_ERR_WORKSPACE;
+  return qkv_rope_f32(a, q, k, v, (float*)ws, (hipStream_t)stream);
 }
 
 int aki_mma_attn_fwd(const aki_mma_attn_args* a, void* ws, size_t ws_bytes, void* stream) {
@@ -127,7 +135,7 @@ int aki_mma_attn_fwd(const aki_mma_attn_args* a, void* ws, size_t ws_bytes, void
   aki_mma_attn_core_args c = {};
   c.q = q; c.k = k; c.v = v; c.o = a->o; c.lse = a->lse; c.rects = a->rects; c.col_valid_bits = a->col_valid_bits;
   c.seq_lens = a->seq_lens; c.max_rects = a->max_rects; c.B = a->B; c.H = a->H; c.L = a->L; c.Dh = a->Dh;
-  c.scale = a->scale; c.dtype = a->dtype; c.dead_rows = a->dead_rows;
+  c.scale = a->scale; c.dtype = a->dtype; c.dead_rows = a->dead_rows; c.kv_capacity = 0;
   return aki_mma_attn_core_fwd(&c, rest, aki_mma_attn_core_workspace_bytes(a->B, a->H, a->L, a->Dh, a->dtype), stream);
 }
 
@@ -140,7 +148,13 @@ int aki_linear_fwd(const aki_linear_args* a, void* stream) {
   AKI_CHECK_ARG(a->act >= AKI_ACT_NONE && a->act <= AKI_ACT_SWIGLU);
   const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
   AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));
-  if (a->dtype == AKI_DT_BF16) return linear_bf16(a, (hipStream_t)stream);
+  if (a->dtype == AKI_DT_BF16) {
+    if (a->M <= 8) {  // decode regime: weight-streaming GEMV (falls through when the shape does not qualify)
+      const int rc = gemv_bf16(a, (hipStream_t)stream);
+      if (rc != AKI_ERR_UNSUPPORTED) return rc;
+    }
+    return linear_bf16(a, (hipStream_t)stream);
+  }
   return linear_f32(a, (hipStream_t)stream);
 }
 
@@ -220,6 +234,24 @@ int aki_connector_proj_fwd(const void* x, const void* ln_w, const void* ln_b, co
   g.x = ws; g.w = w; g.bias = b; g.y = out; g.M = rows; g.N = d_out; g.K = d; g.ldx = d; g.ldw = d; g.ldy = d_out;
   g.act = AKI_ACT_NONE; g.dtype = dtype;
   return aki_linear_fwd(&g, stream);
+}
+
+// ---- decode ------------------------------------------------------------------------------------------
+int aki_rope_append_fwd(const void* qkv, const float* cos, const float* sin, const int32_t* pos, const int32_t* cache_len, void* q_out,
+                        void* k_cache, void* v_cache, int32_t B, int32_t H, int32_t Dh, int32_t capacity, int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(qkv && cos && sin && pos && cache_len && q_out && k_cache && v_cache);
+  AKI_CHECK_ARG(B > 0 && H > 0 && Dh > 0 && (Dh % 2) == 0 && capacity > 0 && dtype_ok(dtype));
+  return rope_append_launch(qkv, cos, sin, pos, cache_len, q_out, k_cache, v_cache, B, H, Dh, capacity, dtype, (hipStream_t)stream);
+}
+
+int aki_decode_attn_fwd(const void* q, const void* k_cache, const void* v_cache, void* o, const int32_t* n_keys,
+                        const uint64_t* col_valid_bits, int32_t nwords, int32_t B, int32_t H, int32_t Dh, int32_t capacity, float scale,
+                        int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(q && k_cache && v_cache && o && n_keys && B > 0 && H > 0 && Dh > 0 && capacity > 0 && scale > 0.f && dtype_ok(dtype));
+  AKI_CHECK_ARG(!col_valid_bits || nwords > 0);
+  return decode_attn_launch(q, k_cache, v_cache, o, n_keys, col_valid_bits, nwords, B, H, Dh, capacity, scale, dtype, (hipStream_t)stream);
 }
 
 // ---- splice / mask -------------------------------------------------------------------------------------

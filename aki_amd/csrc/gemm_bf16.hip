@@ -53,6 +53,7 @@ struct GemmParams {
   const float* sin;
   const int* position_ids;
   int H, L;
+  int kvcap;  // rows per (batch, head) of k_out / v_out (KV cache capacity); q_out always uses L
 };
 
 // Two feature blocks (P = block n, Q = block n+1), each 4 consecutive features per lane as 2 packed dwords.
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[n][r] = acc[n][m][r];
       }
-      bf16_t* dst = outp + ((size_t)(b * p.H + head) * p.L + tt) * 96;
+      bf16_t* dst = outp + ((size_t)(b * p.H + head) * (which == 0 ? p.L : p.kvcap) + tt) * 96;
 #pragma unroll
       for (int n = 0; n < NF; n += 2) {
         const u32x4 o = pair_to_wide(pack_bf16x2(v[n][0], v[n][1]), pack_bf16x2(v[n][2], v[n][3]),
@@ -369,6 +370,7 @@ int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStre
   p.M = a->B * a->L; p.N = 3 * a->H * a->Dh; p.K = a->d_model; p.ldx = a->ldx; p.ldw = a->ldw;
   p.q_out = (bf16_t*)q; p.k_out = (bf16_t*)k; p.v_out = (bf16_t*)v;
   p.cos = a->cos; p.sin = a->sin; p.position_ids = a->position_ids; p.H = a->H; p.L = a->L;
+  p.kvcap = a->kv_capacity > 0 ? a->kv_capacity : a->L;
   // same planning for the 192-feature QKV tiles (small = 192 x 128, 4 waves)
   const int plan = plan_tiles(p.M, p.N, 192, 192, 0.5);
   if (plan == 1) return launch_gemm<6, 4, 2, 2, EPI_QKV_ROPE>(p, stream);

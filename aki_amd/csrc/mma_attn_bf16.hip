@@ -37,6 +37,7 @@ struct AttnParams {
   int max_rects;
   int B, H, L;
   int nqt, nwords;
+  int kvcap;  // rows per (batch, head) of k / v (>= L when they are a KV cache)
   float scale_log2;  // scale * log2(e)
   int dead_uniform;
 };
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   const bool row_uniform = p.dead_uniform && !row_alive;
 
   const bf16_t* qb = p.q + ((size_t)bh * L) * 96;
-  const char* kb = (const char*)(p.k + ((size_t)bh * L) * 96);
-  const char* vb_ = (const char*)(p.v + ((size_t)bh * L) * 96);
+  const char* kb = (const char*)(p.k + ((size_t)bh * p.kvcap) * 96);
+  const char* vb_ = (const char*)(p.v + ((size_t)bh * p.kvcap) * 96);
 
   // Q fragments (B operand of S^T = K Q^T): lane (q=l31, h) holds Q[q][16ks + 8h .. +7]
   bf16x8 qf[6];
@@ -374,6 +375,8 @@ int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, h
   p.B = a->B; p.H = a->H; p.L = a->L;
   p.nqt = (a->L + NW * 32 - 1) / (NW * 32);
   p.nwords = (a->L + 63) / 64;
+  p.kvcap = a->kv_capacity > 0 ? a->kv_capacity : a->L;
+  if (p.kvcap < a->L) return AKI_ERR_INVALID_ARG;
   p.scale_log2 = a->scale * 1.44269504088896340736f;
   p.dead_uniform = a->dead_rows == AKI_DEAD_ROWS_UNIFORM;
   AKI_CLEAR_ERR();

@@ -96,7 +96,7 @@ int linear_f32(const aki_linear_args* a, hipStream_t stream) {
 // HF:phi3/modeling_phi3.py:170-197,228-241.
 // ------------------------------------------------------------------------------------------------
 __global__ void rope_split_f32_kernel(const float* qkv, const float* cos, const float* sin, const int* position_ids,
-                                      float* q, float* k, float* v, int M, int H, int L, int Dh) {
+                                      float* q, float* k, float* v, int M, int H, int L, int Dh, int cap) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)M * 3 * H * Dh;
   if (idx >= total) return;
@@ -113,7 +113,7 @@ __global__ void rope_split_f32_kernel(const float* qkv, const float* cos, const 
     out = x * cos[(size_t)pos * Dh + d] + partner * sin[(size_t)pos * Dh + d];
   }
   float* dst = which == 0 ? q : (which == 1 ? k : v);
-  dst[((size_t)(b * H + head) * L + t) * Dh + d] = out;
+  dst[((size_t)(b * H + head) * (which == 0 ? L : cap) + t) * Dh + d] = out;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -124,7 +124,7 @@ struct AttnF32Params {
   const float* q; const float* k; const float* v; float* o; float* lse;
   const aki_mma_rect* rects; const uint64_t* vbits; const int* seq_lens; const float* vmean;
   int max_rects, B, H, L, Dh, nwords;
-  float scale; int dead_uniform; int causal;
+  float scale; int dead_uniform; int causal; int kvcap;
 };
 
 template <int DPT>
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32Params p) {
     }
   }
   const float* qb = p.q + (size_t)bh * L * Dh;
-  const float* kb = p.k + (size_t)bh * L * Dh;
-  const float* vb = p.v + (size_t)bh * L * Dh;
+  const float* kb = p.k + (size_t)bh * p.kvcap * Dh;
+  const float* vb = p.v + (size_t)bh * p.kvcap * Dh;
   float qr[DPT], acc[DPT];
 #pragma unroll
   for (int i = 0; i < DPT; ++i) { qr[i] = qb[(size_t)min(row, L - 1) * Dh + sub * DPT + i]; acc[i] = 0.f; }
@@ -202,10 +202,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32Params p) {
   }
 }
 
-__global__ void vmean_f32_kernel(const float* v, float* out, int L, int Dh) {
+__global__ void vmean_f32_kernel(const float* v, float* out, int L, int Dh, int cap) {
   const int bh = blockIdx.x, d = threadIdx.x;
   if (d >= Dh) return;
-  const float* base = v + (size_t)bh * L * Dh;
+  const float* base = v + (size_t)bh * cap * Dh;
   float s = 0.f;
   for (int t = 0; t < L; ++t) s += base[(size_t)t * Dh + d];
   out[(size_t)bh * Dh + d] = s / (float)L;
@@ -219,10 +219,10 @@ int attn_core_f32(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hi
   AttnF32Params p = {(const float*)a->q, (const float*)a->k, (const float*)a->v, (float*)a->o, a->lse,
                      a->rects, a->col_valid_bits, a->seq_lens, (const float*)ws,
                      a->rects ? a->max_rects : 0, a->B, a->H, a->L, a->Dh, (a->L + 63) / 64,
-                     a->scale, a->dead_rows == AKI_DEAD_ROWS_UNIFORM, causal};
+                     a->scale, a->dead_rows == AKI_DEAD_ROWS_UNIFORM, causal, a->kv_capacity > 0 ? a->kv_capacity : a->L};
   if (p.dead_uniform) {
     AKI_CLEAR_ERR();
-    hipLaunchKernelGGL(vmean_f32_kernel, dim3(a->B * a->H), dim3(128), 0, stream, p.v, (float*)ws, a->L, a->Dh);
+    hipLaunchKernelGGL(vmean_f32_kernel, dim3(a->B * a->H), dim3(128), 0, stream, p.v, (float*)ws, a->L, a->Dh, p.kvcap);
     AKI_LAUNCH_CHECK();
   }
   const int nqt = (a->L + 63) / 64;
@@ -248,7 +248,7 @@ int qkv_rope_f32(const aki_mma_attn_args* a, void* q, void* k, void* v, float* t
   const size_t total = (size_t)g.M * g.N;
   AKI_CLEAR_ERR();
   hipLaunchKernelGGL(rope_split_f32_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, tmp, a->cos, a->sin,
-                     a->position_ids, (float*)q, (float*)k, (float*)v, g.M, a->H, a->L, a->Dh);
+                     a->position_ids, (float*)q, (float*)k, (float*)v, g.M, a->H, a->L, a->Dh, a->kv_capacity > 0 ? a->kv_capacity : a->L);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }

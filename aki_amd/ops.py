@@ -105,6 +105,17 @@ class MaskTable:
     def max_rects(self) -> int:
         return 0 if self.rects is None else int(self.rects.shape[1])
 
+    def token_counts(self, B: int, device) -> torch.Tensor:
+        """int32 [B]: index of the last valid column + 1 (the sample's own length when right-padded; L when left-padded).
+        NOT `seq_lens`, which is the reference mask's causal extent (the padded length for samples that hold an image)."""
+        if self.col_valid_bits is None:
+            return torch.full((B,), self.L, dtype=torch.int32, device=device)
+        nw = self.col_valid_bits.shape[1]
+        shifts = torch.arange(64, device=device, dtype=torch.int64)
+        valid = ((self.col_valid_bits[:, :, None] >> shifts) & 1).view(B, nw * 64)[:, : self.L]
+        pos = torch.arange(1, self.L + 1, device=device, dtype=torch.int64)
+        return (valid * pos).amax(dim=1).to(torch.int32)
+
     @staticmethod
     def causal(B: int, Lq: int, device) -> "MaskTable":
         return MaskTable(None, None, None, Lq)
@@ -179,16 +190,20 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: 
 
 def mma_attn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: MaskTable, scale: float,
                   dead_rows: int = DEAD_ROWS_UNIFORM, return_lse: bool = False):
-    """q,k,v [B,H,L,Dh] (contiguous) -> o [B,L,H*Dh]."""
+    """q [B,H,L,Dh]; k,v [B,H,cap,Dh] with cap >= L (cap > L: a KV cache whose first L rows are used) -> o [B,L,H*Dh]."""
     dev = _dev(q, k, v)
     B, H, Lq, Dh = q.shape
+    cap = k.shape[2]
+    if v.shape[2] != cap or cap < Lq:
+        raise AkiError("mma_attn_core: k/v capacity mismatch")
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     o = torch.empty((B, Lq, H * Dh), dtype=q.dtype, device=dev)
     lse = torch.empty((B, H, Lq), dtype=torch.float32, device=dev) if return_lse else None
     lib = L.load()
     ws = _ws(lib.aki_mma_attn_core_workspace_bytes(B, H, Lq, Dh, _dt(q)), dev)
     a = L.MmaAttnCoreArgs(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(table.rects), _ptr(table.col_valid_bits),
-                          _ptr(table.seq_lens), table.max_rects, B, H, Lq, Dh, float(scale), _dt(q), dead_rows)
+                          _ptr(table.seq_lens), table.max_rects, B, H, Lq, Dh, float(scale), _dt(q), dead_rows,
+                          0 if cap == Lq else cap)
     end = _TAP.begin(("mma_attn_core", B, H, Lq, Dh)) if (_TAP is not None and _TAP.want(("mma_attn_core",))) else None
     L.check(lib.aki_mma_attn_core_fwd(C.byref(a), _ptr(ws), ws.numel(), _stream()), "aki_mma_attn_core_fwd")
     if end is not None:
@@ -226,11 +241,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -
     return o
 
 
-def _fused_args(x2, w_qkv, cos, sin, position_ids, o, lse, table, B, H, Lq, Dh, scale, dead_rows):
+def _fused_args(x2, w_qkv, cos, sin, position_ids, o, lse, table, B, H, Lq, Dh, scale, dead_rows, kv_capacity=0):
     return L.MmaAttnArgs(_ptr(x2), _ptr(w_qkv), _ptr(cos), _ptr(sin), _ptr(position_ids), _ptr(o), _ptr(lse),
                          _ptr(table.rects), _ptr(table.col_valid_bits), _ptr(table.seq_lens), table.max_rects,
                          B, H, Lq, Dh, x2.shape[1], x2.stride(0), w_qkv.stride(0), cos.shape[0], float(scale),
-                         _dt(x2), dead_rows)
+                         _dt(x2), dead_rows, kv_capacity)
 
 
 def mma_attn(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, table: MaskTable, num_heads: int,
@@ -259,9 +274,11 @@ def mma_attn(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch
 
 
 def qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, num_heads: int,
-             position_ids: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Stage 1 of the fused op (bf16 only): rotated q,k and v, each [B,H,L,Dh]."""
-    dev = _dev(x, w_qkv, cos, sin)
+             position_ids: Optional[torch.Tensor] = None, k_out: Optional[torch.Tensor] = None,
+             v_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Stage 1 of the fused op: rotated q [B,H,L,Dh], rotated k and v.  With k_out / v_out ([B,H,cap,Dh], cap >= L)
+    the keys/values are written straight into a KV cache (prefill)."""
+    dev = _dev(x, w_qkv, cos, sin, k_out, v_out)
     B, Lq, d = x.shape
     Dh = w_qkv.shape[0] // (3 * num_heads)
     x2 = _rows2d(x)
@@ -269,11 +286,44 @@ def qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch
     sin = sin.to(torch.float32).reshape(-1, Dh).contiguous()
     if position_ids is not None:
         position_ids = position_ids.to(torch.int32).expand(B, Lq).contiguous()
-    q, k, v = (torch.empty((B, num_heads, Lq, Dh), dtype=x.dtype, device=dev) for _ in range(3))
+    q = torch.empty((B, num_heads, Lq, Dh), dtype=x.dtype, device=dev)
+    if k_out is None:
+        k_out = torch.empty((B, num_heads, Lq, Dh), dtype=x.dtype, device=dev)
+        v_out = torch.empty((B, num_heads, Lq, Dh), dtype=x.dtype, device=dev)
+    cap = k_out.shape[2]
+    if not (k_out.is_contiguous() and v_out.is_contiguous()) or v_out.shape != k_out.shape or cap < Lq:
+        raise AkiError("qkv_rope: bad KV output buffers")
     a = _fused_args(x2, w_qkv, cos, sin, position_ids, None, None, MaskTable(None, None, None, Lq), B, num_heads, Lq, Dh,
-                    Dh ** -0.5, 0)
-    L.check(L.load().aki_qkv_rope_fwd(C.byref(a), _ptr(q), _ptr(k), _ptr(v), _stream()), "aki_qkv_rope_fwd")
-    return q, k, v
+                    Dh ** -0.5, 0, 0 if cap == Lq else cap)
+    ws = _ws(B * Lq * 3 * num_heads * Dh * 4 if x.dtype == torch.float32 else 256, dev)
+    L.check(L.load().aki_qkv_rope_fwd(C.byref(a), _ptr(q), _ptr(k_out), _ptr(v_out), _ptr(ws), ws.numel(), _stream()),
+            "aki_qkv_rope_fwd")
+    return q, k_out, v_out
+
+
+def rope_append(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, cache_len: torch.Tensor,
+                k_cache: torch.Tensor, v_cache: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """Decode step: qkv [B, 3*H*Dh] of the new tokens -> rotated q [B,H,Dh]; k/v appended to the caches in place."""
+    dev = _dev(qkv, cos, sin, pos, cache_len, k_cache, v_cache)
+    B = qkv.shape[0]
+    Dh = qkv.shape[1] // (3 * num_heads)
+    q = torch.empty((B, num_heads, Dh), dtype=qkv.dtype, device=dev)
+    L.check(L.load().aki_rope_append_fwd(_ptr(qkv.contiguous()), _ptr(cos), _ptr(sin), _ptr(pos), _ptr(cache_len), _ptr(q),
+                                         _ptr(k_cache), _ptr(v_cache), B, num_heads, Dh, k_cache.shape[2], _dt(qkv), _stream()),
+            "aki_rope_append_fwd")
+    return q
+
+
+def decode_attn(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_keys: torch.Tensor, scale: float,
+                col_valid_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [B,H,Dh] against the first n_keys[b] rows of the caches [B,H,cap,Dh] -> o [B, H*Dh]."""
+    dev = _dev(q, k_cache, v_cache, n_keys, col_valid_bits)
+    B, H, Dh = q.shape
+    o = torch.empty((B, H * Dh), dtype=q.dtype, device=dev)
+    nw = 0 if col_valid_bits is None else col_valid_bits.shape[1]
+    L.check(L.load().aki_decode_attn_fwd(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(o), _ptr(n_keys), _ptr(col_valid_bits), nw,
+                                         B, H, Dh, k_cache.shape[2], float(scale), _dt(q), _stream()), "aki_decode_attn_fwd")
+    return o
 
 
 def pad_k(w: torch.Tensor, mult: int = 64) -> torch.Tensor:

@@ -74,6 +74,27 @@ class Phi3RotaryTables(nn.Module):
         return self._cache[key]
 
 
+class AkiKVCache:
+    """Per-layer K/V caches [B, H, capacity, Dh] written by the prefill (QKV+RoPE epilogue stores straight into them)
+    and appended to by the decode kernels.  Lengths and positions live on the device so a decode step never syncs."""
+
+    def __init__(self, n_layers, B, H, Dh, capacity, dtype, device):
+        self.k = [torch.empty((B, H, capacity, Dh), dtype=dtype, device=device) for _ in range(n_layers)]
+        self.v = [torch.empty((B, H, capacity, Dh), dtype=dtype, device=device) for _ in range(n_layers)]
+        self.capacity = capacity
+        self.cache_len = torch.zeros((B,), dtype=torch.int32, device=device)   # tokens cached per sample
+        self.valid_bits = None                                                  # uint64 words of the prompt's 1-D mask
+
+    def get_seq_length(self, layer_idx=0):
+        return int(self.cache_len.max())
+
+    def __getitem__(self, i):   # HF-style past_key_values[layer] -> (k, v)
+        return self.k[i], self.v[i]
+
+    def __len__(self):
+        return len(self.k)
+
+
 class Phi3RMSNorm(nn.Module):
     def __init__(self, hidden_size, eps=1e-6):
         super().__init__()
@@ -97,8 +118,20 @@ class Phi3Attention(nn.Module):
         self.o_proj = nn.Linear(self.num_heads * self.head_dim, config.hidden_size, bias=False)
         self.qkv_proj = nn.Linear(config.hidden_size, op_size, bias=False)
 
-    def forward(self, hidden_states, cos, sin, table, residual, position_ids=None):
-        o = ops.mma_attn(hidden_states, self.qkv_proj.weight, cos, sin, table, self.num_heads, self.scaling, position_ids)
+    def forward(self, hidden_states, cos, sin, table, residual, position_ids=None, cache=None):
+        if cache is None:
+            o = ops.mma_attn(hidden_states, self.qkv_proj.weight, cos, sin, table, self.num_heads, self.scaling, position_ids)
+        else:   # prefill into the KV cache: stage 1 writes rotated K and V straight into the cache tensors
+            q, k, v = ops.qkv_rope(hidden_states, self.qkv_proj.weight, cos, sin, self.num_heads, position_ids,
+                                   k_out=cache.k[self.layer_idx], v_out=cache.v[self.layer_idx])
+            o = ops.mma_attn_core(q, k, v, table, self.scaling)
+        return ops.linear(o, self.o_proj.weight, residual=residual)
+
+    def decode(self, x, cos, sin, residual, cache, pos, n_keys):
+        """One new token per sequence: x [B, d] (normed) -> attention output projected and added to `residual`."""
+        qkv = ops.linear(x, self.qkv_proj.weight)
+        q = ops.rope_append(qkv, cos, sin, pos, cache.cache_len, cache.k[self.layer_idx], cache.v[self.layer_idx], self.num_heads)
+        o = ops.decode_attn(q, cache.k[self.layer_idx], cache.v[self.layer_idx], n_keys, self.scaling, cache.valid_bits)
         return ops.linear(o, self.o_proj.weight, residual=residual)
 
 
@@ -121,8 +154,12 @@ class Phi3DecoderLayer(nn.Module):
         self.input_layernorm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
-    def forward(self, h, cos, sin, table, position_ids=None):
-        h = self.self_attn(self.input_layernorm(h), cos, sin, table, h, position_ids)
+    def forward(self, h, cos, sin, table, position_ids=None, cache=None):
+        h = self.self_attn(self.input_layernorm(h), cos, sin, table, h, position_ids, cache)
+        return self.mlp(self.post_attention_layernorm(h), h)
+
+    def decode(self, h, cos, sin, cache, pos, n_keys):
+        h = self.self_attn.decode(self.input_layernorm(h), cos, sin, h, cache, pos, n_keys)
         return self.mlp(self.post_attention_layernorm(h), h)
 
 
@@ -136,13 +173,26 @@ class Phi3Model(nn.Module):
         self.norm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.rotary_emb = Phi3RotaryTables(config)
 
-    def forward(self, inputs_embeds, table, position_ids=None):
+    def forward(self, inputs_embeds, table, position_ids=None, cache=None):
         B, L, _ = inputs_embeds.shape
         n_pos = L if position_ids is None else int(position_ids.max()) + 1
+        if cache is not None:
+            n_pos = max(n_pos, cache.capacity)
         cos, sin = self.rotary_emb.tables(n_pos, inputs_embeds.device)
         h = inputs_embeds
         for layer in self.layers:
-            h = layer(h, cos, sin, table, position_ids)
+            h = layer(h, cos, sin, table, position_ids, cache)
+        return self.norm(h)
+
+    def decode(self, inputs_embeds, cache):
+        """inputs_embeds [B, d]: the embeddings of the tokens appended at index cache.cache_len[b]."""
+        cos, sin = self.rotary_emb.tables(cache.capacity, inputs_embeds.device)
+        pos = cache.cache_len                       # position of the new token = number of tokens before it
+        n_keys = cache.cache_len + 1
+        h = inputs_embeds
+        for layer in self.layers:
+            h = layer.decode(h, cos, sin, cache, pos, n_keys)
+        cache.cache_len += 1
         return self.norm(h)
 
 
@@ -169,10 +219,17 @@ class Phi3ForCausalLM(nn.Module):
     def set_output_embeddings(self, new_embeddings):
         self.lm_head = new_embeddings
 
+    def _head(self, h):
+        if type(self.lm_head) is nn.Linear:
+            return ops.linear(h, self.lm_head.weight, bias=self.lm_head.bias)
+        return self.lm_head(h)   # DecoupledLinear (src/vlm.py:88-99): one HIP GEMM / GEMV over the fused weight
+
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, labels=None, position_ids=None,
-                use_cache=False, past_key_values=None, **kwargs):
-        if past_key_values is not None or use_cache:
-            raise NotImplementedError("KV-cache decode is SURVEY 8(f) item 1 (next); this build covers the forward/prefill pass")
+                use_cache=False, past_key_values=None, cache_capacity=None, **kwargs):
+        """Prefill / full forward.  With use_cache=True the returned past_key_values is an AkiKVCache holding the
+        rotated keys and the values of every layer (capacity = cache_capacity or L + 256)."""
+        if past_key_values is not None:
+            raise NotImplementedError("continue from an existing cache with decode_step(); chunked prefill is not implemented")
         if inputs_embeds is None:
             inputs_embeds = self.model.embed_tokens(input_ids)
         B, L, _ = inputs_embeds.shape
@@ -181,15 +238,37 @@ class Phi3ForCausalLM(nn.Module):
             table = ops.MaskTable.causal(B, L, inputs_embeds.device)
         elif isinstance(table, torch.Tensor):
             table = mask_table_from_tensor(table, L)
-        h = self.model(inputs_embeds, table, position_ids)
-        if type(self.lm_head) is nn.Linear:
-            logits = ops.linear(h, self.lm_head.weight, bias=self.lm_head.bias)
-        else:  # DecoupledLinear (src/vlm.py:88-99): its forward is one HIP GEMM over the fused weight
-            logits = self.lm_head(h)
+        cache = None
+        if use_cache:
+            cfg = self.config
+            H = cfg.num_attention_heads
+            Dh = getattr(cfg, "head_dim", None) or cfg.hidden_size // H
+            cache = AkiKVCache(len(self.model.layers), B, H, Dh, int(cache_capacity or (L + 256)), inputs_embeds.dtype,
+                               inputs_embeds.device)
+        h = self.model(inputs_embeds, table, position_ids, cache)
+        logits = self._head(h)
+        if cache is not None:
+            cache.cache_len.copy_(table.token_counts(B, h.device))
+            if table.col_valid_bits is not None:
+                # decode appends right after each sample's last valid token (overwriting stacking padding), so only holes INSIDE the prompt stay masked
+                nw = table.col_valid_bits.shape[1]
+                idx = torch.arange(nw * 64, device=h.device, dtype=torch.int32)[None, :]
+                beyond = (idx >= cache.cache_len[:, None]).view(B, nw, 64)
+                weights = (torch.ones(64, dtype=torch.int64, device=h.device) << torch.arange(64, device=h.device))
+                beyond_bits = (beyond.to(torch.int64) * weights).sum(-1)      # wraps into the sign bit exactly like uint64
+                cache.valid_bits = (table.col_valid_bits | beyond_bits).contiguous()
         loss = None
         if labels is not None:
             loss = causal_lm_loss(logits, labels)
-        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None)
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache)
+
+    def decode_step(self, input_ids=None, inputs_embeds=None, past_key_values=None):
+        """One greedy-decoding step: new token ids [B] (or their embeddings [B, d]) -> logits [B, V'].  After the prefill
+        the reference's mask is all ones (src/aki_generation.py:58-62): the token attends to everything cached."""
+        if inputs_embeds is None:
+            inputs_embeds = self.get_input_embeddings()(input_ids)
+        h = self.model.decode(inputs_embeds.reshape(inputs_embeds.shape[0], -1), past_key_values)
+        return self._head(h)
 
 
 def causal_lm_loss(logits, labels, ignore_index=-100):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 1
+#define AKI_ABI_VERSION 2
 
 typedef enum {
   AKI_OK = 0,
@@ -99,6 +99,7 @@ typedef struct {
   float scale;
   int32_t dtype;     /* aki_dtype */
   int32_t dead_rows; /* aki_dead_rows */
+  int32_t kv_capacity; /* rows allocated per (batch, head) in k and v ([B,H,kv_capacity,Dh], a KV cache); 0 = L */
 } aki_mma_attn_core_args;
 
 size_t aki_mma_attn_core_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype);
@@ -134,13 +135,16 @@ typedef struct {
   float scale;
   int32_t dtype;
   int32_t dead_rows;
+  int32_t kv_capacity; /* aki_qkv_rope_fwd: rows per (batch, head) of k_out / v_out (prefill straight into a KV cache); 0 = L */
 } aki_mma_attn_args;
 
 size_t aki_mma_attn_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype);
 int aki_mma_attn_fwd(const aki_mma_attn_args* args, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Stage 1 of the fused op on its own (used by the KV-cache prefill and by tests). q/k/v out: [B,H,L,Dh]. */
-int aki_qkv_rope_fwd(const aki_mma_attn_args* args, void* q_out, void* k_out, void* v_out, void* stream);
+/* Stage 1 of the fused op on its own (KV-cache prefill, tests): q_out [B,H,L,Dh]; k_out / v_out [B,H,kv_capacity,Dh]
+ * (kv_capacity = 0 means L).  AKI_DT_F32 needs a workspace of B*L*3*H*Dh floats; bf16 needs none. */
+int aki_qkv_rope_fwd(const aki_mma_attn_args* args, void* q_out, void* k_out, void* v_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * aki_attn_fwd - plain (unmasked) multi-head attention softmax(Q K^T * scale) V for the vision side.
@@ -262,6 +266,23 @@ typedef struct {
 int aki_splice_plan(const int64_t* lang_x, int32_t B, int32_t T, int64_t media_token_id, int64_t assistant_token_id,
                     int32_t Nv, int32_t* plan, void* stream);
 int aki_splice_fwd(const aki_splice_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Decode path (after the MMA prefill): one new token per sequence.
+ * Replaces the per-token steps of `lang_model.generate` as driven by src/aki.py:136-209 and the patched
+ * `_update_model_kwargs_for_generation` (src/aki_generation.py:36-86): after the prefill the mask is all ones, i.e.
+ * the new token attends to everything cached.  aki_linear_fwd streams weights with a GEMV kernel when M <= 8.
+ * aki_rope_append_fwd : qkv [B,3*H*Dh] of the new tokens -> rotated q [B,H,Dh]; rotated k and v appended to the caches
+ *                       [B,H,capacity,Dh] at index cache_len[b] (device int32); pos[b] = row into cos/sin.
+ * aki_decode_attn_fwd : o [B,H*Dh] = softmax(q K^T * scale) V over the first n_keys[b] cache rows (device int32),
+ *                       optional valid bits [B][nwords] of the prefill columns (padding), NULL = all valid.
+ * ---------------------------------------------------------------------------------------------- */
+int aki_rope_append_fwd(const void* qkv, const float* cos, const float* sin, const int32_t* pos, const int32_t* cache_len,
+                        void* q_out, void* k_cache, void* v_cache, int32_t B, int32_t H, int32_t Dh, int32_t capacity,
+                        int32_t dtype, void* stream);
+int aki_decode_attn_fwd(const void* q, const void* k_cache, const void* v_cache, void* o, const int32_t* n_keys,
+                        const uint64_t* col_valid_bits, int32_t nwords, int32_t B, int32_t H, int32_t Dh, int32_t capacity,
+                        float scale, int32_t dtype, void* stream);
 
 /* aki_mma_mask_dense - materialise the reference's (B,1,L,L) int64 0/1 mask from the table, for
  * callers that still want it (bit-exact vs src/vlm.py:410-443 + src/utils.py:99-108). */

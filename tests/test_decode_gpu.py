@@ -1,0 +1,135 @@
+"""Decode path: GEMV linear for M <= 8, RoPE + KV-cache append, single-query attention, and
+AKI.generate() consistency: every decode step must reproduce the logits of a fresh full (MMA prefill) forward over
+the prompt extended by the tokens generated so far - the reference's semantics after its prefill (all-ones mask,
+src/aki_generation.py:58-62)."""
+import numpy as np
+import pytest
+import torch
+
+from golden import gen
+import aki_oracle as O
+from test_kernels_gpu import check, n, rnd, t, DEV, DTYPES
+from test_model_gpu import build_tiny, batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M", [1, 3, 8])
+@pytest.mark.parametrize("N,K", [(3072, 3072), (1000, 192), (32016, 3072)])
+def test_gemv_linear_bf16(M, N, K):
+    from aki_amd import ops
+    rng = gen.rng_for(f"gemv{M}{N}{K}")
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) * 0.05
+    b = rng.standard_normal((N,), dtype=np.float32) * 0.1
+    r = rng.standard_normal((M, N), dtype=np.float32)
+    dt = torch.bfloat16
+    xr, wr, br, rr = (rnd(a, dt) for a in (x, w, b, r))
+    base = xr @ wr.T
+    check(n(ops.linear(t(x, dt), t(w, dt))), base, dt, "gemv plain")
+    check(n(ops.linear(t(x, dt), t(w, dt), bias=t(b, dt), residual=t(r, dt))), base + br + rr, dt, "gemv bias+residual")
+    check(n(ops.linear(t(x, dt), t(w, dt), bias=t(b, dt), act=ops.ACT_GELU_TANH)), O.gelu_tanh((base + br).astype(np.float32)), dt, "gemv gelu")
+    if N % 2 == 0:
+        up = base
+        check(n(ops.linear(t(x, dt), t(w, dt), act=ops.ACT_SWIGLU)), up[:, N // 2:] * O.silu(up[:, :N // 2].astype(np.float32)), dt, "gemv swiglu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rope_append_and_decode_attention(dtype):
+    from aki_amd import ops
+    B, H, Dh, cap = 3, 4, 96, 300
+    rng = gen.rng_for("decode_attn")
+    kc = rng.standard_normal((B, H, cap, Dh), dtype=np.float32)
+    vc = rng.standard_normal((B, H, cap, Dh), dtype=np.float32)
+    qkv = rng.standard_normal((B, 3 * H * Dh), dtype=np.float32)
+    lens = np.array([17, 200, 299 - 1], dtype=np.int32)
+    cos, sin = O.rope_cos_sin(np.arange(cap)[None], Dh)
+    tk, tv = t(kc, dtype), t(vc, dtype)
+    cache_len = torch.from_numpy(lens).to(DEV)
+    q = ops.rope_append(t(qkv, dtype), torch.from_numpy(cos[0]).to(DEV), torch.from_numpy(sin[0]).to(DEV), cache_len, cache_len, tk, tv, H)
+    qr = rnd(qkv, dtype).reshape(B, 3, H, Dh)
+    kcr, vcr = rnd(kc, dtype), rnd(vc, dtype)
+    want_q = np.zeros((B, H, Dh), dtype=np.float32)
+    for b in range(B):
+        c, s = cos[0][lens[b]][None], sin[0][lens[b]][None]
+        want_q[b] = qr[b, 0] * c + O.rotate_half(qr[b, 0]) * s
+        kcr[b, :, lens[b]] = rnd(qr[b, 1] * c + O.rotate_half(qr[b, 1]) * s, dtype)
+        vcr[b, :, lens[b]] = qr[b, 2]
+    check(n(q), want_q, dtype, "rotated q")
+    check(n(tk), kcr, dtype, "k cache after append")
+    assert np.array_equal(n(tv), vcr), "v append must be a plain copy"
+    # attention of the new token over [0, len] with a hole in sample 1's prompt mask
+    am = np.ones((B, 320), dtype=bool)
+    am[1, 5:9] = False
+    table = ops.MaskTable.from_host([[(0, 0, 0, 0)]] * B, am, None, DEV)
+    o = ops.decode_attn(q, tk, tv, cache_len + 1, Dh ** -0.5, table.col_valid_bits)
+    qn = n(q)
+    want = np.zeros((B, H * Dh), dtype=np.float32)
+    for b in range(B):
+        nk = lens[b] + 1
+        keep = am[b, :nk]
+        for h in range(H):
+            s_ = (kcr[b, h, :nk] @ qn[b, h]) * np.float32(Dh ** -0.5)
+            s_ = np.where(keep, s_, -np.inf)
+            p = O.softmax(s_.astype(np.float32), -1)
+            want[b, h * Dh:(h + 1) * Dh] = p @ vcr[b, h, :nk]
+    check(n(o), want, dtype, "decode attention", scale_atol=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_generate_matches_full_forward(dtype):
+    m, g = build_tiny(dtype)
+    vx, lx, am, _ = batch(g, dtype)
+    n_new = 5
+    toks = m.generate(vx, lx, attention_mask=am, max_new_tokens=n_new, do_sample=False)
+    assert toks.shape == (lx.shape[0], n_new) and toks.dtype == torch.long
+    tol = 2e-4 if dtype == torch.float32 else None
+    for b in range(lx.shape[0]):
+        nreal = int(am[b].sum())
+        ids = lx[b, :nreal]
+        for step in range(n_new):
+            with torch.no_grad():
+                full = m(vx[b:b + 1], ids[None], attention_mask=torch.ones_like(ids)[None]).logits[0, -1].float()
+            want_tok = int(full.argmax())
+            got_tok = int(toks[b, step])
+            if dtype == torch.float32:
+                assert got_tok == want_tok, f"sample {b} step {step}: generate chose {got_tok}, full forward {want_tok}"
+            else:
+                # bf16: the decode path (f32 dot products, different summation order) may flip a near-tie; the chosen token
+                # must be within bf16 noise of the full forward's best logit
+                assert float(full[want_tok] - full[got_tok]) <= 0.05 * max(1.0, float(full.abs().max())), (b, step)
+            ids = torch.cat([ids, toks[b, step:step + 1]])
+
+
+def test_generate_decode_logits_match_full_forward_fp32():
+    """Tighter check on the numbers themselves (fp32): logits of decode_step == logits of the full forward."""
+    m, g = build_tiny(torch.float32)
+    vx, lx, am, _ = batch(g, torch.float32)
+    b = 0
+    nreal = int(am[b].sum())
+    ids = lx[b:b + 1, :nreal]
+    with torch.no_grad():
+        vt = m.vision_tokenizer(m._encode_vision_x(vx[b:b + 1]))
+        prep = m._prepare_inputs_for_forward(vision_tokens=vt, lang_x=ids, attention_mask=torch.ones_like(ids), padding_side="right")
+        out = m.lang_model(inputs_embeds=prep["inputs_embeds"], attention_mask=prep["attention_mask"], use_cache=True, cache_capacity=64)
+        cache = out.past_key_values
+        nxt = out.logits[0, -1].argmax()[None]
+        for step in range(4):
+            dec = m.lang_model.decode_step(input_ids=nxt, past_key_values=cache)[0]
+            ids = torch.cat([ids, nxt[None]], dim=1)
+            full = m(vx[b:b + 1], ids, attention_mask=torch.ones_like(ids)).logits[0, -1]
+            err = (dec.float() - full.float()).abs().max().item()
+            assert err <= 2e-4 * max(1.0, full.abs().max().item()), f"step {step}: decode vs full forward max err {err:.3g}"
+            nxt = dec.argmax()[None]
+    assert cache.get_seq_length() == prep["inputs_embeds"].shape[1] + 4
+
+
+def test_generate_stops_at_eos_and_pads():
+    m, g = build_tiny(torch.float32)
+    vx, lx, am, _ = batch(g, torch.float32)
+    first = m.generate(vx, lx, attention_mask=am, max_new_tokens=3)
+    eos = int(first[0, 0])          # declare sample 0's first token to be EOS
+    toks = m.generate(vx, lx, attention_mask=am, max_new_tokens=6, eos_token_id=eos, pad_token_id=gen.TINY["pad_token_id"])
+    assert int(toks[0, 0]) == eos and bool((toks[0, 1:] == gen.TINY["pad_token_id"]).all())
+    with pytest.raises(NotImplementedError):
+        m.generate(vx, lx, attention_mask=am, num_beams=4)
