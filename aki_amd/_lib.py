@@ -14,7 +14,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 2
+AKI_ABI_VERSION = 3
 
 
 class AkiError(RuntimeError):
@@ -92,7 +92,11 @@ SIGNATURES = {
     "aki_connector_proj_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
                                                                              C.c_void_p]),
     "aki_rope_append_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 5 + [C.c_void_p]),
-    "aki_decode_attn_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 5 + [C.c_float, C.c_int32, C.c_void_p]),
+    "aki_decode_attn_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
+    "aki_decode_attn_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 6 + [C.c_float, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aki_decode_attn_fused_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 6 + [C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
+                                            C.c_void_p]),
+    "aki_decode_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p, C.c_float, C.c_void_p]),
     "aki_splice_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "aki_splice_fwd": (C.c_int, [C.POINTER(SpliceArgs), C.c_void_p]),
     "aki_mma_mask_dense": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,

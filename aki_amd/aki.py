@@ -71,6 +71,9 @@ class AKI(VLMWithLanguageStream):
         eos = kwargs.pop("eos_token_id", None)
         eos_ids = set([eos] if isinstance(eos, int) else (eos or []))
         pad_id = kwargs.pop("pad_token_id", self.pad_token_id)
+        use_graph = kwargs.pop("use_graph", None)
+        if use_graph is None:
+            use_graph = max_new_tokens >= 8          # capture costs about two eager steps
         vision_tokens = self.vision_tokenizer(self._encode_vision_x(vision_x=vision_x)) if vision_x is not None else None
         if vision_tokens is None:
             raise NotImplementedError("text-only generation is outside the AKI hot path")
@@ -87,6 +90,10 @@ class AKI(VLMWithLanguageStream):
         tokens = torch.full((B, max_new_tokens), pad_id, dtype=torch.long, device=lang_x.device)
         done = torch.zeros(B, dtype=torch.bool, device=lang_x.device)
         eos_t = torch.tensor(sorted(eos_ids), dtype=torch.long, device=lang_x.device) if eos_ids else None
+        stepper = None
+        if use_graph:
+            from .phi3 import DecodeGraph
+            stepper = DecodeGraph(self.lang_model, cache)
         for t in range(max_new_tokens):
             nxt = logits.float().argmax(dim=-1)
             nxt = torch.where(done, torch.full_like(nxt, pad_id), nxt)
@@ -97,6 +104,6 @@ class AKI(VLMWithLanguageStream):
                     tokens = tokens[:, : t + 1]
                     break
             if t + 1 < max_new_tokens:
-                logits = self.lang_model.decode_step(input_ids=nxt, past_key_values=cache)
+                logits = stepper.step(nxt) if stepper is not None else self.lang_model.decode_step(input_ids=nxt, past_key_values=cache)
         self._post_forward_hook()
         return tokens

@@ -10,7 +10,11 @@ int qkv_rope_f32(const aki_mma_attn_args* a, void* q, void* k, void* v, float* t
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream);
 int attn_core_f32(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream, int causal);
 int attn_nc_bf16(const aki_attn_args* a, hipStream_t stream);
-int gemv_bf16(const aki_linear_args* a, hipStream_t stream);
+int gemv_bf16(const aki_linear_args* a, const void* rms_w, float eps, hipStream_t stream);
+size_t decode_attn_ws_bytes(int B, int H, int Dh, int cap);
+int decode_attn_split_launch(const void* q_or_qkv, const float* cos, const float* sin, const int* len, void* kc, void* vc, void* o,
+                             const uint64_t* vbits, int nwords, int B, int H, int cap, int max_keys, float scale, bool fused,
+                             void* ws, size_t ws_bytes, hipStream_t s);
 int rope_append_launch(const void* qkv, const float* cos, const float* sin, const int* pos, const int* cache_len, void* q_out,
                        void* k_cache, void* v_cache, int B, int H, int Dh, int cap, int dtype, hipStream_t s);
 int decode_attn_launch(const void* q, const void* kc, const void* vc, void* o, const int* n_keys, const uint64_t* vbits, int nwords,
@@ -150,7 +154,7 @@ int aki_linear_fwd(const aki_linear_args* a, void* stream) {
   AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));
   if (a->dtype == AKI_DT_BF16) {
     if (a->M <= 8) {  // decode regime: weight-streaming GEMV (falls through when the shape does not qualify)
-      const int rc = gemv_bf16(a, (hipStream_t)stream);
+      const int rc = gemv_bf16(a, nullptr, 0.f, (hipStream_t)stream);
       if (rc != AKI_ERR_UNSUPPORTED) return rc;
     }
     return linear_bf16(a, (hipStream_t)stream);
@@ -245,13 +249,45 @@ int aki_rope_append_fwd(const void* qkv, const float* cos, const float* sin, con
   return rope_append_launch(qkv, cos, sin, pos, cache_len, q_out, k_cache, v_cache, B, H, Dh, capacity, dtype, (hipStream_t)stream);
 }
 
+size_t aki_decode_attn_workspace_bytes(int32_t B, int32_t H, int32_t Dh, int32_t capacity) {
+  if (B <= 0 || H <= 0 || Dh <= 0 || capacity <= 0) return 0;
+  return decode_attn_ws_bytes(B, H, Dh, capacity);
+}
+
 int aki_decode_attn_fwd(const void* q, const void* k_cache, const void* v_cache, void* o, const int32_t* n_keys,
-                        const uint64_t* col_valid_bits, int32_t nwords, int32_t B, int32_t H, int32_t Dh, int32_t capacity, float scale,
-                        int32_t dtype, void* stream) {
+                        const uint64_t* col_valid_bits, int32_t nwords, int32_t B, int32_t H, int32_t Dh, int32_t capacity,
+                        int32_t max_keys, float scale, int32_t dtype, void* ws, size_t ws_bytes, void* stream) {
   AKI_CLEAR_ERR();
   AKI_CHECK_ARG(q && k_cache && v_cache && o && n_keys && B > 0 && H > 0 && Dh > 0 && capacity > 0 && scale > 0.f && dtype_ok(dtype));
   AKI_CHECK_ARG(!col_valid_bits || nwords > 0);
+  if (dtype == AKI_DT_BF16 && Dh == 96)
+    return decode_attn_split_launch(q, nullptr, nullptr, n_keys, (void*)k_cache, (void*)v_cache, o, col_valid_bits, nwords, B, H,
+                                    capacity, max_keys, scale, false, ws, ws_bytes, (hipStream_t)stream);
   return decode_attn_launch(q, k_cache, v_cache, o, n_keys, col_valid_bits, nwords, B, H, Dh, capacity, scale, dtype, (hipStream_t)stream);
+}
+
+int aki_decode_attn_fused_fwd(const void* qkv, const float* cos, const float* sin, const int32_t* cache_len, void* k_cache,
+                              void* v_cache, void* o, const uint64_t* col_valid_bits, int32_t nwords, int32_t B, int32_t H,
+                              int32_t Dh, int32_t capacity, int32_t max_keys, float scale, int32_t dtype, void* ws, size_t ws_bytes,
+                              void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(qkv && cos && sin && cache_len && k_cache && v_cache && o);
+  AKI_CHECK_ARG(B > 0 && H > 0 && Dh > 0 && (Dh % 2) == 0 && capacity > 0 && scale > 0.f && dtype_ok(dtype));
+  AKI_CHECK_ARG(!col_valid_bits || nwords > 0);
+  if (dtype == AKI_DT_BF16 && Dh == 96)
+    return decode_attn_split_launch(qkv, cos, sin, cache_len, k_cache, v_cache, o, col_valid_bits, nwords, B, H, capacity, max_keys,
+                                    scale, true, ws, ws_bytes, (hipStream_t)stream);
+  return AKI_ERR_UNSUPPORTED;   // f32 / other head sizes: call aki_rope_append_fwd + aki_decode_attn_fwd
+}
+
+int aki_decode_linear_fwd(const aki_linear_args* a, const void* rms_weight, float rms_eps, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(a && a->x && a->w && a->y && rms_weight && rms_eps > 0.f);
+  AKI_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->dtype == AKI_DT_BF16);
+  AKI_CHECK_ARG(a->act >= AKI_ACT_NONE && a->act <= AKI_ACT_SWIGLU);
+  const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
+  AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));
+  return gemv_bf16(a, rms_weight, rms_eps, (hipStream_t)stream);
 }
 
 // ---- splice / mask -------------------------------------------------------------------------------------

@@ -33,74 +33,130 @@ __device__ __forceinline__ float dot8_bf16(const u32x4 a, const u32x4 b, float a
 
 struct GemvParams {
   const bf16_t* x; const bf16_t* w; const bf16_t* bias; const bf16_t* residual; bf16_t* y;
+  const bf16_t* norm_w; float norm_eps;       // optional fused RMSNorm of the x rows (decode: the layer's pre-norm)
   int M, N, K, ldx, ldw, ldy, ldr, res_row_mod, act;
 };
 
+// U chunks (of 8 k) per lane for NR weight rows: every load is issued before the first dot product
+template <int M, int NR, int U>
+__device__ __forceinline__ void gemv_sweep(const bf16_t* const (&wr)[NR], const char* sx, int nchunk, int c, float (&acc)[NR][M]) {
+  u32x4 w[U][NR];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) w[u][r] = __builtin_nontemporal_load((const u32x4*)(wr[r] + (size_t)(c + 64 * u) * 8));
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const u32x4 xv = *(const u32x4*)(sx + ((size_t)m * nchunk + c + 64 * u) * 16);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r][m] = dot8_bf16(w[u][r], xv, acc[r][m]);
+    }
+}
+
 // FPW output features per wave; SWIGLU: feature f pairs weight rows f (gate) and N/2 + f (up).
+// The K sweep is unrolled KU chunks deep with all weight loads issued before the dot products: a wave keeps
+// NR*KU 16-byte loads in flight per lane, which is what decides the streaming rate at 4-6 waves per CU.
 template <int M, bool SWIGLU>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const GemvParams p) {
   constexpr int FPW = 2;
   constexpr int NR = SWIGLU ? 2 * FPW : FPW;   // weight rows per wave
+  constexpr int KU = 4;
   extern __shared__ __attribute__((aligned(16))) char sx[];
+  __shared__ float s_red[M][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunk = p.K / 8;
-  for (int i = tid; i < M * nchunk; i += 256) {
-    const int m = i / nchunk, c = i - m * nchunk;
-    *(u32x4*)(sx + (size_t)i * 16) = *(const u32x4*)(p.x + (size_t)m * p.ldx + c * 8);
+  if (p.norm_w == nullptr) {
+    for (int i = tid; i < M * nchunk; i += 256) {
+      const int m = i / nchunk, c = i - m * nchunk;
+      *(u32x4*)(sx + (size_t)i * 16) = *(const u32x4*)(p.x + (size_t)m * p.ldx + c * 8);
+    }
+  } else {
+    // y = bf16(x * rsqrt(mean(x^2) + eps) * w): same rounding points as norm_bf16_kernel<true> (aux_kernels.hip)
+    float ss[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      ss[m] = 0.f;
+      for (int c = tid; c < nchunk; c += 256) {
+        const u32x4 v = *(const u32x4*)(p.x + (size_t)m * p.ldx + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = bf16_lo(v[e]), hi = bf16_hi(v[e]);
+          ss[m] = __builtin_fmaf(lo, lo, ss[m]);
+          ss[m] = __builtin_fmaf(hi, hi, ss[m]);
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ss[m] += __shfl_xor(ss[m], o);
+      if (lane == 0) s_red[m][wave] = ss[m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const float r = rsqrtf((s_red[m][0] + s_red[m][1] + s_red[m][2] + s_red[m][3]) / (float)p.K + p.norm_eps);
+      for (int c = tid; c < nchunk; c += 256) {
+        const u32x4 v = *(const u32x4*)(p.x + (size_t)m * p.ldx + c * 8);
+        const u32x4 g = *(const u32x4*)(p.norm_w + c * 8);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // HF Phi3RMSNorm: weight * (x * rstd).to(bf16)
+          o[e] = pack_bf16x2(round_bf16(bf16_lo(v[e]) * r) * bf16_lo(g[e]), round_bf16(bf16_hi(v[e]) * r) * bf16_hi(g[e]));
+        }
+        *(u32x4*)(sx + ((size_t)m * nchunk + c) * 16) = o;
+      }
+    }
   }
   __syncthreads();
   const int n_out = SWIGLU ? p.N / 2 : p.N;
-  const int f0 = (blockIdx.x * 4 + wave) * FPW;
-  if (f0 >= n_out) return;
-  const bf16_t* wr[NR];
+  // a workgroup owns feature groups blockIdx.x, blockIdx.x + gridDim.x, ...: the x rows staged above are reused
+  for (int grp = blockIdx.x; grp * (4 * FPW) < n_out; grp += gridDim.x) {
+    const int f0 = (grp * 4 + wave) * FPW;
+    if (f0 >= n_out) break;
+    const bf16_t* wr[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const int f = min(f0 + (r % FPW), n_out - 1);
-    wr[r] = p.w + (size_t)((SWIGLU && r >= FPW) ? n_out + f : f) * p.ldw;
-  }
-  float acc[NR][M];
-#pragma unroll
-  for (int r = 0; r < NR; ++r)
-#pragma unroll
-    for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
-  for (int c = lane; c < nchunk; c += 64) {
-    u32x4 w[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) w[r] = *(const u32x4*)(wr[r] + c * 8);
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const u32x4 xv = *(const u32x4*)(sx + ((size_t)m * nchunk + c) * 16);
-#pragma unroll
-      for (int r = 0; r < NR; ++r) acc[r][m] = dot8_bf16(w[r], xv, acc[r][m]);
+    for (int r = 0; r < NR; ++r) {
+      const int f = min(f0 + (r % FPW), n_out - 1);
+      wr[r] = p.w + (size_t)((SWIGLU && r >= FPW) ? n_out + f : f) * p.ldw;
     }
-  }
+    float acc[NR][M];
 #pragma unroll
-  for (int r = 0; r < NR; ++r)
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      float v = acc[r][m];
+      for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
+    int c = lane;
+    for (; c + 64 * (KU - 1) < nchunk; c += 64 * KU) gemv_sweep<M, NR, KU>(wr, sx, nchunk, c, acc);
+    for (; c + 64 < nchunk; c += 128) gemv_sweep<M, NR, 2>(wr, sx, nchunk, c, acc);
+    for (; c < nchunk; c += 64) gemv_sweep<M, NR, 1>(wr, sx, nchunk, c, acc);
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      acc[r][m] = v;
-    }
-  if (lane == 0) {
-#pragma unroll
-    for (int f = 0; f < FPW; ++f) {
-      const int n = f0 + f;
-      if (n >= n_out) continue;
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        float v;
-        if (SWIGLU) {
-          v = acc[FPW + f][m] * silu_fast(acc[f][m]);
-        } else {
-          v = acc[f][m];
-          if (p.bias) v += bf16_bits_to_f32(p.bias[n]);
-          if (p.act == AKI_ACT_GELU_ERF) v = gelu_erf_fast(v);
-          else if (p.act == AKI_ACT_GELU_TANH) v = gelu_tanh_fast(v);
+        float v = acc[r][m];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        acc[r][m] = v;
+      }
+    if (lane == 0) {
+#pragma unroll
+      for (int f = 0; f < FPW; ++f) {
+        const int n = f0 + f;
+        if (n >= n_out) continue;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          float v;
+          if (SWIGLU) {
+            v = acc[FPW + f][m] * silu_fast(acc[f][m]);
+          } else {
+            v = acc[f][m];
+            if (p.bias) v += bf16_bits_to_f32(p.bias[n]);
+            if (p.act == AKI_ACT_GELU_ERF) v = gelu_erf_fast(v);
+            else if (p.act == AKI_ACT_GELU_TANH) v = gelu_tanh_fast(v);
+          }
+          if (p.residual) v += bf16_bits_to_f32(p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n]);
+          ((__bf16*)p.y)[(size_t)m * p.ldy + n] = (__bf16)v;
         }
-        if (p.residual) v += bf16_bits_to_f32(p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n]);
-        ((__bf16*)p.y)[(size_t)m * p.ldy + n] = (__bf16)v;
       }
     }
   }
@@ -110,7 +166,11 @@ template <int M>
 static int launch_gemv(const GemvParams& p, hipStream_t stream) {
   const size_t smem = (size_t)M * p.K * 2;
   const int n_out = p.act == AKI_ACT_SWIGLU ? p.N / 2 : p.N;
-  const dim3 grid((n_out + 7) / 8), block(256);
+  // one group = 8 features (4 waves x 2).  Staging x costs M*K*2 bytes per workgroup against 8*K*2 bytes of weights
+  // per group, so for M > 1 a workgroup takes several groups (at most ~512 workgroups stay in flight).
+  const int groups = (n_out + 7) / 8;
+  const int per = M == 1 ? 1 : (groups + 511) / 512;
+  const dim3 grid((groups + per - 1) / per), block(256);
   AKI_CLEAR_ERR();
   if (p.act == AKI_ACT_SWIGLU) {
     static bool set = false;
@@ -125,12 +185,13 @@ static int launch_gemv(const GemvParams& p, hipStream_t stream) {
   return AKI_OK;
 }
 
-// M <= 8 rows and M*K*2 <= 128 KiB of LDS; returns AKI_ERR_UNSUPPORTED otherwise (the caller then uses the MFMA GEMM)
-int gemv_bf16(const aki_linear_args* a, hipStream_t stream) {
+// M <= 8 rows and M*K*2 <= 128 KiB of LDS; returns AKI_ERR_UNSUPPORTED otherwise (the caller then uses the MFMA GEMM).
+// rms_w != NULL: the x rows are RMS-normalised (weight rms_w [K], eps) on the way into LDS.
+int gemv_bf16(const aki_linear_args* a, const void* rms_w, float eps, hipStream_t stream) {
   if (a->M > 8 || a->K % 8 || (size_t)a->M * a->K * 2 > 8 * 8192 * 2 || (a->ldx % 8) || (a->ldw % 8)) return AKI_ERR_UNSUPPORTED;
   if (a->act == AKI_ACT_SWIGLU && (a->bias || (a->N & 1))) return AKI_ERR_UNSUPPORTED;
   GemvParams p = {(const bf16_t*)a->x, (const bf16_t*)a->w, (const bf16_t*)a->bias, (const bf16_t*)a->residual, (bf16_t*)a->y,
-                  a->M, a->N, a->K, a->ldx, a->ldw, a->ldy, a->ldr, a->res_row_mod, a->act};
+                  (const bf16_t*)rms_w, eps, a->M, a->N, a->K, a->ldx, a->ldw, a->ldy, a->ldr, a->res_row_mod, a->act};
   switch (a->M) {
     case 1: return launch_gemv<1>(p, stream);
     case 2: return launch_gemv<2>(p, stream);
@@ -226,6 +287,245 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* q, const T* k
     const float a = s_acc[0][tid] + s_acc[1][tid] + s_acc[2][tid] + s_acc[3][tid];
     o[(size_t)bh * DH + tid] = (T)(lt > 0.f ? a / lt : 0.f);
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Split-KV single-query attention (bf16, Dh = 96), optionally fused with RoPE + cache append of the new token.
+//
+// With one query per (batch, head) there are only B*H independent rows, far too few to pull the cache at HBM rate
+// from 256 CUs, so the keys of each row are split over S single-wave workgroups of T 64-key tiles each:
+//   score phase  lane = key: the lane loads its whole 192-byte K row (12 x 16 B, all in flight) and dots it with q
+//   PV phase     lane = (row group g = lane>>4, 16-byte column chunk i = lane&15 < 12): 16 loads cover the tile's
+//                64 V rows; the probability of row 4*t+g comes from its owner lane through a wave shuffle
+// Every workgroup leaves (m, l, acc[96]) in the workspace; the one that arrives last at the row's counter merges the
+// S partials, writes the bf16 output and re-arms the counter (so the workspace needs zeroing only once).
+// FUSED: q comes un-rotated inside the fused qkv row; every workgroup rotates q itself (96 values), the workgroup
+// whose key range contains the new position also rotates k, appends k/v to the cache and uses them from LDS.
+// ------------------------------------------------------------------------------------------------------------
+struct DecodeAttnParams {
+  const bf16_t* q;            // FUSED: qkv rows [B][3*H*96] (un-rotated); else rotated q [B][H*96]
+  const float* cos; const float* sin;   // FUSED: [capacity][96]
+  const int* len;             // FUSED: cache_len[b] (= position and append index; n_keys = len + 1); else n_keys[b]
+  bf16_t* kc; bf16_t* vc;     // [B][H][cap][96]
+  bf16_t* o;                  // [B][H*96]
+  const uint64_t* vbits; int nwords;
+  unsigned* cnt; float* part; // workspace: arrival counters [B*H], partials [B*H][S][DEC_PSTRIDE]
+  int H, cap, S, T; float scale;
+};
+constexpr int DEC_PSTRIDE = 104;   // m, l, 6 pad, acc[96]
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(64) void decode_attn_split_kernel(const DecodeAttnParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_q[96], s_k[96], s_v[96];
+  const int lane = threadIdx.x, split = blockIdx.x, bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int ln = p.len[b];
+  const int n = FUSED ? ln + 1 : ln;
+  const int k_begin = split * p.T * 64;
+  const int k_end = min(n, k_begin + p.T * 64);
+  bf16_t* kb = p.kc + (size_t)bh * p.cap * 96;
+  bf16_t* vb = p.vc + (size_t)bh * p.cap * 96;
+  float* part = p.part + ((size_t)bh * p.S + split) * DEC_PSTRIDE;
+  const int g = lane >> 4, i16 = lane & 15;
+  float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (k_begin < k_end) {
+    const bool owner = FUSED && ln >= k_begin;          // ln < k_end holds by construction (k_end <= ln + 1)
+    u32x4 kr[12], vr[16];
+    auto issue_tile = [&](int base) {                    // all 28 loads of a tile go out back to back
+      const bf16_t* krow = kb + (size_t)min(base + lane, k_end - 1) * 96;       // clamped rows carry probability 0
+#pragma unroll
+      for (int i = 0; i < 12; ++i) kr[i] = *(const u32x4*)(krow + i * 8);
+#pragma unroll
+      for (int t2 = 0; t2 < 16; ++t2) {
+        const int r = min(base + 4 * t2 + g, k_end - 1);
+        vr[t2] = *(const u32x4*)(vb + (size_t)r * 96 + min(i16, 11) * 8);
+      }
+    };
+    issue_tile(k_begin);                                 // in flight while q is rotated
+    if (FUSED) {
+      if (lane < 48) {
+        const bf16_t* row = p.q + (size_t)b * 3 * p.H * 96 + h * 96;
+        const float c0 = p.cos[(size_t)ln * 96 + lane], c1 = p.cos[(size_t)ln * 96 + lane + 48];
+        const float s0 = p.sin[(size_t)ln * 96 + lane], s1 = p.sin[(size_t)ln * 96 + lane + 48];
+        const float q0 = bf16_bits_to_f32(row[lane]), q1 = bf16_bits_to_f32(row[lane + 48]);
+        ((__bf16*)s_q)[lane] = (__bf16)(q0 * c0 - q1 * s0);          // rotate-half: d < 48 pairs with -x[d+48]
+        ((__bf16*)s_q)[lane + 48] = (__bf16)(q1 * c1 + q0 * s1);
+        if (owner) {
+          const bf16_t* kr = row + p.H * 96;
+          const bf16_t* vr = row + 2 * p.H * 96;
+          const float k0 = bf16_bits_to_f32(kr[lane]), k1 = bf16_bits_to_f32(kr[lane + 48]);
+          const __bf16 kn0 = (__bf16)(k0 * c0 - k1 * s0), kn1 = (__bf16)(k1 * c1 + k0 * s1);
+          ((__bf16*)s_k)[lane] = kn0;
+          ((__bf16*)s_k)[lane + 48] = kn1;
+          ((__bf16*)kb)[(size_t)ln * 96 + lane] = kn0;
+          ((__bf16*)kb)[(size_t)ln * 96 + lane + 48] = kn1;
+          s_v[lane] = vr[lane];
+          s_v[lane + 48] = vr[lane + 48];
+          vb[(size_t)ln * 96 + lane] = vr[lane];
+          vb[(size_t)ln * 96 + lane + 48] = vr[lane + 48];
+        }
+      }
+    } else if (lane < 12) {
+      *(u32x4*)(s_q + lane * 8) = *(const u32x4*)(p.q + (size_t)bh * 96 + lane * 8);
+    }
+    __syncthreads();
+    u32x4 qv[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) qv[i] = *(const u32x4*)(s_q + i * 8);
+    for (int t = 0; t < p.T; ++t) {
+      const int base = k_begin + t * 64;
+      if (base >= k_end) break;
+      const int j = base + lane;
+      if (t > 0) issue_tile(base);
+      if (owner && base <= ln && ln < base + 64) {                     // the new token's row lives in LDS
+        if (j == ln) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) kr[i] = *(const u32x4*)(s_k + i * 8);
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 16; ++t2)
+          if (base + 4 * t2 + g == ln) vr[t2] = *(const u32x4*)(s_v + min(i16, 11) * 8);
+      }
+      bool ok = j < k_end;
+      if (p.vbits && (base >> 6) < p.nwords) ok = ok && ((p.vbits[(size_t)b * p.nwords + (base >> 6)] >> lane) & 1ull);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s = dot8_bf16(kr[i], qv[i], s);
+      s = ok ? s * p.scale : -INFINITY;
+      const float mn = fmaxf(m, wave_max(s));
+      if (mn == -INFINITY) continue;                                   // wave-uniform: nothing visible yet
+      const float a = __expf(m - mn);
+      const float pr = ok ? __expf(s - mn) : 0.f;
+      l = l * a + wave_sum(pr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= a;
+#pragma unroll
+      for (int t2 = 0; t2 < 16; ++t2) {
+        const float w = __shfl(pr, 4 * t2 + g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[2 * e] = __builtin_fmaf(w, bf16_lo(vr[t2][e]), acc[2 * e]);
+          acc[2 * e + 1] = __builtin_fmaf(w, bf16_hi(vr[t2][e]), acc[2 * e + 1]);
+        }
+      }
+      m = mn;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      acc[e] += __shfl_xor(acc[e], 16);
+      acc[e] += __shfl_xor(acc[e], 32);
+    }
+  }
+  // Partials travel between workgroups (possibly on different XCDs, i.e. different L2s) as agent-scope relaxed atomic
+  // stores / loads: those carry sc1 and are written through / read past the non-coherent levels.  A __threadfence()
+  // here would instead make every workgroup write back and invalidate its whole L2 (buffer_wbl2 + buffer_inv).
+#define AKI_ST_AGENT(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define AKI_LD_AGENT(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+  if (lane == 0) { AKI_ST_AGENT(part, m); AKI_ST_AGENT(part + 1, l); }
+  if (lane < 12) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) AKI_ST_AGENT(part + 8 + lane * 8 + e, acc[e]);
+  }
+  // ---- last workgroup of this (batch, head) merges the partials
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores above have reached the coherence point
+  unsigned prev = 0;
+  if (lane == 0) prev = __hip_atomic_fetch_add(p.cnt + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  prev = __shfl(prev, 0);
+  if (prev != (unsigned)(p.S - 1)) return;
+  asm volatile("" ::: "memory");
+  // lane = (split slot sl = lane / 12 in 0..4, column chunk ch = lane % 12): five splits are merged per pass with all of
+  // a pass's loads in flight together (each is a round trip to memory); the five slots then meet through LDS
+  __shared__ float s_mg[5][12][10];
+  const float* pp = p.part + (size_t)bh * p.S * DEC_PSTRIDE;
+  const int sl = lane / 12, ch = lane - sl * 12;
+  float gm = -INFINITY, lt = 0.f, o8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o8[e] = 0.f;
+  if (sl < 5) {
+    for (int s2 = sl; s2 < p.S; s2 += 5) {
+      const float* ps = pp + (size_t)s2 * DEC_PSTRIDE;
+      const float ms = AKI_LD_AGENT(ps), ls = AKI_LD_AGENT(ps + 1);
+      float a[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = AKI_LD_AGENT(ps + 8 + ch * 8 + e);
+      const float mn = fmaxf(gm, ms);
+      const float f0 = gm == -INFINITY ? 0.f : __expf(gm - mn), f1 = ms == -INFINITY ? 0.f : __expf(ms - mn);
+      lt = lt * f0 + ls * f1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = o8[e] * f0 + a[e] * f1;
+      gm = mn;
+    }
+    s_mg[sl][ch][0] = gm;
+    s_mg[sl][ch][1] = lt;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_mg[sl][ch][2 + e] = o8[e];
+  }
+  __syncthreads();
+  if (lane < 12) {
+    float M5 = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) M5 = fmaxf(M5, s_mg[q][lane][0]);
+    lt = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const float mq = s_mg[q][lane][0];
+      const float f = mq == -INFINITY ? 0.f : __expf(mq - M5);
+      lt += s_mg[q][lane][1] * f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] += s_mg[q][lane][2 + e] * f;
+    }
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    u32x4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = pack_bf16x2(o8[2 * e] * inv, o8[2 * e + 1] * inv);
+    *(u32x4*)(p.o + (size_t)bh * 96 + lane * 8) = ov;
+  }
+  if (lane == 0) AKI_ST_AGENT(p.cnt + bh, 0u);
+#undef AKI_ST_AGENT
+#undef AKI_LD_AGENT
+}
+
+static inline size_t dec_cnt_bytes(int B, int H) { return (((size_t)B * H * 4) + 255) / 256 * 256; }
+
+size_t decode_attn_ws_bytes(int B, int H, int Dh, int cap) {
+  const size_t tiles = ((size_t)cap + 63) / 64;
+  const size_t split = dec_cnt_bytes(B, H) + (size_t)B * H * tiles * DEC_PSTRIDE * 4;
+  const size_t f32_q = (size_t)B * H * Dh * 4;      // f32 path: rotated q scratch
+  return split > f32_q ? split : f32_q;
+}
+
+// max_keys: host-side upper bound of n_keys over the batch (sizes the grid; keys beyond it would be ignored).
+int decode_attn_split_launch(const void* q_or_qkv, const float* cos, const float* sin, const int* len, void* kc, void* vc, void* o,
+                             const uint64_t* vbits, int nwords, int B, int H, int cap, int max_keys, float scale, bool fused,
+                             void* ws, size_t ws_bytes, hipStream_t s) {
+  if (max_keys <= 0 || max_keys > cap) max_keys = cap;
+  const int tiles = (max_keys + 63) / 64;
+  int T = (int)(((size_t)B * H * tiles + 2047) / 2048);
+  if (T < 1) T = 1;
+  const int S = (tiles + T - 1) / T;
+  if (ws == nullptr || ws_bytes < dec_cnt_bytes(B, H) + (size_t)B * H * S * DEC_PSTRIDE * 4) return AKI_ERR_WORKSPACE;
+  DecodeAttnParams p = {(const bf16_t*)q_or_qkv, cos, sin, len, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)o, vbits, nwords,
+                        (unsigned*)ws, (float*)((char*)ws + dec_cnt_bytes(B, H)), H, cap, S, T, scale};
+  const dim3 grid(S, B * H), block(64);
+  AKI_CLEAR_ERR();
+  if (fused) hipLaunchKernelGGL(decode_attn_split_kernel<true>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(decode_attn_split_kernel<false>, grid, block, 0, s, p);
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
 }
 
 int rope_append_launch(const void* qkv, const float* cos, const float* sin, const int* pos, const int* cache_len, void* q_out,

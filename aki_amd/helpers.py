@@ -237,6 +237,11 @@ class DecoupledLinear(nn.Linear):
         out = ops.linear(input, w, bias=b)
         return out[..., :n]
 
+    def forward_normed(self, input: torch.Tensor, rms_weight: torch.Tensor, eps: float) -> torch.Tensor:
+        """forward(rmsnorm(input)) for the rows of a decode step (final norm fused into the weight-streaming head)."""
+        w, b, n = self._fused_weight()
+        return ops.decode_linear(input, w, rms_weight, eps, bias=b)[..., :n]
+
     def extra_repr(self) -> str:
         return "in_features={}, out_features={}, additional_out_features={}, bias={}, partially_freeze={}".format(
             self.in_features, self.max_original_id + 1, self.additional_out_features, self.bias is not None,

@@ -314,16 +314,69 @@ def rope_append(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: to
     return q
 
 
+def decode_attn_workspace(B: int, H: int, Dh: int, capacity: int, device) -> torch.Tensor:
+    """Zero-filled workspace for decode_attn / decode_attn_fused (allocate once per KV cache and keep passing it)."""
+    nbytes = int(L.load().aki_decode_attn_workspace_bytes(B, H, Dh, capacity))
+    return torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=device)
+
+
 def decode_attn(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_keys: torch.Tensor, scale: float,
-                col_valid_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q [B,H,Dh] against the first n_keys[b] rows of the caches [B,H,cap,Dh] -> o [B, H*Dh]."""
-    dev = _dev(q, k_cache, v_cache, n_keys, col_valid_bits)
+                col_valid_bits: Optional[torch.Tensor] = None, max_keys: int = 0, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [B,H,Dh] against the first n_keys[b] rows of the caches [B,H,cap,Dh] -> o [B, H*Dh].
+    max_keys: host upper bound of n_keys (0 = capacity); ws: decode_attn_workspace(...) (allocated here if None)."""
+    dev = _dev(q, k_cache, v_cache, n_keys, col_valid_bits, ws)
     B, H, Dh = q.shape
+    cap = k_cache.shape[2]
+    if ws is None:
+        ws = decode_attn_workspace(B, H, Dh, cap, dev)
     o = torch.empty((B, H * Dh), dtype=q.dtype, device=dev)
     nw = 0 if col_valid_bits is None else col_valid_bits.shape[1]
     L.check(L.load().aki_decode_attn_fwd(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(o), _ptr(n_keys), _ptr(col_valid_bits), nw,
-                                         B, H, Dh, k_cache.shape[2], float(scale), _dt(q), _stream()), "aki_decode_attn_fwd")
+                                         B, H, Dh, cap, int(max_keys), float(scale), _dt(q), _ptr(ws), ws.numel() * 4, _stream()),
+            "aki_decode_attn_fwd")
     return o
+
+
+def decode_attn_fused(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, cache_len: torch.Tensor, k_cache: torch.Tensor,
+                      v_cache: torch.Tensor, num_heads: int, scale: float, col_valid_bits: Optional[torch.Tensor] = None,
+                      max_keys: int = 0, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Decode step in one launch: qkv [B, 3*H*Dh] of the new tokens -> RoPE at position cache_len[b], k/v appended at
+    row cache_len[b], attention over cache_len[b]+1 keys -> o [B, H*Dh].  f32 (parity path) runs the two plain kernels."""
+    dev = _dev(qkv, cos, sin, cache_len, k_cache, v_cache, col_valid_bits, ws)
+    B = qkv.shape[0]
+    cap, Dh = k_cache.shape[2], k_cache.shape[3]
+    if qkv.dtype != torch.bfloat16 or Dh != 96:
+        q = rope_append(qkv, cos, sin, cache_len, cache_len, k_cache, v_cache, num_heads)
+        return decode_attn(q, k_cache, v_cache, cache_len + 1, scale, col_valid_bits, max_keys, ws)
+    if ws is None:
+        ws = decode_attn_workspace(B, num_heads, Dh, cap, dev)
+    o = torch.empty((B, num_heads * Dh), dtype=qkv.dtype, device=dev)
+    nw = 0 if col_valid_bits is None else col_valid_bits.shape[1]
+    L.check(L.load().aki_decode_attn_fused_fwd(_ptr(qkv.contiguous()), _ptr(cos), _ptr(sin), _ptr(cache_len), _ptr(k_cache),
+                                               _ptr(v_cache), _ptr(o), _ptr(col_valid_bits), nw, B, num_heads, Dh, cap,
+                                               int(max_keys), float(scale), _dt(qkv), _ptr(ws), ws.numel() * 4, _stream()),
+            "aki_decode_attn_fused_fwd")
+    return o
+
+
+def decode_linear(x: torch.Tensor, w: torch.Tensor, rms_weight: torch.Tensor, eps: float, act: int = ACT_NONE,
+                  bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act(rmsnorm(x; rms_weight, eps) W^T + bias) [+ residual] for the few rows of a decode step: one weight-streaming
+    launch when x is bf16 with <= 8 rows, otherwise the norm kernel followed by linear()."""
+    x2 = _rows2d(x)
+    M, K = x2.shape
+    if x.dtype != torch.bfloat16 or M > 8 or M * K > 65536 or K % 8 or x2.stride(0) % 8 or w.stride(0) % 8:
+        return linear(rmsnorm(x, rms_weight, eps), w, bias=bias, residual=residual, act=act)
+    dev = _dev(x, w, rms_weight, bias, residual)
+    N = w.shape[0]
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    out = torch.empty((*x.shape[:-1], n_out), dtype=x.dtype, device=dev)
+    o2 = out.view(-1, n_out)
+    r2 = None if residual is None else _rows2d(residual)
+    a = L.LinearArgs(_ptr(x2), _ptr(w), _ptr(bias), _ptr(r2), _ptr(o2), M, N, K, x2.stride(0), w.stride(0), o2.stride(0),
+                     0 if r2 is None else r2.stride(0), 0, act, _dt(x))
+    L.check(L.load().aki_decode_linear_fwd(C.byref(a), _ptr(rms_weight), float(eps), _stream()), "aki_decode_linear_fwd")
+    return out
 
 
 def pad_k(w: torch.Tensor, mult: int = 64) -> torch.Tensor:

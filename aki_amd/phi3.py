@@ -59,18 +59,23 @@ class Phi3RotaryTables(nn.Module):
         self._cache = {}
 
     @torch.no_grad()
-    def tables(self, n_pos: int, device):
-        """(cos, sin) f32 [n_pos, head_dim] for positions 0..n_pos-1."""
-        key = (n_pos, str(device))
+    def tables(self, n_pos: int, device, seq_len: Optional[int] = None):
+        """(cos, sin) f32 [n_pos, head_dim] for positions 0..n_pos-1.  LongRoPE picks its factor set from the length of
+        the sequence being processed (`seq_len`, default n_pos; HF: max(position_ids)+1 > original_max -> long factors),
+        which can be smaller than the table when the table is sized for a KV-cache capacity."""
+        use_long = self.short is not None and (n_pos if seq_len is None else seq_len) > self.orig_max
+        key = (n_pos, use_long, str(device))
         if key not in self._cache:
             d = self.head_dim
             base = self.theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d)
             if self.short is not None:
-                base = (self.long if n_pos > self.orig_max else self.short) * base
+                base = (self.long if use_long else self.short) * base
             inv = (1.0 / base).to(device)
             freqs = torch.arange(n_pos, dtype=torch.float32, device=device)[:, None] * inv[None, :]
             emb = torch.cat((freqs, freqs), dim=-1)
-            self._cache = {key: ((emb.cos() * self.attention_scaling).contiguous(), (emb.sin() * self.attention_scaling).contiguous())}
+            if len(self._cache) > 4:
+                self._cache.clear()
+            self._cache[key] = ((emb.cos() * self.attention_scaling).contiguous(), (emb.sin() * self.attention_scaling).contiguous())
         return self._cache[key]
 
 
@@ -84,6 +89,9 @@ class AkiKVCache:
         self.capacity = capacity
         self.cache_len = torch.zeros((B,), dtype=torch.int32, device=device)   # tokens cached per sample
         self.valid_bits = None                                                  # uint64 words of the prompt's 1-D mask
+        self.host_len = 0                                                       # host copy of max(cache_len)
+        self.attn_ws = None                                                     # split-KV attention workspace (zeroed once)
+        self.grid_keys = capacity                                               # host bound of n_keys sizing the decode grid
 
     def get_seq_length(self, layer_idx=0):
         return int(self.cache_len.max())
@@ -93,6 +101,49 @@ class AkiKVCache:
 
     def __len__(self):
         return len(self.k)
+
+
+class DecodeGraph:
+    """One decode step captured as a hipGraph and replayed per token: the step is ~260 short launches whose host-side
+    issue cost exceeds their HBM time, so replaying removes the launch-bound gap (MI355X guide: capture launch-bound
+    inner loops).  Token ids go in through a static buffer; logits come out of one.  Lengths/positions are device
+    tensors advanced inside the graph, so no per-step host value is baked in - except the LongRoPE table choice, which
+    is re-captured if the sequence crosses `original_max_position_embeddings`."""
+
+    def __init__(self, lm: "Phi3ForCausalLM", cache: AkiKVCache):
+        self.lm, self.cache = lm, cache
+        B = cache.cache_len.shape[0]
+        self.ids = torch.zeros((B,), dtype=torch.long, device=cache.cache_len.device)
+        self.graph = None
+        self.logits = None
+        self._long = None
+
+    def _capture(self):
+        lm, cache = self.lm, self.cache
+        saved, saved_host = cache.cache_len.clone(), cache.host_len
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):               # warm-up: allocator pools and lazily-set kernel attributes
+            lm.decode_step(input_ids=self.ids, past_key_values=cache)
+        cur.wait_stream(side)
+        cache.cache_len.copy_(saved)                # the warm-up's K/V row is overwritten by the first real step
+        cache.host_len = saved_host
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logits = lm.decode_step(input_ids=self.ids, past_key_values=cache)
+        cache.host_len = saved_host
+
+    def step(self, ids: torch.Tensor) -> torch.Tensor:
+        rot = self.lm.model.rotary_emb
+        use_long = rot.short is not None and self.cache.host_len + 1 > rot.orig_max
+        if self.graph is None or use_long != self._long:
+            self._long = use_long
+            self._capture()
+        self.ids.copy_(ids)
+        self.graph.replay()
+        self.cache.host_len += 1
+        return self.logits
 
 
 class Phi3RMSNorm(nn.Module):
@@ -127,12 +178,13 @@ class Phi3Attention(nn.Module):
             o = ops.mma_attn_core(q, k, v, table, self.scaling)
         return ops.linear(o, self.o_proj.weight, residual=residual)
 
-    def decode(self, x, cos, sin, residual, cache, pos, n_keys):
-        """One new token per sequence: x [B, d] (normed) -> attention output projected and added to `residual`."""
-        qkv = ops.linear(x, self.qkv_proj.weight)
-        q = ops.rope_append(qkv, cos, sin, pos, cache.cache_len, cache.k[self.layer_idx], cache.v[self.layer_idx], self.num_heads)
-        o = ops.decode_attn(q, cache.k[self.layer_idx], cache.v[self.layer_idx], n_keys, self.scaling, cache.valid_bits)
-        return ops.linear(o, self.o_proj.weight, residual=residual)
+    def decode(self, h, norm, cos, sin, cache):
+        """One new token per sequence: h [B, d] (residual stream, pre-norm) -> h + o_proj(attention).  Three launches:
+        RMSNorm+qkv GEMV, RoPE+append+split-KV attention, o_proj GEMV with the residual add."""
+        qkv = ops.decode_linear(h, self.qkv_proj.weight, norm.weight, norm.variance_epsilon)
+        o = ops.decode_attn_fused(qkv, cos, sin, cache.cache_len, cache.k[self.layer_idx], cache.v[self.layer_idx], self.num_heads,
+                                  self.scaling, cache.valid_bits, cache.grid_keys, cache.attn_ws)
+        return ops.linear(o, self.o_proj.weight, residual=h)
 
 
 class Phi3MLP(nn.Module):
@@ -144,6 +196,10 @@ class Phi3MLP(nn.Module):
     def forward(self, x, residual):
         a = ops.linear(x, self.gate_up_proj.weight, act=ops.ACT_SWIGLU)
         return ops.linear(a, self.down_proj.weight, residual=residual)
+
+    def decode(self, h, norm):
+        a = ops.decode_linear(h, self.gate_up_proj.weight, norm.weight, norm.variance_epsilon, act=ops.ACT_SWIGLU)
+        return ops.linear(a, self.down_proj.weight, residual=h)
 
 
 class Phi3DecoderLayer(nn.Module):
@@ -158,9 +214,9 @@ class Phi3DecoderLayer(nn.Module):
         h = self.self_attn(self.input_layernorm(h), cos, sin, table, h, position_ids, cache)
         return self.mlp(self.post_attention_layernorm(h), h)
 
-    def decode(self, h, cos, sin, cache, pos, n_keys):
-        h = self.self_attn.decode(self.input_layernorm(h), cos, sin, h, cache, pos, n_keys)
-        return self.mlp(self.post_attention_layernorm(h), h)
+    def decode(self, h, cos, sin, cache):
+        h = self.self_attn.decode(h, self.input_layernorm, cos, sin, cache)
+        return self.mlp.decode(h, self.post_attention_layernorm)
 
 
 class Phi3Model(nn.Module):
@@ -175,10 +231,11 @@ class Phi3Model(nn.Module):
 
     def forward(self, inputs_embeds, table, position_ids=None, cache=None):
         B, L, _ = inputs_embeds.shape
-        n_pos = L if position_ids is None else int(position_ids.max()) + 1
+        seq_len = L if position_ids is None else int(position_ids.max()) + 1
+        n_pos = seq_len if cache is None else max(seq_len, cache.capacity)
+        cos, sin = self.rotary_emb.tables(n_pos, inputs_embeds.device, seq_len)
         if cache is not None:
-            n_pos = max(n_pos, cache.capacity)
-        cos, sin = self.rotary_emb.tables(n_pos, inputs_embeds.device)
+            cache.host_len = seq_len
         h = inputs_embeds
         for layer in self.layers:
             h = layer(h, cos, sin, table, position_ids, cache)
@@ -186,14 +243,18 @@ class Phi3Model(nn.Module):
 
     def decode(self, inputs_embeds, cache):
         """inputs_embeds [B, d]: the embeddings of the tokens appended at index cache.cache_len[b]."""
-        cos, sin = self.rotary_emb.tables(cache.capacity, inputs_embeds.device)
-        pos = cache.cache_len                       # position of the new token = number of tokens before it
-        n_keys = cache.cache_len + 1
+        cache.host_len += 1                         # host-side upper bound of max(cache_len)+1: no device sync per step
+        cos, sin = self.rotary_emb.tables(cache.capacity, inputs_embeds.device, cache.host_len)
+        # position of the new token = its cache row = number of tokens before it (cache.cache_len, on the device)
+        if cache.attn_ws is None:
+            cache.attn_ws = ops.decode_attn_workspace(inputs_embeds.shape[0], cache.k[0].shape[1], cache.k[0].shape[3],
+                                                      cache.capacity, inputs_embeds.device)
+        cache.grid_keys = cache.capacity if torch.cuda.is_current_stream_capturing() else min(cache.capacity, cache.host_len)
         h = inputs_embeds
         for layer in self.layers:
-            h = layer.decode(h, cos, sin, cache, pos, n_keys)
+            h = layer.decode(h, cos, sin, cache)
         cache.cache_len += 1
-        return self.norm(h)
+        return h                                    # PRE-norm: the head applies self.norm inside its GEMV
 
 
 class Phi3ForCausalLM(nn.Module):
@@ -268,7 +329,10 @@ class Phi3ForCausalLM(nn.Module):
         if inputs_embeds is None:
             inputs_embeds = self.get_input_embeddings()(input_ids)
         h = self.model.decode(inputs_embeds.reshape(inputs_embeds.shape[0], -1), past_key_values)
-        return self._head(h)
+        norm = self.model.norm
+        if type(self.lm_head) is nn.Linear:
+            return ops.decode_linear(h, self.lm_head.weight, norm.weight, norm.variance_epsilon, bias=self.lm_head.bias)
+        return self.lm_head.forward_normed(h, norm.weight, norm.variance_epsilon)
 
 
 def causal_lm_loss(logits, labels, ignore_index=-100):

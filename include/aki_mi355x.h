@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 2
+#define AKI_ABI_VERSION 3
 
 typedef enum {
   AKI_OK = 0,
@@ -276,13 +276,31 @@ int aki_splice_fwd(const aki_splice_args* args, void* stream);
  *                       [B,H,capacity,Dh] at index cache_len[b] (device int32); pos[b] = row into cos/sin.
  * aki_decode_attn_fwd : o [B,H*Dh] = softmax(q K^T * scale) V over the first n_keys[b] cache rows (device int32),
  *                       optional valid bits [B][nwords] of the prefill columns (padding), NULL = all valid.
+ *                       bf16/Dh=96 runs split over the keys (flash-decoding) and needs the workspace below; max_keys is
+ *                       a HOST upper bound of max_b n_keys[b] (<= capacity; 0 = capacity) that sizes the grid - keys
+ *                       beyond it are not visited.
+ * aki_decode_attn_fused_fwd : the two calls above in one launch (bf16, Dh=96): qkv rows in, rotated k / v appended at
+ *                       cache_len[b] (which is also the RoPE position), attention over cache_len[b]+1 keys.
+ *                       Returns AKI_ERR_UNSUPPORTED for f32 / other head sizes (use the two separate calls).
+ * Workspace: aki_decode_attn_workspace_bytes(B,H,Dh,capacity) bytes, caller-owned, ZERO-FILLED ONCE before its first
+ *                       use and then passed unchanged from call to call (it holds per-row arrival counters that the
+ *                       kernel re-arms itself); calls sharing one workspace must be stream-ordered.
+ * aki_decode_linear_fwd : aki_linear_fwd for M <= 8 bf16 rows with the layer's RMSNorm applied to x on the way in:
+ *                       y = act(rmsnorm(x; rms_weight, eps) W^T + bias) [+ residual]  (HF:phi3/modeling_phi3.py:266-284
+ *                       pre-norm followed by qkv_proj / gate_up_proj).  AKI_ERR_UNSUPPORTED if M > 8 or M*K > 64 Ki.
  * ---------------------------------------------------------------------------------------------- */
 int aki_rope_append_fwd(const void* qkv, const float* cos, const float* sin, const int32_t* pos, const int32_t* cache_len,
                         void* q_out, void* k_cache, void* v_cache, int32_t B, int32_t H, int32_t Dh, int32_t capacity,
                         int32_t dtype, void* stream);
+size_t aki_decode_attn_workspace_bytes(int32_t B, int32_t H, int32_t Dh, int32_t capacity);
 int aki_decode_attn_fwd(const void* q, const void* k_cache, const void* v_cache, void* o, const int32_t* n_keys,
                         const uint64_t* col_valid_bits, int32_t nwords, int32_t B, int32_t H, int32_t Dh, int32_t capacity,
-                        float scale, int32_t dtype, void* stream);
+                        int32_t max_keys, float scale, int32_t dtype, void* ws, size_t ws_bytes, void* stream);
+int aki_decode_attn_fused_fwd(const void* qkv, const float* cos, const float* sin, const int32_t* cache_len, void* k_cache,
+                              void* v_cache, void* o, const uint64_t* col_valid_bits, int32_t nwords, int32_t B, int32_t H,
+                              int32_t Dh, int32_t capacity, int32_t max_keys, float scale, int32_t dtype, void* ws,
+                              size_t ws_bytes, void* stream);
+int aki_decode_linear_fwd(const aki_linear_args* args, const void* rms_weight, float rms_eps, void* stream);
 
 /* aki_mma_mask_dense - materialise the reference's (B,1,L,L) int64 0/1 mask from the table, for
  * callers that still want it (bit-exact vs src/vlm.py:410-443 + src/utils.py:99-108). */

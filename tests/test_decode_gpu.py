@@ -133,3 +133,58 @@ def test_generate_stops_at_eos_and_pads():
     assert int(toks[0, 0]) == eos and bool((toks[0, 1:] == gen.TINY["pad_token_id"]).all())
     with pytest.raises(NotImplementedError):
         m.generate(vx, lx, attention_mask=am, num_beams=4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_generate_graph_replay_equals_eager(dtype):
+    """hipGraph replay of the decode step must give exactly the tokens of eager launches (same kernels, same order)."""
+    m, g = build_tiny(dtype)
+    vx, lx, am, _ = batch(g, dtype)
+    eager = m.generate(vx, lx, attention_mask=am, max_new_tokens=9, use_graph=False)
+    graph = m.generate(vx, lx, attention_mask=am, max_new_tokens=9, use_graph=True)
+    assert torch.equal(eager, graph)
+
+
+@pytest.mark.parametrize("M", [1, 8])
+@pytest.mark.parametrize("act", ["none", "swiglu"])
+def test_decode_linear_fused_rmsnorm(M, act):
+    """aki_decode_linear_fwd == rmsnorm kernel followed by the linear kernel (and the oracle's arithmetic)."""
+    from aki_amd import ops
+    rng = gen.rng_for(f"declin{M}{act}")
+    K, N = 3072, 1024
+    x = rng.standard_normal((M, K), dtype=np.float32) * 3.0
+    g = 1.0 + 0.1 * rng.standard_normal((K,), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) * 0.05
+    r = rng.standard_normal((M, N if act == "none" else N // 2), dtype=np.float32)
+    dt = torch.bfloat16
+    a = ops.ACT_SWIGLU if act == "swiglu" else ops.ACT_NONE
+    fused = ops.decode_linear(t(x, dt), t(w, dt), t(g, dt), 1e-5, act=a, residual=t(r, dt))
+    plain = ops.linear(ops.rmsnorm(t(x, dt), t(g, dt), 1e-5), t(w, dt), act=a, residual=t(r, dt))
+    check(n(fused), n(plain).astype(np.float32), dt, "fused norm+gemv vs norm kernel + gemv", scale_atol=2.0)
+
+
+@pytest.mark.parametrize("B,H,cap,lens", [(3, 4, 300, [17, 200, 298]), (2, 2, 5000, [4100, 63]), (8, 32, 700, [655] * 8), (1, 32, 64, [0])])
+def test_decode_attn_fused_vs_two_kernels(B, H, cap, lens):
+    """RoPE + append + split-KV attention in one launch == rope_append followed by decode_attn; caches end up identical."""
+    from aki_amd import ops
+    Dh, dt = 96, torch.bfloat16
+    rng = gen.rng_for(f"decfused{B}{H}{cap}")
+    kc = t(rng.standard_normal((B, H, cap, Dh), dtype=np.float32), dt)
+    vc = t(rng.standard_normal((B, H, cap, Dh), dtype=np.float32), dt)
+    qkv = t(rng.standard_normal((B, 3 * H * Dh), dtype=np.float32), dt)
+    cos, sin = O.rope_cos_sin(np.arange(cap)[None], Dh)
+    tc, ts = torch.from_numpy(cos[0]).to(DEV), torch.from_numpy(sin[0]).to(DEV)
+    cl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    am = np.ones((B, cap), dtype=bool)
+    am[0, 3:7] = False
+    bits = ops.MaskTable.from_host([[(0, 0, 0, 0)]] * B, am, None, DEV).col_valid_bits
+    k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+    q = ops.rope_append(qkv, tc, ts, cl, cl, k1, v1, H)
+    want = ops.decode_attn(q, k1, v1, cl + 1, Dh ** -0.5, bits)
+    ws = ops.decode_attn_workspace(B, H, Dh, cap, DEV)
+    for rep in range(2):             # twice through the same workspace: the arrival counters must re-arm themselves
+        k2.copy_(kc); v2.copy_(vc)
+        got = ops.decode_attn_fused(qkv, tc, ts, cl, k2, v2, H, Dh ** -0.5, bits, max(lens) + 1, ws)
+        assert torch.equal(k1, k2) and torch.equal(v1, v2), "appended rows differ"
+        check(n(got), n(want).astype(np.float32), dt, f"fused decode attention (pass {rep})", scale_atol=2.0)
+    assert int(ws[: B * H].abs().sum()) == 0

@@ -1,0 +1,53 @@
+"""Decode-path timing on one MI355X: full-size Phi-3.5-mini stream (random weights), MMA prefill into the KV cache,
+then N greedy decode steps - eager launches vs hipGraph replay.  Prints ms/token and the weight-streaming rate
+(every decoder + head weight is read once per token: the HBM roofline of this regime).
+    python tools/decode_bench.py [--batch 1] [--prompt 655] [--steps 64]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--prompt", type=int, default=655)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=32)
+    a = ap.parse_args()
+    from aki_amd import ops
+    from aki_amd.phi3 import Phi3ForCausalLM, make_phi3_config, DecodeGraph
+    from aki_amd.helpers import DecoupledEmbedding, DecoupledLinear
+    dev = "cuda"
+    torch.manual_seed(0)
+    cfg = make_phi3_config(num_hidden_layers=a.layers)
+    lm = Phi3ForCausalLM(cfg)
+    for p in lm.parameters():
+        p.data.normal_(0, 0.02)
+    lm = lm.to(dev).to(torch.bfloat16).eval()
+    wbytes = sum(p.numel() * 2 for n, p in lm.named_parameters() if "embed_tokens" not in n)
+    B, L = a.batch, a.prompt
+    x = torch.randn(B, L, cfg.hidden_size, device=dev, dtype=torch.bfloat16) * 0.5
+    am = torch.ones(B, L, dtype=torch.bool)
+    table = ops.MaskTable.from_host([[(4, 148, 4, 148)]] * B, am.numpy(), [L] * B, dev)
+    res = {"batch": B, "prompt": L, "steps": a.steps, "weight_bytes": wbytes}
+    with torch.no_grad():
+        for mode in ("eager", "graph"):
+            out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=L + 2 * a.steps + 8)
+            cache = out.past_key_values
+            nxt = out.logits[:, -1].float().argmax(-1)
+            stepper = DecodeGraph(lm, cache) if mode == "graph" else None
+            step = (lambda ids: stepper.step(ids)) if stepper else (lambda ids: lm.decode_step(input_ids=ids, past_key_values=cache))
+            for _ in range(4):
+                nxt = step(nxt).float().argmax(-1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                nxt = step(nxt).float().argmax(-1)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3 / a.steps
+            res[mode] = {"ms_per_token": round(ms, 4), "tokens_per_s": round(B * 1e3 / ms, 1), "weight_GBps": round(wbytes / ms / 1e6, 1)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
