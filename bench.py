@@ -46,86 +46,95 @@ def synth_batch(B, device, dtype, media_id, seed):
 
 
 def cpu_baseline(budget_s=25.0):
-    """The oracle's numpy port of the reference eager forward on the host cores, bounded sample: ONE sample of the
-    benchmark workload (L = 655), 2 of 32 decoder layers and 2 of 27 SigLIP layers timed and scaled by layer count
-    (the layers are identical), Perceiver connector, splice/mask and lm_head timed in full."""
+    """The torch (fp32, eager) restatement of the reference forward (oracle/aki_torch.py, pinned to the reference's
+    golden vectors) on ALL host cores, bounded sample: one batch of the benchmark workload (B samples, L = 655);
+    2 of 32 decoder layers and 2 of 27 SigLIP layers are timed (after one warm-up pass) and scaled by layer count - the
+    layers are identical - while patch embed, Perceiver connector, splice + dense MMA mask + 4.41.2 inversion and the
+    lm_head are timed in full."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
-    import aki_oracle as O
+    import torch
+    import aki_torch as OT
+    cores = os.cpu_count() or 1
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count() or 1])
+        cores = len(os.sched_getaffinity(0))
     except Exception:
-        cores = os.cpu_count() or 1
-    rng = np.random.Generator(np.random.PCG64(0))
-    f = lambda *s: (rng.standard_normal(s, dtype=np.float32) * np.float32(0.02))
+        pass
+    torch.set_num_threads(cores)
+    B = BATCH
+    g = torch.Generator().manual_seed(0)
+    f = lambda *s: torch.randn(*s, generator=g) * 0.02
+    ones, zeros = (lambda n: torch.ones(n)), (lambda n: torch.zeros(n))
     d, H, F, V = 3072, 32, 8192, 32064
     L = N_TXT - 1 + NV
     t = {}
-    # --- SigLIP: patch embed + 2 layers --------------------------------------------------------------
-    E, P, G = 1152, 14, IMG_PX // 14
-    px = rng.random((1, 3, IMG_PX, IMG_PX), dtype=np.float32) * 2 - 1
-    t0 = time.perf_counter()
-    h = O.siglip_patch_embed(px, f(E, 3, P, P), f(E), f(G * G, E))
-    t["patch_embed"] = time.perf_counter() - t0
-    lp = {"layer_norm1.weight": np.ones(E, np.float32), "layer_norm1.bias": np.zeros(E, np.float32),
-          "layer_norm2.weight": np.ones(E, np.float32), "layer_norm2.bias": np.zeros(E, np.float32),
-          "mlp.fc1.weight": f(4304, E), "mlp.fc1.bias": f(4304), "mlp.fc2.weight": f(E, 4304), "mlp.fc2.bias": f(E)}
-    for n_ in ("q", "k", "v", "out"):
-        lp[f"self_attn.{n_}_proj.weight"] = f(E, E)
-        lp[f"self_attn.{n_}_proj.bias"] = f(E)
-    O.siglip_encoder_layer(h, lp, 16)            # warm-up (BLAS thread pool)
-    t0 = time.perf_counter()
-    for _ in range(2):
-        h = O.siglip_encoder_layer(h, lp, 16)
-    t["siglip_layer"] = (time.perf_counter() - t0) / 2
-    # --- Perceiver connector (full) --------------------------------------------------------------------
-    pp = {"latents": rng.standard_normal((NV, E), dtype=np.float32), "norm.weight": np.ones(E, np.float32),
-          "norm.bias": np.zeros(E, np.float32), "projection.weight": f(d, E), "projection.bias": f(d)}
-    for l in range(6):
-        for nm in ("norm_media", "norm_latents"):
-            pp[f"layers.{l}.0.{nm}.weight"] = np.ones(E, np.float32)
-            pp[f"layers.{l}.0.{nm}.bias"] = np.zeros(E, np.float32)
-        pp[f"layers.{l}.0.to_q.weight"] = f(512, E)
-        pp[f"layers.{l}.0.to_kv.weight"] = f(1024, E)
-        pp[f"layers.{l}.0.to_out.weight"] = f(E, 512)
-        pp[f"layers.{l}.1.0.weight"] = np.ones(E, np.float32)
-        pp[f"layers.{l}.1.0.bias"] = np.zeros(E, np.float32)
-        pp[f"layers.{l}.1.1.weight"] = f(4 * E, E)
-        pp[f"layers.{l}.1.3.weight"] = f(E, 4 * E)
-    t0 = time.perf_counter()
-    vt = O.perceiver_resampler(h[None, :, None], pp)
-    t["perceiver"] = time.perf_counter() - t0
-    # --- splice + dense MMA mask (the reference materialises it) ------------------------------------------
-    ids = rng.integers(3, 32000, size=(1, N_TXT)).astype(np.int64)
-    ids[0, 6] = 32011
-    ids[0, N_TXT - 17] = 32001
-    emb = f(1, N_TXT, d)
-    t0 = time.perf_counter()
-    prep = O.prepare_inputs_for_forward(vt.reshape(1, 1, NV, d), ids, np.ones_like(ids), None, emb, 32011, 32000, NV)
-    add = O.invert_mask_441(prep["attention_mask"])
-    t["splice_mask"] = time.perf_counter() - t0
-    # --- 2 decoder layers -----------------------------------------------------------------------------------
-    dp = {"input_layernorm.weight": np.ones(d, np.float32), "post_attention_layernorm.weight": np.ones(d, np.float32),
-          "self_attn.qkv_proj.weight": f(3 * d, d), "self_attn.o_proj.weight": f(d, d),
-          "mlp.gate_up_proj.weight": f(2 * F, d), "mlp.down_proj.weight": f(d, F)}
-    cos, sin = O.rope_cos_sin(np.arange(L)[None], 96)
-    x = prep["inputs_embeds"]
-    O.phi3_decoder_layer(x, dp, cos, sin, add, H)
-    t0 = time.perf_counter()
-    for _ in range(2):
-        x = O.phi3_decoder_layer(x, dp, cos, sin, add, H)
-    t["decoder_layer"] = (time.perf_counter() - t0) / 2
-    # --- final norm + lm_head ---------------------------------------------------------------------------------
-    W = f(V, d)
-    t0 = time.perf_counter()
-    O.decoupled_linear(O.rms_norm(x, np.ones(d, np.float32)), W, None, f(2, d), None, 32010)
-    t["lm_head"] = time.perf_counter() - t0
+    with torch.no_grad():
+        # --- SigLIP: patch embed + 2 layers -----------------------------------------------------------------
+        E, P, G = 1152, 14, IMG_PX // 14
+        px = torch.rand(B, 3, IMG_PX, IMG_PX, generator=g) * 2 - 1
+        wpe, bpe, pos = f(E, 3, P, P), f(E), f(G * G, E)
+        OT.siglip_patch_embed(px, wpe, bpe, pos)
+        t0 = time.perf_counter()
+        h = OT.siglip_patch_embed(px, wpe, bpe, pos)
+        t["patch_embed"] = time.perf_counter() - t0
+        lp = {"layer_norm1.weight": ones(E), "layer_norm1.bias": zeros(E), "layer_norm2.weight": ones(E), "layer_norm2.bias": zeros(E),
+              "mlp.fc1.weight": f(4304, E), "mlp.fc1.bias": f(4304), "mlp.fc2.weight": f(E, 4304), "mlp.fc2.bias": f(E)}
+        for n_ in ("q", "k", "v", "out"):
+            lp[f"self_attn.{n_}_proj.weight"] = f(E, E)
+            lp[f"self_attn.{n_}_proj.bias"] = f(E)
+        OT.siglip_encoder_layer(h, lp, 16)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            h = OT.siglip_encoder_layer(h, lp, 16)
+        t["siglip_layer"] = (time.perf_counter() - t0) / 2
+        # --- Perceiver connector (full) -------------------------------------------------------------------------
+        pp = {"latents": torch.randn(NV, E, generator=g), "norm.weight": ones(E), "norm.bias": zeros(E),
+              "projection.weight": f(d, E), "projection.bias": f(d)}
+        for l in range(6):
+            for nm in ("norm_media", "norm_latents"):
+                pp[f"layers.{l}.0.{nm}.weight"] = ones(E)
+                pp[f"layers.{l}.0.{nm}.bias"] = zeros(E)
+            pp[f"layers.{l}.0.to_q.weight"] = f(512, E)
+            pp[f"layers.{l}.0.to_kv.weight"] = f(1024, E)
+            pp[f"layers.{l}.0.to_out.weight"] = f(E, 512)
+            pp[f"layers.{l}.1.0.weight"] = ones(E)
+            pp[f"layers.{l}.1.0.bias"] = zeros(E)
+            pp[f"layers.{l}.1.1.weight"] = f(4 * E, E)
+            pp[f"layers.{l}.1.3.weight"] = f(E, 4 * E)
+        t0 = time.perf_counter()
+        vt = OT.perceiver_resampler(h[:, None, None], pp)
+        t["perceiver"] = time.perf_counter() - t0
+        # --- splice + dense MMA mask + inversion (the reference materialises both) ------------------------------
+        ids = torch.randint(3, 32000, (B, N_TXT), generator=g)
+        ids[:, 6] = 32011
+        ids[:, N_TXT - 17] = 32001
+        emb = f(B, N_TXT, d)
+        t0 = time.perf_counter()
+        prep = OT.prepare_inputs_for_forward(vt, ids, torch.ones_like(ids), None, emb, 32011, 32000, NV)
+        add = OT.invert_mask_441(prep["attention_mask"])
+        t["splice_mask"] = time.perf_counter() - t0
+        # --- 2 decoder layers ---------------------------------------------------------------------------------------
+        dp = {"input_layernorm.weight": ones(d), "post_attention_layernorm.weight": ones(d),
+              "self_attn.qkv_proj.weight": f(3 * d, d), "self_attn.o_proj.weight": f(d, d),
+              "mlp.gate_up_proj.weight": f(2 * F, d), "mlp.down_proj.weight": f(d, F)}
+        cos, sin = OT.rope_cos_sin(np.arange(L)[None], 96)
+        x = prep["inputs_embeds"]
+        OT.phi3_decoder_layer(x, dp, cos, sin, add, H)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            x = OT.phi3_decoder_layer(x, dp, cos, sin, add, H)
+        t["decoder_layer"] = (time.perf_counter() - t0) / 2
+        # --- final norm + lm_head -----------------------------------------------------------------------------------
+        W, Wa = f(V, d), f(2, d)
+        t0 = time.perf_counter()
+        OT.decoupled_linear(OT.rms_norm(x, ones(d)), W, None, Wa, None, 32010)
+        t["lm_head"] = time.perf_counter() - t0
     total = t["patch_embed"] + 27 * t["siglip_layer"] + t["perceiver"] + t["splice_mask"] + 32 * t["decoder_layer"] + t["lm_head"]
-    return {"value": round(L / total, 2), "unit": "tokens/s", "cores": int(cores), "kind": "port",
-            "sample": "1 sample of the benchmark workload (336px image + 512-token prompt, L=655), numpy fp32 oracle: "
-                      "2/32 decoder layers and 2/27 SigLIP layers timed and scaled by layer count, connector, splice+dense "
-                      "mask and lm_head timed in full",
+    return {"value": round(B * L / total, 2), "unit": "tokens/s", "cores": int(cores), "kind": "port",
+            "sample": f"one batch of the benchmark workload ({B} x (336px image + 512-token prompt), L=655), torch fp32 eager "
+                      "restatement of the reference forward on all host cores: 2/32 decoder layers and 2/27 SigLIP layers "
+                      "timed and scaled by layer count, patch embed, connector, splice + dense mask + inversion and lm_head "
+                      "timed in full",
             "seconds_per_forward_est": round(total, 3), "parts_s": {k: round(v, 4) for k, v in t.items()}}
 
 

@@ -90,3 +90,10 @@ def mask_cases() -> List[Tuple[np.ndarray, int, int, int]]:
     cases.append((ones(207), 6, 150, 190 + 144 - 144))                # config-1-like length
     cases.append((np.concatenate((np.ones(600, dtype=np.int64), np.zeros(55, dtype=np.int64))), 6, 150, 638))  # config-2-like
     return cases
+
+
+def grad_sample_idx(numel: int, k: int = 48) -> np.ndarray:
+    """Deterministic flat indices at which gradient fixtures sample a parameter's gradient."""
+    if numel <= k:
+        return np.arange(numel, dtype=np.int64)
+    return (np.arange(k, dtype=np.int64) * 2654435761 + 12345) % numel

@@ -139,6 +139,31 @@ def g_tiny_e2e(ref):
          mask_bits=gen.pack_mask_bits(prep_l["attention_mask"].numpy()), mask_shape=np.array(prep_l["attention_mask"].shape))
 
 
+def g_tiny_grads(ref):
+    """a13/a14: gradients of the reference's own loss.backward() on the tiny model (fp32 eager autograd).  Per trainable
+    parameter: sum, sum of |.|, and the values at gen.grad_sample_idx(numel) (full tensors would be 25 MB)."""
+    model, shapes = build_tiny(ref)
+    model.set_trainable()
+    lang_x, am, labels, vision_x = tiny_batch()
+    tl, ta, tlab, tv = map(torch.from_numpy, (lang_x, am, labels, vision_x))
+    model.zero_grad()
+    with torch.enable_grad():
+        out = model(tv, tl, attention_mask=ta, labels=tlab)
+        out.loss.backward()
+    names, sums, abss, samples = [], [], [], []
+    for n_, p_ in model.named_parameters():
+        if not p_.requires_grad:
+            continue
+        g_ = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+        g64 = g_.double().flatten()
+        idx = gen.grad_sample_idx(g64.numel())
+        smp = np.zeros(48, dtype=np.float32)
+        smp[: len(idx)] = g_.detach().flatten()[torch.from_numpy(idx)].numpy()
+        names.append(n_); sums.append(float(g64.sum())); abss.append(float(g64.abs().sum())); samples.append(smp)
+    save("tiny_grads.npz", names=np.array(json.dumps(names)), sums=np.array(sums), abss=np.array(abss),
+         samples=np.stack(samples), loss=np.array(float(out.loss)))
+
+
 def g_decoupled(ref):
     """a5/a12: DecoupledEmbedding / DecoupledLinear (src/helpers.py:445-484, 594-603)."""
     H = ref.helpers
@@ -265,6 +290,7 @@ def main():
     g_perceiver(ref)
     g_patch_embed()
     g_tiny_e2e(ref)
+    g_tiny_grads(ref)
 
 
 if __name__ == "__main__":

@@ -152,3 +152,51 @@ def test_fixture_files_are_data_only():
     for f in os.listdir(GOLDEN_DIR):
         if f.endswith(".npz"):
             assert os.path.getsize(os.path.join(GOLDEN_DIR, f)) < 2 * 1024 * 1024
+
+
+# ---- torch restatement (oracle/aki_torch.py): forward and autograd gradients pinned to the reference -------------
+def _tiny_torch():
+    import torch
+    import aki_torch as OT
+    g = load_golden("tiny_e2e.npz")
+    p = {k: torch.from_numpy(v.copy()) for k, v in gen.fill_params(_shapes(g), 11).items()}
+    rng = gen.rng_for("tiny_batch")
+    B = g["lang_x"].shape[0]
+    vision_x = torch.from_numpy(rng.standard_normal((B, 1, 1, 3, gen.TINY["image"], gen.TINY["image"]), dtype=np.float32))
+    return OT, g, p, vision_x
+
+
+def test_torch_oracle_forward_matches_reference():
+    import torch
+    OT, g, p, vision_x = _tiny_torch()
+    with torch.no_grad():
+        out = OT.aki_forward(p, tiny_cfg(), vision_x, torch.from_numpy(g["lang_x"]), torch.from_numpy(g["attention_mask"]),
+                             torch.from_numpy(g["labels"]))
+    np.testing.assert_allclose(out["prep"]["inputs_embeds"].numpy(), g["inputs_embeds"], atol=2e-5, rtol=1e-4)
+    assert np.array_equal(out["prep"]["labels"].numpy(), g["new_labels"])
+    np.testing.assert_allclose(out["logits"][:, :, torch.from_numpy(g["logit_cols"])].numpy(), g["logits"], atol=2e-4, rtol=1e-3)
+    assert abs(float(out["loss"]) - float(g["loss"])) < 1e-4
+
+
+def test_torch_oracle_gradients_match_reference_backward():
+    """autograd over the restatement == the reference's loss.backward() (tiny_grads.npz) for every trainable parameter."""
+    import json, torch
+    OT, g, p, vision_x = _tiny_torch()
+    gg = load_golden("tiny_grads.npz")
+    names = json.loads(str(gg["names"]))
+    for n_ in names:
+        p[n_].requires_grad_(True)
+    out = OT.aki_forward(p, tiny_cfg(), vision_x, torch.from_numpy(g["lang_x"]), torch.from_numpy(g["attention_mask"]),
+                         torch.from_numpy(g["labels"]))
+    out["loss"].backward()
+    assert abs(float(out["loss"]) - float(gg["loss"])) < 1e-5
+    assert not any(k.startswith("vision_encoder.") for k in names)          # frozen tower (src/aki.py:52-57)
+    for i, n_ in enumerate(names):
+        gr = p[n_].grad
+        gr = torch.zeros_like(p[n_]) if gr is None else gr
+        idx = gen.grad_sample_idx(gr.numel())
+        got = gr.flatten()[torch.from_numpy(idx)].numpy()
+        want = gg["samples"][i][: len(idx)]
+        scale = max(float(gg["abss"][i]) / gr.numel(), 1e-8)
+        np.testing.assert_allclose(got, want, atol=2e-3 * scale + 1e-9, rtol=2e-3, err_msg=n_)
+        assert abs(float(gr.double().abs().sum()) - float(gg["abss"][i])) <= 1e-3 * float(gg["abss"][i]) + 1e-9, n_
