@@ -14,7 +14,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 3
+AKI_ABI_VERSION = 4
 
 
 class AkiError(RuntimeError):
@@ -46,6 +46,14 @@ class AttnArgs(C.Structure):
                 ("q_stride_b", C.c_int64), ("q_stride_h", C.c_int64), ("q_stride_t", C.c_int64),
                 ("k_stride_b", C.c_int64), ("k_stride_h", C.c_int64), ("k_stride_t", C.c_int64),
                 ("v_stride_b", C.c_int64), ("v_stride_h", C.c_int64), ("v_stride_t", C.c_int64),
+                ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32), ("Dh", C.c_int32),
+                ("scale", C.c_float), ("dtype", C.c_int32), ("lse", C.c_void_p)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("d_o", C.c_void_p), ("lse", C.c_void_p),
+                ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("rects", C.c_void_p), ("max_rects", C.c_int32),
+                ("col_valid_bits", C.c_void_p), ("seq_lens", C.c_void_p), ("masked", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32), ("Dh", C.c_int32),
                 ("scale", C.c_float), ("dtype", C.c_int32)]
 
@@ -97,6 +105,23 @@ SIGNATURES = {
     "aki_decode_attn_fused_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 6 + [C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
                                             C.c_void_p]),
     "aki_decode_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p, C.c_float, C.c_void_p]),
+    "aki_attn_bwd_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
+    "aki_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aki_transpose": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),
+    "aki_norm_bwd_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "aki_norm_bwd": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_int32] * 5 + [C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                                                                  C.c_void_p]),
+    "aki_colsum_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "aki_colsum": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aki_swiglu_fwd": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p]),
+    "aki_swiglu_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_void_p]),
+    "aki_gelu_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "aki_gelu_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_size_t, C.c_int32, C.c_void_p]),
+    "aki_rope_bwd_merge": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p]),
+    "aki_ce_loss_fwd_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_float, C.c_int32, C.c_void_p]),
+    "aki_grad_sqnorm_workspace_bytes": (C.c_size_t, []),
+    "aki_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aki_adamw_step": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p] + [C.c_float] * 7 + [C.c_int32, C.c_void_p]),
     "aki_splice_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "aki_splice_fwd": (C.c_int, [C.POINTER(SpliceArgs), C.c_void_p]),
     "aki_mma_mask_dense": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,

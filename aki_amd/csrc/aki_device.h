@@ -94,6 +94,32 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+// ---- wave / workgroup reductions ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+// sums of a and b over a workgroup of NT threads; red: >= 2*NT/64 floats of LDS
+template <int NT>
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[w] = a; red[w + NT / 64] = b; }
+  __syncthreads();
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) { sa += red[i]; sb += red[i + NT / 64]; }
+  a = sa; b = sb;
+  __syncthreads();
+}
+
 }  // namespace aki
 
 // ---- host side helpers (api translation units) -------------------------------------------------

@@ -27,6 +27,26 @@ int mask_dense_launch(const aki_mma_rect* rects, int max_rects, const uint64_t* 
                       int64_t* out, hipStream_t s);
 int im2col_launch(const void* pix, void* out, int N, int S, int P, int Kp, int dtype, hipStream_t s);
 extern int g_force_tile;
+size_t attn_bwd_ws_bytes(int B, int H, int Lq);
+int attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq, void* dk,
+                  void* dv, const aki_mma_rect* rects, int max_rects, const uint64_t* vbits, const int* seq_lens, int masked, int B,
+                  int H, int Lq, int Lk, int Dh, float scale, void* ws, size_t ws_bytes, hipStream_t s);
+int transpose_bf16_launch(const void* x, void* y, int R, int C, int ldx, int ldy, int Rpad, hipStream_t s);
+size_t norm_bwd_ws_bytes(int cols);
+int norm_bwd_launch(bool rms, const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, int rows, int cols,
+                    int ldx, int lddy, int lddx, float eps, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+size_t colsum_ws_bytes(int cols);
+int colsum_launch(const void* x, void* out, int rows, int cols, int ldx, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int swiglu_launch(int bwd, const void* gu, const void* da, void* out, int rows, int F, int ldg, int ldda, int ldo, hipStream_t s);
+int gelu_launch(int bwd, const void* x, const void* dy, void* out, size_t n, hipStream_t s);
+int rope_bwd_merge_launch(const void* dq, const void* dk, const void* dv, const float* cos, const float* sin, const int* pos, void* dqkv,
+                          int B, int H, int L, int Dh, hipStream_t s);
+int ce_launch(const void* logits, const int64_t* labels, int* n_valid, float* loss_rows, void* dlogits, int B, int L, int V, int ldl,
+              int lddl, float gscale, hipStream_t s);
+size_t grad_sqnorm_ws_bytes();
+int grad_sqnorm_launch(const void* g, size_t n, float* out, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int adamw_launch(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
+                 float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s);
 }  // namespace aki
 
 using namespace aki;
@@ -288,6 +308,111 @@ int aki_decode_linear_fwd(const aki_linear_args* a, const void* rms_weight, floa
   const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
   AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));
   return gemv_bf16(a, rms_weight, rms_eps, (hipStream_t)stream);
+}
+
+// ---- training step ---------------------------------------------------------------------------------------
+#define AKI_BF16_ONLY(dt) do { if ((dt) != AKI_DT_BF16) return AKI_ERR_UNSUPPORTED; } while (0)
+
+size_t aki_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Lq) { return (B > 0 && H > 0 && Lq > 0) ? attn_bwd_ws_bytes(B, H, Lq) : 0; }
+
+int aki_attn_bwd(const aki_attn_bwd_args* a, void* ws, size_t ws_bytes, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(a && a->q && a->k && a->v && a->o && a->d_o && a->lse && a->dq && a->dk && a->dv);
+  AKI_CHECK_ARG(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0 && a->scale > 0.f);
+  AKI_CHECK_ARG(a->max_rects >= 0 && a->max_rects <= AKI_MAX_RECTS);
+  AKI_BF16_ONLY(a->dtype);
+  return attn_bwd_bf16(a->q, a->k, a->v, a->o, a->d_o, a->lse, a->dq, a->dk, a->dv, a->rects, a->max_rects, a->col_valid_bits,
+                       a->seq_lens, a->masked, a->B, a->H, a->Lq, a->Lk, a->Dh, a->scale, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int aki_transpose(const void* x, void* y, int32_t R, int32_t C, int32_t ldx, int32_t ldy, int32_t Rpad, int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(x && y && R > 0 && C > 0 && ldx >= C && Rpad >= R && ldy >= Rpad);
+  AKI_BF16_ONLY(dtype);
+  return transpose_bf16_launch(x, y, R, C, ldx, ldy, Rpad, (hipStream_t)stream);
+}
+
+size_t aki_norm_bwd_workspace_bytes(int32_t cols) { return cols > 0 ? norm_bwd_ws_bytes(cols) : 0; }
+
+int aki_norm_bwd(int32_t rms, const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, int32_t rows, int32_t cols,
+                 int32_t ldx, int32_t lddy, int32_t lddx, float eps, int32_t accumulate, int32_t dtype, void* ws, size_t ws_bytes,
+                 void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(x && w && dy && dx && dw && rows > 0 && cols > 0 && ldx >= cols && lddy >= cols && lddx >= cols);
+  AKI_CHECK_ARG((ldx % 8) == 0 && (lddy % 8) == 0 && (lddx % 8) == 0);
+  AKI_BF16_ONLY(dtype);
+  return norm_bwd_launch(rms != 0, x, w, dy, dx, dw, db, rows, cols, ldx, lddy, lddx, eps, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t aki_colsum_workspace_bytes(int32_t cols) { return cols > 0 ? colsum_ws_bytes(cols) : 0; }
+
+int aki_colsum(const void* x, void* out, int32_t rows, int32_t cols, int32_t ldx, int32_t accumulate, int32_t dtype, void* ws,
+               size_t ws_bytes, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(x && out && rows > 0 && cols > 0 && ldx >= cols);
+  AKI_BF16_ONLY(dtype);
+  return colsum_launch(x, out, rows, cols, ldx, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int aki_swiglu_fwd(const void* gate_up, void* a, int32_t rows, int32_t F, int32_t ldg, int32_t lda, int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(gate_up && a && rows > 0 && F > 0 && ldg >= 2 * F && lda >= F);
+  AKI_BF16_ONLY(dtype);
+  return swiglu_launch(0, gate_up, nullptr, a, rows, F, ldg, 0, lda, (hipStream_t)stream);
+}
+
+int aki_swiglu_bwd(const void* gate_up, const void* da, void* dgate_up, int32_t rows, int32_t F, int32_t ldg, int32_t ldda, int32_t lddg,
+                   int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(gate_up && da && dgate_up && rows > 0 && F > 0 && ldg >= 2 * F && ldda >= F && lddg >= 2 * F);
+  AKI_BF16_ONLY(dtype);
+  return swiglu_launch(1, gate_up, da, dgate_up, rows, F, ldg, ldda, lddg, (hipStream_t)stream);
+}
+
+int aki_gelu_fwd(const void* x, void* y, size_t n, int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(x && y && n > 0);
+  AKI_BF16_ONLY(dtype);
+  return gelu_launch(0, x, nullptr, y, n, (hipStream_t)stream);
+}
+
+int aki_gelu_bwd(const void* x, const void* dy, void* dx, size_t n, int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(x && dy && dx && n > 0);
+  AKI_BF16_ONLY(dtype);
+  return gelu_launch(1, x, dy, dx, n, (hipStream_t)stream);
+}
+
+int aki_rope_bwd_merge(const void* dq, const void* dk, const void* dv, const float* cos, const float* sin, const int32_t* position_ids,
+                       void* dqkv, int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(dq && dk && dv && cos && sin && dqkv && B > 0 && H > 0 && L > 0 && Dh > 0);
+  AKI_BF16_ONLY(dtype);
+  return rope_bwd_merge_launch(dq, dk, dv, cos, sin, position_ids, dqkv, B, H, L, Dh, (hipStream_t)stream);
+}
+
+int aki_ce_loss_fwd_bwd(const void* logits, const int64_t* labels, int32_t* n_valid, float* loss_rows, void* dlogits, int32_t B, int32_t L,
+                        int32_t V, int32_t ldl, int32_t lddl, float gscale, int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(logits && labels && n_valid && loss_rows && B > 0 && L > 0 && V > 0 && ldl >= V && (!dlogits || lddl >= V));
+  AKI_BF16_ONLY(dtype);
+  return ce_launch(logits, labels, n_valid, loss_rows, dlogits, B, L, V, ldl, lddl, gscale, (hipStream_t)stream);
+}
+
+size_t aki_grad_sqnorm_workspace_bytes(void) { return grad_sqnorm_ws_bytes(); }
+
+int aki_grad_sqnorm(const void* g, size_t n, float* out, int32_t accumulate, int32_t dtype, void* ws, size_t ws_bytes, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(g && out && n > 0);
+  AKI_BF16_ONLY(dtype);
+  return grad_sqnorm_launch(g, n, out, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int aki_adamw_step(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(p && m && v && g && w16 && n > 0 && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f);
+  return adamw_launch(p, m, v, g, w16, n, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
 // ---- splice / mask -------------------------------------------------------------------------------------

@@ -26,6 +26,7 @@ struct AttnNcParams {
   int B, H, Lq, Lk;
   int nqt;
   float scale_log2;
+  float* lse;   // [B*H][Lq] natural-log log-sum-exp of the scaled scores, or NULL (needed by the backward)
 };
 
 __device__ __forceinline__ float max3_nc(float a, float b, float c) {
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_nc_bf16_kernel(const AttnNcPa
           *(u32x2*)(orow + dt * 32 + q4 * 8) = pk;
         }
       }
+    if (p.lse && h == 0) p.lse[(size_t)bh * Lq + row] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
   }
 }
 
@@ -228,7 +230,7 @@ int attn_nc_bf16(const aki_attn_args* a, hipStream_t stream) {
   AttnNcParams p = {(const bf16_t*)a->q, (const bf16_t*)a->k, (const bf16_t*)a->v, (bf16_t*)a->o,
                     a->q_stride_b, a->q_stride_h, a->q_stride_t, a->k_stride_b, a->k_stride_h, a->k_stride_t,
                     a->v_stride_b, a->v_stride_h, a->v_stride_t, a->B, a->H, a->Lq, a->Lk, 0,
-                    a->scale * 1.44269504088896340736f};
+                    a->scale * 1.44269504088896340736f, a->lse};
   constexpr int NW = 4;
   p.nqt = (a->Lq + NW * 32 - 1) / (NW * 32);
   // 16-byte loads: every stride a multiple of 8 elements, bases 16-B aligned

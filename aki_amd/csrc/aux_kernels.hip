@@ -5,27 +5,6 @@
 
 namespace aki {
 
-// ---- block reduction helper (sum of up to two values) ----------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-template <int NT>
-__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
-  a = wave_sum(a);
-  b = wave_sum(b);
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) { red[w] = a; red[w + NT / 64] = b; }
-  __syncthreads();
-  float sa = 0.f, sb = 0.f;
-#pragma unroll
-  for (int i = 0; i < NT / 64; ++i) { sa += red[i]; sb += red[i + NT / 64]; }
-  a = sa; b = sb;
-  __syncthreads();
-}
-
 // ------------------------------------------------------------------------------------------------
 // Norms.  One 256-thread block per row, 16-byte vector loads, row kept in registers (cols <= 8192).
 // rmsnorm semantics (HF:phi3/modeling_phi3.py:266-284): y = w * cast_to_input_dtype(x * rsqrt(mean(x^2)+eps)).

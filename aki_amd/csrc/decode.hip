@@ -314,17 +314,6 @@ struct DecodeAttnParams {
 };
 constexpr int DEC_PSTRIDE = 104;   // m, l, 6 pad, acc[96]
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
 template <bool FUSED>
 __global__ __launch_bounds__(64) void decode_attn_split_kernel(const DecodeAttnParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t s_q[96], s_k[96], s_v[96];

@@ -211,7 +211,7 @@ def mma_attn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: Mask
     return (o, lse) if return_lse else o
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, return_lse: bool = False):
     """Plain multi-head attention for the vision side.  q [B,Lq,H,Dh], k/v [B,Lk,H,Dh] as (possibly strided) VIEWS of
     the projection outputs (channel stride 1) -> o [B,Lq,H*Dh].  bf16 reads the views in place; f32 (parity path)
     gathers them into contiguous head-major tensors first."""
@@ -233,12 +233,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -
                 raise AkiError("attention: channel stride must be 1")
         st = lambda t_: (t_.stride(0), t_.stride(2), t_.stride(1))               # (batch, head, token)
     ws = _ws(B * H * Dh * 4 + 256, dev)
-    a = L.AttnArgs(_ptr(q), _ptr(k), _ptr(v), _ptr(o), *st(q), *st(k), *st(v), B, H, Lq, Lk, Dh, float(scale), _dt(q))
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=dev) if return_lse else None
+    if return_lse and q.dtype != torch.bfloat16:
+        raise AkiError("attention: the log-sum-exp output exists on the bf16 path only")
+    a = L.AttnArgs(_ptr(q), _ptr(k), _ptr(v), _ptr(o), *st(q), *st(k), *st(v), B, H, Lq, Lk, Dh, float(scale), _dt(q), _ptr(lse))
     end = _TAP.begin(("attention", B, H, Lq, Lk, Dh)) if (_TAP is not None and _TAP.want(("attention",))) else None
     L.check(lib.aki_attn_fwd(C.byref(a), _ptr(ws), ws.numel(), _stream()), "aki_attn_fwd")
     if end is not None:
         end.record()
-    return o
+    return (o, lse) if return_lse else o
 
 
 def _fused_args(x2, w_qkv, cos, sin, position_ids, o, lse, table, B, H, Lq, Dh, scale, dead_rows, kv_capacity=0):

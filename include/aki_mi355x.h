@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 3
+#define AKI_ABI_VERSION 4
 
 typedef enum {
   AKI_OK = 0,
@@ -166,6 +166,7 @@ typedef struct {
   int32_t B, H, Lq, Lk, Dh;
   float scale;
   int32_t dtype;
+  float* lse;          /* optional [B,H,Lq] f32 log-sum-exp of the scaled scores (bf16 path; consumed by aki_attn_bwd) */
 } aki_attn_args;
 
 int aki_attn_fwd(const aki_attn_args* args, void* workspace, size_t workspace_bytes, void* stream);
@@ -301,6 +302,70 @@ int aki_decode_attn_fused_fwd(const void* qkv, const float* cos, const float* si
                               int32_t Dh, int32_t capacity, int32_t max_keys, float scale, int32_t dtype, void* ws,
                               size_t ws_bytes, void* stream);
 int aki_decode_linear_fwd(const aki_linear_args* args, const void* rms_weight, float rms_eps, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Training step (BASELINE configs[2]).  The reference's backward is torch autograd over its
+ * eager forward under bf16 autocast, followed by clip_grad_norm_(1.0) and AdamW (train/train_utils.py:242-266,
+ * train/train.py:330-337, train/losses.py:83-116).  These entry points are the kernels an autograd wrapper of the
+ * forward ops needs; all of them are bf16 (dtype must be AKI_DT_BF16), caller-owned buffers, stream-ordered.
+ * GEMM-shaped gradients (dX = dY W, dW = dY^T X) run through aki_linear_fwd on operands produced by aki_transpose.
+ *
+ * aki_attn_bwd      backward of aki_mma_attn_core_fwd (masked = 1; needs Lq == Lk) or of aki_attn_fwd (masked = 0):
+ *                   q,k,v [B,H,L,Dh] (k rotated) as the forward saw them, o and d_o [B,Lq,H*Dh], lse [B,H,Lq] from the
+ *                   forward -> dq,dk,dv [B,H,L,Dh].  Dh 96 or 64.  Rows >= seq_lens[b] get zero gradient.
+ * aki_transpose     y[C][ldy] = x[R][C]^T with columns R..Rpad-1 of y zero-filled (Rpad <= ldy).
+ * aki_norm_bwd      RMSNorm (rms=1) / LayerNorm backward: dx [rows,cols]; dw (and db for LayerNorm) [cols], written or
+ *                   accumulated (accumulate=1).  cols % 8 == 0, cols <= 4096.
+ * aki_colsum        out[c] (+)= sum_r x[r][c]   (bias gradients)
+ * aki_swiglu_fwd/_bwd   a = up * silu(gate) on gate_up [rows, 2F] (gate first), and its backward to d(gate_up)
+ * aki_gelu_fwd/_bwd     erf GELU (src/helpers.py:32-39), n elements, n % 8 == 0
+ * aki_rope_bwd_merge    dq,dk,dv [B,H,L,Dh] -> d(qkv) [B*L, 3*H*Dh] through the transpose of the rotate-half RoPE
+ * aki_ce_loss_fwd_bwd   HF shifted cross-entropy: row (b,t) against labels[b][t+1], ignore_index -100;
+ *                       loss_rows [B*L] f32 (sum / *n_valid = loss), n_valid: device int32 (written),
+ *                       dlogits (may alias logits, may be NULL) = d(mean loss)/d(logits) * gscale
+ * aki_grad_sqnorm       *out (+)= sum g^2 over a bf16 gradient buffer (n % 8 == 0)
+ * aki_adamw_step        fp32 master weights p, moments m, v; bf16 gradients g -> updated p/m/v and bf16 weights w16.
+ *                       g is scaled by gscale (1/world, 1/grad_accum) and, when sqnorm != NULL and max_norm > 0, clipped by
+ *                       min(1, max_norm / (sqrt(*sqnorm) * gscale + 1e-6))  (torch.nn.utils.clip_grad_norm_ semantics).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* q; const void* k; const void* v;
+  const void* o; const void* d_o;
+  const float* lse;
+  void* dq; void* dk; void* dv;
+  const aki_mma_rect* rects; int32_t max_rects;
+  const uint64_t* col_valid_bits;
+  const int32_t* seq_lens;
+  int32_t masked;
+  int32_t B, H, Lq, Lk, Dh;
+  float scale;
+  int32_t dtype;
+} aki_attn_bwd_args;
+
+size_t aki_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Lq);
+int aki_attn_bwd(const aki_attn_bwd_args* args, void* workspace, size_t workspace_bytes, void* stream);
+int aki_transpose(const void* x, void* y, int32_t R, int32_t C, int32_t ldx, int32_t ldy, int32_t Rpad, int32_t dtype, void* stream);
+size_t aki_norm_bwd_workspace_bytes(int32_t cols);
+int aki_norm_bwd(int32_t rms, const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, int32_t rows, int32_t cols,
+                 int32_t ldx, int32_t lddy, int32_t lddx, float eps, int32_t accumulate, int32_t dtype, void* workspace,
+                 size_t workspace_bytes, void* stream);
+size_t aki_colsum_workspace_bytes(int32_t cols);
+int aki_colsum(const void* x, void* out, int32_t rows, int32_t cols, int32_t ldx, int32_t accumulate, int32_t dtype, void* workspace,
+               size_t workspace_bytes, void* stream);
+int aki_swiglu_fwd(const void* gate_up, void* a, int32_t rows, int32_t F, int32_t ldg, int32_t lda, int32_t dtype, void* stream);
+int aki_swiglu_bwd(const void* gate_up, const void* da, void* dgate_up, int32_t rows, int32_t F, int32_t ldg, int32_t ldda,
+                   int32_t lddg, int32_t dtype, void* stream);
+int aki_gelu_fwd(const void* x, void* y, size_t n, int32_t dtype, void* stream);
+int aki_gelu_bwd(const void* x, const void* dy, void* dx, size_t n, int32_t dtype, void* stream);
+int aki_rope_bwd_merge(const void* dq, const void* dk, const void* dv, const float* cos, const float* sin, const int32_t* position_ids,
+                       void* dqkv, int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype, void* stream);
+int aki_ce_loss_fwd_bwd(const void* logits, const int64_t* labels, int32_t* n_valid, float* loss_rows, void* dlogits, int32_t B,
+                        int32_t L, int32_t V, int32_t ldl, int32_t lddl, float gscale, int32_t dtype, void* stream);
+size_t aki_grad_sqnorm_workspace_bytes(void);
+int aki_grad_sqnorm(const void* g, size_t n, float* out, int32_t accumulate, int32_t dtype, void* workspace, size_t workspace_bytes,
+                    void* stream);
+int aki_adamw_step(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
 /* aki_mma_mask_dense - materialise the reference's (B,1,L,L) int64 0/1 mask from the table, for
  * callers that still want it (bit-exact vs src/vlm.py:410-443 + src/utils.py:99-108). */

@@ -1,0 +1,222 @@
+"""Training-step kernels: every backward / optimizer entry point against torch autograd on the
+same bf16-rounded inputs (fp32 math), and the whole step against the torch oracle (oracle/aki_torch.py, which is pinned
+to the reference's own loss.backward() by tests/test_oracle_golden.py)."""
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from golden import gen
+import aki_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rt(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(DEV)
+
+
+def close(got, want, tol=2e-2, what=""):
+    got, want = got.float(), want.float()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert math.isfinite(err) and err <= tol * max(ref, 1e-6), f"{what}: max err {err:.4g} vs max |ref| {ref:.4g}"
+    # bf16 outputs: mean error must be far below one bf16 ulp of the typical magnitude
+    merr = (got - want).abs().mean().item()
+    assert merr <= 0.5 * tol * max(want.abs().mean().item(), 1e-6), f"{what}: mean err {merr:.4g}"
+
+
+def test_transpose_pads_with_zeros():
+    from aki_amd import train_ops as T
+    for R, C in [(5240, 3072), (100, 72), (333, 1000)]:
+        x = rt(R, C, seed=R)
+        y = T.transpose(x)
+        Rp = (R + 63) // 64 * 64
+        assert y.shape == (C, Rp)
+        assert torch.equal(y[:, :R], x.t()) and bool((y[:, R:] == 0).all())
+
+
+@pytest.mark.parametrize("rms", [True, False])
+@pytest.mark.parametrize("rows,cols", [(700, 3072), (37, 1152), (5, 192)])
+def test_norm_backward(rms, rows, cols):
+    from aki_amd import train_ops as T
+    x, dy = rt(rows, cols, seed=1, scale=2.0), rt(rows, cols, seed=2)
+    w = (1 + 0.1 * torch.randn(cols)).to(BF).to(DEV)
+    b = (0.1 * torch.randn(cols)).to(BF).to(DEV)
+    xr, wr, br = x.float().requires_grad_(), w.float().requires_grad_(), b.float().requires_grad_()
+    if rms:
+        y = wr * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5))
+    else:
+        y = F.layer_norm(xr, (cols,), wr, br, 1e-5)
+    y.backward(dy.float())
+    dx, dw, db = T.norm_bwd(rms, x, w, dy, 1e-5, need_db=not rms)
+    close(dx, xr.grad, what="dx")
+    close(dw, wr.grad, what="dw")
+    if not rms:
+        close(db, br.grad, what="db")
+
+
+def test_swiglu_gelu_colsum():
+    from aki_amd import train_ops as T
+    gu, da = rt(300, 512, seed=3, scale=2.0), rt(300, 256, seed=4)
+    gr = gu.float().requires_grad_()
+    g, u = gr.chunk(2, -1)
+    a = u * F.silu(g)
+    close(T.swiglu_fwd(gu), a, what="swiglu fwd")
+    a.backward(da.float())
+    close(T.swiglu_bwd(gu, da), gr.grad, what="swiglu bwd")
+    x, dy = rt(77, 1152, seed=5, scale=2.0), rt(77, 1152, seed=6)
+    xr = x.float().requires_grad_()
+    y = F.gelu(xr)
+    close(T.gelu_fwd(x), y, what="gelu fwd")
+    y.backward(dy.float())
+    close(T.gelu_bwd(x, dy), xr.grad, what="gelu bwd")
+    z = rt(5240, 1152, seed=7)
+    close(T.colsum(z), z.float().sum(0), what="colsum")
+
+
+def test_rope_backward_merge():
+    from aki_amd import train_ops as T
+    B, H, Lq, Dh = 2, 3, 50, 96
+    cos, sin = O.rope_cos_sin(np.arange(Lq)[None], Dh)
+    tc, ts = torch.from_numpy(cos[0]).to(DEV), torch.from_numpy(sin[0]).to(DEV)
+    qkv = rt(B, Lq, 3 * H * Dh, seed=8).float().requires_grad_()
+    q, k, v = (t.reshape(B, Lq, H, Dh).transpose(1, 2) for t in qkv.chunk(3, -1))
+    rot = lambda t: torch.cat((-t[..., Dh // 2:], t[..., :Dh // 2]), -1)
+    qr, kr = q * tc + rot(q) * ts, k * tc + rot(k) * ts
+    dq, dk, dv = rt(B, H, Lq, Dh, seed=9), rt(B, H, Lq, Dh, seed=10), rt(B, H, Lq, Dh, seed=11)
+    ((qr * dq.float()).sum() + (kr * dk.float()).sum() + (v * dv.float()).sum()).backward()
+    close(T.rope_bwd_merge(dq, dk, dv, tc, ts), qkv.grad, what="rope bwd merge")
+
+
+def test_ce_loss_forward_backward():
+    from aki_amd import train_ops as T
+    B, Lq, V, ld = 3, 40, 32066, 32128
+    logits = torch.zeros(B, Lq, ld, dtype=BF, device=DEV)
+    logits[..., :V] = rt(B, Lq, V, seed=12, scale=3.0)
+    labels = torch.randint(0, V, (B, Lq), generator=torch.Generator().manual_seed(1)).to(DEV)
+    labels[0, :7] = -100
+    labels[2, 30:] = -100
+    lr = logits[..., :V].float().requires_grad_()
+    want = F.cross_entropy(lr[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), ignore_index=-100)
+    want.backward()
+    buf = logits.clone()
+    loss, nv = T.ce_loss(buf, labels, V)
+    assert int(nv) == int((labels[:, 1:] != -100).sum())
+    assert abs(float(loss) - float(want)) < 2e-3 * max(1.0, abs(float(want)))
+    g = buf[..., :V].float()
+    assert bool((buf[..., V:] == 0).all())
+    err = (g - lr.grad).abs().max().item()
+    assert err <= 1e-2 * lr.grad.abs().max().item() + 1e-6, err
+
+
+def _dense_attention(q, k, v, mask01, scale):
+    s = (q @ k.transpose(-1, -2)) * scale
+    s = s.masked_fill(~mask01, float("-inf"))
+    dead = ~mask01.any(-1, keepdim=True)
+    p = torch.where(dead, torch.zeros_like(s), torch.softmax(s.masked_fill(dead, 0.0), -1))
+    return (p @ v).transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
+
+
+@pytest.mark.parametrize("case", ["single_image", "multi_image_padded", "long"])
+def test_mma_attention_backward(case):
+    """dq/dk/dv of the MMA attention core vs autograd over a dense-mask fp32 attention on the same bf16 inputs."""
+    from aki_amd import ops, train_ops as T
+    if case == "single_image":
+        B, H, Lq, rects, lens = 2, 4, 200, [[(6, 150, 150, 183)], [(0, 0, 0, 0)]], [200, 200]
+    elif case == "multi_image_padded":
+        B, H, Lq, rects, lens = 2, 2, 333, [[(3, 147, 147, 320), (160, 304, 304, 320)], [(10, 154, 154, 250)]], [333, 260]
+    else:
+        B, H, Lq, rects, lens = 1, 2, 1100, [[(6, 150, 150, 1000)]], [1100]
+    Dh, scale = 96, 96 ** -0.5
+    am = np.zeros((B, Lq), dtype=bool)
+    for b_, n_ in enumerate(lens):
+        am[b_, :n_] = True
+    table = ops.MaskTable.from_host(rects, am, [Lq if r[0][1] > r[0][0] else n_ for r, n_ in zip(rects, lens)], DEV)
+    dense = torch.from_numpy(np.stack([O.mask_from_spans(am[b_].astype(np.int64), rects[b_]).reshape(Lq, Lq)
+                                       for b_ in range(B)]).astype(bool)).to(DEV)
+    # rows beyond seq_len: no gradient flows (they are padding); make the dense reference skip them too
+    sl = table.seq_lens.cpu().numpy() if table.seq_lens is not None else [Lq] * B
+    for b_ in range(B):
+        dense[b_, sl[b_]:] = False
+    q, k, v = rt(B, H, Lq, Dh, seed=20), rt(B, H, Lq, Dh, seed=21), rt(B, H, Lq, Dh, seed=22)
+    d_o = rt(B, Lq, H * Dh, seed=23)
+    for b_ in range(B):
+        d_o[b_, lens[b_]:] = 0            # what the real backward delivers for padded rows
+    o, lse = ops.mma_attn_core(q, k, v, table, scale, return_lse=True)
+    dq, dk, dv = T.attn_bwd(q, k, v, o, d_o, lse, table, scale)
+    qr, kr, vr = (t.float().requires_grad_() for t in (q, k, v))
+    ref = _dense_attention(qr, kr, vr, dense[:, None], scale)
+    ref.backward(d_o.float())
+    close(dq, qr.grad, tol=3e-2, what="dq")
+    close(dk, kr.grad, tol=3e-2, what="dk")
+    close(dv, vr.grad, tol=3e-2, what="dv")
+
+
+def test_plain_attention_backward_perceiver_shape():
+    from aki_amd import ops, train_ops as T
+    B, H, Lq, Lk, Dh = 2, 8, 144, 873, 64
+    q, k, v = rt(B, Lq, H, Dh, seed=30), rt(B, Lk, H, Dh, seed=31), rt(B, Lk, H, Dh, seed=32)
+    d_o = rt(B, Lq, H * Dh, seed=33)
+    scale = Dh ** -0.5
+    qr, kr, vr = (t.float().requires_grad_() for t in (q, k, v))
+    p = torch.softmax((qr.transpose(1, 2) @ kr.transpose(1, 2).transpose(-1, -2)) * scale, -1)
+    ref = (p @ vr.transpose(1, 2)).transpose(1, 2).reshape(B, Lq, H * Dh)
+    ref.backward(d_o.float())
+    qg, kg, vg = (t.clone().requires_grad_() for t in (q, k, v))
+    o = T.PlainAttnFn.apply(qg, kg, vg, scale)
+    close(o, ref, what="o")
+    o.backward(d_o)
+    close(qg.grad, qr.grad, tol=3e-2, what="dq")
+    close(kg.grad, kr.grad, tol=3e-2, what="dk")
+    close(vg.grad, vr.grad, tol=3e-2, what="dv")
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(5240, 3072, 3072, False), (300, 1000, 192, True), (144, 4608, 1152, False)])
+def test_linear_autograd(M, N, K, bias):
+    from aki_amd import train_ops as T
+    x, w = rt(M, K, seed=40), rt(N, K, seed=41, scale=0.05)
+    b = rt(N, seed=42, scale=0.1) if bias else None
+    r = rt(M, N, seed=43)
+    dy = rt(M, N, seed=44)
+    xr, wr, rr = x.float().requires_grad_(), w.float().requires_grad_(), r.float().requires_grad_()
+    br = b.float().requires_grad_() if bias else None
+    (F.linear(xr, wr, br) + rr).backward(dy.float())
+    xg, wg, rg = x.clone().requires_grad_(), w.clone().requires_grad_(), r.clone().requires_grad_()
+    bg = b.clone().requires_grad_() if bias else None
+    T.linear(xg, wg, bg, rg).backward(dy)
+    close(xg.grad, xr.grad, what="dx")
+    close(wg.grad, wr.grad, what="dw")
+    close(rg.grad, rr.grad, what="dres")
+    if bias:
+        close(bg.grad, br.grad, what="db")
+
+
+def test_adamw_and_clip_match_torch():
+    from aki_amd import train_ops as T
+    n = 8 * 1000 + 64
+    p0 = torch.randn(n, generator=torch.Generator().manual_seed(50))
+    g = (torch.randn(n, generator=torch.Generator().manual_seed(51)) * 3).to(BF)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    p, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    w16 = torch.empty(n, dtype=BF, device=DEV)
+    sq = torch.zeros(1, device=DEV)
+    for step in (1, 2, 3):
+        gs = g.float() * (0.5 if step == 2 else 1.0)
+        pt.grad = gs.clone()
+        torch.nn.utils.clip_grad_norm_([pt], 1.0)
+        opt.step()
+        gd = gs.to(BF).to(DEV)
+        T.grad_sqnorm(gd, sq)
+        T.adamw_step(p, m, v, gd, w16, sq, 1.0, 1.0, 1e-3, 0.9, 0.95, 1e-8, 0.1, step)
+    assert abs(float(sq) - float((gs.to(BF).float() ** 2).sum())) <= 1e-3 * float(sq)
+    assert (p.cpu() - pt.detach()).abs().max().item() < 2e-6
+    assert torch.equal(w16.cpu(), p.cpu().to(BF))
