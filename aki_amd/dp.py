@@ -109,3 +109,52 @@ class GradAllReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+class FlatGradReducer:
+    """Gradient all-reduce over a FLAT gradient buffer (aki_amd/trainer.py): buckets are contiguous slices of the
+    buffer, so nothing is packed or unpacked - RCCL reads and writes the gradients where the wgrad GEMMs put them.
+
+    A bucket is launched (async, on the process group's own stream) as soon as every parameter that lives in it has been
+    delivered by the backward pass (`notify`), overlapping the remaining backward; `finish()` launches whatever is left
+    and waits.  The SUM is left in place; the 1/world average is folded into the optimizer kernel's gradient scale.
+    Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU) and ring collectives are per-link bound, so few
+    large messages (default 512 MiB) rather than DDP's 25 MiB.
+    """
+
+    def __init__(self, flat_grad: torch.Tensor, spans, bucket_bytes: int = 512 << 20, group=None):
+        """spans: list of (param, start, stop) element ranges inside flat_grad, in buffer order."""
+        self.flat, self.group = flat_grad, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        per = max(1, bucket_bytes // flat_grad.element_size())
+        self.buckets = []             # [start, stop, n_params, pending, work]
+        self._owner = {}
+        cur_start, cur_n = None, 0
+        for p, lo, hi in spans:
+            if cur_start is None:
+                cur_start = lo
+            self._owner[id(p)] = len(self.buckets)
+            cur_n += 1
+            if hi - cur_start >= per:
+                self.buckets.append([cur_start, hi, cur_n, cur_n, None])
+                cur_start, cur_n = None, 0
+        if cur_start is not None:
+            self.buckets.append([cur_start, spans[-1][2], cur_n, cur_n, None])
+
+    def notify(self, p) -> None:
+        b = self.buckets[self._owner[id(p)]]
+        b[3] -= 1
+        if b[3] == 0:
+            self._launch(b)
+
+    def _launch(self, b) -> None:
+        if self.world > 1 and b[4] is None:
+            b[4] = dist.all_reduce(self.flat[b[0]: b[1]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self) -> None:
+        for b in self.buckets:
+            self._launch(b)
+        for b in self.buckets:
+            if b[4] is not None:
+                b[4].wait()
+            b[3], b[4] = b[2], None

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
+from . import train_ops as TR
 
 try:  # the HF output container the reference returns (src/helpers.py:11,16)
     from transformers.modeling_outputs import CausalLMOutputWithPast
@@ -35,6 +36,11 @@ except Exception:  # pragma: no cover - transformers is present in this image
 class VLMOutputWithPast(CausalLMOutputWithPast):
     past_media_locations: Optional[torch.Tensor] = None
     past_vision_tokens: Optional[torch.Tensor] = None
+
+
+def _ag(x, *params) -> bool:
+    return (torch.is_grad_enabled() and x.dtype == torch.bfloat16
+            and (x.requires_grad or any(p is not None and p.requires_grad for p in params)))
 
 
 def exists(val):
@@ -76,18 +82,25 @@ class PerceiverAttention(nn.Module):
     def forward(self, x, latents):
         """x (b,T,n1,D), latents (b,T,n2,D) -> to_out(attn) + latents  (the residual of src/helpers.py:193 is
         fused into the output projection's epilogue)."""
-        b, T, n1, D = x.shape
+        b, T_, n1, D = x.shape
         n2 = latents.shape[2]
         h, dh = self.heads, self.dim_head
+        if _ag(latents, *self.parameters()):       # training: same kernels, outputs kept for the HIP backward
+            xn = TR.layernorm(x, self.norm_media.weight, self.norm_media.bias, self.norm_media.eps)
+            ln = TR.layernorm(latents, self.norm_latents.weight, self.norm_latents.bias, self.norm_latents.eps)
+            q = TR.linear(ln, self.to_q.weight)
+            kv = TR.linear(torch.cat((xn, ln), dim=-2), self.to_kv.weight).view(b * T_, n1 + n2, 2, h, dh)
+            out = TR.PlainAttnFn.apply(q.view(b * T_, n2, h, dh), kv[:, :, 0], kv[:, :, 1], self.scale)
+            return TR.linear(out.view(b, T_, n2, h * dh), self.to_out.weight, None, latents)
         xn = ops.layernorm(x, self.norm_media.weight, self.norm_media.bias, self.norm_media.eps)
         ln = ops.layernorm(latents, self.norm_latents.weight, self.norm_latents.bias, self.norm_latents.eps)
         q = ops.linear(ln, self.to_q.weight)
         kv = ops.linear(torch.cat((xn, ln), dim=-2), self.to_kv.weight)
-        kv = kv.view(b * T, n1 + n2, 2, h, dh)
+        kv = kv.view(b * T_, n1 + n2, 2, h, dh)
         # 8 x 64 heads, 144 queries over 873 keys: HIP attention reading k / v in place from the fused kv projection
         # (q * scale then softmax(sim - max) of the reference == softmax(scale * q k^T))
-        out = ops.attention(q.view(b * T, n2, h, dh), kv[:, :, 0], kv[:, :, 1], self.scale)
-        return ops.linear(out.view(b, T, n2, h * dh), self.to_out.weight, residual=latents)
+        out = ops.attention(q.view(b * T_, n2, h, dh), kv[:, :, 0], kv[:, :, 1], self.scale)
+        return ops.linear(out.view(b, T_, n2, h * dh), self.to_out.weight, residual=latents)
 
 
 class PerceiverResampler(VisionTokenizer):
@@ -118,6 +131,15 @@ class PerceiverResampler(VisionTokenizer):
         if exists(self.media_time_embs):
             x = x + self.media_time_embs[:T]
         latents = self.latents.to(x.dtype)[None, None].expand(b, T, -1, -1).contiguous()
+        if _ag(latents, *self.parameters()):
+            for attn, ff in self.layers:
+                latents = attn(x, latents)
+                hmid = TR.GeluFn.apply(TR.linear(TR.layernorm(latents, ff[0].weight, ff[0].bias, ff[0].eps), ff[1].weight))
+                latents = TR.linear(hmid, ff[3].weight, None, latents)
+            latents = TR.layernorm(latents, self.norm.weight, self.norm.bias, self.norm.eps)
+            if exists(self.projection):
+                return TR.linear(latents, self.projection.weight, self.projection.bias, None)
+            return latents
         for attn, ff in self.layers:
             latents = attn(x, latents)                                     # attention + residual
             latents = ops.connector_mlp(latents, ff[0].weight, ff[0].bias, ff[1].weight, ff[3].weight, ff[0].eps)
@@ -214,7 +236,7 @@ class DecoupledLinear(nn.Linear):
     def _fused_weight(self):
         n0 = self.max_original_id + 1
         extra = self.additional_out_features
-        key = (self.weight.data_ptr(), self.weight._version, self.weight.dtype, self.weight.device,
+        key = (TR._EPOCH, self.weight.data_ptr(), self.weight._version, self.weight.dtype, self.weight.device,
                self.additional_fc.weight._version if extra else 0, self.additional_fc.weight.data_ptr() if extra else 0)
         if self._fused is None or self._fused[0] != key:
             n = n0 + extra

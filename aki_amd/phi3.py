@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
+from . import train_ops as T
 from .helpers import CausalLMOutputWithPast
 
 
@@ -77,6 +78,12 @@ class Phi3RotaryTables(nn.Module):
                 self._cache.clear()
             self._cache[key] = ((emb.cos() * self.attention_scaling).contiguous(), (emb.sin() * self.attention_scaling).contiguous())
         return self._cache[key]
+
+
+def _ag(x, *params) -> bool:
+    """Take the autograd (training) path?  bf16 only: the forward reads the bf16 image of the fp32 master weights."""
+    return (torch.is_grad_enabled() and x.dtype == torch.bfloat16
+            and (x.requires_grad or any(p is not None and p.requires_grad for p in params)))
 
 
 class AkiKVCache:
@@ -153,6 +160,8 @@ class Phi3RMSNorm(nn.Module):
         self.variance_epsilon = eps
 
     def forward(self, x):
+        if _ag(x, self.weight):
+            return T.rmsnorm(x, self.weight, self.variance_epsilon)
         return ops.rmsnorm(x, self.weight, self.variance_epsilon)
 
 
@@ -170,6 +179,11 @@ class Phi3Attention(nn.Module):
         self.qkv_proj = nn.Linear(config.hidden_size, op_size, bias=False)
 
     def forward(self, hidden_states, cos, sin, table, residual, position_ids=None, cache=None):
+        if cache is None and _ag(hidden_states, self.qkv_proj.weight, self.o_proj.weight):
+            # training: the same two kernels with their outputs kept for the backward (q, k, v, o, log-sum-exp)
+            q, k, v = T.QkvRopeFn.apply(hidden_states, self.qkv_proj.weight, cos, sin, self.num_heads, position_ids)
+            o = T.MmaAttnCoreFn.apply(q, k, v, table, self.scaling)
+            return T.linear(o, self.o_proj.weight, None, residual)
         if cache is None:
             o = ops.mma_attn(hidden_states, self.qkv_proj.weight, cos, sin, table, self.num_heads, self.scaling, position_ids)
         else:   # prefill into the KV cache: stage 1 writes rotated K and V straight into the cache tensors
@@ -194,6 +208,10 @@ class Phi3MLP(nn.Module):
         self.down_proj = nn.Linear(config.intermediate_size, config.hidden_size, bias=False)
 
     def forward(self, x, residual):
+        if _ag(x, self.gate_up_proj.weight, self.down_proj.weight):
+            # training: gate_up is kept for the SwiGLU backward, so the activation is its own (HBM-bound) kernel
+            a = T.SwigluFn.apply(T.linear(x, self.gate_up_proj.weight))
+            return T.linear(a, self.down_proj.weight, None, residual)
         a = ops.linear(x, self.gate_up_proj.weight, act=ops.ACT_SWIGLU)
         return ops.linear(a, self.down_proj.weight, residual=residual)
 
@@ -285,6 +303,31 @@ class Phi3ForCausalLM(nn.Module):
             return ops.linear(h, self.lm_head.weight, bias=self.lm_head.bias)
         return self.lm_head(h)   # DecoupledLinear (src/vlm.py:88-99): one HIP GEMM / GEMV over the fused weight
 
+    def _head_train(self, h):
+        """lm_head on the autograd path: one GEMM over the row-concatenated weight, rows padded to a multiple of 64 (the
+        dgrad GEMM contracts over them) -> (logits [B, L, pad64(n)], n)."""
+        head = self.lm_head
+        if type(head) is nn.Linear:
+            ws, bs = [head.weight], ([head.bias] if head.bias is not None else None)
+        else:   # DecoupledLinear (src/helpers.py:594-603)
+            n0 = head.max_original_id + 1
+            ws = [head.weight[:n0]] + ([head.additional_fc.weight] if head.additional_out_features else [])
+            bs = None
+            if head.has_bias and head.bias is not None:
+                bs = [head.bias[:n0]]
+                if head.additional_out_features:
+                    ab = head.additional_fc.bias
+                    bs.append(ab if ab is not None else torch.zeros(head.additional_out_features, dtype=h.dtype, device=h.device))
+        n = sum(w.shape[0] for w in ws)
+        pad = (n + 63) // 64 * 64 - n
+        if pad:
+            ws = ws + [torch.zeros((pad, ws[0].shape[1]), dtype=h.dtype, device=h.device)]
+            if bs is not None:
+                bs = bs + [torch.zeros((pad,), dtype=h.dtype, device=h.device)]
+        w = torch.cat(ws, 0) if len(ws) > 1 else ws[0]
+        b = None if bs is None else (torch.cat(bs, 0) if len(bs) > 1 else bs[0])
+        return T.linear(h, w, b, None), n
+
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, labels=None, position_ids=None,
                 use_cache=False, past_key_values=None, cache_capacity=None, **kwargs):
         """Prefill / full forward.  With use_cache=True the returned past_key_values is an AkiKVCache holding the
@@ -307,6 +350,12 @@ class Phi3ForCausalLM(nn.Module):
             cache = AkiKVCache(len(self.model.layers), B, H, Dh, int(cache_capacity or (L + 256)), inputs_embeds.dtype,
                                inputs_embeds.device)
         h = self.model(inputs_embeds, table, position_ids, cache)
+        if labels is not None and cache is None and _ag(h, *self.lm_head.parameters()):
+            # training: padded logits -> fused shifted cross-entropy whose kernel also leaves d(loss)/d(logits) in the
+            # logits buffer (so the output carries no logits; train/losses.py:110-115 only reads [0] = loss)
+            logits_pad, n_cols = self._head_train(h)
+            loss = T.CELossFn.apply(logits_pad, labels, n_cols)
+            return CausalLMOutputWithPast(loss=loss, logits=None, past_key_values=None)
         logits = self._head(h)
         if cache is not None:
             cache.cache_len.copy_(table.token_counts(B, h.device))

@@ -196,14 +196,14 @@ def _deliver(param: torch.Tensor, grad_writer):
     autograd), else return a fresh tensor."""
     tgt = getattr(param, "_aki_grad", None)
     if tgt is not None:
-        if getattr(param, "_aki_grad_live", False):        # second use in one step (grad accumulation): add
+        if getattr(param, "_aki_grad_live", False):        # second use inside one backward: add (already announced)
             tgt += grad_writer(None)
-        else:
-            grad_writer(tgt)
-            param._aki_grad_live = True
+            return None
+        grad_writer(tgt)
+        param._aki_grad_live = True
         hook = getattr(param, "_aki_grad_hook", None)
         if hook is not None:
-            hook(param)
+            hook(param)                                    # lets the reducer launch the bucket this gradient completes
         return None
     return grad_writer(None)
 
@@ -371,3 +371,63 @@ class CELossFn(torch.autograd.Function):
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
         return dl * g.to(dl.dtype), None, None
+
+
+class SpliceGradFn(torch.autograd.Function):
+    """Backward of the language-stream splice (src/vlm.py:445-603 = torch.cat of embedding slices and vision tokens in the
+    reference).  The forward output was produced by the HIP splice kernel; this node only routes d(inputs_embeds) to the
+    vision tokens and to the rows of the two embedding tables (gather / index_add bookkeeping on precomputed indices)."""
+
+    @staticmethod
+    def forward(ctx, embeds, vision_tokens, embed_weight, embed_additional, lang_x, pos_lang, pos_vis, max_original_id):
+        ctx.save_for_backward(lang_x, pos_lang, pos_vis)
+        ctx.vshape, ctx.max_id = vision_tokens.shape, max_original_id
+        ctx.w_ref, ctx.a_ref = embed_weight, embed_additional
+        return embeds.view_as(embeds)
+
+    @staticmethod
+    def backward(ctx, g):
+        lang_x, pos_lang, pos_vis = ctx.saved_tensors
+        gf = g.reshape(-1, g.shape[-1])
+        d_vis = d_w = d_a = None
+        if ctx.needs_input_grad[1]:
+            sel = gf.index_select(0, pos_vis.clamp(min=0).reshape(-1))
+            d_vis = torch.where((pos_vis >= 0).reshape(-1, 1), sel, torch.zeros_like(sel)).view(ctx.vshape)
+        if ctx.needs_input_grad[2] or (ctx.a_ref is not None and ctx.needs_input_grad[3]):
+            keep = (pos_lang >= 0).reshape(-1)
+            ids = lang_x.reshape(-1)[keep]
+            rows = gf.index_select(0, pos_lang.reshape(-1)[keep])
+            hi = ids > ctx.max_id
+            if ctx.needs_input_grad[2]:
+                def w_grad(out):
+                    out = torch.zeros_like(ctx.w_ref) if out is None else out.zero_()
+                    return out.index_add_(0, ids[~hi], rows[~hi])
+                d_w = _deliver(ctx.w_ref, w_grad)
+            if ctx.a_ref is not None and ctx.needs_input_grad[3]:
+                def a_grad(out):
+                    out = torch.zeros_like(ctx.a_ref) if out is None else out.zero_()
+                    return out.index_add_(0, ids[hi] - ctx.max_id - 1, rows[hi])
+                d_a = _deliver(ctx.a_ref, a_grad)
+        return None, d_vis, d_w, d_a, None, None, None, None
+
+
+def splice_positions(plan_h, lang_x_shape, n_img_max: int, Nv: int, L_out: int, padding_side: str, device):
+    """From the host copy of the splice plan: where each original token and each vision vector landed in the output.
+    pos_lang [B,T] / pos_vis [B,T_img,Nv]: flat row index into [B*L_out], -1 = not present."""
+    import numpy as np
+    B, Tn = lang_x_shape
+    plan = plan_h.numpy()
+    pos_lang = np.full((B, Tn), -1, dtype=np.int64)
+    pos_vis = np.full((B, n_img_max, Nv), -1, dtype=np.int64)
+    t = np.arange(Tn)
+    for b in range(B):
+        n_img, L_b = int(plan[b, 0]), int(plan[b, 2])
+        tk = plan[b, 4:4 + n_img].astype(np.int64)
+        off = (L_out - L_b) if padding_side == "left" else 0
+        before = (t[:, None] > tk[None, :]).sum(1) if n_img else np.zeros(Tn, dtype=np.int64)
+        p = off + t + before * (Nv - 1)
+        is_img = np.isin(t, tk)
+        pos_lang[b] = np.where(is_img, -1, b * L_out + p)
+        for k in range(n_img):
+            pos_vis[b, k] = b * L_out + off + tk[k] + k * (Nv - 1) + np.arange(Nv)
+    return torch.from_numpy(pos_lang).to(device), torch.from_numpy(pos_vis).to(device)

@@ -1,0 +1,116 @@
+"""The pre-training step of BASELINE configs[2]: forward, backward, gradient all-reduce, clip
+to 1.0 and AdamW - the body of ``train_one_epoch`` (train/train_utils.py:242-266) for a data-parallel replica
+(train/train.py:311-312, 330-337), with every tensor op on HIP kernels.
+
+Mixed precision the way bf16 autocast does it, made explicit: the optimizer owns fp32 master weights and moments in
+flat buffers; the model's parameters are bf16 views into one flat bf16 buffer that the AdamW kernel rewrites after every
+update; gradients are bf16 views into one flat buffer that the wgrad GEMMs write directly and RCCL all-reduces in place.
+Per GPU for AKI-4B (3.90 B trainable parameters): 15.6 GB master + 31.2 GB moments + 7.8 GB weights + 7.8 GB gradients
+(+7.8 GB transposed weights cached for the dgrad GEMMs) of the 288 GB HBM.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import train_ops as T
+from .dp import FlatGradReducer
+
+
+class AkiTrainer:
+    def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
+                 max_grad_norm: float = 1.0, bucket_bytes: int = 512 << 20, group=None):
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.step_count = 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        wd, nwd = model.group_params_by_weight_decay() if hasattr(model, "group_params_by_weight_decay") else (
+            [p for p in model.parameters() if p.requires_grad], [])
+        groups = [(list(wd), weight_decay), (list(nwd), 0.0)]
+        dev = next(model.parameters()).device
+        spans, off = [], 0
+        self.segments = []                       # (start, stop, weight_decay)
+        for ps, decay in groups:
+            start = off
+            for p in ps:
+                spans.append((p, off, off + p.numel()))
+                off = (off + p.numel() + 7) // 8 * 8          # 16-byte aligned views
+            if off > start:
+                self.segments.append((start, off, decay))
+        n = off
+        self.numel = n
+        self.master = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.w16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        self.g16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.reducer = FlatGradReducer(self.g16, spans, bucket_bytes, group)
+        self.params = []
+        self.span_of = {id(p): (lo, hi) for p, lo, hi in spans}
+        for p, lo, hi in spans:
+            self.master[lo:hi].copy_(p.detach().reshape(-1).float())
+            self.w16[lo:hi].copy_(self.master[lo:hi])
+            p.data = self.w16[lo:hi].view(p.shape)
+            p._aki_grad = self.g16[lo:hi].view(p.shape)
+            p._aki_grad_live = False
+            p._aki_grad_hook = self.reducer.notify
+            p.grad = None
+            self.params.append(p)
+        # everything that is not trained (the frozen vision tower) is read as bf16 as well
+        for p in model.parameters():
+            if not p.requires_grad and p.dtype != torch.bfloat16:
+                p.data = p.data.to(torch.bfloat16)
+        for b_ in model.buffers():
+            if b_.dtype == torch.float32 and b_.dim() > 0:
+                pass                               # RoPE tables etc. stay f32 (the kernels take f32 cos/sin)
+        T.bump_weight_epoch()
+
+    # ---- one step ---------------------------------------------------------------------------------------------------
+    def zero_grad(self) -> None:
+        for p in self.params:
+            p._aki_grad_live = False
+            p.grad = None
+
+    def backward(self, loss: torch.Tensor) -> None:
+        loss.backward()
+        for p in self.params:
+            if p.grad is not None:               # a gradient autograd produced itself (no HIP writer took it): fold it in
+                if p._aki_grad_live:
+                    p._aki_grad += p.grad.to(torch.bfloat16)
+                else:
+                    p._aki_grad.copy_(p.grad)
+                    p._aki_grad_live = True
+                p.grad = None
+                self.reducer.notify(p)
+            elif not p._aki_grad_live:           # unused this step
+                p._aki_grad.zero_()
+                self.reducer.notify(p)
+        self.reducer.finish()
+
+    def optimizer_step(self) -> None:
+        self.step_count += 1
+        gscale = 1.0 / self.world
+        first = True
+        for lo, hi, _ in self.segments:
+            T.grad_sqnorm(self.g16[lo:hi], self.sqnorm, accumulate=not first)
+            first = False
+        for lo, hi, decay in self.segments:
+            T.adamw_step(self.master[lo:hi], self.m[lo:hi], self.v[lo:hi], self.g16[lo:hi], self.w16[lo:hi], self.sqnorm,
+                         self.max_grad_norm, gscale, self.lr, self.betas[0], self.betas[1], self.eps, decay, self.step_count)
+        T.bump_weight_epoch()
+
+    def grad_norm(self) -> torch.Tensor:
+        """Global L2 norm of the (averaged) gradients of the last step, as clip_grad_norm_ returns it."""
+        return self.sqnorm.sqrt() / self.world
+
+    def train_step(self, vision_x, lang_x, attention_mask=None, labels=None) -> torch.Tensor:
+        """forward -> backward (+ overlapped gradient all-reduce) -> clip -> AdamW.  Returns the detached loss."""
+        self.zero_grad()
+        out = self.model(vision_x, lang_x, attention_mask=attention_mask, labels=labels)
+        loss = out[0] if not hasattr(out, "loss") else out.loss
+        self.backward(loss)
+        self.optimizer_step()
+        return loss.detach()

@@ -167,6 +167,13 @@ class VLMWithLanguageStream(VLM):
                                    "splice a second image into one sample (src/vlm.py:547-554); set "
                                    "model.allow_multi_image = True for the build-defined multi-image mask") from e
             raise
+        if torch.is_grad_enabled() and embeds.dtype == torch.bfloat16 and (
+                vision_tokens.requires_grad or emb.weight.requires_grad or emb.additional_embedding.weight.requires_grad):
+            from . import train_ops as T    # training: attach the backward of the splice to the kernel's output
+            pos_lang, pos_vis = T.splice_positions(plan, tuple(lang_x.shape), vision_tokens.shape[1], vision_tokens.shape[2],
+                                                   embeds.shape[1], padding_side, embeds.device)
+            embeds = T.SpliceGradFn.apply(embeds, vision_tokens, emb.weight, emb.additional_embedding.weight,
+                                          lang_x.to(torch.int64), pos_lang, pos_vis, emb.max_original_id)
         return {"inputs_embeds": embeds, "attention_mask": table, "labels": new_labels}
 
     def _post_forward_hook(self):
