@@ -71,3 +71,56 @@ def test_grad_all_reduce_world2_matches_full_batch():
         assert set(ret[r].keys()) == set(want.keys())
         for n in want:
             torch.testing.assert_close(ret[r][n], want[n], atol=1e-6, rtol=1e-5)
+
+
+def _flat_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aki_amd.dp import FlatGradReducer
+    # the trainer's layout: parameters are views of one flat buffer, 8-element aligned; gradients likewise
+    shapes = [(16, 8), (5,), (32, 16), (3, 3), (64,)]
+    spans, off = [], 0
+    params = []
+    for s in shapes:
+        n = 1
+        for d in s:
+            n *= d
+        p = torch.nn.Parameter(torch.zeros(s))
+        spans.append((p, off, off + n))
+        params.append(p)
+        off = (off + n + 7) // 8 * 8
+    flat = torch.zeros(off, dtype=torch.float32)
+    red = FlatGradReducer(flat, spans, bucket_bytes=600 * 4 // 4, group=None)
+    assert len(red.buckets) >= 2
+    for step in range(2):                                   # twice: pending counters must re-arm
+        flat.zero_()
+        order = list(reversed(range(len(params))))          # backward order
+        for i in order:
+            p, lo, hi = spans[i]
+            flat[lo:hi] = float(rank + 1) * (i + 1) + step
+            red.notify(p)                                   # launches a bucket as soon as it is complete
+        red.finish()
+    ret[rank] = flat.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_flat_grad_reducer_world2_sums_in_place():
+    """FlatGradReducer (the trainer's gradient exchange): contiguous buckets of the flat buffer are all-reduced in place,
+    launched from notify() in backward order; both ranks end with the SUM; alignment gaps stay zero."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_flat_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    assert torch.equal(a, b)
+    shapes_n = [128, 5, 512, 9, 64]
+    off = 0
+    for i, n in enumerate(shapes_n):
+        want = (1 + 2) * (i + 1) + 2 * 1                    # step 1 value: sum over ranks of (rank+1)*(i+1) + 1
+        assert bool((a[off: off + n] == want).all()), (i, a[off: off + n][:4], want)
+        nxt = (off + n + 7) // 8 * 8
+        assert bool((a[off + n: nxt] == 0).all())
+        off = nxt
