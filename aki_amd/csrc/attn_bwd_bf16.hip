@@ -64,18 +64,29 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, const 
 typedef short v4i16_t __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) v4i16_t* lds_v4i16_ptr;
 
+// LDS tiles are stored with the 16-byte chunk index XOR-ed by (row >> 2) & 3 (as the K tile of the forward kernel): the
+// ds_read_b128 row reads of the score products become bank-conflict free with 192-byte rows, and the transposed reads keep
+// their pattern because the four rows one 16-lane group touches share the same XOR value.  off_lo / off_hi are the lane's
+// byte offsets for the first / second read (rows r0 + 4h + j and r0 + 8 + 4h + j have XOR values h and (h + 2) & 3).
 template <int ROW>
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int lane_off, int r0, int dt) {
-  const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(tile + lane_off + r0 * ROW + dt * 64));
-  const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(tile + lane_off + (r0 + 8) * ROW + dt * 64));
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off_lo, int off_hi, int r0, int dt) {
+  const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(tile + off_lo + r0 * ROW + dt * 64));
+  const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(tile + off_hi + (r0 + 8) * ROW + dt * 64));
   const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
   const u32x4 v = {l2[0], l2[1], h2[0], h2[1]};
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// lane byte offset of a transposed read inside a 16-row block whose rows have XOR value x
+__device__ __forceinline__ int tr_lane_off(int lane, int row_bytes, int x) {
+  const int h = lane >> 5, j = (lane & 15) >> 2;
+  const int cl = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);       // low two bits of the 16-byte chunk index
+  return (4 * h + j) * row_bytes + ((cl ^ x) << 4) + (lane & 1) * 8;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 template <int DH, bool MASKED>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
   constexpr int KS = DH / 16, DT = DH / 32, ROW = DH * 2, TILE = 32 * ROW;
   constexpr int CPT = DH / 32;                       // 16-B chunks per thread per tile pair: 2*32*DH/8 / 256
   constexpr int STAGE = 2 * TILE + 256;              // Q tile, dO tile, lse[32], delta[32]
@@ -99,24 +110,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
   }
   bool key_ok = key < p.Lk;
   if (MASKED && p.vbits && key_ok) key_ok = ((p.vbits[(size_t)b * p.nwords + (key >> 6)] >> (key & 63)) & 1ull) != 0ull;
-  unsigned rect_bits = 0;                             // rectangles whose column range holds this lane's key
-  if (MASKED) {
+  // rectangles as wave-uniform scalars (SGPRs): every test against them below is branch-free
+  int r_rlo[AKI_MAX_RECTS], r_rhi[AKI_MAX_RECTS], r_clo[AKI_MAX_RECTS], r_chi[AKI_MAX_RECTS];
 #pragma unroll
-    for (int i = 0; i < AKI_MAX_RECTS; ++i) {
-      const aki_mma_rect r = sR[i];
-      if (r.row_hi > r.row_lo && key >= r.col_lo && key < r.col_hi) rect_bits |= 1u << i;
-    }
+  for (int i = 0; i < AKI_MAX_RECTS; ++i) {
+    const aki_mma_rect r = sR[i];
+    const bool ok = MASKED && i < p.max_rects && r.row_hi > r.row_lo && r.col_hi > r.col_lo;
+    r_rlo[i] = __builtin_amdgcn_readfirstlane(ok ? r.row_lo : 0);
+    r_rhi[i] = __builtin_amdgcn_readfirstlane(ok ? r.row_hi : 0);
+    r_clo[i] = __builtin_amdgcn_readfirstlane(ok ? r.col_lo : 0);
+    r_chi[i] = __builtin_amdgcn_readfirstlane(ok ? r.col_hi : 0);
   }
   // which query tiles can see any of the workgroup's keys
   auto need = [&](int t) -> bool {
     if (t * 32 >= Lb) return false;
     if (!MASKED) return true;
-    if (t * 32 + 31 >= kb0) return true;
-    for (int i = 0; i < AKI_MAX_RECTS; ++i) {
-      const aki_mma_rect r = sR[i];
-      if (r.row_hi > r.row_lo && r.row_lo < t * 32 + 32 && r.row_hi > t * 32 && r.col_lo < kb0 + 128 && r.col_hi > kb0) return true;
-    }
-    return false;
+    bool nd = t * 32 + 31 >= kb0;
+#pragma unroll
+    for (int i = 0; i < AKI_MAX_RECTS; ++i)
+      nd = nd || (r_rlo[i] < t * 32 + 32 && r_rhi[i] > t * 32 && r_clo[i] < kb0 + 128 && r_chi[i] > kb0);
+    return nd;
   };
   const int nqt = (Lb + 31) / 32;
   auto next_needed = [&](int t) { while (t < nqt && !need(t)) ++t; return t; };
@@ -163,11 +176,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
   auto stash = [&](int stage) {                        // registers -> LDS stage
     char* base = smem + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) *(u32x4*)(base + (size_t)(i * 256 + tid) * 16) = pre[i];
+    for (int i = 0; i < CPT; ++i) {
+      const int g = i * 256 + tid;
+      const int which = g / (32 * DH / 8), gg = g - which * (32 * DH / 8);
+      const int r = gg / (DH / 8), c = gg - r * (DH / 8);
+      *(u32x4*)(base + which * TILE + r * ROW + ((c ^ ((r >> 2) & 3)) << 4)) = pre[i];
+    }
     if (tid < 64) ((float*)(base + 2 * TILE))[tid] = pre_s;
   };
 
-  const int tr_off = (4 * h + ((lane & 15) >> 2)) * ROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int tr_lo = tr_lane_off(lane, ROW, h), tr_hi = tr_lane_off(lane, ROW, (h + 2) & 3);
+  const int rsw = (l31 >> 2) & 3;                    // XOR value of this lane's row in the row reads
   const float lse_k = 1.44269504088896340736f;
 
   int t = next_needed(0);
@@ -187,12 +206,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 qa = *(const bf16x8*)(Qs + l31 * ROW + (2 * ks + h) * 16);
-      const bf16x8 da = *(const bf16x8*)(Ds + l31 * ROW + (2 * ks + h) * 16);
+      const bf16x8 qa = *(const bf16x8*)(Qs + l31 * ROW + (((2 * ks + h) ^ rsw) << 4));
+      const bf16x8 da = *(const bf16x8*)(Ds + l31 * ROW + (((2 * ks + h) ^ rsw) << 4));
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
     }
-    // accumulator register r <-> query row q0 + (r&3) + 8*(r>>2) + 4h; this lane's key is fixed
+    // accumulator register r <-> query row q0 + (r&3) + 8*(r>>2) + 4h; this lane's key is fixed.
+    // visibility of the 16 (row, key) pairs as a bit mask: causal part, then one branch-free pass per rectangle that
+    // touches this tile (wave-uniform test), finally rows beyond seq_len and invalid keys
+    unsigned vis = 0;
+    const int qb = q0 + 4 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qrow = qb + (r & 3) + 8 * (r >> 2);
+      const bool c = MASKED ? (key <= qrow) : true;
+      vis |= (c && qrow < Lb) ? (1u << r) : 0u;
+    }
+    if (MASKED && !causal_full) {
+#pragma unroll
+      for (int i = 0; i < AKI_MAX_RECTS; ++i) {
+        if (r_rlo[i] < q0 + 32 && r_rhi[i] > q0) {                   // uniform
+          const bool kin = key >= r_clo[i] && key < r_chi[i];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qrow = qb + (r & 3) + 8 * (r >> 2);
+            vis |= (kin && qrow >= r_rlo[i] && qrow < r_rhi[i] && qrow < Lb) ? (1u << r) : 0u;
+          }
+        }
+      }
+    }
+    if (!key_ok) vis = 0;
     float ds[16];
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
@@ -200,18 +243,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g4 + e;
-        const int qrow = q0 + 8 * g4 + 4 * h + e;
-        bool vis = key_ok && qrow < Lb;
-        if (MASKED) {
-          bool un = key <= qrow;
-          if (rect_bits && !causal_full) {
-#pragma unroll
-            for (int i = 0; i < AKI_MAX_RECTS; ++i)
-              if ((rect_bits >> i) & 1u) un = un || (qrow >= sR[i].row_lo && qrow < sR[i].row_hi);
-          }
-          vis = vis && un;
-        }
-        const float pv = vis ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.scale_log2, -l4[e] * lse_k)) : 0.f;
+        const float pv = ((vis >> r) & 1u) ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.scale_log2, -l4[e] * lse_k)) : 0.f;
         s[r] = pv;
         ds[r] = pv * (dp[r] - d4[e]);
       }
@@ -223,8 +255,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
       for (int e = 0; e < 8; ++e) { pa[e] = (__bf16)s[8 * m + e]; dsa[e] = (__bf16)ds[8 * m + e]; }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<ROW>(Ds, tr_off, 16 * m, dt), dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, tr_frag<ROW>(Qs, tr_off, 16 * m, dt), dk[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<ROW>(Ds, tr_lo, tr_hi, 16 * m, dt), dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, tr_frag<ROW>(Qs, tr_lo, tr_hi, 16 * m, dt), dk[dt], 0, 0, 0);
       }
     }
     if (tn < nqt) stash(stage ^ 1);
@@ -248,12 +280,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 
 // ------------------------------------------------------------------------------------------------------------
 template <int DH, bool MASKED>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams p) {
   constexpr int KS = DH / 16, DT = DH / 32, ROW = DH * 2, TILE = 32 * ROW;
   constexpr int CPT = DH / 32;
   constexpr int STAGE = 2 * TILE;                    // K tile, V tile
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + AKI_MAX_RECTS * 16];
+  constexpr int MAXW = 256;                          // valid-column words kept in LDS (Lk <= 16384): a per-tile global
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + AKI_MAX_RECTS * 16 + MAXW * 8];   // load would drain the prefetch
   const aki_mma_rect* sR = (const aki_mma_rect*)(smem + 2 * STAGE);
+  unsigned long long* sVB = (unsigned long long*)(smem + 2 * STAGE + AKI_MAX_RECTS * 16);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int nqb = (p.Lq + 127) / 128;
@@ -269,25 +303,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
       if (tid < p.max_rects) r = ((const u32x4*)p.rects)[(size_t)b * p.max_rects + tid];
       ((u32x4*)sR)[tid] = r;
     }
+    for (int w = tid; w < p.nwords && w < MAXW; w += 256) sVB[w] = p.vbits ? p.vbits[(size_t)b * p.nwords + w] : ~0ull;
     __syncthreads();
   }
   int rc0 = 0, rc1 = 0;                               // unlocked column interval of this lane's row (one rectangle per row)
-  if (MASKED) {
+  int r_rlo[AKI_MAX_RECTS], r_rhi[AKI_MAX_RECTS], r_clo[AKI_MAX_RECTS], r_chi[AKI_MAX_RECTS];
 #pragma unroll
-    for (int i = 0; i < AKI_MAX_RECTS; ++i) {
-      const aki_mma_rect r = sR[i];
-      if (r.row_hi > r.row_lo && row >= r.row_lo && row < r.row_hi) { rc0 = r.col_lo; rc1 = r.col_hi; }
-    }
+  for (int i = 0; i < AKI_MAX_RECTS; ++i) {
+    const aki_mma_rect r = sR[i];
+    const bool ok = MASKED && i < p.max_rects && r.row_hi > r.row_lo && r.col_hi > r.col_lo;
+    r_rlo[i] = __builtin_amdgcn_readfirstlane(ok ? r.row_lo : 0);
+    r_rhi[i] = __builtin_amdgcn_readfirstlane(ok ? r.row_hi : 0);
+    r_clo[i] = __builtin_amdgcn_readfirstlane(ok ? r.col_lo : 0);
+    r_chi[i] = __builtin_amdgcn_readfirstlane(ok ? r.col_hi : 0);
+    if (row >= r_rlo[i] && row < r_rhi[i]) { rc0 = r_clo[i]; rc1 = r_chi[i]; }
   }
   auto need = [&](int t) -> bool {
     if (t * 32 >= p.Lk || q0 >= Lb) return false;
     if (!MASKED) return true;
-    if (t * 32 <= q0 + 127) return true;
-    for (int i = 0; i < AKI_MAX_RECTS; ++i) {
-      const aki_mma_rect r = sR[i];
-      if (r.row_hi > r.row_lo && r.row_lo < q0 + 128 && r.row_hi > q0 && r.col_lo < t * 32 + 32 && r.col_hi > t * 32) return true;
-    }
-    return false;
+    bool nd = t * 32 <= q0 + 127;
+#pragma unroll
+    for (int i = 0; i < AKI_MAX_RECTS; ++i)
+      nd = nd || (r_rlo[i] < q0 + 128 && r_rhi[i] > q0 && r_clo[i] < t * 32 + 32 && r_chi[i] > t * 32);
+    return nd;
   };
   const int nkt = (p.Lk + 31) / 32;
   auto next_needed = [&](int t) { while (t < nkt && !need(t)) ++t; return t; };
@@ -328,9 +366,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
   auto stash = [&](int stage) {
     char* base = smem + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) *(u32x4*)(base + (size_t)(i * 256 + tid) * 16) = pre[i];
+    for (int i = 0; i < CPT; ++i) {
+      const int g = i * 256 + tid;
+      const int which = g / (32 * DH / 8), gg = g - which * (32 * DH / 8);
+      const int r = gg / (DH / 8), c = gg - r * (DH / 8);
+      *(u32x4*)(base + which * TILE + r * ROW + ((c ^ ((r >> 2) & 3)) << 4)) = pre[i];
+    }
   };
-  const int tr_off = (4 * h + ((lane & 15) >> 2)) * ROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int tr_lo = tr_lane_off(lane, ROW, h), tr_hi = tr_lane_off(lane, ROW, (h + 2) & 3);
+  const int rsw = (l31 >> 2) & 3;
 
   int t = next_needed(0);
   if (t < nkt) { fetch(t); stash(0); }
@@ -347,14 +391,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 ka = *(const bf16x8*)(Ks + l31 * ROW + (2 * ks + h) * 16);
-      const bf16x8 va = *(const bf16x8*)(Vs + l31 * ROW + (2 * ks + h) * 16);
+      const bf16x8 ka = *(const bf16x8*)(Ks + l31 * ROW + (((2 * ks + h) ^ rsw) << 4));
+      const bf16x8 va = *(const bf16x8*)(Vs + l31 * ROW + (((2 * ks + h) ^ rsw) << 4));
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dp, 0, 0, 0);
     }
     // accumulator register r <-> key k0 + (r&3) + 8*(r>>2) + 4h; this lane's query row is fixed
     unsigned vword = 0xffffffffu;
-    if (MASKED && p.vbits) vword = (unsigned)(p.vbits[(size_t)b * p.nwords + (k0 >> 6)] >> (k0 & 63));
+    if (MASKED) vword = (unsigned)(sVB[k0 >> 6] >> (k0 & 63));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kl = (r & 3) + 8 * (r >> 2) + 4 * h, kk = k0 + kl;
@@ -369,7 +413,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
 #pragma unroll
       for (int e = 0; e < 8; ++e) dsb[e] = (__bf16)s[8 * m + e];
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<ROW>(Ks, tr_off, 16 * m, dt), dsb, dq[dt], 0, 0, 0);
+      for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<ROW>(Ks, tr_lo, tr_hi, 16 * m, dt), dsb, dq[dt], 0, 0, 0);
     }
     if (tn < nkt) stash(stage ^ 1);
     __syncthreads();
@@ -405,6 +449,7 @@ int attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, co
                   int H, int Lq, int Lk, int Dh, float scale, void* ws, size_t ws_bytes, hipStream_t s) {
   if (Dh != 96 && Dh != 64) return AKI_ERR_UNSUPPORTED;
   if (masked && Lq != Lk) return AKI_ERR_INVALID_ARG;
+  if (masked && (Lk + 63) / 64 > 256) return AKI_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < attn_bwd_ws_bytes(B, H, Lq)) return AKI_ERR_WORKSPACE;
   AttnBwdParams p = {(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, lse, (const float*)ws,
                      (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, rects, vbits, seq_lens, rects ? max_rects : 0, (Lk + 63) / 64,
