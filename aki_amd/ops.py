@@ -64,12 +64,15 @@ class EventTap:
     """Optional per-kernel timing with HIP events on the stream the kernels are launched on (torch's current
     stream).  bench.py installs one for the timed region; when no tap is installed the cost is one `is None` test."""
 
-    def __init__(self, tags=None):
+    def __init__(self, tags=None, select=None):
         self.tags = tags          # None = every tagged launch
-        self.events = {}
+        self.select = select      # optional predicate on the full tag (e.g. only one GEMM shape): every bracketed launch
+        self.events = {}          # costs two event records on the stream, so time only what is reported
 
     def want(self, tag) -> bool:
-        return self.tags is None or tag[0] in self.tags
+        if self.tags is not None and tag[0] not in self.tags:
+            return False
+        return self.select is None or bool(self.select(tag))
 
     def begin(self, tag):
         a = torch.cuda.Event(enable_timing=True)
@@ -163,7 +166,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         r2 = _rows2d(residual)
     a = L.LinearArgs(_ptr(x2), _ptr(w), _ptr(bias), _ptr(r2), _ptr(o2), M, N, K, x2.stride(0), w.stride(0), o2.stride(0),
                      0 if r2 is None else r2.stride(0), res_row_mod, act, _dt(x))
-    end = _TAP.begin(("linear", M, N, K, act)) if (_TAP is not None and _TAP.want(("linear",))) else None
+    end = _TAP.begin(("linear", M, N, K, act)) if (_TAP is not None and _TAP.want(("linear", M, N, K, act))) else None
     L.check(lib.aki_linear_fwd(C.byref(a), _stream()), "aki_linear_fwd")
     if end is not None:
         end.record()

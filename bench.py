@@ -60,6 +60,21 @@ def cpu_baseline(budget_s=25.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # give the CPU its best shot: the affinity mask can exceed what the box really grants (cgroup quota, SMT), and
+    # oversubscribed OpenMP teams are several times slower - pick the team size with the best GEMM rate, report it
+    avail = cores
+    xa, wa = torch.randn(2048, 3072), torch.randn(8192, 3072)
+    best = (0.0, cores)
+    for nt in sorted({c for c in (4, 8, 16, 32, 48, 64, 96, 128, 192, 256, avail) if c <= avail}):
+        torch.set_num_threads(nt)
+        torch.mm(xa, wa.t())
+        t0 = time.perf_counter()
+        for _ in range(3):
+            torch.mm(xa, wa.t())
+        rate = 3 * 2.0 * 2048 * 3072 * 8192 / (time.perf_counter() - t0)
+        if rate > best[0] * 1.05:
+            best = (rate, nt)
+    cores = best[1]
     torch.set_num_threads(cores)
     B = BATCH
     g = torch.Generator().manual_seed(0)
@@ -130,9 +145,10 @@ def cpu_baseline(budget_s=25.0):
         OT.decoupled_linear(OT.rms_norm(x, ones(d)), W, None, Wa, None, 32010)
         t["lm_head"] = time.perf_counter() - t0
     total = t["patch_embed"] + 27 * t["siglip_layer"] + t["perceiver"] + t["splice_mask"] + 32 * t["decoder_layer"] + t["lm_head"]
-    return {"value": round(B * L / total, 2), "unit": "tokens/s", "cores": int(cores), "kind": "port",
+    return {"value": round(B * L / total, 2), "unit": "tokens/s", "cores": int(cores), "cores_visible": int(avail),
+            "cpu_gemm_gflops": round(best[0] / 1e9, 1), "kind": "port",
             "sample": f"one batch of the benchmark workload ({B} x (336px image + 512-token prompt), L=655), torch fp32 eager "
-                      "restatement of the reference forward on all host cores: 2/32 decoder layers and 2/27 SigLIP layers "
+                      "restatement of the reference forward on the host cores (thread count = best measured GEMM rate): 2/32 decoder layers and 2/27 SigLIP layers "
                       "timed and scaled by layer count, patch embed, connector, splice + dense mask + inversion and lm_head "
                       "timed in full",
             "seconds_per_forward_est": round(total, 3), "parts_s": {k: round(v, 4) for k, v in t.items()}}
@@ -178,7 +194,10 @@ def main():
         out = step()
     assert out.logits.shape[:2] == (B, L)
     torch.cuda.synchronize()
-    tap = ops.EventTap(tags={"linear", "mma_attn"})
+    # HIP events on the launch stream around the kernels that are reported: the dominant GEMM (gate_up + SwiGLU, known
+    # from profiles/) and the MMA op.  --kernel-table brackets every GEMM instead (costs ~4 % of the step).
+    tap = ops.EventTap(tags={"linear", "mma_attn"},
+                       select=None if args.kernel_table else (lambda tag: tag[0] == "mma_attn" or tag[4] == ops.ACT_SWIGLU))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
