@@ -112,34 +112,55 @@ class GradAllReducer:
 
 
 class FlatGradReducer:
-    """Gradient all-reduce over a FLAT gradient buffer (aki_amd/trainer.py): buckets are contiguous slices of the
+    """Gradient exchange over a FLAT gradient buffer (aki_amd/trainer.py): buckets are contiguous slices of the
     buffer, so nothing is packed or unpacked - RCCL reads and writes the gradients where the wgrad GEMMs put them.
 
     A bucket is launched (async, on the process group's own stream) as soon as every parameter that lives in it has been
     delivered by the backward pass (`notify`), overlapping the remaining backward; `finish()` launches whatever is left
-    and waits.  The SUM is left in place; the 1/world average is folded into the optimizer kernel's gradient scale.
-    Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU) and ring collectives are per-link bound, so few
-    large messages (default 512 MiB) rather than DDP's 25 MiB.
+    and waits.  Two modes:
+      shard=False  all-reduce (DDP, train/train.py:311-312): every rank ends with the SUM of the whole bucket
+      shard=True   in-place reduce-scatter (the FSDP / ZeRO exchange, train/distributed.py:170-243): rank r ends with
+                   the SUM of sub-slice r of every bucket (`owned(b)`); the trainer updates only that slice and
+                   `all_gather_weights` redistributes the bf16 weights - optimizer state is 1/world per rank
+    The 1/world average is folded into the optimizer kernel's gradient scale.  Bucket size: xGMI is point-to-point
+    (7 links x ~153 GB/s per GPU) and ring collectives are per-link bound, so few large messages (default 512 MiB)
+    rather than DDP's 25 MiB.  Bucket boundaries also fall on `breaks` (optimizer segments) and, when sharding, bucket
+    lengths are multiples of 8*world elements (the flat buffer is padded accordingly by the trainer).
     """
 
-    def __init__(self, flat_grad: torch.Tensor, spans, bucket_bytes: int = 512 << 20, group=None):
+    def __init__(self, flat_grad: torch.Tensor, spans, bucket_bytes: int = 512 << 20, group=None, shard: bool = False,
+                 breaks=()):
         """spans: list of (param, start, stop) element ranges inside flat_grad, in buffer order."""
-        self.flat, self.group = flat_grad, group
+        self.flat, self.group, self.shard = flat_grad, group, shard
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         per = max(1, bucket_bytes // flat_grad.element_size())
+        brk = sorted(set(int(b) for b in breaks) | {flat_grad.numel()})
         self.buckets = []             # [start, stop, n_params, pending, work]
         self._owner = {}
         cur_start, cur_n = None, 0
-        for p, lo, hi in spans:
+        for i, (p, lo, hi) in enumerate(spans):
             if cur_start is None:
                 cur_start = lo
             self._owner[id(p)] = len(self.buckets)
             cur_n += 1
-            if hi - cur_start >= per:
-                self.buckets.append([cur_start, hi, cur_n, cur_n, None])
+            nxt = spans[i + 1][1] if i + 1 < len(spans) else flat_grad.numel()   # bucket ends where the next param starts
+            if nxt - cur_start >= per or nxt in brk:
+                self.buckets.append([cur_start, nxt, cur_n, cur_n, None])
                 cur_start, cur_n = None, 0
         if cur_start is not None:
-            self.buckets.append([cur_start, spans[-1][2], cur_n, cur_n, None])
+            self.buckets.append([cur_start, flat_grad.numel(), cur_n, cur_n, None])
+        if shard:
+            for b in self.buckets:
+                if (b[1] - b[0]) % (8 * self.world):
+                    raise ValueError("sharded exchange needs bucket lengths that are multiples of 8*world elements")
+
+    def owned(self, b):
+        """(start, stop) of this rank's sub-slice of bucket b (the whole bucket when not sharding)."""
+        if not self.shard:
+            return b[0], b[1]
+        c = (b[1] - b[0]) // self.world
+        return b[0] + self.rank * c, b[0] + (self.rank + 1) * c
 
     def notify(self, p) -> None:
         b = self.buckets[self._owner[id(p)]]
@@ -148,8 +169,17 @@ class FlatGradReducer:
             self._launch(b)
 
     def _launch(self, b) -> None:
-        if self.world > 1 and b[4] is None:
-            b[4] = dist.all_reduce(self.flat[b[0]: b[1]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.world == 1 or b[4] is not None:
+            return
+        buf = self.flat[b[0]: b[1]]
+        if not self.shard:
+            b[4] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return
+        lo, hi = self.owned(b)
+        try:
+            b[4] = dist.reduce_scatter_tensor(self.flat[lo:hi], buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        except (RuntimeError, NotImplementedError):    # gloo (CPU tests) has no reduce-scatter: same result via all-reduce
+            b[4] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:
         for b in self.buckets:
@@ -158,3 +188,21 @@ class FlatGradReducer:
             if b[4] is not None:
                 b[4].wait()
             b[3], b[4] = b[2], None
+
+    def all_gather_weights(self, flat_w: torch.Tensor) -> None:
+        """After the sharded optimizer step: every rank's freshly written sub-slices -> the full flat weight buffer."""
+        if not self.shard or self.world == 1:
+            return
+        works = []
+        for b in self.buckets:
+            lo, hi = self.owned(b)
+            try:
+                works.append(dist.all_gather_into_tensor(flat_w[b[0]: b[1]], flat_w[lo:hi], group=self.group, async_op=True))
+            except (RuntimeError, NotImplementedError):    # gloo fallback: zero the foreign slices and sum
+                seg = flat_w[b[0]: b[1]]
+                keep = flat_w[lo:hi].clone()
+                seg.zero_()
+                flat_w[lo:hi].copy_(keep)
+                works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()

@@ -21,7 +21,10 @@ from .dp import FlatGradReducer
 
 class AkiTrainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
-                 max_grad_norm: float = 1.0, bucket_bytes: int = 512 << 20, group=None):
+                 max_grad_norm: float = 1.0, bucket_bytes: int = 512 << 20, group=None, shard_optimizer: bool = False):
+        """shard_optimizer: keep fp32 master weights and moments only for this rank's 1/world slice of every gradient
+        bucket (reduce-scatter + all-gather instead of all-reduce) - the memory behaviour of the reference's FSDP launch
+        configs (train/distributed.py:170-243, scripts/run_train.sh:23) for the optimizer state."""
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
@@ -30,29 +33,54 @@ class AkiTrainer:
             [p for p in model.parameters() if p.requires_grad], [])
         groups = [(list(wd), weight_decay), (list(nwd), 0.0)]
         dev = next(model.parameters()).device
-        spans, off = [], 0
+        self.shard = bool(shard_optimizer) and self.world > 1
+        self.group = group
+        # flat layout: [decay params | no-decay params], every parameter 16-byte aligned; when sharding, bucket ends (and
+        # therefore segment ends) are padded to multiples of 8*world so every bucket splits evenly over the ranks
+        align = 8 * self.world if self.shard else 8
+        per = max(1, bucket_bytes // 2)
+        spans, off, breaks = [], 0, []
         self.segments = []                       # (start, stop, weight_decay)
         for ps, decay in groups:
-            start = off
+            start, bstart = off, off
             for p in ps:
                 spans.append((p, off, off + p.numel()))
                 off = (off + p.numel() + 7) // 8 * 8          # 16-byte aligned views
+                if off - bstart >= per:                        # the reducer closes a bucket here: pad so it splits evenly
+                    off = (off + align - 1) // align * align
+                    bstart = off
+            off = (off + align - 1) // align * align
             if off > start:
                 self.segments.append((start, off, decay))
+                breaks.append(off)
         n = off
         self.numel = n
-        self.master = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.w16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
         self.g16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
         self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.reducer = FlatGradReducer(self.g16, spans, bucket_bytes, group)
+        self.reducer = FlatGradReducer(self.g16, spans, bucket_bytes, group, shard=self.shard, breaks=breaks)
         self.params = []
         self.span_of = {id(p): (lo, hi) for p, lo, hi in spans}
         for p, lo, hi in spans:
-            self.master[lo:hi].copy_(p.detach().reshape(-1).float())
-            self.w16[lo:hi].copy_(self.master[lo:hi])
+            self.w16[lo:hi].copy_(p.detach().reshape(-1))
+        # optimizer state: the slices this rank owns (everything when not sharding), stored compactly
+        self.owned = []                          # (flat start, flat stop, state offset, weight_decay)
+        so = 0
+        for b in self.reducer.buckets:
+            lo, hi = self.reducer.owned(b)
+            decay = next(d for s0, s1, d in self.segments if s0 <= b[0] < s1)
+            self.owned.append((lo, hi, so, decay))
+            so += hi - lo
+        self.master = torch.zeros(so, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(so, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(so, dtype=torch.float32, device=dev)
+        for p, lo, hi in spans:                  # fp32 master copy of what this rank owns (from the incoming weights)
+            src = p.detach().reshape(-1).float()
+            for olo, ohi, so_, _ in self.owned:
+                a_, b_ = max(lo, olo), min(hi, ohi)
+                if a_ < b_:
+                    self.master[so_ + a_ - olo: so_ + b_ - olo].copy_(src[a_ - lo: b_ - lo])
+        for p, lo, hi in spans:
             p.data = self.w16[lo:hi].view(p.shape)
             p._aki_grad = self.g16[lo:hi].view(p.shape)
             p._aki_grad_live = False
@@ -94,12 +122,17 @@ class AkiTrainer:
         self.step_count += 1
         gscale = 1.0 / self.world
         first = True
-        for lo, hi, _ in self.segments:
+        for lo, hi, _, _ in self.owned:
             T.grad_sqnorm(self.g16[lo:hi], self.sqnorm, accumulate=not first)
             first = False
-        for lo, hi, decay in self.segments:
-            T.adamw_step(self.master[lo:hi], self.m[lo:hi], self.v[lo:hi], self.g16[lo:hi], self.w16[lo:hi], self.sqnorm,
-                         self.max_grad_norm, gscale, self.lr, self.betas[0], self.betas[1], self.eps, decay, self.step_count)
+        if self.shard:                           # every rank holds the sum over its own slices: one scalar all-reduce
+            dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
+        for lo, hi, so, decay in self.owned:
+            n = hi - lo
+            T.adamw_step(self.master[so:so + n], self.m[so:so + n], self.v[so:so + n], self.g16[lo:hi], self.w16[lo:hi],
+                         self.sqnorm, self.max_grad_norm, gscale, self.lr, self.betas[0], self.betas[1], self.eps, decay,
+                         self.step_count)
+        self.reducer.all_gather_weights(self.w16)
         T.bump_weight_epoch()
 
     def grad_norm(self) -> torch.Tensor:

@@ -124,3 +124,68 @@ def test_flat_grad_reducer_world2_sums_in_place():
         nxt = (off + n + 7) // 8 * 8
         assert bool((a[off + n: nxt] == 0).all())
         off = nxt
+
+
+def _shard_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aki_amd.dp import FlatGradReducer
+    align = 8 * world
+    sizes = [130, 40, 500, 9, 64, 33]
+    spans, off, params = [], 0, []
+    per = 300                                               # elements per bucket (bucket_bytes = per * 4 for fp32)
+    bstart = 0
+    for n in sizes:
+        p = torch.nn.Parameter(torch.zeros(n))
+        spans.append((p, off, off + n))
+        params.append(p)
+        off = (off + n + 7) // 8 * 8
+        if off - bstart >= per:
+            off = (off + align - 1) // align * align
+            bstart = off
+    off = (off + align - 1) // align * align
+    g = torch.zeros(off)
+    w = torch.zeros(off)
+    red = FlatGradReducer(g, spans, bucket_bytes=per * 4, group=None, shard=True, breaks=[off])
+    assert len(red.buckets) >= 2 and all((b[1] - b[0]) % align == 0 for b in red.buckets)
+    for step in range(2):
+        g.zero_()
+        for i in reversed(range(len(params))):
+            p, lo, hi = spans[i]
+            g[lo:hi] = float(rank + 1) * (i + 1) + step
+            red.notify(p)
+        red.finish()
+        for b in red.buckets:                               # "optimizer": each rank updates only what it owns
+            lo, hi = red.owned(b)
+            w[lo:hi] = -g[lo:hi]
+        red.all_gather_weights(w)
+    ret[rank] = (w.clone(), [tuple(red.owned(b)) for b in red.buckets], [tuple(b[:2]) for b in red.buckets])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_sharded_exchange_world2_reduce_scatter_then_all_gather():
+    """shard=True (the FSDP / ZeRO exchange): every rank owns 1/world of each bucket, updates it, and the all-gather
+    leaves identical full weights everywhere, equal to what the un-sharded all-reduce path would have produced."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    (w0, own0, bk0), (w1, own1, bk1) = ret[0], ret[1]
+    assert torch.equal(w0, w1) and bk0 == bk1
+    for (lo0, hi0), (lo1, hi1), (s, e) in zip(own0, own1, bk0):
+        assert (lo0, hi1) == (s, e) and hi0 == lo1            # the two ranks' slices tile each bucket
+    sizes = [130, 40, 500, 9, 64, 33]
+    # recompute the layout exactly as the worker did
+    off, bstart, starts = 0, 0, []
+    for n in sizes:
+        starts.append(off)
+        off = (off + n + 7) // 8 * 8
+        if off - bstart >= 300:
+            off = (off + 15) // 16 * 16
+            bstart = off
+    for i, (st, n) in enumerate(zip(starts, sizes)):
+        want = -((1 + 2) * (i + 1) + 2 * 1)
+        assert bool((w0[st: st + n] == want).all()), (i, w0[st: st + 4], want)
