@@ -9,12 +9,12 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaki_mi355x.so")
 
-AKI_DT_BF16, AKI_DT_F32 = 0, 1
+AKI_DT_BF16, AKI_DT_F32, AKI_DT_FP8_E4M3 = 0, 1, 2
 AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 4
+AKI_ABI_VERSION = 5
 
 
 class AkiError(RuntimeError):
@@ -38,7 +38,8 @@ class MmaAttnArgs(C.Structure):
                 ("col_valid_bits", C.c_void_p), ("seq_lens", C.c_void_p), ("max_rects", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("Dh", C.c_int32), ("d_model", C.c_int32),
                 ("ldx", C.c_int32), ("ldw", C.c_int32), ("pos_rows", C.c_int32), ("scale", C.c_float),
-                ("dtype", C.c_int32), ("dead_rows", C.c_int32), ("kv_capacity", C.c_int32)]
+                ("dtype", C.c_int32), ("dead_rows", C.c_int32), ("kv_capacity", C.c_int32),
+                ("x_scale", C.c_void_p), ("w_scale", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -62,7 +63,7 @@ class LinearArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldx", C.c_int32), ("ldw", C.c_int32),
                 ("ldy", C.c_int32), ("ldr", C.c_int32), ("res_row_mod", C.c_int32), ("act", C.c_int32),
-                ("dtype", C.c_int32)]
+                ("dtype", C.c_int32), ("x_scale", C.c_void_p), ("w_scale", C.c_void_p)]
 
 
 class SpliceArgs(C.Structure):
@@ -122,6 +123,7 @@ SIGNATURES = {
     "aki_grad_sqnorm_workspace_bytes": (C.c_size_t, []),
     "aki_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_adamw_step": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p] + [C.c_float] * 7 + [C.c_int32, C.c_void_p]),
+    "aki_quant_rows_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "aki_splice_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "aki_splice_fwd": (C.c_int, [C.POINTER(SpliceArgs), C.c_void_p]),
     "aki_mma_mask_dense": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libaki_mi355x.so")
-SOURCES = ["api.hip", "gemm_bf16.hip", "mma_attn_bf16.hip", "attn_nc_bf16.hip", "decode.hip", "train_kernels.hip", "attn_bwd_bf16.hip", "simple_f32.hip", "aux_kernels.hip"]
+SOURCES = ["api.hip", "gemm_bf16.hip", "mma_attn_bf16.hip", "attn_nc_bf16.hip", "decode.hip", "train_kernels.hip", "attn_bwd_bf16.hip", "fp8_quant.hip", "simple_f32.hip", "aux_kernels.hip"]
 ARCH = "gfx950"
 
 

@@ -6,6 +6,10 @@ namespace aki {
 int linear_bf16(const aki_linear_args* a, hipStream_t stream);
 int linear_f32(const aki_linear_args* a, hipStream_t stream);
 int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStream_t stream);
+int qkv_rope_fp8(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStream_t stream);
+int linear_fp8(const aki_linear_args* a, hipStream_t stream);
+int quant_rows_fp8_launch(const void* x, const void* rms_w, float eps, void* q, float* scale, int rows, int cols, int ldx, int ldq,
+                          hipStream_t s);
 int qkv_rope_f32(const aki_mma_attn_args* a, void* q, void* k, void* v, float* tmp, hipStream_t stream);
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream);
 int attn_core_f32(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream, int causal);
@@ -121,7 +125,7 @@ static int check_fused(const aki_mma_attn_args* a) {
   AKI_CHECK_ARG(a->B > 0 && a->H > 0 && a->L > 0 && a->Dh > 0 && a->d_model > 0);
   AKI_CHECK_ARG(a->ldx >= a->d_model && a->ldw >= a->d_model && a->pos_rows > 0);
   AKI_CHECK_ARG(a->position_ids || a->pos_rows >= a->L);
-  AKI_CHECK_ARG(dtype_ok(a->dtype));
+  AKI_CHECK_ARG(dtype_ok(a->dtype) || (a->dtype == AKI_DT_FP8_E4M3 && a->x_scale && a->w_scale));
   return AKI_OK;
 }
 
@@ -132,6 +136,7 @@ int aki_qkv_rope_fwd(const aki_mma_attn_args* a, void* q, void* k, void* v, void
   AKI_CHECK_ARG(q && k && v);
   AKI_CHECK_ARG(a->kv_capacity == 0 || a->kv_capacity >= a->L);
   if (a->dtype == AKI_DT_BF16) return qkv_rope_bf16(a, q, k, v, (hipStream_t)stream);
+  if (a->dtype == AKI_DT_FP8_E4M3) return qkv_rope_fp8(a, q, k, v, (hipStream_t)stream);
   // f32 parity path: scratch for the un-rotated projection
   if (!ws || ws_bytes < (size_t)a->B * a->L * 3 * a->H * a->Dh * sizeof(float)) return AKI_ERR_WORKSPACE;
   return qkv_rope_f32(a, q, k, v, (float*)ws, (hipStream_t)stream);
@@ -143,14 +148,17 @@ int aki_mma_attn_fwd(const aki_mma_attn_args* a, void* ws, size_t ws_bytes, void
   if (rc) return rc;
   AKI_CHECK_ARG(a->o && a->scale > 0.f);
   AKI_CHECK_ARG(a->max_rects >= 0 && (a->max_rects == 0 || a->rects));
-  if (!ws || ws_bytes < aki_mma_attn_workspace_bytes(a->B, a->H, a->L, a->Dh, a->dtype)) return AKI_ERR_WORKSPACE;
+  const int cdt = a->dtype == AKI_DT_FP8_E4M3 ? AKI_DT_BF16 : a->dtype;     // q, k, v, o and the core are bf16 on the fp8 path
+  if (!ws || ws_bytes < aki_mma_attn_workspace_bytes(a->B, a->H, a->L, a->Dh, cdt)) return AKI_ERR_WORKSPACE;
   AKI_CHECK_ALIGN16(ws);
-  const size_t qb = qkv_bytes(a->B, a->H, a->L, a->Dh, a->dtype);
+  const size_t qb = qkv_bytes(a->B, a->H, a->L, a->Dh, cdt);
   char* w = (char*)ws;
   void* q = w; void* k = w + qb; void* v = w + 2 * qb;
   char* rest = w + 3 * qb;
   if (a->dtype == AKI_DT_BF16) {
     rc = qkv_rope_bf16(a, q, k, v, (hipStream_t)stream);
+  } else if (a->dtype == AKI_DT_FP8_E4M3) {
+    rc = qkv_rope_fp8(a, q, k, v, (hipStream_t)stream);
   } else {
     rc = qkv_rope_f32(a, q, k, v, (float*)rest, (hipStream_t)stream);
     rest += 3 * qb;
@@ -159,8 +167,8 @@ int aki_mma_attn_fwd(const aki_mma_attn_args* a, void* ws, size_t ws_bytes, void
   aki_mma_attn_core_args c = {};
   c.q = q; c.k = k; c.v = v; c.o = a->o; c.lse = a->lse; c.rects = a->rects; c.col_valid_bits = a->col_valid_bits;
   c.seq_lens = a->seq_lens; c.max_rects = a->max_rects; c.B = a->B; c.H = a->H; c.L = a->L; c.Dh = a->Dh;
-  c.scale = a->scale; c.dtype = a->dtype; c.dead_rows = a->dead_rows; c.kv_capacity = 0;
-  return aki_mma_attn_core_fwd(&c, rest, aki_mma_attn_core_workspace_bytes(a->B, a->H, a->L, a->Dh, a->dtype), stream);
+  c.scale = a->scale; c.dtype = cdt; c.dead_rows = a->dead_rows; c.kv_capacity = 0;
+  return aki_mma_attn_core_fwd(&c, rest, aki_mma_attn_core_workspace_bytes(a->B, a->H, a->L, a->Dh, cdt), stream);
 }
 
 // ---- linear ------------------------------------------------------------------------------------------
@@ -168,10 +176,11 @@ int aki_linear_fwd(const aki_linear_args* a, void* stream) {
   AKI_CLEAR_ERR();
   AKI_CHECK_ARG(a && a->x && a->w && a->y);
   AKI_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0);
-  AKI_CHECK_ARG(dtype_ok(a->dtype));
+  AKI_CHECK_ARG(dtype_ok(a->dtype) || (a->dtype == AKI_DT_FP8_E4M3 && a->x_scale && a->w_scale));
   AKI_CHECK_ARG(a->act >= AKI_ACT_NONE && a->act <= AKI_ACT_SWIGLU);
   const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
   AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));
+  if (a->dtype == AKI_DT_FP8_E4M3) return linear_fp8(a, (hipStream_t)stream);
   if (a->dtype == AKI_DT_BF16) {
     if (a->M <= 8) {  // decode regime: weight-streaming GEMV (falls through when the shape does not qualify)
       const int rc = gemv_bf16(a, nullptr, 0.f, (hipStream_t)stream);
@@ -180,6 +189,14 @@ int aki_linear_fwd(const aki_linear_args* a, void* stream) {
     return linear_bf16(a, (hipStream_t)stream);
   }
   return linear_f32(a, (hipStream_t)stream);
+}
+
+// ---- fp8 quantisation --------------------------------------------------------------------------------------
+int aki_quant_rows_fp8(const void* x, const void* rms_weight, float rms_eps, void* q, float* scale, int32_t rows, int32_t cols,
+                       int32_t ldx, int32_t ldq, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(x && q && scale && rows > 0 && cols > 0 && ldx >= cols && ldq >= cols && (!rms_weight || rms_eps > 0.f));
+  return quant_rows_fp8_launch(x, rms_weight, rms_eps, q, scale, rows, cols, ldx, ldq, (hipStream_t)stream);
 }
 
 // ---- norms -------------------------------------------------------------------------------------------

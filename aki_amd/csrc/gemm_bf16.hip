@@ -54,6 +54,9 @@ struct GemmParams {
   const int* position_ids;
   int H, L;
   int kvcap;  // rows per (batch, head) of k_out / v_out (KV cache capacity); q_out always uses L
+  // fp8 (e4m3) operands: x and w point at bytes, ldx / ldw count bytes, one f32 scale per token row / weight row
+  const float* sx;
+  const float* sw;
 };
 
 // Two feature blocks (P = block n, Q = block n+1), each 4 consecutive features per lane as 2 packed dwords.
@@ -67,9 +70,14 @@ __device__ __forceinline__ u32x4 pair_to_wide(unsigned p0, unsigned p1, unsigned
 // ACT is a template parameter on purpose: with a runtime switch the 32-fold unrolled epilogue inlines 32 copies of
 // erff/tanhf; even when never executed they bloat the code enough to cost 13 % on the large GEMMs (I-cache misses
 // once per tile; measured in tools/gemm_lab.hip against the identical kernel without them).
-template <int NF, int NT, int WN, int WM, int EPI, int ACT>
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+
+// FP8: e4m3 operands through v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate).  A 128-byte
+// LDS row then holds BK = 128 k-values instead of 64, so staging, swizzle and the epilogues are byte-for-byte the same; the
+// per-row dequantisation scales (one per token, one per weight row) multiply the f32 accumulators before the epilogue.
+template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false>
 __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
-  constexpr int BK = 64, NWAVES = WN * WM;
+  constexpr int BK = FP8 ? 128 : 64, ES = FP8 ? 1 : 2, NWAVES = WN * WM;
   constexpr int WROWS = NF * 16;      // features per wave
   constexpr int BN = WN * WROWS;      // features per block tile
   constexpr int WTOK = NT * 16;       // tokens per wave
@@ -115,10 +123,10 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
       } else {
         wrow = min(n0 + row, p.N - 1);
       }
-      src[j] = (const char*)(p.w + (size_t)wrow * p.ldw + chunk * 8);
+      src[j] = (const char*)p.w + (size_t)wrow * p.ldw * ES + chunk * 16;
     } else {
       const int xrow = min(m0 + row - BN, p.M - 1);
-      src[j] = (const char*)(p.x + (size_t)xrow * p.ldx + chunk * 8);
+      src[j] = (const char*)p.x + (size_t)xrow * p.ldx * ES + chunk * 16;
     }
   }
 
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       char* dst = smem + s * STAGE_BYTES + (j * NWAVES + wave) * 1024;
-      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[j] + (size_t)kt * (BK * 2)), AKI_LDS_PTR(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[j] + (size_t)kt * 128), AKI_LDS_PTR(dst), 16, 0, 0);
     }
   };
 
@@ -148,18 +156,59 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     __syncthreads();  // (vmcnt(0) + barrier): tile kt landed, the other buffer is no longer being read
     if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
     const char* sb = smem + (kt & 1) * STAGE_BYTES;
+    if constexpr (FP8) {   // one k128 step per BK: the lane's 32 bytes are chunks 2kg and 2kg+1 of its row
+      const int c0 = ((2 * kg) ^ swz) << 4, c1 = ((2 * kg + 1) ^ swz) << 4;
+      v8i_t a[NF], b[NT];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {  // two k32 steps per BK
-      const int coff = ((4 * ks + kg) ^ swz) << 4;
-      bf16x8 a[NF], b[NT];
+      for (int n = 0; n < NF; ++n) {
+        const u32x4 lo = *(const u32x4*)(sb + wbase + n * 2048 + c0), hi = *(const u32x4*)(sb + wbase + n * 2048 + c1);
+        a[n] = v8i_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
 #pragma unroll
-      for (int n = 0; n < NF; ++n) a[n] = *(const bf16x8*)(sb + wbase + n * 2048 + coff);
-#pragma unroll
-      for (int m = 0; m < NT; ++m) b[m] = *(const bf16x8*)(sb + xbase + m * 2048 + coff);
+      for (int m = 0; m < NT; ++m) {
+        const u32x4 lo = *(const u32x4*)(sb + xbase + m * 2048 + c0), hi = *(const u32x4*)(sb + xbase + m * 2048 + c1);
+        b[m] = v8i_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
 #pragma unroll
       for (int n = 0; n < NF; ++n)
 #pragma unroll
-        for (int m = 0; m < NT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], b[m], acc[n][m], 0, 0, 0);
+        for (int m = 0; m < NT; ++m)
+          acc[n][m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[n], b[m], acc[n][m], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {  // two k32 steps per BK
+        const int coff = ((4 * ks + kg) ^ swz) << 4;
+        bf16x8 a[NF], b[NT];
+#pragma unroll
+        for (int n = 0; n < NF; ++n) a[n] = *(const bf16x8*)(sb + wbase + n * 2048 + coff);
+#pragma unroll
+        for (int m = 0; m < NT; ++m) b[m] = *(const bf16x8*)(sb + xbase + m * 2048 + coff);
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+          for (int m = 0; m < NT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], b[m], acc[n][m], 0, 0, 0);
+      }
+    }
+  }
+
+  if constexpr (FP8) {   // dequantise: acc[feature][token] *= sw[weight row] * sx[token]
+    float sxm[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) sxm[m] = p.sx[min(m0 + wm * WTOK + m * 16 + l15, p.M - 1)];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      int wrow;
+      if (EPI == EPI_SWIGLU) {
+        const int f = n0 + wn * (WROWS / 2) + (n % (NF / 2)) * 16 + 4 * kg;
+        wrow = (n < NF / 2) ? min(f, n_out - 4) : n_out + min(f, n_out - 4);
+      } else {
+        wrow = min(n0 + wn * WROWS + n * 16 + 4 * kg, p.N - 4);
+      }
+      const f32x4 s4 = *(const f32x4*)(p.sw + wrow);
+#pragma unroll
+      for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[n][m][r] *= s4[r] * sxm[m];
     }
   }
 
@@ -271,13 +320,13 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   }
 }
 
-template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0>
+template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
   constexpr int SMEM = 2 * (BN + BM) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return AKI_ERR_LAUNCH;
     attr_set = true;
   }
@@ -286,7 +335,7 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (n_out + bn_out - 1) / bn_out;
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }
@@ -316,21 +365,22 @@ static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_w
   return 0;
 }
 
-template <int EPI, int ACT>
+template <int EPI, int ACT, bool FP8 = false>
 static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
-  if (plan == 1) return launch_gemm<4, 4, 2, 2, EPI, ACT>(p, stream);
-  if (plan == 0) return launch_gemm<8, 4, 2, 4, EPI, ACT>(p, stream);
+  if (plan == 1) return launch_gemm<4, 4, 2, 2, EPI, ACT, FP8>(p, stream);
+  if (plan == 0) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8>(p, stream);
   const int m_main = p.M / 256 * 256;
   GemmParams a = p, b = p;
   a.M = m_main;
-  int rc = launch_gemm<8, 4, 2, 4, EPI, ACT>(a, stream);
+  int rc = launch_gemm<8, 4, 2, 4, EPI, ACT, FP8>(a, stream);
   if (rc) return rc;
   b.M = p.M - m_main;
   b.m_offset = p.m_offset + m_main;
-  b.x = p.x + (size_t)m_main * p.ldx;
+  b.x = (const bf16_t*)((const char*)p.x + (size_t)m_main * p.ldx * (FP8 ? 1 : 2));
+  if (FP8) b.sx = p.sx + m_main;
   b.y = p.y + (size_t)m_main * p.ldy;
   if (p.residual && p.res_row_mod <= 0) b.residual = p.residual + (size_t)m_main * p.ldr;
-  return launch_gemm<4, 4, 2, 2, EPI, ACT>(b, stream);
+  return launch_gemm<4, 4, 2, 2, EPI, ACT, FP8>(b, stream);
 }
 
 int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
@@ -384,6 +434,57 @@ int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStre
   b1.m_offset = m_main;
   b1.x = p.x + (size_t)m_main * p.ldx;
   return launch_gemm<6, 4, 2, 2, EPI_QKV_ROPE>(b1, stream);
+}
+
+// ---- fp8 (e4m3) operands, bf16 output: BASELINE configs[4] ------------------------------------------------------
+int linear_fp8(const aki_linear_args* a, hipStream_t stream) {
+  if (a->K % 128 != 0 || !a->x_scale || !a->w_scale) return AKI_ERR_UNSUPPORTED;
+  const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
+  if (n_out % 4 != 0 || (a->act == AKI_ACT_SWIGLU && (a->N % 8 != 0))) return AKI_ERR_UNSUPPORTED;
+  if ((a->ldx % 16) || (a->ldw % 16) || (a->ldy % 4) || (a->residual && (a->ldr % 4))) return AKI_ERR_ALIGNMENT;
+  AKI_CHECK_ALIGN16(a->x);
+  AKI_CHECK_ALIGN16(a->w);
+  AKI_CHECK_ALIGN16(a->w_scale);
+  if (((uintptr_t)a->y & 7) || ((uintptr_t)a->residual & 7) || ((uintptr_t)a->bias & 7)) return AKI_ERR_ALIGNMENT;
+  GemmParams p = {};
+  p.x = (const bf16_t*)a->x; p.w = (const bf16_t*)a->w; p.bias = (const bf16_t*)a->bias;
+  p.residual = (const bf16_t*)a->residual; p.y = (bf16_t*)a->y;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr;
+  p.res_row_mod = a->res_row_mod; p.act = a->act; p.sx = a->x_scale; p.sw = a->w_scale;
+  p.wide = (n_out % 8 == 0) && (a->ldy % 8 == 0) && (((uintptr_t)a->y & 15) == 0);
+  if (a->act == AKI_ACT_SWIGLU) {
+    if (a->bias) return AKI_ERR_UNSUPPORTED;
+    return run_planned<EPI_SWIGLU, 0, true>(p, plan_tiles(a->M, n_out, 128, 64), stream);
+  }
+  if (a->act != AKI_ACT_NONE) return AKI_ERR_UNSUPPORTED;      // the fp8 path serves the language model's projections
+  return run_planned<EPI_PLAIN, 0, true>(p, plan_tiles(a->M, n_out, 256, 128), stream);
+}
+
+int qkv_rope_fp8(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStream_t stream) {
+  if (a->Dh != 96 || a->d_model % 128 != 0 || !a->x_scale || !a->w_scale) return AKI_ERR_UNSUPPORTED;
+  if ((a->ldx % 16) || (a->ldw % 16)) return AKI_ERR_ALIGNMENT;
+  AKI_CHECK_ALIGN16(a->x); AKI_CHECK_ALIGN16(a->w_qkv); AKI_CHECK_ALIGN16(a->cos); AKI_CHECK_ALIGN16(a->sin);
+  AKI_CHECK_ALIGN16(q); AKI_CHECK_ALIGN16(k); AKI_CHECK_ALIGN16(v); AKI_CHECK_ALIGN16(a->w_scale);
+  GemmParams p = {};
+  p.x = (const bf16_t*)a->x; p.w = (const bf16_t*)a->w_qkv;
+  p.M = a->B * a->L; p.N = 3 * a->H * a->Dh; p.K = a->d_model; p.ldx = a->ldx; p.ldw = a->ldw;
+  p.q_out = (bf16_t*)q; p.k_out = (bf16_t*)k; p.v_out = (bf16_t*)v;
+  p.cos = a->cos; p.sin = a->sin; p.position_ids = a->position_ids; p.H = a->H; p.L = a->L;
+  p.kvcap = a->kv_capacity > 0 ? a->kv_capacity : a->L;
+  p.sx = a->x_scale; p.sw = a->w_scale;
+  const int plan = plan_tiles(p.M, p.N, 192, 192, 0.5);
+  if (plan == 1) return launch_gemm<6, 4, 2, 2, EPI_QKV_ROPE, 0, true>(p, stream);
+  if (plan == 0) return launch_gemm<6, 4, 2, 4, EPI_QKV_ROPE, 0, true>(p, stream);
+  const int m_main = p.M / 256 * 256;
+  GemmParams a1 = p, b1 = p;
+  a1.M = m_main;
+  int rc = launch_gemm<6, 4, 2, 4, EPI_QKV_ROPE, 0, true>(a1, stream);
+  if (rc) return rc;
+  b1.M = p.M - m_main;
+  b1.m_offset = m_main;
+  b1.x = (const bf16_t*)((const char*)p.x + (size_t)m_main * p.ldx);
+  b1.sx = p.sx + m_main;
+  return launch_gemm<6, 4, 2, 2, EPI_QKV_ROPE, 0, true>(b1, stream);
 }
 
 }  // namespace aki

@@ -385,6 +385,63 @@ def decode_linear(x: torch.Tensor, w: torch.Tensor, rms_weight: torch.Tensor, ep
     return out
 
 
+# ---- fp8 (e4m3) projections: BASELINE configs[4] -------------------------------------------------------------------
+def quant_rows_fp8(x: torch.Tensor, rms_weight: Optional[torch.Tensor] = None, eps: float = 0.0):
+    """bf16 rows -> (e4m3 bytes [rows, cols] as uint8, f32 scale per row).  With rms_weight the Phi-3 RMSNorm is applied on
+    the way (same rounding points as ops.rmsnorm), i.e. this is `quantize(norm(x))` in one HBM pass."""
+    dev = _dev(x, rms_weight)
+    if x.dtype != torch.bfloat16:
+        raise AkiError("quant_rows_fp8 takes bf16 input")
+    x2 = _rows2d(x)
+    rows, cols = x2.shape
+    q = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+    s = torch.empty((rows,), dtype=torch.float32, device=dev)
+    L.check(L.load().aki_quant_rows_fp8(_ptr(x2), _ptr(rms_weight), float(eps), _ptr(q), _ptr(s), rows, cols, x2.stride(0),
+                                        q.stride(0), _stream()), "aki_quant_rows_fp8")
+    return q, s
+
+
+def linear_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, out_shape=None) -> torch.Tensor:
+    """y (bf16) = act((xq * xs) (wq * ws)^T + bias) [+ residual] on the fp8 MFMA path; xq [M,K] / wq [N,K] uint8 (e4m3)."""
+    dev = _dev(xq, xs, wq, ws, bias, residual)
+    M, K = xq.shape
+    N = wq.shape[0]
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    out = torch.empty((M, n_out), dtype=torch.bfloat16, device=dev)
+    r2 = None if residual is None else _rows2d(residual)
+    a = L.LinearArgs(_ptr(xq), _ptr(wq), _ptr(bias), _ptr(r2), _ptr(out), M, N, K, xq.stride(0), wq.stride(0), out.stride(0),
+                     0 if r2 is None else r2.stride(0), 0, act, L.AKI_DT_FP8_E4M3, _ptr(xs), _ptr(ws))
+    end = _TAP.begin(("linear_fp8", M, N, K, act)) if (_TAP is not None and _TAP.want(("linear_fp8", M, N, K, act))) else None
+    L.check(L.load().aki_linear_fwd(C.byref(a), _stream()), "aki_linear_fwd[fp8]")
+    if end is not None:
+        end.record()
+    return out if out_shape is None else out.view(*out_shape)
+
+
+def mma_attn_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                 table: "MaskTable", B: int, num_heads: int, scale: Optional[float] = None,
+                 position_ids: Optional[torch.Tensor] = None, dead_rows: int = DEAD_ROWS_UNIFORM) -> torch.Tensor:
+    """Fused MMA op with fp8 QKV projection: xq [B*L, d] e4m3 + scales -> o [B, L, H*Dh] bf16 (RoPE, attention core in bf16)."""
+    dev = _dev(xq, xs, wq, ws, cos, sin)
+    lib = L.load()
+    M, d = xq.shape
+    Lq = M // B
+    Dh = wq.shape[0] // (3 * num_heads)
+    scale = Dh ** -0.5 if scale is None else scale
+    o = torch.empty((B, Lq, num_heads * Dh), dtype=torch.bfloat16, device=dev)
+    ws_buf = _ws(lib.aki_mma_attn_workspace_bytes(B, num_heads, Lq, Dh, L.AKI_DT_BF16), dev)
+    pos = None if position_ids is None else position_ids.to(torch.int32).contiguous()
+    a = L.MmaAttnArgs(_ptr(xq), _ptr(wq), _ptr(cos), _ptr(sin), _ptr(pos), _ptr(o), None, _ptr(table.rects),
+                      _ptr(table.col_valid_bits), _ptr(table.seq_lens), table.max_rects, B, num_heads, Lq, Dh, d, xq.stride(0),
+                      wq.stride(0), cos.shape[0], float(scale), L.AKI_DT_FP8_E4M3, dead_rows, 0, _ptr(xs), _ptr(ws))
+    end = _TAP.begin(("mma_attn_fp8", B, num_heads, Lq, Dh)) if (_TAP is not None and _TAP.want(("mma_attn_fp8",))) else None
+    L.check(lib.aki_mma_attn_fwd(C.byref(a), _ptr(ws_buf), ws_buf.numel(), _stream()), "aki_mma_attn_fwd[fp8]")
+    if end is not None:
+        end.record()
+    return o
+
+
 def pad_k(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
     """Zero-pad the K (last) dimension of a weight to a multiple of `mult` (one-time host-side prep)."""
     K = w.shape[-1]

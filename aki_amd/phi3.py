@@ -227,10 +227,34 @@ class Phi3DecoderLayer(nn.Module):
         self.mlp = Phi3MLP(config)
         self.input_layernorm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self._fp8 = None
 
     def forward(self, h, cos, sin, table, position_ids=None, cache=None):
+        if self._fp8 is not None and cache is None and not torch.is_grad_enabled():
+            return self._forward_fp8(h, cos, sin, table, position_ids)
         h = self.self_attn(self.input_layernorm(h), cos, sin, table, h, position_ids, cache)
         return self.mlp(self.post_attention_layernorm(h), h)
+
+    def _forward_fp8(self, h, cos, sin, table, position_ids):
+        """BASELINE configs[4]: the four projections on the fp8 (e4m3) MFMA path with per-token activation scales and
+        per-feature weight scales; RMSNorm is fused into the quantiser, RoPE / attention / residual stream stay bf16."""
+        w = self._fp8
+        B, L, d = h.shape
+        n1, n2, at = self.input_layernorm, self.post_attention_layernorm, self.self_attn
+        xq, xs = ops.quant_rows_fp8(h, n1.weight, n1.variance_epsilon)
+        o = ops.mma_attn_fp8(xq, xs, *w["qkv"], cos, sin, table, B, at.num_heads, at.scaling, position_ids)
+        oq, os_ = ops.quant_rows_fp8(o)
+        h = ops.linear_fp8(oq, os_, *w["o"], residual=h, out_shape=(B, L, d))
+        xq, xs = ops.quant_rows_fp8(h, n2.weight, n2.variance_epsilon)
+        a = ops.linear_fp8(xq, xs, *w["gate_up"], act=ops.ACT_SWIGLU)
+        aq, as_ = ops.quant_rows_fp8(a)
+        return ops.linear_fp8(aq, as_, *w["down"], residual=h, out_shape=(B, L, d))
+
+    def quantize_fp8(self):
+        at, mlp = self.self_attn, self.mlp
+        self._fp8 = {"qkv": ops.quant_rows_fp8(at.qkv_proj.weight.detach()), "o": ops.quant_rows_fp8(at.o_proj.weight.detach()),
+                     "gate_up": ops.quant_rows_fp8(mlp.gate_up_proj.weight.detach()),
+                     "down": ops.quant_rows_fp8(mlp.down_proj.weight.detach())}
 
     def decode(self, h, cos, sin, cache):
         h = self.self_attn.decode(h, self.input_layernorm, cos, sin, cache)
@@ -246,6 +270,7 @@ class Phi3Model(nn.Module):
         self.layers = nn.ModuleList([Phi3DecoderLayer(config, i) for i in range(config.num_hidden_layers)])
         self.norm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.rotary_emb = Phi3RotaryTables(config)
+        self.skip_final_norm = False
 
     def forward(self, inputs_embeds, table, position_ids=None, cache=None):
         B, L, _ = inputs_embeds.shape
@@ -257,6 +282,8 @@ class Phi3Model(nn.Module):
         h = inputs_embeds
         for layer in self.layers:
             h = layer(h, cos, sin, table, position_ids, cache)
+        if self.skip_final_norm:                 # the fp8 head fuses the final RMSNorm into its quantiser
+            return h
         return self.norm(h)
 
     def decode(self, inputs_embeds, cache):
@@ -298,7 +325,32 @@ class Phi3ForCausalLM(nn.Module):
     def set_output_embeddings(self, new_embeddings):
         self.lm_head = new_embeddings
 
+    def enable_fp8(self, enable: bool = True):
+        """Quantise the decoder's projection weights (and the lm_head) to e4m3 once; inference forwards without a KV cache
+        then run their GEMMs on the fp8 MFMA path.  The bf16 weights stay in place (decode, training, disable)."""
+        if not enable:
+            for layer in self.model.layers:
+                layer._fp8 = None
+            self._fp8_head = None
+            return self
+        if self.model.embed_tokens.weight.dtype != torch.bfloat16:
+            raise ops.AkiError("enable_fp8: the model must hold bf16 weights")
+        for layer in self.model.layers:
+            layer.quantize_fp8()
+        head = self.lm_head
+        if type(head) is nn.Linear:
+            w, b, n = head.weight.detach(), head.bias, head.weight.shape[0]
+        else:
+            w, b, n = head._fused_weight()
+        self._fp8_head = (*ops.quant_rows_fp8(w), b, n)
+        return self
+
     def _head(self, h):
+        if getattr(self, "_fp8_head", None) is not None and not torch.is_grad_enabled() and getattr(self, "_pre_norm_h", None) is not None:
+            wq, ws, b, n = self._fp8_head
+            hq, hs = ops.quant_rows_fp8(self._pre_norm_h, self.model.norm.weight, self.model.norm.variance_epsilon)
+            self._pre_norm_h = None
+            return ops.linear_fp8(hq, hs, wq, ws, bias=b, out_shape=(*h.shape[:-1], wq.shape[0]))[..., :n]
         if type(self.lm_head) is nn.Linear:
             return ops.linear(h, self.lm_head.weight, bias=self.lm_head.bias)
         return self.lm_head(h)   # DecoupledLinear (src/vlm.py:88-99): one HIP GEMM / GEMV over the fused weight
@@ -349,7 +401,11 @@ class Phi3ForCausalLM(nn.Module):
             Dh = getattr(cfg, "head_dim", None) or cfg.hidden_size // H
             cache = AkiKVCache(len(self.model.layers), B, H, Dh, int(cache_capacity or (L + 256)), inputs_embeds.dtype,
                                inputs_embeds.device)
+        fp8_head = getattr(self, "_fp8_head", None) is not None and cache is None and not torch.is_grad_enabled()
+        self.model.skip_final_norm = fp8_head
         h = self.model(inputs_embeds, table, position_ids, cache)
+        self.model.skip_final_norm = False
+        self._pre_norm_h = h if fp8_head else None
         if labels is not None and cache is None and _ag(h, *self.lm_head.parameters()):
             # training: padded logits -> fused shifted cross-entropy whose kernel also leaves d(loss)/d(logits) in the
             # logits buffer (so the output carries no logits; train/losses.py:110-115 only reads [0] = loss)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 4
+#define AKI_ABI_VERSION 5
 
 typedef enum {
   AKI_OK = 0,
@@ -37,7 +37,7 @@ typedef enum {
   AKI_ERR_LAUNCH = -5        /* hipGetLastError() after launch was not hipSuccess               */
 } aki_status;
 
-typedef enum { AKI_DT_BF16 = 0, AKI_DT_F32 = 1 } aki_dtype;
+typedef enum { AKI_DT_BF16 = 0, AKI_DT_F32 = 1, AKI_DT_FP8_E4M3 = 2 } aki_dtype;
 
 /* Activation fused into aki_linear_fwd. */
 typedef enum {
@@ -136,6 +136,10 @@ typedef struct {
   int32_t dtype;
   int32_t dead_rows;
   int32_t kv_capacity; /* aki_qkv_rope_fwd: rows per (batch, head) of k_out / v_out (prefill straight into a KV cache); 0 = L */
+  /* dtype == AKI_DT_FP8_E4M3: x / w_qkv are e4m3 bytes with per-row scales (see aki_linear_args); q, k, v, o are bf16 and
+   * the attention core runs exactly as in the bf16 path. */
+  const float* x_scale;
+  const float* w_scale;
 } aki_mma_attn_args;
 
 size_t aki_mma_attn_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype);
@@ -191,6 +195,11 @@ typedef struct {
   int32_t res_row_mod;
   int32_t act;   /* aki_act */
   int32_t dtype; /* aki_dtype */
+  /* AKI_DT_FP8_E4M3 (BASELINE configs[4]): x and w hold OCP e4m3 bytes (ldx / ldw in bytes, multiples of 16; K a multiple
+   * of 128) produced by aki_quant_rows_fp8, with one f32 dequantisation scale per x row / per w row; bias, residual and
+   * y stay bf16.  act: NONE or SWIGLU.  Ignored for the other dtypes. */
+  const float* x_scale;
+  const float* w_scale;
 } aki_linear_args;
 
 int aki_linear_fwd(const aki_linear_args* args, void* stream);
@@ -366,6 +375,13 @@ int aki_grad_sqnorm(const void* g, size_t n, float* out, int32_t accumulate, int
                     void* stream);
 int aki_adamw_step(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+/* aki_quant_rows_fp8 - q[r][c] = e4m3(y[r][c] / scale[r]), scale[r] = max_c |y[r][c]| / 448, with y = x (bf16 [rows, cols])
+ * or, when rms_weight != NULL, y = Phi3RMSNorm(x; rms_weight, rms_eps) (HF:phi3/modeling_phi3.py:266-284) - the input side
+ * of the fp8 projections of BASELINE configs[4].  Also used once per nn.Linear weight (one scale per output feature).
+ * cols % 8 == 0, cols <= 8192; q is [rows, ldq] bytes. */
+int aki_quant_rows_fp8(const void* x, const void* rms_weight, float rms_eps, void* q, float* scale, int32_t rows, int32_t cols,
+                       int32_t ldx, int32_t ldq, void* stream);
 
 /* aki_mma_mask_dense - materialise the reference's (B,1,L,L) int64 0/1 mask from the table, for
  * callers that still want it (bit-exact vs src/vlm.py:410-443 + src/utils.py:99-108). */
