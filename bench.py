@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE configs[1]: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8 = BASELINE configs[4]: e4m3 weights/activations for the decoder projections (use with --batch 16)")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel timing table to stderr")
     args = ap.parse_args()
 
@@ -183,6 +185,9 @@ def main():
     B = args.batch
     model = build_aki(dtype=torch.bfloat16, device=dev, seed=rank)
     model.eval()
+    fp8 = args.dtype == "fp8"
+    if fp8:
+        model.lang_model.enable_fp8()
     vx, ids, am = synth_batch(B, dev, torch.bfloat16, model.media_token_id, seed=1000 + rank)
     L = N_TXT - 1 + NV
 
@@ -196,8 +201,9 @@ def main():
     torch.cuda.synchronize()
     # HIP events on the launch stream around the kernels that are reported: the dominant GEMM (gate_up + SwiGLU, known
     # from profiles/) and the MMA op.  --kernel-table brackets every GEMM instead (costs ~4 % of the step).
-    tap = ops.EventTap(tags={"linear", "mma_attn"},
-                       select=None if args.kernel_table else (lambda tag: tag[0] == "mma_attn" or tag[4] == ops.ACT_SWIGLU))
+    tap = ops.EventTap(tags={"linear", "mma_attn", "linear_fp8", "mma_attn_fp8"},
+                       select=None if args.kernel_table else (lambda tag: tag[0].startswith("mma_attn") or
+                                                              (tag[4] == ops.ACT_SWIGLU and tag[0] == ("linear_fp8" if fp8 else "linear"))))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -222,15 +228,15 @@ def main():
         summ = tap.summary()
         rows = []
         for tag, (n_calls, avg_ms) in summ.items():
-            if tag[0] == "linear":
+            if tag[0] in ("linear", "linear_fp8"):
                 _, M, N, K, act = tag
                 fl = 2.0 * M * N * K
-                name = f"gemm_bf16 M{M} N{N} K{K}" + (" +swiglu" if act == 3 else "")
+                name = ("gemm_fp8" if tag[0] == "linear_fp8" else "gemm_bf16") + f" M{M} N{N} K{K}" + (" +swiglu" if act == 3 else "")
             else:
                 _, b_, h_, l_, dh = tag
                 pairs = l_ * (l_ + 1) // 2 + NV * max(0, (N_TXT - 17 + NV) - (6 + NV))
                 fl = 2.0 * b_ * l_ * 3 * h_ * dh * (h_ * dh) + 4.0 * h_ * dh * pairs * b_
-                name = f"mma_attn (qkv+rope+attention) B{b_} H{h_} L{l_}"
+                name = ("mma_attn_fp8" if tag[0] == "mma_attn_fp8" else "mma_attn") + f" (qkv+rope+attention) B{b_} H{h_} L{l_}"
             rows.append(dict(kernel=name, tag=tag[0], calls_per_step=n_calls / args.steps, avg_ms=avg_ms,
                              total_ms_per_step=avg_ms * n_calls / args.steps, tflops=fl / avg_ms / 1e9, flops=fl))
         rows.sort(key=lambda r: -r["total_ms_per_step"])
@@ -239,21 +245,22 @@ def main():
                 print(f"  {r['kernel']:<48s} x{r['calls_per_step']:5.1f}/step  {r['avg_ms']:8.4f} ms  {r['tflops']:7.1f} TF/s  "
                       f"{r['total_ms_per_step']:8.3f} ms/step", file=sys.stderr)
         dom = rows[0]
-        mk = lambda r: {"kernel": r["kernel"], "bound": "mfma", "achieved": round(r["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(r["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        peak_of = lambda r: 5000.0 if r["tag"] == "linear_fp8" else PEAK_BF16_TFLOPS     # dense fp8 MFMA peak (guide): ~5 PF
+        mk = lambda r: {"kernel": r["kernel"], "bound": "mfma", "achieved": round(r["tflops"], 1), "peak": peak_of(r),
+                        "unit": "TFLOP/s", "frac": round(r["tflops"] / peak_of(r), 4), "traffic": None,
                         "avg_launch_ms": round(r["avg_ms"], 4), "algorithmic_flops_per_launch": r["flops"]}
         res = {
             "metric": "image+text tokens/sec forward, AKI-4B, 336px img + 512 txt",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "fp8-e4m3 projections (f32 accumulate), bf16 attention/residual" if fp8 else "bf16", "data": "synthetic",
             "config": {"workload": "AKI-4B (Phi-3.5-mini + SigLIP-so400m/14 + Perceiver) forward, bf16, 1x336px image + "
-                                   "512-token chat prompt per sample, batch 8 per GPU (BASELINE configs[1]); random-init weights",
+                                   f"512-token chat prompt per sample, batch {B} per GPU (BASELINE configs[{4 if fp8 else 1}]); random-init weights",
                        "global_batch": B * world, "seq_len": L, "tokens_per_sample": L, "patch_plus_text_tokens": 576 + N_TXT,
                        "parallelism": f"dp{world}"},
             "roofline": mk(dom),
         }
-        mma = [r for r in rows if r["tag"] == "mma_attn"]
+        mma = [r for r in rows if r["tag"].startswith("mma_attn")]
         if mma:
             res["mma_kernel"] = mk(mma[0])
         if world == 1 and not args.no_cpu_baseline:
