@@ -542,3 +542,34 @@ def test_errors_are_loud():
         ops.linear(torch.zeros(4, 100, device=DEV, dtype=torch.bfloat16), torch.zeros(8, 100, device=DEV, dtype=torch.bfloat16))
     with pytest.raises(AkiError):
         ops.mma_attn_core(*(torch.zeros(1, 1, 8, 80, device=DEV, dtype=torch.bfloat16),) * 3, ops.MaskTable.causal(1, 8, DEV), 0.1)
+
+
+def test_config4_long_context_four_images():
+    """BASELINE configs[3]: seq = 4096 with 4 interleaved images (multi-image MMA mask, build-defined rule: every image's
+    rows see the columns from its own end up to <|assistant|>).  bf16 MFMA kernel vs the exact-f32 kernel on all 32 heads,
+    f32 kernel vs the numpy oracle on one head, the dense mask bit-exact, and the convex-combination property."""
+    ops = _ops()
+    B, H, L, Nv = 1, 32, 4096, 144
+    starts = [6, 900, 1800, 2700]
+    q_end = L - 64
+    g = torch.Generator(device="cpu").manual_seed(4)
+    q, k, v = (torch.randn(B, H, L, 96, generator=g) for _ in range(3))
+    am = np.ones((B, L), dtype=np.int64)
+    rects = [[O.clamp_span(L, s, s + Nv, q_end) for s in starts]]
+    table = ops.MaskTable.from_host(rects, am, [L], DEV)
+    qb, kb, vb = (a.to(torch.bfloat16).to(DEV) for a in (q, k, v))
+    o16 = ops.mma_attn_core(qb, kb, vb, table, 96 ** -0.5)
+    o32 = ops.mma_attn_core(qb.float(), kb.float(), vb.float(), table, 96 ** -0.5)
+    check(n(o16), n(o32), torch.bfloat16, "L=4096, 4 images: bf16 MFMA kernel vs exact-f32 kernel")
+    h = 13
+    sl = lambda a: a[:, h:h + 1].to(torch.bfloat16).float().numpy()
+    want = O.mma_attention_core_spans(sl(q), sl(k), sl(v), am, rects, 96 ** -0.5)
+    check(n(o32)[:, :, h * 96:(h + 1) * 96], want, torch.float32, "f32 kernel vs oracle, head 13", scale_atol=2.0)
+    dense = ops.mask_dense(table, B).cpu().numpy()
+    assert np.array_equal(dense[0, 0], O.mask_from_spans(am[0], rects[0]).reshape(L, L))
+    # image rows really see their unlocked text: row starts[1] + 3 attends beyond itself, row 5 (before the first image) does not
+    m = dense[0, 0]
+    assert m[starts[1] + 3, starts[1] + Nv + 10] == 1 and m[starts[1] + 3, starts[1] + 5] == 0 and m[5, 6:].sum() == 0
+    vmin, vmax = vb.float().amin(dim=2), vb.float().amax(dim=2)
+    o = o16.float().reshape(B, L, H, 96).permute(0, 2, 1, 3)
+    assert bool(((o >= vmin[:, :, None] - 2e-2) & (o <= vmax[:, :, None] + 2e-2)).all())
