@@ -245,6 +245,22 @@ def main():
                 print(f"  {r['kernel']:<48s} x{r['calls_per_step']:5.1f}/step  {r['avg_ms']:8.4f} ms  {r['tflops']:7.1f} TF/s  "
                       f"{r['total_ms_per_step']:8.3f} ms/step", file=sys.stderr)
         dom = rows[0]
+
+        def pmc_traffic(kernel_sig):
+            """HBM-side bytes per launch of one kernel from the committed rocprofv3 --pmc passes of THIS command
+            (profiles/*_pmc_summary.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE; counters cannot be read from
+            inside the process).  None when no profile of the same configuration is committed."""
+            if fp8 or world != 1 or B != BATCH:
+                return None, None
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+                try:
+                    for e in json.load(open(f)):
+                        if kernel_sig in e["kernel"] and "hbm_read_bytes_corrected_x2" in e and "hbm_write_bytes" in e:
+                            return int(e["hbm_read_bytes_corrected_x2"] + e["hbm_write_bytes"]), os.path.relpath(f, ROOT)
+                except Exception:
+                    continue
+            return None, None
         peak_of = lambda r: 5000.0 if r["tag"] == "linear_fp8" else PEAK_BF16_TFLOPS     # dense fp8 MFMA peak (guide): ~5 PF
         mk = lambda r: {"kernel": r["kernel"], "bound": "mfma", "achieved": round(r["tflops"], 1), "peak": peak_of(r),
                         "unit": "TFLOP/s", "frac": round(r["tflops"] / peak_of(r), 4), "traffic": None,
@@ -260,6 +276,13 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": mk(dom),
         }
+        if dom["tag"] == "linear" and "+swiglu" in dom["kernel"]:
+            tr, src = pmc_traffic("gemm_bf16_kernel<8, 4, 2, 4, 1, 0>")
+            res["roofline"]["traffic"] = tr
+            if src:
+                res["roofline"]["traffic_unit"] = "bytes per launch (L2<->fabric: FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache hits)"
+                res["roofline"]["traffic_source"] = src
+                res["roofline"]["algorithmic_bytes_per_launch"] = int(2 * (dom["flops"] / 2 / 16384 / 3072 * 3072 + 16384 * 3072 + dom["flops"] / 2 / 16384 / 3072 * 8192))
         mma = [r for r in rows if r["tag"].startswith("mma_attn")]
         if mma:
             res["mma_kernel"] = mk(mma[0])
