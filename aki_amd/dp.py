@@ -132,6 +132,7 @@ class FlatGradReducer:
                  breaks=()):
         """spans: list of (param, start, stop) element ranges inside flat_grad, in buffer order."""
         self.flat, self.group, self.shard = flat_grad, group, shard
+        self.enabled = True           # False during the non-final micro-batches of a gradient-accumulation window
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         per = max(1, bucket_bytes // flat_grad.element_size())
@@ -163,6 +164,8 @@ class FlatGradReducer:
         return b[0] + self.rank * c, b[0] + (self.rank + 1) * c
 
     def notify(self, p) -> None:
+        if not self.enabled:
+            return
         b = self.buckets[self._owner[id(p)]]
         b[3] -= 1
         if b[3] == 0:

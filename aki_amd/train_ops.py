@@ -196,11 +196,11 @@ def _deliver(param: torch.Tensor, grad_writer):
     autograd), else return a fresh tensor."""
     tgt = getattr(param, "_aki_grad", None)
     if tgt is not None:
-        if getattr(param, "_aki_grad_live", False):        # second use inside one backward: add (already announced)
+        if getattr(param, "_aki_grad_live", False):        # later micro-batch of an accumulation window (or a second use): add
             tgt += grad_writer(None)
-            return None
-        grad_writer(tgt)
-        param._aki_grad_live = True
+        else:
+            grad_writer(tgt)
+            param._aki_grad_live = True
         hook = getattr(param, "_aki_grad_hook", None)
         if hook is not None:
             hook(param)                                    # lets the reducer launch the bucket this gradient completes

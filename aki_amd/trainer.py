@@ -102,7 +102,12 @@ class AkiTrainer:
             p._aki_grad_live = False
             p.grad = None
 
-    def backward(self, loss: torch.Tensor) -> None:
+    def backward(self, loss: torch.Tensor, last_microbatch: bool = True) -> None:
+        """loss.backward() through the HIP kernels.  Gradient accumulation (train/train_utils.py:242-266 divides the loss
+        by `gradient_accumulation_steps` and steps every k-th micro-batch): call zero_grad() once, then backward(loss / k,
+        last_microbatch=False) for the first k-1 micro-batches - gradients add up in the flat buffer, nothing is
+        exchanged - and backward(loss / k) for the last one, which also runs the (overlapped) gradient exchange."""
+        self.reducer.enabled = bool(last_microbatch)
         loss.backward()
         for p in self.params:
             if p.grad is not None:               # a gradient autograd produced itself (no HIP writer took it): fold it in
@@ -113,10 +118,13 @@ class AkiTrainer:
                     p._aki_grad_live = True
                 p.grad = None
                 self.reducer.notify(p)
-            elif not p._aki_grad_live:           # unused this step
-                p._aki_grad.zero_()
-                self.reducer.notify(p)
-        self.reducer.finish()
+            elif not p._aki_grad_live:           # unused so far in this window
+                if last_microbatch:
+                    p._aki_grad.zero_()
+                    self.reducer.notify(p)
+        if last_microbatch:
+            self.reducer.finish()
+        self.reducer.enabled = True
 
     def optimizer_step(self) -> None:
         self.step_count += 1
