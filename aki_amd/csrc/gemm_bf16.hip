@@ -343,15 +343,18 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
 int g_force_tile = 0;  // test hook (aki_debug_set_gemm_tile): 0 = heuristic, 1 = 256^2, 2 = 128^2
 
 // Cost model in units of one 256x256 tile's run time.  256^2 tiles: one workgroup per CU.  128-token tiles do a
-// quarter of the work at ~75 % of the efficiency; up to 256 of them run one per CU, beyond that two share a CU.
+// quarter of the work; up to 256 of them run one per CU at ~75 % of the big tile's efficiency, beyond that two share a CU
+// and overlap each other's prologue / epilogue (~90 %: tools/siglip_gemm_bench.py - SigLIP fc1, 1224 small tiles in three
+// half-rounds, 903 TF/s vs 696 for 306 big tiles in two rounds at 60 % occupancy).
 static double cost_big(long tiles) { return (double)((tiles + 255) / 256); }
 // `work` = small-tile work relative to the big tile (0.25 for 128x128 vs 256x256, 0.5 for the 192x128 QKV tile).
 static double cost_small(long tiles, double work) {
-  return tiles <= 256 ? (tiles ? work / 0.75 : 0.0) : (double)((tiles + 511) / 512) * (2.0 * work / 0.75);
+  return tiles <= 256 ? (tiles ? work / 0.75 : 0.0) : (double)((tiles + 511) / 512) * (2.0 * work / 0.9);
 }
 
 // plan: 0 = all big, 1 = all small, 2 = big on the first floor(M/256)*256 rows + small tiles on the M tail
 // (removes the wave-quantisation loss of a last, mostly idle round: 1344 tiles on 256 CUs = 5.25 rounds).
+// (A 128-feature x 256-token tile was measured too: never better than the 128^2 tiles on any AKI shape.)
 static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_work = 0.25) {
   if (g_force_tile) return g_force_tile == 2 ? 1 : 0;
   const long nb = (n_out + bn_big - 1) / bn_big, ns = (n_out + bn_small - 1) / bn_small;
