@@ -8,7 +8,7 @@
 // (features), B-operand = x rows (tokens), i.e. each 16x16 accumulator block is C^T[feature][token] with
 //   token   = lane & 15                 (on the lanes)
 //   feature = 4*(lane>>4) + reg         (4 consecutive features per lane)
-// so per-token epilogues are lane-local: RoPE (partner d+48 = 3 blocks further, same lane and register),
+// so per-token epilogues are lane-local: RoPE (the feature order is permuted so that d and d+48 share lane and register),
 // residual add, SwiGLU (gate/up blocks of the same features are staged into the same wave), and one
 // v_permlane16_swap per dword turns two blocks' 8-byte runs into 16-byte row-major stores.
 //
@@ -17,8 +17,7 @@
 // the 16x16 shape (cdna guide rule 28); in this kernel the switch was worth +8..19 %, the 16-byte stores +3..6 %.
 //
 // Tiles (waves = WN x WM, wave tile = NF*16 features x NT*16 tokens, BK = 64):
-//   BIG   2x4 waves, 8x4 blocks -> 256 x 256     generic large GEMMs
-//   QKV   2x4 waves, 6x4 blocks -> 192 x 256     one 96-wide head per wave (QKV + RoPE epilogue)
+//   BIG   2x4 waves, 8x4 blocks -> 256 x 256     generic large GEMMs (also QKV + RoPE, see EPI_QKV_ROPE8)
 //   SMALL 2x2 waves, 4x4 blocks -> 128 x 128     shapes whose 256^2 tiling cannot fill 256 CUs (2 WGs/CU)
 // LDS: 2 stages x (BN + BM) rows x 128 B filled by global_load_lds (16 B/lane; 1 KiB per wave-instruction =
 // 8 rows).  The LDS image is lane-linear; the bank-conflict swizzle (chunk ^= (row>>1)&7) is applied on the
@@ -30,7 +29,7 @@
 
 namespace aki {
 
-enum { EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_QKV_ROPE = 2, EPI_QKV_ROPE8 = 3 };
+enum { EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_QKV_ROPE8 = 3 };
 
 // EPI_QKV_ROPE8: QKV + RoPE on the generic 256x256 / 128x128 tiles.  RoPE only needs d and d + 48 of a head in the same lane
 // and register slot, not a whole head per wave, so the 3*H*96 output features are re-ordered into 32-feature UNITS - for q
@@ -38,7 +37,7 @@ enum { EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_QKV_ROPE = 2, EPI_QKV_ROPE8 = 3 };
 // and a wave with NF blocks owns NF/2 consecutive units, first halves in blocks [0, NF/2), partners in [NF/2, NF).  The
 // permutation lives in the weight-row gather of the LDS staging (every LDS row already has its own source pointer) and in
 // the epilogue's destination address: no weight copy, identical arithmetic, and the kernel gets the big tile's efficiency
-// (the 192-wide one-head-per-wave tile of EPI_QKV_ROPE measured 1080 TF/s against 1190-1300 for 256x256).
+// (the earlier 192-wide one-head-per-wave tile measured 1080 TF/s against 1190-1300 for 256x256).
 __device__ __forceinline__ int qkv_unit_row(int u, int s_, int H) {   // first weight row of block (unit u, half s_)
   const int nqk = 6 * H;
   if (u < nqk) { const int hs = u / 3, j = u - 3 * hs; return hs * 96 + 16 * j + 48 * s_; }
@@ -234,50 +233,6 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   }
 
   // ---- epilogue: lane (token = l15 of block m, row group kg) owns features 4kg..4kg+3 of every feature block ----
-  if (EPI == EPI_QKV_ROPE) {
-    const int hs = (n0 + wn * WROWS) / 96;  // head slot of q|k|v handled by this wave (NF = 6)
-    if (hs >= 3 * p.H) return;
-    const int which = hs / p.H, head = hs % p.H;
-    bf16_t* outp = which == 0 ? p.q_out : (which == 1 ? p.k_out : p.v_out);
-#pragma unroll
-    for (int m = 0; m < NT; ++m) {
-      const int mrow = m0 + wm * WTOK + m * 16 + l15;
-      const bool ok = mrow < p.M;
-      const int mr = min(mrow, p.M - 1) + p.m_offset;   // global token index
-      const int b = mr / p.L, tt = mr - b * p.L;
-      float v[NF][4];
-      if (which < 2) {
-        const int pos = p.position_ids ? p.position_ids[mr] : tt;
-        const float* cp = p.cos + (size_t)pos * 96 + 4 * kg;
-        const float* sp = p.sin + (size_t)pos * 96 + 4 * kg;
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {  // d = 16n + 4kg + r and its rotate-half partner d + 48 (block n + 3)
-          const f32x4 c4 = *(const f32x4*)(cp + n * 16);
-          const f32x4 s4 = *(const f32x4*)(sp + n * 16);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float x1 = acc[n][m][r], x2 = acc[n + 3][m][r];
-            v[n][r] = x1 * c4[r] - x2 * s4[r];
-            v[n + 3][r] = x2 * c4[r] + x1 * s4[r];
-          }
-        }
-      } else {
-#pragma unroll
-        for (int n = 0; n < NF; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[n][r] = acc[n][m][r];
-      }
-      bf16_t* dst = outp + ((size_t)(b * p.H + head) * (which == 0 ? p.L : p.kvcap) + tt) * 96;
-#pragma unroll
-      for (int n = 0; n < NF; n += 2) {
-        const u32x4 o = pair_to_wide(pack_bf16x2(v[n][0], v[n][1]), pack_bf16x2(v[n][2], v[n][3]),
-                                     pack_bf16x2(v[n + 1][0], v[n + 1][1]), pack_bf16x2(v[n + 1][2], v[n + 1][3]));
-        if (ok) *(u32x4*)(dst + (n + (kg & 1)) * 16 + 8 * (kg >> 1)) = o;
-      }
-    }
-    return;
-  }
-
   if (EPI == EPI_QKV_ROPE8) {
     constexpr int UW = NF / 2;
     const int u0 = n0 / 32 + wn * UW, nqk = 6 * p.H;
