@@ -173,11 +173,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # AKI_BENCH_BACKEND=gloo is a test hook: several ranks may then share one GPU (the data path has no collective, only the
+    # barrier and the max-over-ranks of the elapsed time go through the process group)
+    backend = os.environ.get("AKI_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from aki_amd import ops
@@ -216,7 +224,7 @@ def main():
     ops.set_event_tap(None)
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out.logits.float()).all()
