@@ -58,11 +58,10 @@ __device__ __forceinline__ void gemv_sweep(const bf16_t* const (&wr)[NR], const 
 // FPW output features per wave; SWIGLU: feature f pairs weight rows f (gate) and N/2 + f (up).
 // The K sweep is unrolled KU chunks deep with all weight loads issued before the dot products: a wave keeps
 // NR*KU 16-byte loads in flight per lane, which is what decides the streaming rate at 4-6 waves per CU.
-template <int M, bool SWIGLU>
+template <int M, bool SWIGLU, int FPW = 2>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const GemvParams p) {
-  constexpr int FPW = 2;
   constexpr int NR = SWIGLU ? 2 * FPW : FPW;   // weight rows per wave
-  constexpr int KU = 4;
+  constexpr int KU = NR <= 2 ? 8 : 4;          // up to 16 sixteen-byte loads in flight per lane
   extern __shared__ __attribute__((aligned(16))) char sx[];
   __shared__ float s_red[M][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,6 +126,9 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const GemvParams p) {
       for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
     int c = lane;
     for (; c + 64 * (KU - 1) < nchunk; c += 64 * KU) gemv_sweep<M, NR, KU>(wr, sx, nchunk, c, acc);
+    if constexpr (KU > 4) {
+      for (; c + 64 * 3 < nchunk; c += 64 * 4) gemv_sweep<M, NR, 4>(wr, sx, nchunk, c, acc);
+    }
     for (; c + 64 < nchunk; c += 128) gemv_sweep<M, NR, 2>(wr, sx, nchunk, c, acc);
     for (; c < nchunk; c += 64) gemv_sweep<M, NR, 1>(wr, sx, nchunk, c, acc);
 #pragma unroll
@@ -162,27 +164,33 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const GemvParams p) {
   }
 }
 
-template <int M>
-static int launch_gemv(const GemvParams& p, hipStream_t stream) {
+template <int M, bool SWIGLU, int FPW>
+static int launch_gemv_cfg(const GemvParams& p, int n_out, hipStream_t stream) {
   const size_t smem = (size_t)M * p.K * 2;
-  const int n_out = p.act == AKI_ACT_SWIGLU ? p.N / 2 : p.N;
-  // one group = 8 features (4 waves x 2).  Staging x costs M*K*2 bytes per workgroup against 8*K*2 bytes of weights
-  // per group, so for M > 1 a workgroup takes several groups (at most ~512 workgroups stay in flight).
-  const int groups = (n_out + 7) / 8;
+  // one group = 4 waves x FPW features.  Staging x costs M*K*2 bytes per workgroup against 4*FPW*K*2 bytes of weights per
+  // group, so for M > 1 a workgroup takes several groups (at most ~512 workgroups stay in flight).
+  const int groups = (n_out + 4 * FPW - 1) / (4 * FPW);
   const int per = M == 1 ? 1 : (groups + 511) / 512;
   const dim3 grid((groups + per - 1) / per), block(256);
-  AKI_CLEAR_ERR();
-  if (p.act == AKI_ACT_SWIGLU) {
-    static bool set = false;
-    if (!set) { if (hipFuncSetAttribute((const void*)gemv_bf16_kernel<M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192 * 2) != hipSuccess) return AKI_ERR_LAUNCH; set = true; }
-    hipLaunchKernelGGL((gemv_bf16_kernel<M, true>), grid, block, smem, stream, p);
-  } else {
-    static bool set = false;
-    if (!set) { if (hipFuncSetAttribute((const void*)gemv_bf16_kernel<M, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192 * 2) != hipSuccess) return AKI_ERR_LAUNCH; set = true; }
-    hipLaunchKernelGGL((gemv_bf16_kernel<M, false>), grid, block, smem, stream, p);
+  static bool set = false;
+  if (!set) {
+    if (hipFuncSetAttribute((const void*)gemv_bf16_kernel<M, SWIGLU, FPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192 * 2) != hipSuccess)
+      return AKI_ERR_LAUNCH;
+    set = true;
   }
+  AKI_CLEAR_ERR();
+  hipLaunchKernelGGL((gemv_bf16_kernel<M, SWIGLU, FPW>), grid, block, smem, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
+}
+
+template <int M>
+static int launch_gemv(const GemvParams& p, hipStream_t stream) {
+  const int n_out = p.act == AKI_ACT_SWIGLU ? p.N / 2 : p.N;
+  if (p.act == AKI_ACT_SWIGLU) return launch_gemv_cfg<M, true, 2>(p, n_out, stream);
+  // wide outputs (qkv, lm_head) have waves to spare: 4 features per wave doubles the loads each wave keeps in flight
+  if (M <= 2 && n_out >= 8192) return launch_gemv_cfg<M, false, 4>(p, n_out, stream);
+  return launch_gemv_cfg<M, false, 2>(p, n_out, stream);
 }
 
 // M <= 8 rows and M*K*2 <= 128 KiB of LDS; returns AKI_ERR_UNSUPPORTED otherwise (the caller then uses the MFMA GEMM).
