@@ -116,3 +116,38 @@ def test_cpu_tensors_fail_loudly():
     vx, lx, am, lab = batch(g, torch.float32)
     with pytest.raises((AkiError, RuntimeError)):
         m.cpu()(vx.cpu(), lx.cpu(), attention_mask=am.cpu())
+
+
+def test_config1_full_width_fp32_vs_oracle():
+    """BASELINE configs[0] - one image + 64-token prompt, batch 1, fp32 (L = 207) - at the FULL WIDTH of AKI-4B (d 3072,
+    32 heads x 96, FFN 8192, vocab 32011+2, SigLIP 1152 / 16 heads / MLP 4304 at 384 px = 729 patches, Perceiver 6 layers
+    with 144 latents) and reduced depth (2 decoder + 2 SigLIP layers, so the fp32 weights fit the test budget): the exact-f32
+    HIP path against the torch oracle (oracle/aki_torch.py, pinned to the reference) on the same weights."""
+    import aki_torch as OT
+    from aki_amd.factory import build_aki
+    from aki_amd.phi3 import make_phi3_config
+    from aki_amd.siglip import make_siglip_config
+    m = build_aki(make_phi3_config(num_hidden_layers=2), make_siglip_config(num_hidden_layers=2), dtype=torch.float32, device=DEV, seed=3)
+    m.eval()
+    g = torch.Generator().manual_seed(5)
+    N_TXT = 64
+    ids = torch.randint(3, 31999, (1, N_TXT), generator=g)
+    ids[0, 0], ids[0, 6], ids[0, N_TXT - 17], ids[0, -1] = 1, m.media_token_id, 32001, 2
+    am = torch.ones_like(ids)
+    labels = ids.clone()
+    labels[labels == m.media_token_id] = -100
+    vx = torch.rand(1, 1, 1, 3, 384, 384, generator=g) * 2 - 1
+    with torch.no_grad():
+        out = m(vx.to(DEV), ids.to(DEV), attention_mask=am.to(DEV), labels=labels.to(DEV))
+    assert out.logits.shape == (1, N_TXT - 1 + 144, 32011 + 2)
+    p = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    cfg = dict(vis_layers=2, vis_heads=16, lm_layers=2, lm_heads=32, max_original_id=32010, media_token_id=m.media_token_id,
+               pad_token_id=32000, num_vision_tokens=144)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = OT.aki_forward(p, cfg, vx, ids, am, labels)
+    cols = torch.cat([torch.arange(0, 32013, 499), torch.tensor([1, 2, 32000, 32001, 32011, 32012])])
+    got, want = out.logits[0][:, cols.to(DEV)].cpu(), ref["logits"][0][:, cols]
+    err = (got - want).abs().max().item()
+    assert err <= 2e-4 * max(1.0, want.abs().max().item()), f"fp32 logits at full width: max err {err:.3g} (max |ref| {want.abs().max().item():.3g})"
+    assert abs(float(out.loss) - float(ref["loss"])) < 1e-4
