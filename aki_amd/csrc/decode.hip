@@ -12,6 +12,8 @@
 // After the prefill the reference switches to an all-ones 2-D mask (src/aki_generation.py:58-62), i.e. plain causal
 // attention over everything cached; per-sample cache lengths and the prefill's valid-column bits are honoured here,
 // which lifts the reference's batch-1 restriction.
+#include <type_traits>
+
 #include "aki_device.h"
 
 namespace aki {
@@ -191,6 +193,134 @@ static int launch_gemv(const GemvParams& p, hipStream_t stream) {
   // wide outputs (qkv, lm_head) have waves to spare: 4 features per wave doubles the loads each wave keeps in flight
   if (M <= 2 && n_out >= 8192) return launch_gemv_cfg<M, false, 4>(p, n_out, stream);
   return launch_gemv_cfg<M, false, 2>(p, n_out, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Skinny MFMA GEMM for 2 <= M <= 16 rows (batched decode): y[M][N] = act(x W^T + b) [+ residual].
+// The dot-product GEMV above spends M FMAs and M LDS reads per weight element and stops being HBM-bound beyond M ~ 2;
+// here the tokens ride on the 16 columns of v_mfma_f32_16x16x32_bf16 instead.  One workgroup = one 16-feature tile,
+// its KS waves split K; every lane streams 32 contiguous bytes of ITS weight row per step (lane = (row l15, k-group kg):
+// the four k-groups of a row read one full 128-byte line) straight from HBM into registers - no LDS staging, 16 loads in
+// flight per lane - and the matching 32 bytes of x come from L2 (x is M*K*2 bytes, read by every tile).  The two MFMAs of
+// a step take the first / second 16 bytes of both operands (any k order is fine as long as A and B agree).  Partial tiles
+// of the KS waves meet in LDS; wave 0 runs the epilogue.  SWIGLU: the wave carries the gate tile and the up tile.
+// ------------------------------------------------------------------------------------------------------------
+template <int KS, bool SWIGLU, int FT>
+__global__ __launch_bounds__(KS * 64) void skinny_gemm_bf16_kernel(const GemvParams p) {
+  constexpr int NS = FT * (SWIGLU ? 2 : 1);          // weight streams per wave, all fed by one x fragment
+  constexpr int UN = NS >= 4 ? 2 : (NS == 2 ? 4 : 8);   // steps of 64 k whose loads are issued together (<= 20 loads in flight)
+  __shared__ float red[KS][NS][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+  const int n_out = SWIGLU ? p.N / 2 : p.N;
+  const int f0 = blockIdx.x * 16 * FT;
+  const int Kw = p.K / KS, kbeg = wave * Kw;
+  const bf16_t* wp[NS];
+#pragma unroll
+  for (int t = 0; t < FT; ++t) {
+    const int frow = min(f0 + 16 * t + l15, n_out - 1);
+    wp[t] = p.w + (size_t)frow * p.ldw + kbeg + 16 * kg;
+    if (SWIGLU) wp[FT + t] = p.w + (size_t)(n_out + frow) * p.ldw + kbeg + 16 * kg;
+  }
+  const bf16_t* xr = p.x + (size_t)min(l15, p.M - 1) * p.ldx + kbeg + 16 * kg;
+  f32x4 acc[NS];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = Kw / 64;
+  int it = 0;
+  auto run = [&](auto un_c) {
+    constexpr int U = decltype(un_c)::value;
+    for (; it + U <= nsteps; it += U) {
+      u32x4 wa[U][NS][2], xa[U][2];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+          wa[u][t][0] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)(it + u) * 64));
+          wa[u][t][1] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)(it + u) * 64 + 8));
+        }
+        xa[u][0] = *(const u32x4*)(xr + (size_t)(it + u) * 64);
+        xa[u][1] = *(const u32x4*)(xr + (size_t)(it + u) * 64 + 8);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const bf16x8 xb = __builtin_bit_cast(bf16x8, xa[u][hh]);
+#pragma unroll
+          for (int t = 0; t < NS; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[u][t][hh]), xb, acc[t], 0, 0, 0);
+        }
+    }
+  };
+  run(std::integral_constant<int, UN>{});          // ladder: a wave's K slice can be shorter than the deepest unroll
+  if constexpr (UN > 4) run(std::integral_constant<int, 4>{});
+  if constexpr (UN > 2) run(std::integral_constant<int, 2>{});
+  run(std::integral_constant<int, 1>{});
+  // accumulator: lane (token = l15, features 4kg..4kg+3 of each tile); fold the KS partial tiles
+  if (KS > 1) {
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][t][lane * 4 + r] = acc[t][r];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < KS; ++w)
+#pragma unroll
+      for (int t = 0; t < NS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += red[w][t][lane * 4 + r];
+  }
+  const int tok = l15;
+  if (tok >= p.M) return;
+#pragma unroll
+  for (int t = 0; t < FT; ++t) {
+    const int f = f0 + 16 * t + 4 * kg;
+    if (f >= n_out) continue;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (SWIGLU) {
+        v[r] = acc[FT + t][r] * silu_fast(acc[t][r]);
+      } else {
+        v[r] = acc[t][r];
+        if (p.bias) v[r] += bf16_bits_to_f32(p.bias[f + r]);
+        if (p.act == AKI_ACT_GELU_ERF) v[r] = gelu_erf_fast(v[r]);
+        else if (p.act == AKI_ACT_GELU_TANH) v[r] = gelu_tanh_fast(v[r]);
+      }
+      if (p.residual) v[r] += bf16_bits_to_f32(p.residual[(size_t)(p.res_row_mod > 0 ? tok % p.res_row_mod : tok) * p.ldr + f + r]);
+    }
+    *(u32x2*)(p.y + (size_t)tok * p.ldy + f) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  }
+}
+
+template <int KS, int FT>
+static int launch_skinny(const GemvParams& p, hipStream_t stream) {
+  const int n_out = p.act == AKI_ACT_SWIGLU ? p.N / 2 : p.N;
+  const dim3 grid((n_out + 16 * FT - 1) / (16 * FT)), block(KS * 64);
+  AKI_CLEAR_ERR();
+  if (p.act == AKI_ACT_SWIGLU) hipLaunchKernelGGL((skinny_gemm_bf16_kernel<KS, true, FT>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((skinny_gemm_bf16_kernel<KS, false, FT>), grid, block, 0, stream, p);
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
+}
+
+// 2 <= M <= 16; n_out, ldy, ldr multiples of 4; K a multiple of 64 (per wave).  AKI_ERR_UNSUPPORTED otherwise.
+int skinny_gemm_bf16(const aki_linear_args* a, hipStream_t stream) {
+  const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
+  if (a->M < 2 || a->M > 16 || a->K % 64 || (a->ldx % 8) || (a->ldw % 8) || (n_out % 4) || (a->ldy % 4) || (a->residual && (a->ldr % 4)))
+    return AKI_ERR_UNSUPPORTED;
+  if (a->act == AKI_ACT_SWIGLU && (a->bias || (a->N & 1))) return AKI_ERR_UNSUPPORTED;
+  if (((uintptr_t)a->x & 15) || ((uintptr_t)a->w & 15) || ((uintptr_t)a->y & 7) || ((uintptr_t)a->bias & 7)) return AKI_ERR_ALIGNMENT;
+  GemvParams p = {(const bf16_t*)a->x, (const bf16_t*)a->w, (const bf16_t*)a->bias, (const bf16_t*)a->residual, (bf16_t*)a->y,
+                  nullptr, 0.f, a->M, a->N, a->K, a->ldx, a->ldw, a->ldy, a->ldr, a->res_row_mod, a->act};
+  // One 16-feature tile per wave and a K split that keeps >= ~4 waves per CU.  (Two tiles per wave sharing the x fragment
+  // were measured: fewer x loads, but the lost wave parallelism cost more - 3.85 vs 3.30 ms per step at batch 8.)
+  const int tiles = (n_out + 15) / 16;
+  if (tiles < 768 && a->K % 512 == 0) return launch_skinny<8, 1>(p, stream);
+  if (tiles < 1536 && a->K % 256 == 0) return launch_skinny<4, 1>(p, stream);
+  if (a->K % 128 == 0) return launch_skinny<2, 1>(p, stream);
+  return launch_skinny<1, 1>(p, stream);
 }
 
 // M <= 8 rows and M*K*2 <= 128 KiB of LDS; returns AKI_ERR_UNSUPPORTED otherwise (the caller then uses the MFMA GEMM).

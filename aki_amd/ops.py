@@ -371,7 +371,8 @@ def decode_linear(x: torch.Tensor, w: torch.Tensor, rms_weight: torch.Tensor, ep
     launch when x is bf16 with <= 8 rows, otherwise the norm kernel followed by linear()."""
     x2 = _rows2d(x)
     M, K = x2.shape
-    if x.dtype != torch.bfloat16 or M > 8 or M * K > 65536 or K % 8 or x2.stride(0) % 8 or w.stride(0) % 8:
+    # one row: the fused norm + GEMV launch; 2..16 rows: the norm kernel, then the skinny MFMA GEMM inside linear()
+    if x.dtype != torch.bfloat16 or M != 1 or K > 65536 or K % 8 or x2.stride(0) % 8 or w.stride(0) % 8:
         return linear(rmsnorm(x, rms_weight, eps), w, bias=bias, residual=residual, act=act)
     dev = _dev(x, w, rms_weight, bias, residual)
     N = w.shape[0]
