@@ -14,9 +14,10 @@ from test_model_gpu import build_tiny, batch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M", [1, 3, 8])
-@pytest.mark.parametrize("N,K", [(3072, 3072), (1000, 192), (32016, 3072)])
+@pytest.mark.parametrize("M", [1, 2, 3, 8, 16])
+@pytest.mark.parametrize("N,K", [(3072, 3072), (1000, 192), (32016, 3072), (3072, 8192), (9216, 3072)])
 def test_gemv_linear_bf16(M, N, K):
+    """M = 1: dot-product GEMV; 2 <= M <= 16: skinny MFMA GEMM (every K split: 8 / 4 / 2 / 1 waves per tile)."""
     from aki_amd import ops
     rng = gen.rng_for(f"gemv{M}{N}{K}")
     x = rng.standard_normal((M, K), dtype=np.float32)
