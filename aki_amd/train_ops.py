@@ -47,14 +47,17 @@ def transpose(x: torch.Tensor, pad_to: int = 64, out: Optional[torch.Tensor] = N
     return out
 
 
-def norm_bwd(rms: bool, x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps: float, need_db: bool = False):
+def norm_bwd(rms: bool, x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps: float, need_db: bool = False,
+             dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
+    """dx, dw, db of RMSNorm / LayerNorm.  dw_out / db_out: write the weight gradients there (e.g. a view of the trainer's
+    flat gradient buffer) instead of into fresh tensors."""
     _need_bf16(x, w, dy)
     dev = _dev(x, w, dy)
     x2, dy2 = _rows2d(x), _rows2d(dy)
     rows, cols = x2.shape
     dx = torch.empty_like(x2)
-    dw = torch.empty((cols,), dtype=x.dtype, device=dev)
-    db = torch.empty((cols,), dtype=x.dtype, device=dev) if need_db else None
+    dw = dw_out if dw_out is not None else torch.empty((cols,), dtype=x.dtype, device=dev)
+    db = (db_out if db_out is not None else torch.empty((cols,), dtype=x.dtype, device=dev)) if need_db else None
     lib = L.load()
     ws = _ws(lib.aki_norm_bwd_workspace_bytes(cols), dev)
     L.check(lib.aki_norm_bwd(1 if rms else 0, _ptr(x2), _ptr(w), _ptr(dy2), _ptr(dx), _ptr(dw), _ptr(db), rows, cols, x2.stride(0),
@@ -191,6 +194,14 @@ def _weight_t(w: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def _fresh_target(param) -> Optional[torch.Tensor]:
+    """The flat-buffer view a kernel may write this parameter's gradient into directly (None: no trainer, or the view
+    already holds a gradient of this accumulation window and has to be added to)."""
+    if param is None or getattr(param, "_aki_grad_live", False):
+        return None
+    return getattr(param, "_aki_grad", None)
+
+
 def _deliver(param: torch.Tensor, grad_writer):
     """Give a weight gradient to its owner: write into the trainer's flat buffer when there is one (returns None for
     autograd), else return a fresh tensor."""
@@ -261,11 +272,14 @@ class NormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dx, dw, db = norm_bwd(ctx.rms, x, w, dy, ctx.eps, need_db=(not ctx.rms and ctx.b_ref is not None))
-        gw = _deliver(ctx.w_ref, lambda out: dw if out is None else out.copy_(dw)) if ctx.needs_input_grad[1] else None
+        need_db = not ctx.rms and ctx.b_ref is not None
+        wt = _fresh_target(ctx.w_ref) if ctx.needs_input_grad[1] else None
+        bt = _fresh_target(ctx.b_ref) if (need_db and ctx.needs_input_grad[2]) else None
+        dx, dw, db = norm_bwd(ctx.rms, x, w, dy, ctx.eps, need_db=need_db, dw_out=wt, db_out=bt)   # written in place when possible
+        gw = _deliver(ctx.w_ref, lambda out: dw if (out is None or out is wt) else out.copy_(dw)) if ctx.needs_input_grad[1] else None
         gb = None
         if db is not None and ctx.needs_input_grad[2]:
-            gb = _deliver(ctx.b_ref, lambda out: db if out is None else out.copy_(db))
+            gb = _deliver(ctx.b_ref, lambda out: db if (out is None or out is bt) else out.copy_(db))
         return dx, gw, gb, None, None
 
 
