@@ -38,8 +38,8 @@ int attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, co
                   int H, int Lq, int Lk, int Dh, float scale, void* ws, size_t ws_bytes, hipStream_t s);
 int transpose_bf16_launch(const void* x, void* y, int R, int C, int ldx, int ldy, int Rpad, hipStream_t s);
 size_t norm_bwd_ws_bytes(int cols);
-int norm_bwd_launch(bool rms, const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, int rows, int cols,
-                    int ldx, int lddy, int lddx, float eps, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int norm_bwd_launch(bool rms, const void* x, const void* w, const void* dy, const void* dres, void* dx, void* dw, void* db, int rows,
+                    int cols, int ldx, int lddy, int lddx, int lddr, float eps, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 size_t colsum_ws_bytes(int cols);
 int colsum_launch(const void* x, void* out, int rows, int cols, int ldx, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int swiglu_launch(int bwd, const void* gu, const void* da, void* out, int rows, int F, int ldg, int ldda, int ldo, hipStream_t s);
@@ -356,14 +356,15 @@ int aki_transpose(const void* x, void* y, int32_t R, int32_t C, int32_t ldx, int
 
 size_t aki_norm_bwd_workspace_bytes(int32_t cols) { return cols > 0 ? norm_bwd_ws_bytes(cols) : 0; }
 
-int aki_norm_bwd(int32_t rms, const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, int32_t rows, int32_t cols,
-                 int32_t ldx, int32_t lddy, int32_t lddx, float eps, int32_t accumulate, int32_t dtype, void* ws, size_t ws_bytes,
-                 void* stream) {
+int aki_norm_bwd(int32_t rms, const void* x, const void* w, const void* dy, const void* dres, void* dx, void* dw, void* db, int32_t rows,
+                 int32_t cols, int32_t ldx, int32_t lddy, int32_t lddr, int32_t lddx, float eps, int32_t accumulate, int32_t dtype,
+                 void* ws, size_t ws_bytes, void* stream) {
   AKI_CLEAR_ERR();
   AKI_CHECK_ARG(x && w && dy && dx && dw && rows > 0 && cols > 0 && ldx >= cols && lddy >= cols && lddx >= cols);
-  AKI_CHECK_ARG((ldx % 8) == 0 && (lddy % 8) == 0 && (lddx % 8) == 0);
+  AKI_CHECK_ARG((ldx % 8) == 0 && (lddy % 8) == 0 && (lddx % 8) == 0 && (!dres || (lddr >= cols && (lddr % 8) == 0)));
   AKI_BF16_ONLY(dtype);
-  return norm_bwd_launch(rms != 0, x, w, dy, dx, dw, db, rows, cols, ldx, lddy, lddx, eps, accumulate, ws, ws_bytes, (hipStream_t)stream);
+  return norm_bwd_launch(rms != 0, x, w, dy, dres, dx, dw, db, rows, cols, ldx, lddy, lddx, lddr, eps, accumulate, ws, ws_bytes,
+                         (hipStream_t)stream);
 }
 
 size_t aki_colsum_workspace_bytes(int32_t cols) { return cols > 0 ? colsum_ws_bytes(cols) : 0; }

@@ -69,9 +69,9 @@ int transpose_bf16_launch(const void* x, void* y, int R, int C, int ldx, int ldy
 // and keeps its dw/db partial sums in registers; the partials [gridDim.x][cols] are folded by norm_bwd_finish.
 // ------------------------------------------------------------------------------------------------------------
 template <bool RMS>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* x, const bf16_t* w, const bf16_t* dy, bf16_t* dx,
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* x, const bf16_t* w, const bf16_t* dy, const bf16_t* dres, bf16_t* dx,
                                                        float* dw_part, float* db_part, int rows, int cols, int ldx, int lddy,
-                                                       int lddx, float eps) {
+                                                       int lddx, int lddr, float eps) {
   constexpr int MAXC = 2;          // cols <= 4096
   __shared__ float red[16];
   const int nchunk = cols / 8, tid = threadIdx.x;
@@ -145,10 +145,12 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* x, const bf
     for (int i = 0; i < MAXC; ++i) {
       const int c = tid + i * 256;
       if (c < nchunk) {
-        u32x4 o;
+        u32x4 o, rr = {0u, 0u, 0u, 0u};
+        if (dres) rr = *(const u32x4*)(dres + (size_t)row * lddr + c * 8);     // gradient of the residual branch, summed in here
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          o[e] = pack_bf16x2(rstd * (dxh[i][2 * e] - c2 - xh[i][2 * e] * c1), rstd * (dxh[i][2 * e + 1] - c2 - xh[i][2 * e + 1] * c1));
+          o[e] = pack_bf16x2(rstd * (dxh[i][2 * e] - c2 - xh[i][2 * e] * c1) + bf16_lo(rr[e]),
+                             rstd * (dxh[i][2 * e + 1] - c2 - xh[i][2 * e + 1] * c1) + bf16_hi(rr[e]));
         *(u32x4*)(dx + (size_t)row * lddx + c * 8) = o;
       }
     }
@@ -191,16 +193,16 @@ constexpr int NORM_BWD_GROUPS = 512;
 
 size_t norm_bwd_ws_bytes(int cols) { return (size_t)2 * NORM_BWD_GROUPS * cols * 4; }
 
-int norm_bwd_launch(bool rms, const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, int rows, int cols,
-                    int ldx, int lddy, int lddx, float eps, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+int norm_bwd_launch(bool rms, const void* x, const void* w, const void* dy, const void* dres, void* dx, void* dw, void* db, int rows,
+                    int cols, int ldx, int lddy, int lddx, int lddr, float eps, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   if (cols % 8 || cols > 4096) return AKI_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < norm_bwd_ws_bytes(cols)) return AKI_ERR_WORKSPACE;
   const int G = rows < NORM_BWD_GROUPS ? rows : NORM_BWD_GROUPS;
   float* dwp = (float*)ws;
   float* dbp = dwp + (size_t)NORM_BWD_GROUPS * cols;
   AKI_CLEAR_ERR();
-  if (rms) hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(G), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)dy, (bf16_t*)dx, dwp, dbp, rows, cols, ldx, lddy, lddx, eps);
-  else hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(G), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)dy, (bf16_t*)dx, dwp, dbp, rows, cols, ldx, lddy, lddx, eps);
+  if (rms) hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(G), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dwp, dbp, rows, cols, ldx, lddy, lddx, lddr, eps);
+  else hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(G), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dwp, dbp, rows, cols, ldx, lddy, lddx, lddr, eps);
   hipLaunchKernelGGL(fold_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, dwp, (bf16_t*)dw, G, cols, accumulate);
   if (!rms && db) hipLaunchKernelGGL(fold_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, dbp, (bf16_t*)db, G, cols, accumulate);
   AKI_LAUNCH_CHECK();

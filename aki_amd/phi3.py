@@ -232,6 +232,13 @@ class Phi3DecoderLayer(nn.Module):
     def forward(self, h, cos, sin, table, position_ids=None, cache=None):
         if self._fp8 is not None and cache is None and not torch.is_grad_enabled():
             return self._forward_fp8(h, cos, sin, table, position_ids)
+        if cache is None and _ag(h, *self.parameters()):
+            # training: the norms also hand out the residual stream, so their backward sums both gradient paths in-kernel
+            n1, n2 = self.input_layernorm, self.post_attention_layernorm
+            x, hr = T.rmsnorm_residual(h, n1.weight, n1.variance_epsilon)
+            h = self.self_attn(x, cos, sin, table, hr, position_ids, None)
+            x, hr = T.rmsnorm_residual(h, n2.weight, n2.variance_epsilon)
+            return self.mlp(x, hr)
         h = self.self_attn(self.input_layernorm(h), cos, sin, table, h, position_ids, cache)
         return self.mlp(self.post_attention_layernorm(h), h)
 

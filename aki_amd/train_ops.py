@@ -48,7 +48,7 @@ def transpose(x: torch.Tensor, pad_to: int = 64, out: Optional[torch.Tensor] = N
 
 
 def norm_bwd(rms: bool, x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps: float, need_db: bool = False,
-             dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
+             dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None, dres: Optional[torch.Tensor] = None):
     """dx, dw, db of RMSNorm / LayerNorm.  dw_out / db_out: write the weight gradients there (e.g. a view of the trainer's
     flat gradient buffer) instead of into fresh tensors."""
     _need_bf16(x, w, dy)
@@ -60,8 +60,10 @@ def norm_bwd(rms: bool, x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps:
     db = (db_out if db_out is not None else torch.empty((cols,), dtype=x.dtype, device=dev)) if need_db else None
     lib = L.load()
     ws = _ws(lib.aki_norm_bwd_workspace_bytes(cols), dev)
-    L.check(lib.aki_norm_bwd(1 if rms else 0, _ptr(x2), _ptr(w), _ptr(dy2), _ptr(dx), _ptr(dw), _ptr(db), rows, cols, x2.stride(0),
-                             dy2.stride(0), dx.stride(0), float(eps), 0, _BF16, _ptr(ws), ws.numel(), _stream()), "aki_norm_bwd")
+    r2 = None if dres is None else _rows2d(dres)
+    L.check(lib.aki_norm_bwd(1 if rms else 0, _ptr(x2), _ptr(w), _ptr(dy2), _ptr(r2), _ptr(dx), _ptr(dw), _ptr(db), rows, cols,
+                             x2.stride(0), dy2.stride(0), 0 if r2 is None else r2.stride(0), dx.stride(0), float(eps), 0, _BF16,
+                             _ptr(ws), ws.numel(), _stream()), "aki_norm_bwd")
     return dx.view(x.shape), dw, db
 
 
@@ -281,6 +283,31 @@ class NormFn(torch.autograd.Function):
         if db is not None and ctx.needs_input_grad[2]:
             gb = _deliver(ctx.b_ref, lambda out: db if (out is None or out is bt) else out.copy_(db))
         return dx, gw, gb, None, None
+
+
+class NormResidualFn(torch.autograd.Function):
+    """Pre-norm block entry: (y, h) = (rmsnorm(h), h).  The second output is the residual stream handed to the block's
+    output projection; having it leave through this node means the backward receives BOTH gradients (through the norm and
+    through the residual) and the kernel sums them - no separate elementwise add over [tokens, d] per block."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        y = ops.rmsnorm(x, w, eps)
+        ctx.save_for_backward(x, w)
+        ctx.eps, ctx.w_ref = eps, w
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, w = ctx.saved_tensors
+        wt = _fresh_target(ctx.w_ref) if ctx.needs_input_grad[1] else None
+        dx, dw, _ = norm_bwd(True, x, w, dy, ctx.eps, dw_out=wt, dres=dres)
+        gw = _deliver(ctx.w_ref, lambda out: dw if (out is None or out is wt) else out.copy_(dw)) if ctx.needs_input_grad[1] else None
+        return dx, gw, None
+
+
+def rmsnorm_residual(x, w, eps):
+    return NormResidualFn.apply(x, w, eps)
 
 
 def rmsnorm(x, w, eps):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 5
+#define AKI_ABI_VERSION 6
 
 typedef enum {
   AKI_OK = 0,
@@ -323,8 +323,9 @@ int aki_decode_linear_fwd(const aki_linear_args* args, const void* rms_weight, f
  *                   q,k,v [B,H,L,Dh] (k rotated) as the forward saw them, o and d_o [B,Lq,H*Dh], lse [B,H,Lq] from the
  *                   forward -> dq,dk,dv [B,H,L,Dh].  Dh 96 or 64.  Rows >= seq_lens[b] get zero gradient.
  * aki_transpose     y[C][ldy] = x[R][C]^T with columns R..Rpad-1 of y zero-filled (Rpad <= ldy).
- * aki_norm_bwd      RMSNorm (rms=1) / LayerNorm backward: dx [rows,cols]; dw (and db for LayerNorm) [cols], written or
- *                   accumulated (accumulate=1).  cols % 8 == 0, cols <= 4096.
+ * aki_norm_bwd      RMSNorm (rms=1) / LayerNorm backward: dx [rows,cols] (+ dres when given: the gradient arriving through
+ *                   the residual branch of a pre-norm block, so the two are summed without a separate pass); dw (and db
+ *                   for LayerNorm) [cols], written or accumulated (accumulate=1).  cols % 8 == 0, cols <= 4096.
  * aki_colsum        out[c] (+)= sum_r x[r][c]   (bias gradients)
  * aki_swiglu_fwd/_bwd   a = up * silu(gate) on gate_up [rows, 2F] (gate first), and its backward to d(gate_up)
  * aki_gelu_fwd/_bwd     erf GELU (src/helpers.py:32-39), n elements, n % 8 == 0
@@ -355,9 +356,9 @@ size_t aki_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Lq);
 int aki_attn_bwd(const aki_attn_bwd_args* args, void* workspace, size_t workspace_bytes, void* stream);
 int aki_transpose(const void* x, void* y, int32_t R, int32_t C, int32_t ldx, int32_t ldy, int32_t Rpad, int32_t dtype, void* stream);
 size_t aki_norm_bwd_workspace_bytes(int32_t cols);
-int aki_norm_bwd(int32_t rms, const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, int32_t rows, int32_t cols,
-                 int32_t ldx, int32_t lddy, int32_t lddx, float eps, int32_t accumulate, int32_t dtype, void* workspace,
-                 size_t workspace_bytes, void* stream);
+int aki_norm_bwd(int32_t rms, const void* x, const void* w, const void* dy, const void* dres, void* dx, void* dw, void* db,
+                 int32_t rows, int32_t cols, int32_t ldx, int32_t lddy, int32_t lddr, int32_t lddx, float eps, int32_t accumulate,
+                 int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
 size_t aki_colsum_workspace_bytes(int32_t cols);
 int aki_colsum(const void* x, void* out, int32_t rows, int32_t cols, int32_t ldx, int32_t accumulate, int32_t dtype, void* workspace,
                size_t workspace_bytes, void* stream);
