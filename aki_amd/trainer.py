@@ -143,6 +143,31 @@ class AkiTrainer:
         self.reducer.all_gather_weights(self.w16)
         T.bump_weight_epoch()
 
+    # ---- checkpoint / resume (train/train_utils.py:395-460 saves model + optimizer state; the I/O itself is out of scope) ----
+    def refresh_master(self) -> None:
+        """Re-derive the fp32 master weights from the model's current bf16 weights (after model.load_state_dict)."""
+        for lo, hi, so, _ in self.owned:
+            self.master[so: so + hi - lo].copy_(self.w16[lo:hi])
+        T.bump_weight_epoch()
+
+    def state_dict(self) -> dict:
+        """Optimizer state of THIS rank (all of it when the optimizer is not sharded): fp32 master weights, both moments and
+        the step counter, as flat tensors in the trainer's parameter order."""
+        return {"step": self.step_count, "numel": self.numel, "sharded": self.shard, "owned": [(lo, hi) for lo, hi, _, _ in self.owned],
+                "master": self.master.clone(), "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone()}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if sd["numel"] != self.numel or [tuple(o) for o in sd["owned"]] != [(lo, hi) for lo, hi, _, _ in self.owned]:
+            raise ValueError("optimizer state does not match this model / sharding layout")
+        self.step_count = int(sd["step"])
+        self.master.copy_(sd["master"])
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+        for lo, hi, so, _ in self.owned:                    # the forward reads the bf16 image of the restored master weights
+            self.w16[lo:hi].copy_(self.master[so: so + hi - lo])
+        self.reducer.all_gather_weights(self.w16)
+        T.bump_weight_epoch()
+
     def grad_norm(self) -> torch.Tensor:
         """Global L2 norm of the (averaged) gradients of the last step, as clip_grad_norm_ returns it."""
         return self.sqnorm.sqrt() / self.world

@@ -332,3 +332,32 @@ def test_gradient_accumulation_matches_full_batch():
     acc = tr.g16.float()
     rel = float((acc - full).norm() / full.norm())
     assert rel < 2e-2, rel
+
+
+def test_trainer_checkpoint_resume():
+    """state_dict() after 2 steps -> a fresh model + trainer -> load_state_dict() -> step 3 gives the same loss and the same
+    weights as the uninterrupted run (the forward is bit-identical; the embedding gradient's index_add_ uses atomics, so
+    the update may differ in the last bits of a few elements)."""
+    from aki_amd.trainer import AkiTrainer
+    _, _, m, _, (vx, lx, am, lab) = _tiny_train_setup()
+    tr = AkiTrainer(m, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1)
+    for _ in range(2):
+        tr.train_step(vx, lx, attention_mask=am, labels=lab)
+    sd_opt = tr.state_dict()
+    sd_model = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    l3 = float(tr.train_step(vx, lx, attention_mask=am, labels=lab))
+    w3 = tr.master.clone()
+    _, _, m2, _, _ = _tiny_train_setup()
+    tr2 = AkiTrainer(m2, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1)
+    m2.load_state_dict(sd_model)
+    tr2.load_state_dict(sd_opt)
+    assert tr2.step_count == 2
+    l3b = float(tr2.train_step(vx, lx, attention_mask=am, labels=lab))
+    assert l3b == l3
+    diff = (tr2.master - w3).abs()
+    assert float(diff.max()) <= 2.5 * 2e-3 and float(diff.mean()) < 1e-6, (float(diff.max()), float(diff.mean()))
+    # refresh_master(): fp32 master := the model's (bf16) weights
+    m2.load_state_dict(sd_model)
+    tr2.refresh_master()
+    lo, hi = tr2.span_of[id(next(iter(tr2.params)))]
+    assert torch.equal(tr2.master[lo:hi], tr2.w16[lo:hi].float())
