@@ -9,12 +9,12 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaki_mi355x.so")
 
-AKI_DT_BF16, AKI_DT_F32, AKI_DT_FP8_E4M3 = 0, 1, 2
+AKI_DT_BF16, AKI_DT_F32, AKI_DT_FP8_E4M3, AKI_DT_W8A16 = 0, 1, 2, 3
 AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 6
+AKI_ABI_VERSION = 7
 
 
 class AkiError(RuntimeError):

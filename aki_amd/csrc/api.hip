@@ -177,11 +177,12 @@ int aki_linear_fwd(const aki_linear_args* a, void* stream) {
   AKI_CLEAR_ERR();
   AKI_CHECK_ARG(a && a->x && a->w && a->y);
   AKI_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0);
-  AKI_CHECK_ARG(dtype_ok(a->dtype) || (a->dtype == AKI_DT_FP8_E4M3 && a->x_scale && a->w_scale));
+  AKI_CHECK_ARG(dtype_ok(a->dtype) || (a->dtype == AKI_DT_FP8_E4M3 && a->x_scale && a->w_scale) || (a->dtype == AKI_DT_W8A16 && a->w_scale));
   AKI_CHECK_ARG(a->act >= AKI_ACT_NONE && a->act <= AKI_ACT_SWIGLU);
   const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
   AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));
   if (a->dtype == AKI_DT_FP8_E4M3) return linear_fp8(a, (hipStream_t)stream);
+  if (a->dtype == AKI_DT_W8A16) return gemv_bf16(a, nullptr, 0.f, (hipStream_t)stream);
   if (a->dtype == AKI_DT_BF16) {
     if (a->M >= 2 && a->M <= 16) {  // batched decode: weight-streaming skinny MFMA GEMM
       const int rc = skinny_gemm_bf16(a, (hipStream_t)stream);
@@ -325,7 +326,7 @@ int aki_decode_attn_fused_fwd(const void* qkv, const float* cos, const float* si
 int aki_decode_linear_fwd(const aki_linear_args* a, const void* rms_weight, float rms_eps, void* stream) {
   AKI_CLEAR_ERR();
   AKI_CHECK_ARG(a && a->x && a->w && a->y && rms_weight && rms_eps > 0.f);
-  AKI_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->dtype == AKI_DT_BF16);
+  AKI_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && (a->dtype == AKI_DT_BF16 || (a->dtype == AKI_DT_W8A16 && a->w_scale)));
   AKI_CHECK_ARG(a->act >= AKI_ACT_NONE && a->act <= AKI_ACT_SWIGLU);
   const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
   AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));

@@ -37,6 +37,7 @@ struct GemvParams {
   const bf16_t* x; const bf16_t* w; const bf16_t* bias; const bf16_t* residual; bf16_t* y;
   const bf16_t* norm_w; float norm_eps;       // optional fused RMSNorm of the x rows (decode: the layer's pre-norm)
   int M, N, K, ldx, ldw, ldy, ldr, res_row_mod, act;
+  const float* w_scale;                       // W8: w points at e4m3 bytes (ldw in bytes), one f32 scale per weight row
 };
 
 // U chunks (of 8 k) per lane for NR weight rows: every load is issued before the first dot product
@@ -57,10 +58,46 @@ __device__ __forceinline__ void gemv_sweep(const bf16_t* const (&wr)[NR], const 
     }
 }
 
+// weight-only fp8 (e4m3 weights, bf16 activations): a 16-byte weight chunk holds 16 k-values and meets two 16-byte x chunks;
+// v_cvt_pk_f32_fp8 + v_cvt_pk_bf16_f32 turn two weights into a bf16 pair (exact: e4m3 fits bf16) for the same dot2.
+__device__ __forceinline__ float dot16_w8(const u32x4 w, const u32x4 x0, const u32x4 x1, float acc) {
+  const bf16x8_t xa = __builtin_bit_cast(bf16x8_t, x0), xb = __builtin_bit_cast(bf16x8_t, x1);
+#define AKI_W8_PAIR(word, hi, xv, i0)                                                                               \
+  {                                                                                                                 \
+    const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)(word), hi);                                                \
+    bf16x2_t wb;                                                                                                    \
+    wb[0] = (__bf16)f2[0];                                                                                          \
+    wb[1] = (__bf16)f2[1];                                                                                          \
+    acc = __builtin_amdgcn_fdot2_f32_bf16(wb, __builtin_shufflevector(xv, xv, i0, i0 + 1), acc, false);             \
+  }
+  AKI_W8_PAIR(w[0], false, xa, 0) AKI_W8_PAIR(w[0], true, xa, 2) AKI_W8_PAIR(w[1], false, xa, 4) AKI_W8_PAIR(w[1], true, xa, 6)
+  AKI_W8_PAIR(w[2], false, xb, 0) AKI_W8_PAIR(w[2], true, xb, 2) AKI_W8_PAIR(w[3], false, xb, 4) AKI_W8_PAIR(w[3], true, xb, 6)
+#undef AKI_W8_PAIR
+  return acc;
+}
+
+template <int M, int NR, int U>
+__device__ __forceinline__ void gemv_sweep_w8(const uint8_t* const (&wr)[NR], const char* sx, int nchunk_x, int c, float (&acc)[NR][M]) {
+  u32x4 w[U][NR];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) w[u][r] = __builtin_nontemporal_load((const u32x4*)(wr[r] + (size_t)(c + 64 * u) * 16));
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const u32x4 x0 = *(const u32x4*)(sx + ((size_t)m * nchunk_x + 2 * (c + 64 * u)) * 16);
+      const u32x4 x1 = *(const u32x4*)(sx + ((size_t)m * nchunk_x + 2 * (c + 64 * u) + 1) * 16);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r][m] = dot16_w8(w[u][r], x0, x1, acc[r][m]);
+    }
+}
+
 // FPW output features per wave; SWIGLU: feature f pairs weight rows f (gate) and N/2 + f (up).
 // The K sweep is unrolled KU chunks deep with all weight loads issued before the dot products: a wave keeps
 // NR*KU 16-byte loads in flight per lane, which is what decides the streaming rate at 4-6 waves per CU.
-template <int M, bool SWIGLU, int FPW = 2>
+template <int M, bool SWIGLU, int FPW = 2, bool W8 = false>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const GemvParams p) {
   constexpr int NR = SWIGLU ? 2 * FPW : FPW;   // weight rows per wave
   constexpr int KU = NR <= 2 ? 8 : 4;          // up to 16 sixteen-byte loads in flight per lane
@@ -115,24 +152,42 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const GemvParams p) {
   for (int grp = blockIdx.x; grp * (4 * FPW) < n_out; grp += gridDim.x) {
     const int f0 = (grp * 4 + wave) * FPW;
     if (f0 >= n_out) break;
-    const bf16_t* wr[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int f = min(f0 + (r % FPW), n_out - 1);
-      wr[r] = p.w + (size_t)((SWIGLU && r >= FPW) ? n_out + f : f) * p.ldw;
-    }
     float acc[NR][M];
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
       for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
-    int c = lane;
-    for (; c + 64 * (KU - 1) < nchunk; c += 64 * KU) gemv_sweep<M, NR, KU>(wr, sx, nchunk, c, acc);
-    if constexpr (KU > 4) {
-      for (; c + 64 * 3 < nchunk; c += 64 * 4) gemv_sweep<M, NR, 4>(wr, sx, nchunk, c, acc);
+    float wsc[NR];
+    if constexpr (W8) {
+      const uint8_t* wr[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int f = min(f0 + (r % FPW), n_out - 1);
+        const int row = (SWIGLU && r >= FPW) ? n_out + f : f;
+        wr[r] = (const uint8_t*)p.w + (size_t)row * p.ldw;
+        wsc[r] = p.w_scale[row];
+      }
+      const int nchunk_w = p.K / 16;                         // 16-byte weight chunks = 16 k-values each
+      int c = lane;
+      for (; c + 64 * 3 < nchunk_w; c += 64 * 4) gemv_sweep_w8<M, NR, 4>(wr, sx, nchunk, c, acc);
+      for (; c + 64 < nchunk_w; c += 128) gemv_sweep_w8<M, NR, 2>(wr, sx, nchunk, c, acc);
+      for (; c < nchunk_w; c += 64) gemv_sweep_w8<M, NR, 1>(wr, sx, nchunk, c, acc);
+    } else {
+      const bf16_t* wr[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int f = min(f0 + (r % FPW), n_out - 1);
+        wr[r] = p.w + (size_t)((SWIGLU && r >= FPW) ? n_out + f : f) * p.ldw;
+        wsc[r] = 1.f;
+      }
+      int c = lane;
+      for (; c + 64 * (KU - 1) < nchunk; c += 64 * KU) gemv_sweep<M, NR, KU>(wr, sx, nchunk, c, acc);
+      if constexpr (KU > 4) {
+        for (; c + 64 * 3 < nchunk; c += 64 * 4) gemv_sweep<M, NR, 4>(wr, sx, nchunk, c, acc);
+      }
+      for (; c + 64 < nchunk; c += 128) gemv_sweep<M, NR, 2>(wr, sx, nchunk, c, acc);
+      for (; c < nchunk; c += 64) gemv_sweep<M, NR, 1>(wr, sx, nchunk, c, acc);
     }
-    for (; c + 64 < nchunk; c += 128) gemv_sweep<M, NR, 2>(wr, sx, nchunk, c, acc);
-    for (; c < nchunk; c += 64) gemv_sweep<M, NR, 1>(wr, sx, nchunk, c, acc);
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
@@ -140,7 +195,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const GemvParams p) {
         float v = acc[r][m];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        acc[r][m] = v;
+        acc[r][m] = W8 ? v * wsc[r] : v;
       }
     if (lane == 0) {
 #pragma unroll
@@ -166,7 +221,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const GemvParams p) {
   }
 }
 
-template <int M, bool SWIGLU, int FPW>
+template <int M, bool SWIGLU, int FPW, bool W8 = false>
 static int launch_gemv_cfg(const GemvParams& p, int n_out, hipStream_t stream) {
   const size_t smem = (size_t)M * p.K * 2;
   // one group = 4 waves x FPW features.  Staging x costs M*K*2 bytes per workgroup against 4*FPW*K*2 bytes of weights per
@@ -176,12 +231,12 @@ static int launch_gemv_cfg(const GemvParams& p, int n_out, hipStream_t stream) {
   const dim3 grid((groups + per - 1) / per), block(256);
   static bool set = false;
   if (!set) {
-    if (hipFuncSetAttribute((const void*)gemv_bf16_kernel<M, SWIGLU, FPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192 * 2) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemv_bf16_kernel<M, SWIGLU, FPW, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192 * 2) != hipSuccess)
       return AKI_ERR_LAUNCH;
     set = true;
   }
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL((gemv_bf16_kernel<M, SWIGLU, FPW>), grid, block, smem, stream, p);
+  hipLaunchKernelGGL((gemv_bf16_kernel<M, SWIGLU, FPW, W8>), grid, block, smem, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }
@@ -189,6 +244,14 @@ static int launch_gemv_cfg(const GemvParams& p, int n_out, hipStream_t stream) {
 template <int M>
 static int launch_gemv(const GemvParams& p, hipStream_t stream) {
   const int n_out = p.act == AKI_ACT_SWIGLU ? p.N / 2 : p.N;
+  if (p.w_scale) {                       // weight-only fp8: single-sequence decode in the fp8 configuration
+    if constexpr (M == 1) {
+      if (p.act == AKI_ACT_SWIGLU) return launch_gemv_cfg<1, true, 2, true>(p, n_out, stream);
+      return launch_gemv_cfg<1, false, 2, true>(p, n_out, stream);
+    } else {
+      return AKI_ERR_UNSUPPORTED;
+    }
+  }
   if (p.act == AKI_ACT_SWIGLU) return launch_gemv_cfg<M, true, 2>(p, n_out, stream);
   // wide outputs (qkv, lm_head) have waves to spare: 4 features per wave doubles the loads each wave keeps in flight
   if (M <= 2 && n_out >= 8192) return launch_gemv_cfg<M, false, 4>(p, n_out, stream);
@@ -313,7 +376,7 @@ int skinny_gemm_bf16(const aki_linear_args* a, hipStream_t stream) {
   if (a->act == AKI_ACT_SWIGLU && (a->bias || (a->N & 1))) return AKI_ERR_UNSUPPORTED;
   if (((uintptr_t)a->x & 15) || ((uintptr_t)a->w & 15) || ((uintptr_t)a->y & 7) || ((uintptr_t)a->bias & 7)) return AKI_ERR_ALIGNMENT;
   GemvParams p = {(const bf16_t*)a->x, (const bf16_t*)a->w, (const bf16_t*)a->bias, (const bf16_t*)a->residual, (bf16_t*)a->y,
-                  nullptr, 0.f, a->M, a->N, a->K, a->ldx, a->ldw, a->ldy, a->ldr, a->res_row_mod, a->act};
+                  nullptr, 0.f, a->M, a->N, a->K, a->ldx, a->ldw, a->ldy, a->ldr, a->res_row_mod, a->act, nullptr};
   // One 16-feature tile per wave and a K split that keeps >= ~4 waves per CU.  (Two tiles per wave sharing the x fragment
   // were measured: fewer x loads, but the lost wave parallelism cost more - 3.85 vs 3.30 ms per step at batch 8.)
   const int tiles = (n_out + 15) / 16;
@@ -326,10 +389,13 @@ int skinny_gemm_bf16(const aki_linear_args* a, hipStream_t stream) {
 // M <= 8 rows and M*K*2 <= 128 KiB of LDS; returns AKI_ERR_UNSUPPORTED otherwise (the caller then uses the MFMA GEMM).
 // rms_w != NULL: the x rows are RMS-normalised (weight rms_w [K], eps) on the way into LDS.
 int gemv_bf16(const aki_linear_args* a, const void* rms_w, float eps, hipStream_t stream) {
-  if (a->M > 8 || a->K % 8 || (size_t)a->M * a->K * 2 > 8 * 8192 * 2 || (a->ldx % 8) || (a->ldw % 8)) return AKI_ERR_UNSUPPORTED;
+  const bool w8 = a->dtype == AKI_DT_W8A16;
+  if (a->M > 8 || a->K % (w8 ? 16 : 8) || (size_t)a->M * a->K * 2 > 8 * 8192 * 2 || (a->ldx % 8) || (a->ldw % (w8 ? 16 : 8))) return AKI_ERR_UNSUPPORTED;
   if (a->act == AKI_ACT_SWIGLU && (a->bias || (a->N & 1))) return AKI_ERR_UNSUPPORTED;
+  if (w8 && (!a->w_scale || a->M != 1)) return AKI_ERR_UNSUPPORTED;
   GemvParams p = {(const bf16_t*)a->x, (const bf16_t*)a->w, (const bf16_t*)a->bias, (const bf16_t*)a->residual, (bf16_t*)a->y,
-                  (const bf16_t*)rms_w, eps, a->M, a->N, a->K, a->ldx, a->ldw, a->ldy, a->ldr, a->res_row_mod, a->act};
+                  (const bf16_t*)rms_w, eps, a->M, a->N, a->K, a->ldx, a->ldw, a->ldy, a->ldr, a->res_row_mod, a->act,
+                  w8 ? a->w_scale : nullptr};
   switch (a->M) {
     case 1: return launch_gemv<1>(p, stream);
     case 2: return launch_gemv<2>(p, stream);

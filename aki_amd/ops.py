@@ -443,6 +443,58 @@ def mma_attn_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch
     return o
 
 
+def qkv_rope_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, B: int,
+                 num_heads: int, position_ids: Optional[torch.Tensor] = None, k_out: Optional[torch.Tensor] = None,
+                 v_out: Optional[torch.Tensor] = None):
+    """fp8 QKV projection + RoPE -> bf16 q [B,H,L,Dh], k, v (optionally straight into a KV cache, like qkv_rope)."""
+    dev = _dev(xq, xs, wq, ws, cos, sin, k_out, v_out)
+    M, d = xq.shape
+    Lq = M // B
+    Dh = wq.shape[0] // (3 * num_heads)
+    cos = cos.to(torch.float32).reshape(-1, Dh).contiguous()
+    sin = sin.to(torch.float32).reshape(-1, Dh).contiguous()
+    pos = None if position_ids is None else position_ids.to(torch.int32).expand(B, Lq).contiguous()
+    q = torch.empty((B, num_heads, Lq, Dh), dtype=torch.bfloat16, device=dev)
+    if k_out is None:
+        k_out = torch.empty((B, num_heads, Lq, Dh), dtype=torch.bfloat16, device=dev)
+        v_out = torch.empty((B, num_heads, Lq, Dh), dtype=torch.bfloat16, device=dev)
+    cap = k_out.shape[2]
+    if not (k_out.is_contiguous() and v_out.is_contiguous()) or v_out.shape != k_out.shape or cap < Lq:
+        raise AkiError("qkv_rope_fp8: bad KV output buffers")
+    a = L.MmaAttnArgs(_ptr(xq), _ptr(wq), _ptr(cos), _ptr(sin), _ptr(pos), None, None, None, None, None, 0, B, num_heads, Lq, Dh, d,
+                      xq.stride(0), wq.stride(0), cos.shape[0], float(Dh ** -0.5), L.AKI_DT_FP8_E4M3, 0, 0 if cap == Lq else cap,
+                      _ptr(xs), _ptr(ws))
+    wsb = _ws(256, dev)
+    L.check(L.load().aki_qkv_rope_fwd(C.byref(a), _ptr(q), _ptr(k_out), _ptr(v_out), _ptr(wsb), wsb.numel(), _stream()),
+            "aki_qkv_rope_fwd[fp8]")
+    return q, k_out, v_out
+
+
+def linear_w8(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias: Optional[torch.Tensor] = None,
+              residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, rms_weight: Optional[torch.Tensor] = None,
+              eps: float = 0.0) -> torch.Tensor:
+    """Weight-only fp8 GEMV for ONE row (single-sequence decode in the fp8 configuration): x bf16 [1, K], wq e4m3 [N, K] with one
+    scale per row; optional fused RMSNorm of x (rms_weight).  y bf16 [1, N_out]."""
+    dev = _dev(x, wq, ws, bias, residual, rms_weight)
+    x2 = _rows2d(x)
+    M, K = x2.shape
+    if M != 1 or x.dtype != torch.bfloat16:
+        raise AkiError("linear_w8 serves single-row bf16 inputs")
+    N = wq.shape[0]
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    out = torch.empty((*x.shape[:-1], n_out), dtype=torch.bfloat16, device=dev)
+    o2 = out.view(-1, n_out)
+    r2 = None if residual is None else _rows2d(residual)
+    a = L.LinearArgs(_ptr(x2), _ptr(wq), _ptr(bias), _ptr(r2), _ptr(o2), M, N, K, x2.stride(0), wq.stride(0), o2.stride(0),
+                     0 if r2 is None else r2.stride(0), 0, act, L.AKI_DT_W8A16, None, _ptr(ws))
+    lib = L.load()
+    if rms_weight is not None:
+        L.check(lib.aki_decode_linear_fwd(C.byref(a), _ptr(rms_weight), float(eps), _stream()), "aki_decode_linear_fwd[w8]")
+    else:
+        L.check(lib.aki_linear_fwd(C.byref(a), _stream()), "aki_linear_fwd[w8]")
+    return out
+
+
 def pad_k(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
     """Zero-pad the K (last) dimension of a weight to a multiple of `mult` (one-time host-side prep)."""
     K = w.shape[-1]

@@ -230,8 +230,8 @@ class Phi3DecoderLayer(nn.Module):
         self._fp8 = None
 
     def forward(self, h, cos, sin, table, position_ids=None, cache=None):
-        if self._fp8 is not None and cache is None and not torch.is_grad_enabled():
-            return self._forward_fp8(h, cos, sin, table, position_ids)
+        if self._fp8 is not None and not torch.is_grad_enabled():
+            return self._forward_fp8(h, cos, sin, table, position_ids, cache)
         if cache is None and _ag(h, *self.parameters()):
             # training: the norms also hand out the residual stream, so their backward sums both gradient paths in-kernel
             n1, n2 = self.input_layernorm, self.post_attention_layernorm
@@ -242,14 +242,19 @@ class Phi3DecoderLayer(nn.Module):
         h = self.self_attn(self.input_layernorm(h), cos, sin, table, h, position_ids, cache)
         return self.mlp(self.post_attention_layernorm(h), h)
 
-    def _forward_fp8(self, h, cos, sin, table, position_ids):
+    def _forward_fp8(self, h, cos, sin, table, position_ids, cache=None):
         """BASELINE configs[4]: the four projections on the fp8 (e4m3) MFMA path with per-token activation scales and
         per-feature weight scales; RMSNorm is fused into the quantiser, RoPE / attention / residual stream stay bf16."""
         w = self._fp8
         B, L, d = h.shape
         n1, n2, at = self.input_layernorm, self.post_attention_layernorm, self.self_attn
         xq, xs = ops.quant_rows_fp8(h, n1.weight, n1.variance_epsilon)
-        o = ops.mma_attn_fp8(xq, xs, *w["qkv"], cos, sin, table, B, at.num_heads, at.scaling, position_ids)
+        if cache is None:
+            o = ops.mma_attn_fp8(xq, xs, *w["qkv"], cos, sin, table, B, at.num_heads, at.scaling, position_ids)
+        else:   # prefill: rotated K and V go straight into the (bf16) KV cache
+            q, k, v = ops.qkv_rope_fp8(xq, xs, *w["qkv"], cos, sin, B, at.num_heads, position_ids,
+                                       k_out=cache.k[at.layer_idx], v_out=cache.v[at.layer_idx])
+            o = ops.mma_attn_core(q, k, v, table, at.scaling)
         oq, os_ = ops.quant_rows_fp8(o)
         h = ops.linear_fp8(oq, os_, *w["o"], residual=h, out_shape=(B, L, d))
         xq, xs = ops.quant_rows_fp8(h, n2.weight, n2.variance_epsilon)
@@ -264,6 +269,16 @@ class Phi3DecoderLayer(nn.Module):
                      "down": ops.quant_rows_fp8(mlp.down_proj.weight.detach())}
 
     def decode(self, h, cos, sin, cache):
+        if self._fp8 is not None and h.shape[0] == 1:
+            # fp8 configuration, one sequence: weight-only e4m3 GEMVs (half the bytes of the HBM-bound step), same 5 launches
+            w, at = self._fp8, self.self_attn
+            n1, n2 = self.input_layernorm, self.post_attention_layernorm
+            qkv = ops.linear_w8(h, *w["qkv"], rms_weight=n1.weight, eps=n1.variance_epsilon)
+            o = ops.decode_attn_fused(qkv, cos, sin, cache.cache_len, cache.k[at.layer_idx], cache.v[at.layer_idx], at.num_heads,
+                                      at.scaling, cache.valid_bits, cache.grid_keys, cache.attn_ws)
+            h = ops.linear_w8(o, *w["o"], residual=h)
+            a = ops.linear_w8(h, *w["gate_up"], act=ops.ACT_SWIGLU, rms_weight=n2.weight, eps=n2.variance_epsilon)
+            return ops.linear_w8(a, *w["down"], residual=h)
         h = self.self_attn.decode(h, self.input_layernorm, cos, sin, cache)
         return self.mlp.decode(h, self.post_attention_layernorm)
 
@@ -408,7 +423,7 @@ class Phi3ForCausalLM(nn.Module):
             Dh = getattr(cfg, "head_dim", None) or cfg.hidden_size // H
             cache = AkiKVCache(len(self.model.layers), B, H, Dh, int(cache_capacity or (L + 256)), inputs_embeds.dtype,
                                inputs_embeds.device)
-        fp8_head = getattr(self, "_fp8_head", None) is not None and cache is None and not torch.is_grad_enabled()
+        fp8_head = getattr(self, "_fp8_head", None) is not None and not torch.is_grad_enabled()
         self.model.skip_final_norm = fp8_head
         h = self.model(inputs_embeds, table, position_ids, cache)
         self.model.skip_final_norm = False
@@ -442,6 +457,9 @@ class Phi3ForCausalLM(nn.Module):
             inputs_embeds = self.get_input_embeddings()(input_ids)
         h = self.model.decode(inputs_embeds.reshape(inputs_embeds.shape[0], -1), past_key_values)
         norm = self.model.norm
+        if getattr(self, "_fp8_head", None) is not None and h.shape[0] == 1:
+            wq, ws, b, n = self._fp8_head
+            return ops.linear_w8(h, wq, ws, bias=b, rms_weight=norm.weight, eps=norm.variance_epsilon)[..., :n]
         if type(self.lm_head) is nn.Linear:
             return ops.decode_linear(h, self.lm_head.weight, norm.weight, norm.variance_epsilon, bias=self.lm_head.bias)
         return self.lm_head.forward_normed(h, norm.weight, norm.variance_epsilon)

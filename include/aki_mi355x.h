@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 6
+#define AKI_ABI_VERSION 7
 
 typedef enum {
   AKI_OK = 0,
@@ -37,7 +37,12 @@ typedef enum {
   AKI_ERR_LAUNCH = -5        /* hipGetLastError() after launch was not hipSuccess               */
 } aki_status;
 
-typedef enum { AKI_DT_BF16 = 0, AKI_DT_F32 = 1, AKI_DT_FP8_E4M3 = 2 } aki_dtype;
+typedef enum {
+  AKI_DT_BF16 = 0,
+  AKI_DT_F32 = 1,
+  AKI_DT_FP8_E4M3 = 2, /* e4m3 x and w with per-row scales (aki_linear_args / aki_mma_attn_args) */
+  AKI_DT_W8A16 = 3     /* weight-only fp8: e4m3 w + w_scale, bf16 x; single-row decode (aki_linear_fwd / aki_decode_linear_fwd, M = 1) */
+} aki_dtype;
 
 /* Activation fused into aki_linear_fwd. */
 typedef enum {

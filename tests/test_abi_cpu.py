@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/aki_mi355x.h but not exported"
-    assert lib.aki_abi_version() == 6
+    assert lib.aki_abi_version() == 7
     assert b"aligned" in lib.aki_strerror(-3)
 
 

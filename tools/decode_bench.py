@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--prompt", type=int, default=655)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--fp8", action="store_true", help="fp8 configuration: e4m3 prefill GEMMs, weight-only e4m3 GEMVs for batch 1")
     a = ap.parse_args()
     from aki_amd import ops
     from aki_amd.phi3 import Phi3ForCausalLM, make_phi3_config, DecodeGraph
@@ -24,12 +25,16 @@ def main():
     for p in lm.parameters():
         p.data.normal_(0, 0.02)
     lm = lm.to(dev).to(torch.bfloat16).eval()
+    if a.fp8:
+        lm.enable_fp8()
     wbytes = sum(p.numel() * 2 for n, p in lm.named_parameters() if "embed_tokens" not in n)
     B, L = a.batch, a.prompt
     x = torch.randn(B, L, cfg.hidden_size, device=dev, dtype=torch.bfloat16) * 0.5
     am = torch.ones(B, L, dtype=torch.bool)
     table = ops.MaskTable.from_host([[(4, 148, 4, 148)]] * B, am.numpy(), [L] * B, dev)
-    res = {"batch": B, "prompt": L, "steps": a.steps, "weight_bytes": wbytes}
+    if a.fp8 and B == 1:
+        wbytes //= 2
+    res = {"batch": B, "prompt": L, "steps": a.steps, "weight_bytes": wbytes, "fp8": bool(a.fp8)}
     with torch.no_grad():
         for mode in ("eager", "graph"):
             out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=L + 2 * a.steps + 8)
