@@ -285,7 +285,7 @@ def main():
             "roofline": mk(dom),
         }
         if dom["tag"] == "linear" and "+swiglu" in dom["kernel"]:
-            tr, src = pmc_traffic("gemm_bf16_kernel<8, 4, 2, 4, 1, 0>")
+            tr, src = pmc_traffic("gemm_bf16_kernel<8, 4, 2, 4, 1, 0")
             res["roofline"]["traffic"] = tr
             if src:
                 res["roofline"]["traffic_unit"] = "bytes per launch (L2<->fabric: FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache hits)"
