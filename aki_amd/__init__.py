@@ -7,7 +7,7 @@ libaki_mi355x.so (hand-written HIP); see include/aki_mi355x.h for the C ABI.
 from ._lib import AkiError  # noqa: F401
 
 _LAZY = {"AKI": ("aki", "AKI"), "create_model_and_transforms": ("factory", "create_model_and_transforms"),
-         "build_aki": ("factory", "build_aki")}
+         "build_aki": ("factory", "build_aki"), "AKIPretrained": ("modeling_aki", "AKI")}
 
 
 def __getattr__(name):  # lazy: `import aki_amd` alone must not pull torch (tooling, build script)
