@@ -151,3 +151,50 @@ def test_config1_full_width_fp32_vs_oracle():
     err = (got - want).abs().max().item()
     assert err <= 2e-4 * max(1.0, want.abs().max().item()), f"fp32 logits at full width: max err {err:.3g} (max |ref| {want.abs().max().item():.3g})"
     assert abs(float(out.loss) - float(ref["loss"])) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_full_width_decoder_vs_transformers_eager_under_441_mask(dtype):
+    """The arithmetic the reference delegates to (transformers' Phi3 eager attention, HF:phi3/modeling_phi3.py:145-263) under
+    the transformers==4.41.2 mask hand-off (dense 0/1 MMA mask -> 1 - mask -> finfo.min), at the FULL WIDTH of Phi-3.5-mini
+    (d 3072, 32 heads x 96, FFN 8192, vocab 32064; 2 layers): HF runs on the CPU with the dense mask materialised from the
+    MaskTable (bit-exact vs the reference, test_mask_dense_all_reference_cases), the HIP path consumes the table itself.
+    fp32: logits equal to 2e-4; bf16: HIP error vs HF-fp32 no larger than 1.5x HF's own bf16-eager error."""
+    from transformers import Phi3Config, Phi3ForCausalLM as HFPhi3
+    from aki_amd import ops
+    from aki_amd.phi3 import Phi3ForCausalLM
+    torch.manual_seed(0)
+    cfg = Phi3Config(vocab_size=32064, hidden_size=3072, intermediate_size=8192, num_hidden_layers=2, num_attention_heads=32,
+                     num_key_value_heads=32, max_position_embeddings=4096, original_max_position_embeddings=4096,
+                     pad_token_id=32000, attn_implementation="eager")
+    hf = HFPhi3(cfg).eval()
+    B, L = 2, 300
+    x = torch.randn(B, L, 3072, generator=torch.Generator().manual_seed(1)) * 0.5
+    am = np.ones((B, L), dtype=bool)
+    am[1, 260:] = False
+    rects = [[(6, 150, 150, 283)], [(10, 154, 154, 240)]]
+    table = ops.MaskTable.from_host(rects, am, [L, L], DEV)
+    dense = ops.mask_dense(table, B).cpu()                                   # (B,1,L,L) int64 0/1, the reference's tensor
+    inv = 1.0 - dense.float()
+    add_mask = inv.masked_fill(inv.bool(), torch.finfo(torch.float32).min)  # transformers==4.41.2 _prepare_4d_causal_attention_mask
+    pos = torch.arange(L)[None]
+    valid = torch.from_numpy(am)[..., None]
+    with torch.no_grad():
+        want = hf(inputs_embeds=x, attention_mask=add_mask, position_ids=pos).logits
+        lm = Phi3ForCausalLM(cfg)
+        lm.load_state_dict(hf.state_dict(), strict=True)
+        lm = lm.to(DEV).to(dtype).eval()
+        got = lm(inputs_embeds=x.to(DEV).to(dtype), attention_mask=table).logits.float().cpu()
+        if dtype == torch.float32:
+            err = ((got - want).abs() * valid).max().item()
+            assert err <= 2e-4 * max(1.0, want.abs().max().item()), err
+            # padded rows (all-zero mask rows): uniform softmax under finfo.min, reproduced by the kernel
+            errp = ((got - want).abs() * (~valid)).max().item()
+            assert errp <= 1e-3 * max(1.0, want.abs().max().item()), errp
+        else:
+            hf16 = hf.to(torch.bfloat16)
+            m16 = add_mask.to(torch.bfloat16).masked_fill(inv.bool(), torch.finfo(torch.bfloat16).min)
+            ref16 = hf16(inputs_embeds=x.to(torch.bfloat16), attention_mask=m16, position_ids=pos).logits.float()
+            e_hip = ((got - want).abs() * valid).mean().item()
+            e_ref = ((ref16 - want).abs() * valid).mean().item()
+            assert e_hip <= 1.5 * e_ref + 1e-3, (e_hip, e_ref)
