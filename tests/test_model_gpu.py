@@ -198,3 +198,32 @@ def test_full_width_decoder_vs_transformers_eager_under_441_mask(dtype):
             e_hip = ((got - want).abs() * valid).mean().item()
             e_ref = ((ref16 - want).abs() * valid).mean().item()
             assert e_hip <= 1.5 * e_ref + 1e-3, (e_hip, e_ref)
+
+
+@pytest.mark.parametrize("px", [384, 336])
+def test_full_width_siglip_tower_vs_transformers(px):
+    """SigLIP-so400m/14 at its real width (1152, 16 heads x 72, MLP 4304; 2 of the 27 layers) against transformers'
+    SiglipVisionModel on the CPU: 384 px (729 patches, what the reference runs) and 336 px - BASELINE's metric resolution,
+    576 patches with the bicubic position-embedding interpolation of HF:siglip/modeling_siglip.py (interpolate_pos_encoding),
+    which the reference itself never exercises.  fp32: 2e-4; bf16: <= 1.5x transformers' own bf16-eager error."""
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    from aki_amd.siglip import SiglipVisionTransformer
+    torch.manual_seed(0)
+    cfg = SiglipVisionConfig(hidden_size=1152, intermediate_size=4304, num_hidden_layers=2, num_attention_heads=16, image_size=384,
+                             patch_size=14, attn_implementation="eager")
+    hf = SiglipVisionModel(cfg).eval()
+    x = torch.rand(2, 3, px, px, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    with torch.no_grad():
+        want = hf(pixel_values=x, interpolate_pos_encoding=(px != 384)).last_hidden_state
+        assert want.shape[1] == (px // 14) ** 2
+        vt = SiglipVisionTransformer(cfg)
+        sd = {k[len("vision_model."):] if k.startswith("vision_model.") else k: v for k, v in hf.state_dict().items()}
+        missing = vt.load_state_dict(sd, strict=False)       # the pooling head is not used by AKI
+        assert not missing.missing_keys
+        got32 = vt.to(DEV).eval()(x.to(DEV), interpolate_pos_encoding=(px != 384)).last_hidden_state.cpu()
+        err = (got32 - want).abs().max().item()
+        assert err <= 2e-4 * max(1.0, want.abs().max().item()), err
+        got16 = vt.to(torch.bfloat16)(x.to(DEV).to(torch.bfloat16), interpolate_pos_encoding=(px != 384)).last_hidden_state.float().cpu()
+        ref16 = hf.to(torch.bfloat16)(pixel_values=x.to(torch.bfloat16), interpolate_pos_encoding=(px != 384)).last_hidden_state.float()
+        e_hip, e_ref = (got16 - want).abs().mean().item(), (ref16 - want).abs().mean().item()
+        assert e_hip <= 1.5 * e_ref + 1e-3, (e_hip, e_ref)
