@@ -5,7 +5,8 @@ import torch, bench
 from aki_amd.factory import build_aki
 dev = torch.device("cuda", 0)
 model = build_aki(dtype=torch.bfloat16, device=dev).eval()
-vx, ids, am = bench.synth_batch(8, dev, torch.bfloat16, model.media_token_id, seed=1)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+vx, ids, am = bench.synth_batch(B, dev, torch.bfloat16, model.media_token_id, seed=1)
 
 
 def timeit(fn, n=10):
