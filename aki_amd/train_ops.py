@@ -187,10 +187,14 @@ def bump_weight_epoch() -> None:
 
 
 def _weight_t(w: torch.Tensor) -> torch.Tensor:
-    """W [N,K] -> W^T [K, pad64(N)] (zero padded), cached until the next optimizer step."""
-    key = (w.data_ptr(), tuple(w.shape), _EPOCH)
+    """W [N,K] -> W^T [K, pad64(N)] (zero padded), cached until the weights change: the trainer bumps the epoch after every
+    optimizer step (its kernels write through raw pointers), in-place torch updates show up in `_version`.  Temporaries (the
+    lm_head's concatenated weight is a new tensor every forward) would pile up without a trainer, hence the size cap."""
+    key = (w.data_ptr(), tuple(w.shape), w._version, _EPOCH)
     t = _WT.get(key)
     if t is None:
+        if len(_WT) >= 320:                  # > every 2-D weight of AKI-4B (32 x 4 + connector + heads)
+            _WT.clear()
         t = transpose(w if w.stride(1) == 1 else w.contiguous())
         _WT[key] = t
     return t
