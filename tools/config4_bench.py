@@ -1,0 +1,33 @@
+"""BASELINE configs[3]: AKI-4B forward at seq = 4096 with 4 interleaved 336x336 images (multi-image MMA mask), bf16, one MI355X."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from aki_amd.factory import build_aki
+dev = torch.device("cuda", 0)
+model = build_aki(dtype=torch.bfloat16, device=dev).eval()
+model.allow_multi_image = True
+NV, N_IMG, L = 144, 4, 4096
+N_TXT = L - N_IMG * (NV - 1)                      # 3524 prompt tokens incl. 4 placeholders
+res = []
+for B in (1, 2, 4):
+    g = torch.Generator().manual_seed(B)
+    ids = torch.randint(3, 31999, (B, N_TXT), generator=g)
+    ids[:, 0] = 1
+    for k, s in enumerate((6, 900 - 143, 1800 - 286, 2700 - 429)):   # placeholders so that the images start at 6 / 900 / 1800 / 2700 of the stream
+        ids[:, s] = model.media_token_id
+    ids[:, N_TXT - 64] = 32001
+    vx = (torch.rand(B, N_IMG, 1, 3, 336, 336, generator=g) * 2 - 1).to(dev).to(torch.bfloat16)
+    ids, am = ids.to(dev), torch.ones(B, N_TXT, dtype=torch.long, device=dev)
+    with torch.no_grad():
+        for _ in range(2):
+            out = model(vx, ids, attention_mask=am)
+        assert out.logits.shape[1] == L and torch.isfinite(out.logits.float()).all()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            model(vx, ids, attention_mask=am)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+    res.append({"batch": B, "seq_len": L, "images_per_sample": N_IMG, "ms_per_forward": round(ms, 2), "tokens_per_s": round(B * L / ms * 1e3, 1)})
+print(json.dumps(res))
