@@ -573,3 +573,64 @@ def test_config4_long_context_four_images():
     vmin, vmax = vb.float().amin(dim=2), vb.float().amax(dim=2)
     o = o16.float().reshape(B, L, H, 96).permute(0, 2, 1, 3)
     assert bool(((o >= vmin[:, :, None] - 2e-2) & (o <= vmax[:, :, None] + 2e-2)).all())
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_mma_attn_core_random_masks(seed):
+    """Seeded random mask configurations: 1-4 rectangles per sample anywhere in the sequence (overlapping column ranges,
+    rows before or after their columns), ragged lengths, holes in the 1-D mask (left padding and interior), both dead-row
+    conventions.  Exact-f32 kernel vs the numpy oracle, bf16 MFMA kernel vs the f32 kernel."""
+    ops = _ops()
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    B, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    L = int(rng.choice([33, 64, 65, 130, 257, 400, 641]))
+    q, k, v = (rng.standard_normal((B, H, L, 96), dtype=np.float32) for _ in range(3))
+    am = np.ones((B, L), dtype=np.int64)
+    seq, rects = [], []
+    nrect = int(rng.integers(1, 5))
+    for b in range(B):
+        nlen = L if rng.random() < 0.5 else int(rng.integers(L // 2 + 1, L + 1))
+        seq.append(nlen)
+        am[b, nlen:] = 0
+        if rng.random() < 0.4:
+            am[b, : int(rng.integers(1, max(2, nlen // 4)))] = 0          # left padding -> dead rows at the top
+        if rng.random() < 0.4:
+            lo = int(rng.integers(0, nlen))
+            am[b, lo: min(nlen, lo + int(rng.integers(1, 9)))] = 0          # an interior hole
+        rs, used = [], 0
+        for _ in range(nrect):                                            # disjoint row ranges (one rectangle per row)
+            if used >= nlen - 2:
+                rs.append((0, 0, 0, 0))
+                continue
+            r0 = int(rng.integers(used, nlen - 1))
+            r1 = int(rng.integers(r0 + 1, min(nlen, r0 + 1 + max(2, nlen // 3)) + 1))
+            c0 = int(rng.integers(0, nlen))
+            c1 = int(rng.integers(c0, nlen + 1))
+            rs.append((r0, r1, c0, c1))
+            used = r1
+        rects.append(rs)
+    dead = ops.DEAD_ROWS_UNIFORM if seed % 2 == 0 else ops.DEAD_ROWS_ZERO
+    table = ops.MaskTable.from_host(rects, am, seq, DEV)
+    tq, tk, tv = (torch.from_numpy(a).to(DEV) for a in (q, k, v))
+    o32 = ops.mma_attn_core(tq, tk, tv, table, 96 ** -0.5, dead_rows=dead)
+    o16 = ops.mma_attn_core(tq.to(torch.bfloat16), tk.to(torch.bfloat16), tv.to(torch.bfloat16), table, 96 ** -0.5, dead_rows=dead)
+    # dense visibility from the table definition: valid(c) and r < seq_len and (c <= r or (r, c) inside a rectangle)
+    rr, cc = np.arange(L)[:, None], np.arange(L)[None, :]
+    want = np.zeros((B, L, H * 96), dtype=np.float32)
+    for b in range(B):
+        vis = (cc <= rr)
+        for (r0, r1, c0, c1) in rects[b]:
+            vis = vis | ((rr >= r0) & (rr < r1) & (cc >= c0) & (cc < c1))
+        vis = vis & (am[b][None, :] != 0) & (rr < seq[b])
+        for h_ in range(H):
+            s_ = (q[b, h_] @ k[b, h_].T) * np.float32(96 ** -0.5)
+            s_ = np.where(vis, s_, -np.inf)
+            alive = vis.any(-1)
+            p_ = np.zeros_like(s_)
+            p_[alive] = O.softmax(s_[alive], -1)
+            out = p_ @ v[b, h_]
+            if dead == ops.DEAD_ROWS_UNIFORM:
+                out[~alive] = v[b, h_].mean(0)                            # finfo.min convention: uniform over all L columns
+            want[b, :, h_ * 96:(h_ + 1) * 96] = out
+    check(n(o32), want, torch.float32, f"f32 kernel vs dense oracle (seed {seed}, B{B} H{H} L{L})", scale_atol=2.0)
+    check(n(o16), rnd(n(o32), torch.float32), torch.bfloat16, f"bf16 kernel vs f32 kernel (seed {seed})", scale_atol=4.0)
