@@ -634,3 +634,42 @@ def test_mma_attn_core_random_masks(seed):
             want[b, :, h_ * 96:(h_ + 1) * 96] = out
     check(n(o32), want, torch.float32, f"f32 kernel vs dense oracle (seed {seed}, B{B} H{H} L{L})", scale_atol=2.0)
     check(n(o16), rnd(n(o32), torch.float32), torch.bfloat16, f"bf16 kernel vs f32 kernel (seed {seed})", scale_atol=4.0)
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_splice_random_prompts_vs_oracle(seed):
+    """Seeded random prompt batches through the splice / mask-table kernels against the oracle's restatement of
+    _prepare_inputs_for_forward (src/vlm.py:445-603), bit for bit: image placeholder at a random position or absent,
+    <|assistant|> (32001) present or not (and before or after the image), ragged right padding of the prompts, additional
+    (> max_original_id) token ids, right and left padding of the output."""
+    ops = _ops()
+    rng = np.random.Generator(np.random.PCG64(3000 + seed))
+    B, T_, d, Nv = int(rng.integers(1, 6)), int(rng.integers(8, 80)), 64, int(rng.choice([4, 8, 144]))
+    V, media, pad_id = 32011, 32011, 32000
+    lang_x = rng.integers(3, 31000, size=(B, T_)).astype(np.int64)
+    am = np.ones((B, T_), dtype=np.int64)
+    labels = lang_x.copy()
+    for b in range(B):
+        nlen = T_ if rng.random() < 0.5 else int(rng.integers(T_ // 2 + 1, T_ + 1))
+        am[b, nlen:] = 0
+        lang_x[b, nlen:] = pad_id
+        if rng.random() < 0.8:
+            lang_x[b, int(rng.integers(0, nlen))] = media
+        if rng.random() < 0.7:
+            lang_x[b, int(rng.integers(0, nlen))] = 32001 if rng.random() < 0.9 else 32012
+        labels[b] = np.where(am[b] == 0, -100, lang_x[b])
+    if (lang_x == media).sum(1).max() == 0:
+        lang_x[0, 1] = media
+    W = rng.standard_normal((V, d), dtype=np.float32)
+    Wadd = rng.standard_normal((2, d), dtype=np.float32)
+    vt = rng.standard_normal((B, 1, Nv, d), dtype=np.float32)
+    emb_in = O.decoupled_embedding(lang_x, W, Wadd, V - 1)
+    side = "right" if seed % 2 == 0 else "left"
+    want = O.prepare_inputs_for_forward(vt, lang_x, am, labels, emb_in, media, pad_id, Nv, side)
+    emb, lab, table, _ = ops.splice(torch.from_numpy(lang_x).to(DEV), torch.from_numpy(am).to(DEV), torch.from_numpy(labels).to(DEV),
+                                    torch.from_numpy(W).to(DEV), torch.from_numpy(Wadd).to(DEV), V - 1, torch.from_numpy(vt).to(DEV),
+                                    media, pad_id, padding_side=side)
+    assert np.array_equal(n(emb), want["inputs_embeds"]), "inputs_embeds must be a bit-exact gather / copy"
+    assert np.array_equal(lab.cpu().numpy(), want["labels"])
+    # the reference stacks the per-sample masks top-left (src/utils.py:99-108) whatever the padding side of the embeddings
+    assert np.array_equal(ops.mask_dense(table, B).cpu().numpy(), want["attention_mask"])
