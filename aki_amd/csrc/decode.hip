@@ -582,14 +582,17 @@ __global__ __launch_bounds__(64) void decode_attn_split_kernel(const DecodeAttnP
       if (base >= k_end) break;
       const int j = base + lane;
       if (t > 0) issue_tile(base);
-      if (owner && base <= ln && ln < base + 64) {                     // the new token's row lives in LDS
-        if (j == ln) {
+      if (owner && base <= ln && ln < base + 64) {
+        // The new token's row lives in LDS: the tile loads were issued before it was stored, so every lane whose (clamped)
+        // row index is ln - the row itself and all rows past k_end - 1 = ln, which carry probability 0 - holds stale
+        // cache contents (0 * NaN would poison the sum) and takes the row from LDS instead.
+        if (min(j, k_end - 1) == ln) {
 #pragma unroll
           for (int i = 0; i < 12; ++i) kr[i] = *(const u32x4*)(s_k + i * 8);
         }
 #pragma unroll
         for (int t2 = 0; t2 < 16; ++t2)
-          if (base + 4 * t2 + g == ln) vr[t2] = *(const u32x4*)(s_v + min(i16, 11) * 8);
+          if (min(base + 4 * t2 + g, k_end - 1) == ln) vr[t2] = *(const u32x4*)(s_v + min(i16, 11) * 8);
       }
       bool ok = j < k_end;
       if (p.vbits && (base >> 6) < p.nwords) ok = ok && ((p.vbits[(size_t)b * p.nwords + (base >> 6)] >> lane) & 1ull);
