@@ -36,3 +36,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _poison_recycled_gpu_memory(request):
+    """Before every GPU test: leave blocks full of 0xFF bytes (NaN as bf16 / f32, -1 as integers) in torch's caching
+    allocator, so that `torch.empty` hands the test recycled memory that is NOT benign.  Kernels that touch unwritten memory
+    "with probability 0" (clamped rows, padding columns) then fail loudly instead of passing by luck on zero-filled pages - the
+    fused decode attention once did exactly that (0 * NaN from a stale KV-cache row)."""
+    if "gpu" in request.keywords and _has_gpu():
+        import torch
+        junk = [torch.full((n,), 0xFF, dtype=torch.uint8, device="cuda") for n in (1 << 12, 1 << 16, 1 << 20, 1 << 24, 1 << 27, 3 << 27)]
+        del junk
+    yield
