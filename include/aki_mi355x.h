@@ -1,4 +1,5 @@
-/* aki_mi355x.h - C ABI of the MI355X-native AKI modality-mutual-attention (MMA) forward path.
+/* aki_mi355x.h - C ABI of the MI355X-native AKI modality-mutual-attention (MMA) path: forward, KV-cache decode, the
+ * pre-training step (backward, loss, optimizer) and the fp8 (e4m3) projection variants.
  *
  * The reference (sony/aki) has no FFI layer: its boundary is Python object protocol
  * (SURVEY.md section 8(b)).  Each entry point below names the reference function whose work it
@@ -10,11 +11,13 @@
  *  - Plain C: raw DEVICE pointers, sizes and strides in ELEMENTS, no torch/HIP types.
  *    `stream` is a hipStream_t passed as void* (NULL = default stream).
  *  - Ownership: the caller owns every buffer, including workspaces.  Kernels allocate nothing,
- *    keep no state between calls, never synchronise the host and are graph-capturable.
+ *    keep no state between calls (one documented exception: the decode-attention workspace holds arrival counters
+ *    that the kernel re-arms itself), never synchronise the host and are graph-capturable.
  *  - Errors: int return, 0 = AKI_OK, < 0 = aki_status code; never throws or aborts.  Shapes and
  *    alignment are validated on the host before anything is launched.
  *  - Threading: re-entrant; ordering only through `stream`.
- *  - dtype: AKI_DT_BF16 (MFMA path, fp32 accumulate/softmax) or AKI_DT_F32 (exact-f32 parity path).
+ *  - dtype: AKI_DT_BF16 (MFMA path, fp32 accumulate/softmax) or AKI_DT_F32 (exact-f32 parity path, forward only);
+ *    AKI_DT_FP8_E4M3 / AKI_DT_W8A16 where an entry point says so.  The backward / optimizer entry points are bf16.
  */
 #ifndef AKI_MI355X_H
 #define AKI_MI355X_H
