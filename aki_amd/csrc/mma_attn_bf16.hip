@@ -23,6 +23,10 @@
 
 #include "aki_device.h"
 
+#ifndef AKI_ATTN_SCHED_MAX
+#define AKI_ATTN_SCHED_MAX 64
+#endif
+
 namespace aki {
 
 struct AttnParams {
@@ -37,6 +41,7 @@ struct AttnParams {
   int max_rects;
   int B, H, L;
   int nqt, nwords;
+  int group_bh;  // (batch, head) pairs per dispatch group
   int kvcap;  // rows per (batch, head) of k / v (>= L when they are a KV cache)
   float scale_log2;  // scale * log2(e)
   int dead_uniform;
@@ -65,6 +70,20 @@ __device__ __forceinline__ int count_le(int x) {
   return x < 0 ? 0 : min(n, 32);
 }
 
+// the n lowest bits set, n in [0, 32]
+__device__ __forceinline__ unsigned low_bits(int n) { return n >= 32 ? ~0u : ((1u << n) - 1u); }
+
+// bit BIT of hid -> -inf (hidden) or 0 (visible), two VALU ops and no VCC round trip (hipcc turns the C form into
+// v_and / v_cmp / v_cndmask with hazard nops)
+template <int BIT>
+__device__ __forceinline__ float mask_bias(int hid, int ninf) {
+  int t;
+  float b;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t) : "v"(hid), "n"(BIT));
+  asm("v_and_b32 %0, %1, %2" : "=v"(b) : "s"(ninf), "v"(t));
+  return b;
+}
+
 // compile-time loop (the tr-read offsets below must be immediates of an inline-asm statement)
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -89,50 +108,141 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   constexpr int BQ = NW * 32;
   constexpr int NT = NW * 64;
   constexpr int NCH = (64 * 12 + NT - 1) / NT;  // 16-B chunks per thread per tile (K and V each)
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * KTILE + NSTAGE * VTILE + AKI_MAX_RECTS * 16 + MAX_VB_WORDS * 8];
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * KTILE + NSTAGE * VTILE + MAX_VB_WORDS * 8];
   char* const sK = smem;
   char* const sV = smem + NSTAGE * KTILE;
-  const aki_mma_rect* sR = (const aki_mma_rect*)(smem + NSTAGE * KTILE + NSTAGE * VTILE);
-  unsigned long long* const sVB = (unsigned long long*)(smem + NSTAGE * KTILE + NSTAGE * VTILE + AKI_MAX_RECTS * 16);
+  unsigned long long* const sVB = (unsigned long long*)(smem + NSTAGE * KTILE + NSTAGE * VTILE);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
 
-  const int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = t / p.nqt;
-  const int qt = p.nqt - 1 - (t - bh * p.nqt);  // late (heavy) query tiles first
+  // Dispatch order.  The (batch, head) pairs are cut into groups of p.group_bh; inside a group the workgroups are
+  // issued heaviest rank first ACROSS all its pairs (rank-major), so the hardware's in-order dispatch packs the long
+  // workgroups first and fills the tail with short ones (bh-major order left 17 % on the table at L = 655, three
+  // workgroups per slot).  group_bh is a multiple of 8: blockIdx % 8 = bh % 8, every pair stays on one XCD's L2.
+  const int grp = blockIdx.x / (p.group_bh * p.nqt);
+  const int bh0 = grp * p.group_bh;
+  const int gbh = min(p.group_bh, p.B * p.H - bh0);
+  const int within = blockIdx.x - bh0 * p.nqt;
+  const int g = within / gbh;                  // workgroup rank inside (batch, head): 0 = heaviest
+  const int bh = bh0 + within - g * gbh;
   const int b = bh / p.H, head = bh - b * p.H;
   const int L = p.L;
-  const int q0 = qt * BQ;
-  const int wq0 = q0 + wave * 32;
-  const int row = wq0 + l31;
-  const int Lb = p.seq_lens ? min(p.seq_lens[b], L) : L;
+  const bf16_t* qb = p.q + ((size_t)bh * L) * 96;
+  const char* kb = (const char*)(p.k + ((size_t)bh * p.kvcap) * 96);
+  const char* vb_ = (const char*)(p.v + ((size_t)bh * p.kvcap) * 96);
 
-  if (tid < AKI_MAX_RECTS) {
-    u32x4 r = {0u, 0u, 0u, 0u};
-    if (tid < p.max_rects) r = ((const u32x4*)p.rects)[(size_t)b * p.max_rects + tid];
-    ((u32x4*)sR)[tid] = r;
-  }
+  // K/V tiles go global -> LDS directly (global_load_lds, 16 B/lane): the LDS image is lane-linear, i.e. exactly the
+  // contiguous 12 KiB tile of the head-major layout; the K swizzle is applied on the per-lane SOURCE address.
+  auto issue_tile = [&](int j, int stage) {
+    const int c0 = j * 64;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = i * NT + tid;                // 16-B chunk index inside the tile image
+      const int kr = ch / 12, pos = ch - kr * 12;
+      const size_t rowoff = (size_t)min(c0 + kr, L - 1) * 192;
+      const int srcchunk = pos ^ ((kr >> 2) & 3);
+      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(kb + rowoff + srcchunk * 16), AKI_LDS_PTR(sK + stage * KTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(vb_ + rowoff + pos * 16), AKI_LDS_PTR(sV + stage * VTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  // ---- prologue: every global read the workgroup needs before its first MFMA is put in flight at once ----------
+  // (the first two K/V tiles, the valid words, and - in position order - the Q fragments); the rectangles come
+  // through the scalar cache into SGPRs.  At L = 655 a wave lives for ~7 tiles: a prologue of dependent round trips
+  // with workgroup barriers between them (table -> LDS -> extents -> ranks -> Q -> tile 0) was a sixth of its life.
+  constexpr int SCHED_MAX = AKI_ATTN_SCHED_MAX;   // <= 64: one lane per 32-row block
+  const int nblk = (L + 31) >> 5;
+  const bool sched = nblk <= SCHED_MAX;        // kernel-uniform
+  const int Lb = p.seq_lens ? min(p.seq_lens[b], L) : L;
+  issue_tile(0, 0);
+  if (L > 64) issue_tile(1, 1);
+  bf16x8 qf[6];
+  auto load_q = [&](int row) {   // Q fragments (B operand of S^T = K Q^T): lane (q=l31, h) holds Q[q][16ks + 8h .. +7]
+    const bf16_t* qrow = qb + (size_t)min(row, L - 1) * 96 + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
+  };
+  if (!sched) load_q((p.nqt - 1 - g) * BQ + wave * 32 + l31);
   // Valid-column words of this sample go to LDS once: a per-tile global load would share the vmcnt queue with the
-  // K/V prefetch and its wait would drain the prefetch before the tile's compute (measured: 3x slower loop).
+  // K/V prefetch and its wait would drain the prefetch before the tile's compute (measured: 3x slower loop).  The
+  // first barrier of the tile loop orders these writes before their first read.
   for (int w = tid; w < p.nwords; w += NT) {
     unsigned long long vbw;
     if (p.vbits) vbw = p.vbits[(size_t)b * p.nwords + w];
     else vbw = (w * 64 + 64 <= L) ? ~0ull : ((1ull << (L - w * 64)) - 1ull);
     sVB[w] = vbw;
   }
-  __syncthreads();
+  const aki_mma_rect* const rects_b = p.rects + (size_t)b * p.max_rects;
+  auto rect_at = [&](int i) -> aki_mma_rect {       // wave-uniform: one s_load_dwordx4
+    const unsigned long long pa = (unsigned long long)(rects_b + i);
+    const unsigned long long pu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pa);
+    u32x4 r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(pu) : "memory");
+    aki_mma_rect o;
+    o.row_lo = (int)r[0]; o.row_hi = (int)r[1]; o.col_lo = (int)r[2]; o.col_hi = (int)r[3];
+    return o;
+  };
 
-  // ---- column extent of the workgroup, per-wave rectangle summary, per-lane unlock range ---------
-  int hi_col = min(q0 + BQ, L);
+  // Columns a 32-row block starting at r0 has to walk: its causal extent, widened by every rectangle that touches
+  // it.  Rows >= seq_len are the all-zero mask rows of batch stacking: under the reference's finfo.min hand-off they
+  // get a UNIFORM softmax over all L columns; they run through the normal MFMA path as "every column visible,
+  // score 0", so a block that owns such rows walks all KV tiles.
+  //
+  // Which 32-row block a wave owns: the four waves of a workgroup share one K/V tile stream, so the workgroup walks to
+  // the LARGEST extent among its blocks and a wave whose block ends earlier idles at the barriers.  In position
+  // order that wastes a lot when the sequence is short (image rows inside a rectangle walk ~L columns, their text
+  // neighbours a few tiles): up to SCHED_MAX blocks are therefore ranked by extent (descending, later block first on
+  // ties) and workgroup g takes ranks 4g .. 4g+3 - blocks of similar length share a stream.  Every wave does the
+  // ranking for itself (lane i <-> block i, v_readlane): no LDS, no barrier.  Longer sequences keep position order
+  // (neighbouring blocks differ by at most two tiles there), late blocks first.
+  int wq0, hi_col;
+  {
+    const int r0 = sched ? 32 * lane : (p.nqt - 1 - g) * BQ + 32 * (lane & (NW - 1));
+    int ext = min(r0 + 32, L);
+    for (int i = 0; i < p.max_rects; ++i) {
+      const aki_mma_rect r = rect_at(i);
+      if (r.row_hi > r.row_lo && r.col_hi > r.col_lo && r.row_lo < r0 + 32 && r.row_hi > r0) ext = max(ext, min(r.col_hi, L));
+    }
+    if (p.dead_uniform && min(r0 + 32, L) > Lb) ext = L;
+    if (r0 >= L) ext = -1;                        // no such block
+    if (sched) {
+      int rank = 0;
+      for (int i = 0; i < nblk; ++i) {
+        const int e = __builtin_amdgcn_readlane(ext, i);
+        rank += (e > ext || (e == ext && i > lane)) ? 1 : 0;
+      }
+      if (lane >= nblk) rank = 0x7fff;
+      hi_col = 0;
+      wq0 = L;                                    // rank past nblk (last workgroup): the wave idles
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const unsigned long long m = __ballot(rank == 4 * g + w);
+        if (m != 0ull) {
+          const int l = __builtin_ctzll(m);
+          hi_col = max(hi_col, __builtin_amdgcn_readlane(ext, l));
+          if (w == wave) wq0 = 32 * l;
+        }
+      }
+      load_q(wq0 + l31);
+    } else {
+      wq0 = (p.nqt - 1 - g) * BQ + wave * 32;
+      hi_col = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) hi_col = max(hi_col, __builtin_amdgcn_readlane(ext, w));
+    }
+    wq0 = __builtin_amdgcn_readfirstlane(wq0);
+    hi_col = __builtin_amdgcn_readfirstlane(hi_col);
+  }
+  const int row = wq0 + l31;
+
+  // ---- per-wave rectangle summary, per-lane unlock range -----------------------------------------
   int touch_lo = 0x7fffffff, touch_hi = 0, full_lo = 0, full_hi = 0;
   int rc0 = 0, rc1 = 0;
-#pragma unroll
-  for (int i = 0; i < AKI_MAX_RECTS; ++i) {
-    const aki_mma_rect r = sR[i];
+  for (int i = 0; i < p.max_rects; ++i) {
+    const aki_mma_rect r = rect_at(i);
     if (r.row_hi > r.row_lo && r.col_hi > r.col_lo) {
-      if (r.row_lo < q0 + BQ && r.row_hi > q0) hi_col = max(hi_col, min(r.col_hi, L));
       if (r.row_lo < wq0 + 32 && r.row_hi > wq0) {
         touch_lo = min(touch_lo, r.col_lo);
         touch_hi = max(touch_hi, r.col_hi);
@@ -141,27 +251,16 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
       if (row >= r.row_lo && row < r.row_hi) { rc0 = r.col_lo; rc1 = r.col_hi; }
     }
   }
-  // Rows >= seq_len are the all-zero mask rows of batch stacking: under the reference's finfo.min hand-off they
-  // get a UNIFORM softmax over all L columns.  They run through the normal MFMA path as "every column visible,
-  // score 0"; a workgroup that owns such rows therefore walks all KV tiles.
-  if (p.dead_uniform && q0 + BQ > Lb) hi_col = L;
   const int jend = (hi_col + 63) >> 6;
   const bool wave_alive = wq0 < Lb;            // wave-uniform
-  const bool wave_has_dead = wq0 + 32 > Lb;    // some rows of the wave are beyond seq_len
+  const bool wave_has_dead = min(wq0 + 32, L) > Lb;   // some rows of the wave are beyond seq_len (rows >= L do not exist)
   const bool row_alive = row < Lb;
   const bool has_uniform = p.dead_uniform && wave_has_dead;   // wave-uniform
   const bool row_uniform = p.dead_uniform && !row_alive;
 
-  const bf16_t* qb = p.q + ((size_t)bh * L) * 96;
-  const char* kb = (const char*)(p.k + ((size_t)bh * p.kvcap) * 96);
-  const char* vb_ = (const char*)(p.v + ((size_t)bh * p.kvcap) * 96);
-
-  // Q fragments (B operand of S^T = K Q^T): lane (q=l31, h) holds Q[q][16ks + 8h .. +7]
-  bf16x8 qf[6];
-  {
-    const bf16_t* qrow = qb + (size_t)min(row, L - 1) * 96 + 8 * h;
+  if (row_uniform) {   // uniform-softmax rows: score 0 on every column = an all-zero query
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
+    for (int ks = 0; ks < 6; ++ks) qf[ks] = bf16x8{};
   }
 
   f32x16 o[3];
@@ -171,32 +270,15 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1e30f, l_part = 0.f;
 
-  // K/V tiles go global -> LDS directly (global_load_lds, 16 B/lane): the LDS image is lane-linear, i.e. exactly the
-  // contiguous 12 KiB tile of the head-major layout; the K swizzle is applied on the per-lane SOURCE address.
-  auto issue_tile = [&](int j, int stage) {
-    const int c0 = j * 64;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int g = i * NT + tid;                 // 16-B chunk index inside the tile image
-      const int kr = g / 12, pos = g - kr * 12;
-      const size_t rowoff = (size_t)min(c0 + kr, L - 1) * 192;
-      const int srcchunk = pos ^ ((kr >> 2) & 3);
-      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(kb + rowoff + srcchunk * 16), AKI_LDS_PTR(sK + stage * KTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(vb_ + rowoff + pos * 16), AKI_LDS_PTR(sV + stage * VTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
-    }
-  };
-
   // per-lane LDS offsets
   const int kswz = (l31 >> 2) & 3;   // (row>>2)&3 for row = 32*blk + l31
   const int krow = l31 * KROW;
   const int voff = (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
-  // Retire the Q-fragment loads with a wait hipcc can see (builtin), BEFORE the ring is primed: otherwise the compiler
-  // guards the Q registers with its own vmcnt(0) in front of the first MFMA of every iteration, which drains the
-  // LDS-DMA prefetch (its model does not see the inline-asm counted waits below).
+  // Retire everything issued above with a wait hipcc can see (builtin) before the loop: otherwise the compiler guards
+  // the Q registers with its own vmcnt(0) in front of the first MFMA of EVERY iteration, which drains the LDS-DMA
+  // prefetch (its model does not see the inline-asm counted waits below).
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  issue_tile(0, 0);
-  if (jend > 1) issue_tile(1, 1);
 
   int stage = 0;
   for (int j = 0; j < jend; ++j) {
@@ -220,9 +302,6 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     if (!skip) {
       const char* Kb = sK + stage * KTILE;
       const char* Vb = sV + stage * VTILE;
-      f32x16 s0, s1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
       // All K fragments of the tile are fetched before the first MFMA (one LDS wait instead of one in front of every
       // MFMA pair: with 2 waves per SIMD that ~128-cycle LDS latency, 24 times per tile, was the dominant stall).
       bf16x8 ka[6], kc[6];
@@ -231,6 +310,48 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
         const int coff = ((2 * ks + h) ^ kswz) << 4;
         ka[ks] = *(const bf16x8*)(Kb + krow + coff);
         kc[ks] = *(const bf16x8*)(Kb + krow + 32 * KROW + coff);
+      }
+      // The mask enters as the INITIAL VALUE of the score accumulators (0 = visible, -inf = hidden): S = bias + K Q^T
+      // costs the MFMAs nothing, the bias is computed while the K reads above are in flight, and the softmax below
+      // is the same code for FULL and PARTIAL tiles.  (Rows that get the uniform softmax carry an all-zero Q.)
+      f32x16 s0, s1;
+      const bool full = (vb == ~0ull) && (causal_full || rect_full) && !wave_has_dead;
+      // ROWWISE tiles: right of the diagonal, every column valid, and each row's rectangle either covers the whole tile
+      // or misses it (image rows sharing a 32-row block with text rows): the bias is one value per lane.
+      const bool lane_covers = rc0 <= c0 && c0 + 64 <= rc1;
+      const bool lane_cut = !lane_covers && rc0 < c0 + 64 && rc1 > c0;
+      const bool rowwise = !full && causal_none && vb == ~0ull && !wave_has_dead && !__any(lane_cut);
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      } else if (rowwise) {
+        const float lane_bias = lane_covers ? 0.f : -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = lane_bias; s1[r] = lane_bias; }
+      } else {
+        // Per-lane visibility word in register order (bit i <-> register i of s0:s1, see count_le): the causal part is a
+        // prefix, the rectangle an interval; valid bits that form a prefix (right padding, the usual case) are one
+        // more prefix, anything else is gathered bit group by bit group.
+        const int base = c0 + 4 * h;
+        unsigned valid;                                                       // valid columns, register order
+        if ((vb & (vb + 1ull)) == 0ull) {                                     // wave-uniform: the bits form a prefix
+          valid = low_bits(count_le(c0 + (int)__builtin_popcountll(vb) - 1 - base));
+        } else {                                                              // holes in the 1-D mask (rare)
+          const unsigned long long vbh = vb >> (4 * h);
+          valid = 0u;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) valid |= ((unsigned)(vbh >> (8 * k)) & 0xFu) << (4 * k);
+        }
+        const unsigned alive = (low_bits(count_le(row - base)) | (low_bits(count_le(rc1 - 1 - base)) & ~low_bits(count_le(rc0 - 1 - base)))) & valid;
+        const unsigned uniform = low_bits(count_le(L - 1 - base));            // every column < L
+        const unsigned vis = row_uniform ? uniform : (row_alive ? alive : 0u);
+        const int hid = (int)~vis;
+        const int ninf = 0xFF800000;
+        static_for<16>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          s0[r] = mask_bias<r>(hid, ninf);
+          s1[r] = mask_bias<r + 16>(hid, ninf);
+        });
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -251,38 +372,6 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
         });
       }
       __builtin_amdgcn_sched_barrier(0);
-      const bool full = (vb == ~0ull) && (causal_full || rect_full) && !wave_has_dead;
-      if (!full) {
-        // visibility as prefix / interval tests in register order (see count_le); valid bits that form a prefix
-        // (right padding, the usual case) fold into the same thresholds, anything else takes the per-bit path.
-        const int base = c0 + 4 * h;
-        const bool vprefix = (vb & (vb + 1ull)) == 0ull;                      // wave-uniform
-        const int nvalid = vprefix ? count_le(c0 + (int)__builtin_popcountll(vb) - 1 - base) : 32;
-        int n_c = min(count_le(row - base), nvalid);                          // causal prefix
-        int i0 = count_le(rc0 - 1 - base), i1 = min(count_le(rc1 - 1 - base), nvalid);  // unlock interval [i0, i1)
-        if (!row_alive) { n_c = 0; i0 = 0; i1 = row_uniform ? count_le(L - 1 - base) : 0; }   // uniform rows: every column < L
-        const unsigned long long vbh = vb >> (4 * h);
-        if (vprefix) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const bool v0 = (r < n_c) | ((r >= i0) & (r < i1));
-            const bool v1 = (r + 16 < n_c) | ((r + 16 >= i0) & (r + 16 < i1));
-            s0[r] = v0 ? (row_uniform ? 0.f : s0[r]) : -INFINITY;
-            s1[r] = v1 ? (row_uniform ? 0.f : s1[r]) : -INFINITY;
-          }
-        } else {   // holes in the 1-D mask: per-bit test (rare)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int cr = (r & 3) + 8 * (r >> 2);
-            bool v0 = (r < n_c) | ((r >= i0) & (r < i1));
-            bool v1 = (r + 16 < n_c) | ((r + 16 >= i0) & (r + 16 < i1));
-            v0 = v0 & ((((vbh >> cr) & 1ull) != 0ull) | row_uniform);
-            v1 = v1 & ((((vbh >> (cr + 32)) & 1ull) != 0ull) | row_uniform);
-            s0[r] = v0 ? (row_uniform ? 0.f : s0[r]) : -INFINITY;
-            s1[r] = v1 ? (row_uniform ? 0.f : s1[r]) : -INFINITY;
-          }
-        }
-      }
       float mx = max3(s0[0], s0[1], s1[0]);
       mx = max3(mx, s1[1], s0[2]);
 #pragma unroll
@@ -331,12 +420,17 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   }
 
   // ---- epilogue: O = O^T / l.  A row that is inside seq_len but saw no visible column at all (e.g. left padding)
-  // is rare: under AKI_DEAD_ROWS_UNIFORM its lanes average V themselves; otherwise it is written as zeros. ----
+  // is rare: under AKI_DEAD_ROWS_UNIFORM its lanes average V themselves; otherwise it is written as zeros.
+  // The lane-local layout (one query row per lane, 4 features per register quad) would store 8-byte pieces at a
+  // 6 KiB row stride - 32 cache lines per store instruction.  Each wave therefore passes its 32 x 96 tile through
+  // its own 6.5 KiB of the (now idle) K ring and writes whole 192-B rows, 16 B per lane. ----
   const float l_tot = halves_sum(l_part);
-  if (row < L) {
-    const bool dead = !(l_tot > 0.f);
+  const bool dead = !(l_tot > 0.f);
+  __syncthreads();                       // every wave is done reading the ring
+  constexpr int OROW = 208;              // 192 B + 16: the 8-B writes of 32 rows land 2-way instead of 8-way conflicted
+  char* const sO = sK + wave * (32 * OROW);
+  {
     const float inv = dead ? 0.f : 1.0f / l_tot;
-    bf16_t* orow = p.o + ((size_t)(b * L + row) * p.H + head) * 96 + 4 * h;
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
@@ -344,7 +438,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = o[dt][4 * q4 + e] * inv;
-        if (dead && p.dead_uniform) {
+        if (dead && p.dead_uniform && row < L) {
           float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
           const char* vp = vb_ + (dt * 32 + q4 * 8 + 4 * h) * 2;
           for (int t2 = 0; t2 < L; ++t2) {
@@ -354,11 +448,20 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
           const float il = 1.0f / (float)L;
           v[0] = a0 * il; v[1] = a1 * il; v[2] = a2 * il; v[3] = a3 * il;
         }
-        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        *(u32x2*)(orow + dt * 32 + q4 * 8) = pk;
+        const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *(u32x2*)(sO + l31 * OROW + (dt * 32 + q4 * 8 + 4 * h) * 2) = pk;
       }
-    if (p.lse && h == 0) p.lse[(size_t)bh * L + row] = dead ? -INFINITY : (m_run + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
   }
+  // same-wave LDS round trip: the compiler's lgkmcnt wait between the writes and the reads is all the ordering needed
+  bf16_t* const obase = p.o + ((size_t)b * L * p.H + head) * 96;
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int ch = it * 64 + lane;                 // 16-B chunk of the wave's tile: row ch/12, chunk ch%12
+    const int r = ch / 12, c = ch - r * 12;
+    const u32x4 w4 = *(const u32x4*)(sO + r * OROW + c * 16);
+    if (wq0 + r < L) *(u32x4*)((char*)(obase + (size_t)(wq0 + r) * p.H * 96) + c * 16) = w4;
+  }
+  if (p.lse && h == 0 && row < L) p.lse[(size_t)bh * L + row] = dead ? -INFINITY : (m_run + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
 }
 
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -375,6 +478,19 @@ int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, h
   p.B = a->B; p.H = a->H; p.L = a->L;
   p.nqt = (a->L + NW * 32 - 1) / (NW * 32);
   p.nwords = (a->L + 63) / 64;
+  {
+    // K/V of one group should stay cache resident while its ranks are walked: everything when the whole problem fits
+    // the 256 MB Infinity Cache with room to spare, else about 6 MB per XCD (8 XCDs; measured best at L = 1024 .. 4096).
+    const size_t kv_pair = (size_t)a->L * 96 * 2 * 2;
+    const int nbh = a->B * a->H;
+    int grp = nbh;
+    if (kv_pair * nbh > ((size_t)128 << 20)) grp = (int)((((size_t)48 << 20) / kv_pair) & ~(size_t)7);
+#ifdef AKI_ATTN_GROUP
+    grp = AKI_ATTN_GROUP;
+#endif
+    p.group_bh = grp < 8 ? 8 : (grp > nbh ? nbh : grp);
+    if (nbh < 8) p.group_bh = nbh;
+  }
   p.kvcap = a->kv_capacity > 0 ? a->kv_capacity : a->L;
   if (p.kvcap < a->L) return AKI_ERR_INVALID_ARG;
   p.scale_log2 = a->scale * 1.44269504088896340736f;
