@@ -156,6 +156,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   const int nblk = (L + 31) >> 5;
   const bool sched = nblk <= SCHED_MAX;        // kernel-uniform
   const int Lb = p.seq_lens ? min(p.seq_lens[b], L) : L;
+  // this thread's first valid-column word: its load goes out ahead of the DMA so that its wait does not drain them
+  unsigned long long vbw0 = ~0ull;
+  if (p.vbits && tid < p.nwords) vbw0 = p.vbits[(size_t)b * p.nwords + tid];
   issue_tile(0, 0);
   if (L > 64) issue_tile(1, 1);
   bf16x8 qf[6];
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   // first barrier of the tile loop orders these writes before their first read.
   for (int w = tid; w < p.nwords; w += NT) {
     unsigned long long vbw;
-    if (p.vbits) vbw = p.vbits[(size_t)b * p.nwords + w];
+    if (p.vbits) vbw = w == tid ? vbw0 : p.vbits[(size_t)b * p.nwords + w];
     else vbw = (w * 64 + 64 <= L) ? ~0ull : ((1ull << (L - w * 64)) - 1ull);
     sVB[w] = vbw;
   }
@@ -208,10 +211,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     if (p.dead_uniform && min(r0 + 32, L) > Lb) ext = L;
     if (r0 >= L) ext = -1;                        // no such block
     if (sched) {
+      const int key = ext < 0 ? -1 : ext * 64 + lane;          // unique; lanes past nblk never outrank a block
       int rank = 0;
-      for (int i = 0; i < nblk; ++i) {
-        const int e = __builtin_amdgcn_readlane(ext, i);
-        rank += (e > ext || (e == ext && i > lane)) ? 1 : 0;
+      for (int i = 0; i < nblk; i += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rank += __builtin_amdgcn_readlane(key, i + k) > key ? 1 : 0;
       }
       if (lane >= nblk) rank = 0x7fff;
       hi_col = 0;
@@ -322,8 +326,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
       const bool lane_cut = !lane_covers && rc0 < c0 + 64 && rc1 > c0;
       const bool rowwise = !full && causal_none && vb == ~0ull && !wave_has_dead && !__any(lane_cut);
       if (full) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        // no bias: the first MFMA of each chain takes the constant 0 as its C operand (no 32 v_mov per tile)
+        __builtin_amdgcn_sched_barrier(0);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0], f32x16{}, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[0], qf[0], f32x16{}, 0, 0, 0);
       } else if (rowwise) {
         const float lane_bias = lane_covers ? 0.f : -INFINITY;
 #pragma unroll
@@ -354,8 +360,12 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
         });
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (!full) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[0], qf[0], s1, 0, 0, 0);
+      }
 #pragma unroll
-      for (int ks = 0; ks < 6; ++ks) {
+      for (int ks = 1; ks < 6; ++ks) {
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[ks], s1, 0, 0, 0);
       }
