@@ -28,7 +28,7 @@ rep("  const int grp = blockIdx.x / (p.group_bh * p.nqt);","  const unsigned t_e
 rep("  const aki_mma_rect* const rects_b =","  const unsigned t_sync1 = stamp();\n  const aki_mma_rect* const rects_b =")
 rep("  const int row = wq0 + l31;\n","  const int row = wq0 + l31;\n  const unsigned t_q = stamp();\n")
 rep("    __builtin_amdgcn_s_barrier();\n    if (j + 2 < jend) issue_tile(","    __builtin_amdgcn_s_barrier();\n    const unsigned ta = stamp();\n    unsigned tb = ta, tc = ta, td = ta, te = ta;\n    if (j + 2 < jend) issue_tile(")
-rep("      __builtin_amdgcn_sched_barrier(0);\n#pragma unroll\n      for (int ks = 0; ks < 6; ++ks) {\n        s0 = __builtin_amdgcn_mfma","      asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n      tb = stamp();\n#pragma unroll\n      for (int ks = 0; ks < 6; ++ks) {\n        s0 = __builtin_amdgcn_mfma")
+rep("      const bool lane_covers = ","      asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n      tb = stamp();\n      const bool lane_covers = ")
 rep("      // The V^T fragments do not depend on the softmax","      { float tmp; asm volatile(\"v_add_f32 %0, %1, %2\" : \"=v\"(tmp) : \"v\"(s0[15]), \"v\"(s1[15])); asm volatile(\"s_nop 0\" :: \"v\"(tmp)); }\n      tc = stamp();\n      // The V^T fragments do not depend on the softmax")
 rep("      // every transposed read has to be back before its registers are touched","      td = stamp();\n      // every transposed read has to be back before its registers are touched")
 rep("""          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
@@ -47,7 +47,7 @@ rep("""          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_c
   }
   if (rec) dbg[15 * 8 + 4] = stamp();""")
 rep("    if (!skip) {\n      const char* Kb","    int full_tile = 0;\n    if (!skip) {\n      const char* Kb")
-rep("      if (full) {\n#pragma unroll\n        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }","      full_tile = full ? 1 : (rowwise ? 3 : 2);\n      if (full) {\n#pragma unroll\n        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }")
+rep("      if (full) {\n        // no bias:","      full_tile = full ? 1 : (rowwise ? 3 : 2);\n      if (full) {\n        // no bias:")
 rep("  if (p.lse && h == 0 && row < L) p.lse","  if (rec) dbg[15 * 8 + 7] = stamp();\n  if (false) p.lse")
 os.makedirs(os.path.join(ROOT, "aki_amd/lib/abl"), exist_ok=True)
 src = os.path.join(ROOT, "aki_amd/lib/abl/attn_timing.hip")
