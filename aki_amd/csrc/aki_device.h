@@ -75,6 +75,16 @@ __device__ __forceinline__ void halves_pair(float x, float& lo, float& hi) {
   hi = b;
 }
 // max / sum over lanes l and l^32, result in every lane.
+// Call between a chain of 16-pass MFMAs (32x32x16) and INLINE-ASM VALU code that reads their results.  hipcc's hazard
+// recognizer pads an XDL-write -> VALU-read pair only when it can see both instructions; an asm consumer placed right after
+// the last MFMA reads the register's previous content (cdna_hip_programming.md 5.7 item 2).  In the attention kernels that
+// consumer is the v_max3_f32 chain: a stale score only perturbs the running max, which softmax is invariant to, so every
+// tolerance test passed while ~0.5 % of the outputs differed by an ulp from launch to launch.  The nops are tied to both
+// accumulators by data dependency, so they can be scheduled neither before the MFMAs nor after the first reader.
+__device__ __forceinline__ void mfma_results_settle(f32x16& a, f32x16& b) {
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b));
+}
+
 __device__ __forceinline__ float halves_max(float x) {
   float lo, hi;
   halves_pair(x, lo, hi);

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_nc_bf16_kernel(const AttnNcPa
         s1[r] = (r + 16 < nv) ? s1[r] : -INFINITY;
       }
     }
+    mfma_results_settle(s0, s1);   // the max3 chain below is inline asm
     float mx = max3_nc(s0[0], s0[1], s1[0]);
     mx = max3_nc(mx, s1[1], s0[2]);
 #pragma unroll

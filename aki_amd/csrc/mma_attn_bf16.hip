@@ -358,6 +358,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
           s0[r] = mask_bias<r>(hid, ninf);
           s1[r] = mask_bias<r + 16>(hid, ninf);
         });
+        // VALU write inside inline asm -> MFMA C operand: hipcc pads no hazard whose producer it cannot see (guide 5.7
+        // item 2).  Without these two wait states the MFMA occasionally read the register's previous content - one score
+        // of a PARTIAL tile off, run-to-run differences of an ulp in ~0.5 % of the outputs.
+        asm volatile("s_nop 1" : "+v"(s0), "+v"(s1));   // data-dependent on every bias register: cannot be moved ahead of them
       }
       __builtin_amdgcn_sched_barrier(0);
       if (!full) {
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
         });
       }
       __builtin_amdgcn_sched_barrier(0);
+      mfma_results_settle(s0, s1);   // the max3 chain below is inline asm
       float mx = max3(s0[0], s0[1], s1[0]);
       mx = max3(mx, s1[1], s0[2]);
 #pragma unroll

@@ -636,6 +636,84 @@ def test_mma_attn_core_random_masks(seed):
     check(n(o16), rnd(n(o32), torch.float32), torch.bfloat16, f"bf16 kernel vs f32 kernel (seed {seed})", scale_atol=4.0)
 
 
+def _f32_reference_rows(ops, q, k, v, table, rows):
+    """Exact-f32 kernel output restricted to a few query rows (the f32 kernel is itself pinned to the numpy oracle)."""
+    o32 = ops.mma_attn_core(q.float(), k.float(), v.float(), table, 96 ** -0.5)
+    return o32[:, rows]
+
+
+@pytest.mark.parametrize("L", [2048, 2080])
+def test_mma_attn_core_block_ranking_boundary(L):
+    """64 blocks of 32 rows is the last length whose blocks are ranked by extent inside the kernel; 65 blocks run in
+    position order.  Both sides of the switch, with a rectangle that makes early rows walk the whole sequence."""
+    ops = _ops()
+    B, H = 1, 2
+    g = torch.Generator(device=DEV).manual_seed(L)
+    q, k, v = (torch.randn(B, H, L, 96, device=DEV, generator=g).to(torch.bfloat16) for _ in range(3))
+    rects = [[(70, 214, 214, L - 40)]]
+    table = ops.MaskTable.from_host(rects, np.ones((B, L)), [L] * B, DEV)
+    o = ops.mma_attn_core(q, k, v, table, 96 ** -0.5)
+    rows = torch.tensor([0, 31, 69, 70, 100, 213, 214, 215, 1023, 1024, L - 41, L - 40, L - 1], device=DEV)
+    want = _f32_reference_rows(ops, q, k, v, table, rows)
+    check(n(o[:, rows]), n(want), torch.bfloat16, f"ranking boundary L={L}", scale_atol=4.0)
+
+
+def test_mma_attn_core_is_run_to_run_deterministic():
+    """Race screen at the benchmark shape (1536 workgroups, two per CU): six launches on the same inputs must agree
+    bit for bit, outputs and log-sum-exp.  (A VALU->MFMA operand hazard behind inline asm once made ~0.5 % of the
+    outputs wobble by an ulp without ever failing a tolerance check.)"""
+    ops = _ops()
+    B, H, L = 8, 32, 655
+    g = torch.Generator(device=DEV).manual_seed(3)
+    q, k, v = (torch.randn(B, H, L, 96, device=DEV, generator=g).to(torch.bfloat16) for _ in range(3))
+    am = np.ones((B, L))
+    am[1, L - 50:] = 0
+    table = ops.MaskTable.from_host([[(6, 150, 150, L - 17)]] * B, am, [L] * (B - 1) + [L - 90], DEV)
+    o0, l0 = ops.mma_attn_core(q, k, v, table, 96 ** -0.5, return_lse=True)
+    o0, l0 = o0.clone(), l0.clone()
+    for i in range(5):
+        o, lse = ops.mma_attn_core(q, k, v, table, 96 ** -0.5, return_lse=True)
+        assert torch.equal(o, o0), f"launch {i + 1}: {int((o != o0).sum())} output elements differ from launch 0"
+        assert torch.equal(lse, l0), f"launch {i + 1}: lse differs"
+
+
+def test_mma_attn_core_dispatch_grouping_is_invisible():
+    """K+V above 128 MB switches the workgroup order from whole-grid rank-major to groups of (batch, head) pairs; the
+    order must not change a single bit of any row.  B*H = 72 pairs of L = 2560 (141 MB) against the same pairs run
+    24 at a time (47 MB: whole-grid order); 72 is not a multiple of the group size, so the last group is short."""
+    ops = _ops()
+    B, H, L = 3, 24, 2560
+    g = torch.Generator(device=DEV).manual_seed(7)
+    q, k, v = (torch.randn(B, H, L, 96, device=DEV, generator=g).to(torch.bfloat16) for _ in range(3))
+    rects = [[(10, 154, 154, L - 8)], [(0, 0, 0, 0)], [(300, 444, 444, 2000), (900, 1044, 1044, 2000)]]
+    am = np.ones((B, L))
+    am[1, L - 100:] = 0
+    table = ops.MaskTable.from_host(rects, am, [L, L, L - 37], DEV)
+    o = ops.mma_attn_core(q, k, v, table, 96 ** -0.5)
+    for b in range(B):
+        tb = ops.MaskTable.from_host([rects[b]], am[b:b + 1], [[L, L, L - 37][b]], DEV)
+        ob = ops.mma_attn_core(q[b:b + 1].contiguous(), k[b:b + 1].contiguous(), v[b:b + 1].contiguous(), tb, 96 ** -0.5)
+        assert torch.equal(o[b:b + 1], ob), f"sample {b} differs between grouped and whole-grid dispatch"
+
+
+def test_mma_attn_core_rowwise_tiles_and_odd_pair_count():
+    """Image rows and text rows in one 32-row block, rectangle columns covering whole 64-key tiles (the ROWWISE bias
+    path), two rectangles with different column ranges touching the same block (falls back to the visibility word), and a
+    (batch, head) count that is neither a multiple of 8 nor of the 4 waves."""
+    ops = _ops()
+    B, H, L = 3, 3, 450
+    g = torch.Generator(device=DEV).manual_seed(11)
+    q, k, v = (torch.randn(B, H, L, 96, device=DEV, generator=g).to(torch.bfloat16) for _ in range(3))
+    rects = [[(6, 150, 150, 440)],                       # rows 128..149 share block 4 with text rows 150..159
+             [(40, 50, 128, 384), (50, 60, 192, 448)],    # two rectangles inside block 1, different columns
+             [(0, 0, 0, 0)]]
+    table = ops.MaskTable.from_host(rects, np.ones((B, L)), [L] * B, DEV)
+    o = ops.mma_attn_core(q, k, v, table, 96 ** -0.5)
+    rows = torch.arange(0, L, device=DEV)
+    want = _f32_reference_rows(ops, q, k, v, table, rows)
+    check(n(o), n(want), torch.bfloat16, "rowwise tiles", scale_atol=4.0)
+
+
 @pytest.mark.parametrize("seed", list(range(10)))
 def test_splice_random_prompts_vs_oracle(seed):
     """Seeded random prompt batches through the splice / mask-table kernels against the oracle's restatement of
