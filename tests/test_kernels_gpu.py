@@ -677,6 +677,17 @@ def test_mma_attn_core_is_run_to_run_deterministic():
         assert torch.equal(lse, l0), f"launch {i + 1}: lse differs"
 
 
+def test_plain_attention_is_run_to_run_deterministic():
+    """Same race screen for the un-masked attention kernel (SigLIP 16 x 72 heads, 8 images of 576 patches)."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    q, k, v = (torch.randn(8, 576, 16, 72, device=DEV, generator=g).to(torch.bfloat16) for _ in range(3))   # [B,L,H,Dh]
+    o0 = ops.attention(q, k, v, 72 ** -0.5).clone()
+    for i in range(5):
+        o = ops.attention(q, k, v, 72 ** -0.5)
+        assert torch.equal(o, o0), f"launch {i + 1}: {int((o != o0).sum())} elements differ"
+
+
 def test_mma_attn_core_dispatch_grouping_is_invisible():
     """K+V above 128 MB switches the workgroup order from whole-grid rank-major to groups of (batch, head) pairs; the
     order must not change a single bit of any row.  B*H = 72 pairs of L = 2560 (141 MB) against the same pairs run

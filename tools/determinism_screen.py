@@ -49,3 +49,12 @@ for i in range(1, 3):
     rel = float((grads[i][1].float() - grads[0][1].float()).norm() / grads[0][1].float().norm())
     print(f"training step {i}: loss {grads[i][0]:.6f} vs {grads[0][0]:.6f}; {nd} of {grads[0][1].numel()} gradient elements differ, relative L2 {rel:.3e}")
 print("FORWARD/GENERATE DETERMINISTIC" if ok else "NONDETERMINISM FOUND")
+# where do the differing gradient elements live?
+names = {id(p): n for n, p in model.named_parameters()}
+spans = sorted(((lo, hi, names.get(pid, "?")) for pid, (lo, hi) in tr.span_of.items()))
+where = {}
+for lo, hi, name in spans:
+    nd = int((grads[2][1][lo:hi] != grads[0][1][lo:hi]).sum())
+    if nd:
+        where[name] = nd
+print("differing gradient elements by parameter:", where)
