@@ -284,6 +284,13 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   // prefetch (its model does not see the inline-asm counted waits below).
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
+  auto valid_word = [&](int w) -> unsigned long long {
+    const unsigned long long vbv = sVB[min(w, p.nwords - 1)];
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)vbv), hi = __builtin_amdgcn_readfirstlane((unsigned)(vbv >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+  };
+  unsigned long long vb_next = 0ull;
+
   int stage = 0;
   for (int j = 0; j < jend; ++j) {
     // tile j's pieces are older than tile j+1's 2*NCH: wait for them, then make it a workgroup-wide fact
@@ -292,12 +299,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     __builtin_amdgcn_s_barrier();
     if (j + 2 < jend) issue_tile(j + 2, stage >= 1 ? stage - 1 : NSTAGE - 1);   // the stage read in iteration j-1
     const int c0 = j * 64;
-    unsigned long long vb;
-    {
-      const unsigned long long vbv = sVB[j];
-      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)vbv), hi = __builtin_amdgcn_readfirstlane((unsigned)(vbv >> 32));
-      vb = ((unsigned long long)hi << 32) | lo;
-    }
+    // valid-column word of the tile (wave-uniform, SGPRs): word 0 is read here, behind the barrier that publishes the
+    // prologue's LDS writes; every later word is fetched at the end of the previous tile, under its PV MFMAs
+    const unsigned long long vb = j == 0 ? valid_word(0) : vb_next;
     const bool causal_full = (c0 + 63 <= wq0);
     const bool causal_none = (c0 > wq0 + 31);
     const bool rect_full = (c0 >= full_lo && c0 + 64 <= full_hi);
@@ -431,6 +435,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
         }
       }
     }
+    vb_next = valid_word(j + 1);
     if (++stage == NSTAGE) stage = 0;
   }
 
