@@ -7,7 +7,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaki_mi355x.so")
+# AKI_MI355X_LIB: A/B hook for lab builds of the same ABI (tools/attn_*.py); the product path never sets it
+LIB_PATH = os.environ.get("AKI_MI355X_LIB") or os.path.join(_HERE, "lib", "libaki_mi355x.so")
 
 AKI_DT_BF16, AKI_DT_F32, AKI_DT_FP8_E4M3, AKI_DT_W8A16 = 0, 1, 2, 3
 AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3

@@ -23,6 +23,9 @@
 
 #include "aki_device.h"
 
+#ifndef AKI_ATTN_L2_ROWS
+#define AKI_ATTN_L2_ROWS 256
+#endif
 #ifndef AKI_ATTN_SCHED_MAX
 #define AKI_ATTN_SCHED_MAX 64
 #endif
@@ -41,7 +44,8 @@ struct AttnParams {
   int max_rects;
   int B, H, L;
   int nqt, nwords;
-  int group_bh;  // (batch, head) pairs per dispatch group
+  int splits;    // workgroups per (batch, head) pair
+  int group_bh;  // pairs per dispatch group
   int kvcap;  // rows per (batch, head) of k / v (>= L when they are a KV cache)
   float scale_log2;  // scale * log2(e)
   int dead_uniform;
@@ -117,16 +121,22 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
 
-  // Dispatch order.  The (batch, head) pairs are cut into groups of p.group_bh; inside a group the workgroups are
-  // issued heaviest rank first ACROSS all its pairs (rank-major), so the hardware's in-order dispatch packs the long
-  // workgroups first and fills the tail with short ones (bh-major order left 17 % on the table at L = 655, three
-  // workgroups per slot).  group_bh is a multiple of 8: blockIdx % 8 = bh % 8, every pair stays on one XCD's L2.
-  const int grp = blockIdx.x / (p.group_bh * p.nqt);
+  // Persistent workgroups.  A (batch, head) pair has nqt workgroup-sized pieces of work ("ranks", 0 = heaviest, four
+  // 32-row blocks each); it is served by p.splits workgroups, and workgroup `sidx` of the pair walks the ranks
+  // k*splits + (k even ? sidx : splits-1-sidx), k = 0, 1, ... - a snake over the descending order, so the splits of a
+  // pair carry about the same work and the grid (B*H*splits, chosen by the host to be about the number of resident
+  // workgroup slots) is one balanced round with no dispatch gaps, where rank-sized workgroups packed at ~75 %.  All
+  // ranks of a workgroup read the same K/V (L2 / Infinity-Cache hits after the first), and the per-sample work - valid
+  // words to LDS, block extents and their ranking - is done once.  blockIdx = sidx * (B*H) + pair: the splits of a pair
+  // share blockIdx % 8, i.e. the XCD and its L2, whenever B*H is a multiple of 8.
+  // Pairs are issued in groups of p.group_bh (a multiple of 8), split-major inside a group, so that all splits of a
+  // pair are resident together and few enough pairs are in flight per XCD for their K/V to stay in its L2.
+  const int grp = blockIdx.x / (p.group_bh * p.splits);
   const int bh0 = grp * p.group_bh;
   const int gbh = min(p.group_bh, p.B * p.H - bh0);
-  const int within = blockIdx.x - bh0 * p.nqt;
-  const int g = within / gbh;                  // workgroup rank inside (batch, head): 0 = heaviest
-  const int bh = bh0 + within - g * gbh;
+  const int within = blockIdx.x - bh0 * p.splits;
+  const int sidx = within / gbh;
+  const int bh = bh0 + within - sidx * gbh;
   const int b = bh / p.H, head = bh - b * p.H;
   const int L = p.L;
   const bf16_t* qb = p.q + ((size_t)bh * L) * 96;
@@ -135,11 +145,13 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
 
   // K/V tiles go global -> LDS directly (global_load_lds, 16 B/lane): the LDS image is lane-linear, i.e. exactly the
   // contiguous 12 KiB tile of the head-major layout; the K swizzle is applied on the per-lane SOURCE address.
+  int tid_o = tid;   // re-made opaque once per rank: keeps hipcc from hoisting the per-chunk address arithmetic out of
+                     // the rank loop (with it hoisted the tile loop spilled: 256 VGPRs + 31 in scratch)
   auto issue_tile = [&](int j, int stage) {
     const int c0 = j * 64;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int ch = i * NT + tid;                // 16-B chunk index inside the tile image
+      const int ch = i * NT + tid_o;              // 16-B chunk index inside the tile image
       const int kr = ch / 12, pos = ch - kr * 12;
       const size_t rowoff = (size_t)min(c0 + kr, L - 1) * 192;
       const int srcchunk = pos ^ ((kr >> 2) & 3);
@@ -148,37 +160,22 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     }
   };
 
-  // ---- prologue: every global read the workgroup needs before its first MFMA is put in flight at once ----------
-  // (the first two K/V tiles, the valid words, and - in position order - the Q fragments); the rectangles come
-  // through the scalar cache into SGPRs.  At L = 655 a wave lives for ~7 tiles: a prologue of dependent round trips
-  // with workgroup barriers between them (table -> LDS -> extents -> ranks -> Q -> tile 0) was a sixth of its life.
+  // ---- once per workgroup: the sample's valid words, rectangles, block extents and their ranking -------------
   constexpr int SCHED_MAX = AKI_ATTN_SCHED_MAX;   // <= 64: one lane per 32-row block
   const int nblk = (L + 31) >> 5;
   const bool sched = nblk <= SCHED_MAX;        // kernel-uniform
   const int Lb = p.seq_lens ? min(p.seq_lens[b], L) : L;
-  // this thread's first valid-column word: its load goes out ahead of the DMA so that its wait does not drain them
-  unsigned long long vbw0 = ~0ull;
-  if (p.vbits && tid < p.nwords) vbw0 = p.vbits[(size_t)b * p.nwords + tid];
-  issue_tile(0, 0);
-  if (L > 64) issue_tile(1, 1);
-  bf16x8 qf[6];
-  auto load_q = [&](int row) {   // Q fragments (B operand of S^T = K Q^T): lane (q=l31, h) holds Q[q][16ks + 8h .. +7]
-    const bf16_t* qrow = qb + (size_t)min(row, L - 1) * 96 + 8 * h;
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
-  };
-  if (!sched) load_q((p.nqt - 1 - g) * BQ + wave * 32 + l31);
   // Valid-column words of this sample go to LDS once: a per-tile global load would share the vmcnt queue with the
   // K/V prefetch and its wait would drain the prefetch before the tile's compute (measured: 3x slower loop).  The
   // first barrier of the tile loop orders these writes before their first read.
   for (int w = tid; w < p.nwords; w += NT) {
     unsigned long long vbw;
-    if (p.vbits) vbw = w == tid ? vbw0 : p.vbits[(size_t)b * p.nwords + w];
+    if (p.vbits) vbw = p.vbits[(size_t)b * p.nwords + w];
     else vbw = (w * 64 + 64 <= L) ? ~0ull : ((1ull << (L - w * 64)) - 1ull);
     sVB[w] = vbw;
   }
   const aki_mma_rect* const rects_b = p.rects + (size_t)b * p.max_rects;
-  auto rect_at = [&](int i) -> aki_mma_rect {       // wave-uniform: one s_load_dwordx4
+  auto rect_at = [&](int i) -> aki_mma_rect {       // wave-uniform: one s_load_dwordx4 through the scalar cache
     const unsigned long long pa = (unsigned long long)(rects_b + i);
     const unsigned long long pu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pa);
     u32x4 r;
@@ -187,58 +184,81 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     o.row_lo = (int)r[0]; o.row_hi = (int)r[1]; o.col_lo = (int)r[2]; o.col_hi = (int)r[3];
     return o;
   };
-
   // Columns a 32-row block starting at r0 has to walk: its causal extent, widened by every rectangle that touches
   // it.  Rows >= seq_len are the all-zero mask rows of batch stacking: under the reference's finfo.min hand-off they
   // get a UNIFORM softmax over all L columns; they run through the normal MFMA path as "every column visible,
   // score 0", so a block that owns such rows walks all KV tiles.
-  //
-  // Which 32-row block a wave owns: the four waves of a workgroup share one K/V tile stream, so the workgroup walks to
-  // the LARGEST extent among its blocks and a wave whose block ends earlier idles at the barriers.  In position
-  // order that wastes a lot when the sequence is short (image rows inside a rectangle walk ~L columns, their text
-  // neighbours a few tiles): up to SCHED_MAX blocks are therefore ranked by extent (descending, later block first on
-  // ties) and workgroup g takes ranks 4g .. 4g+3 - blocks of similar length share a stream.  Every wave does the
-  // ranking for itself (lane i <-> block i, v_readlane): no LDS, no barrier.  Longer sequences keep position order
-  // (neighbouring blocks differ by at most two tiles there), late blocks first.
-  int wq0, hi_col;
-  {
-    const int r0 = sched ? 32 * lane : (p.nqt - 1 - g) * BQ + 32 * (lane & (NW - 1));
+  auto block_extent = [&](int r0) -> int {
+    if (r0 >= L) return -1;                       // no such block
     int ext = min(r0 + 32, L);
     for (int i = 0; i < p.max_rects; ++i) {
       const aki_mma_rect r = rect_at(i);
       if (r.row_hi > r.row_lo && r.col_hi > r.col_lo && r.row_lo < r0 + 32 && r.row_hi > r0) ext = max(ext, min(r.col_hi, L));
     }
     if (p.dead_uniform && min(r0 + 32, L) > Lb) ext = L;
-    if (r0 >= L) ext = -1;                        // no such block
-    if (sched) {
-      const int key = ext < 0 ? -1 : ext * 64 + lane;          // unique; lanes past nblk never outrank a block
-      int rank = 0;
-      for (int i = 0; i < nblk; i += 4) {
+    return ext;
+  };
+  // Which 32-row block a wave owns: the four waves of a workgroup share one K/V tile stream, so a rank walks to the
+  // LARGEST extent among its blocks and a wave whose block ends earlier idles at the barriers.  In position order that
+  // wastes a lot when the sequence is short (image rows inside a rectangle walk ~L columns, their text neighbours a few
+  // tiles): up to SCHED_MAX blocks are therefore ranked by extent (descending, later block first on ties) and rank g
+  // takes blocks 4g .. 4g+3 of that order - blocks of similar length share a stream.  Every wave does the ranking for
+  // itself (lane i <-> block i, v_readlane): no LDS, no barrier.  Longer sequences keep position order (neighbouring
+  // blocks differ by at most two tiles there), late blocks first.
+  int ext_s = -1, rank_s = 0x7fff;               // sched: lane i holds extent and rank of block i
+  if (sched) {
+    ext_s = block_extent(32 * lane);
+    const int key = ext_s < 0 ? -1 : ext_s * 64 + lane;        // unique; lanes past nblk never outrank a block
+    int rank = 0;
+    for (int i = 0; i < nblk; i += 4) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rank += __builtin_amdgcn_readlane(key, i + k) > key ? 1 : 0;
-      }
-      if (lane >= nblk) rank = 0x7fff;
-      hi_col = 0;
-      wq0 = L;                                    // rank past nblk (last workgroup): the wave idles
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const unsigned long long m = __ballot(rank == 4 * g + w);
-        if (m != 0ull) {
-          const int l = __builtin_ctzll(m);
-          hi_col = max(hi_col, __builtin_amdgcn_readlane(ext, l));
-          if (w == wave) wq0 = 32 * l;
-        }
-      }
-      load_q(wq0 + l31);
-    } else {
-      wq0 = (p.nqt - 1 - g) * BQ + wave * 32;
-      hi_col = 0;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) hi_col = max(hi_col, __builtin_amdgcn_readlane(ext, w));
+      for (int k = 0; k < 4; ++k) rank += __builtin_amdgcn_readlane(key, i + k) > key ? 1 : 0;
     }
-    wq0 = __builtin_amdgcn_readfirstlane(wq0);
-    hi_col = __builtin_amdgcn_readfirstlane(hi_col);
+    rank_s = lane < nblk ? rank : 0x7fff;
   }
+  bf16x8 qf[6];
+  auto load_q = [&](int row) {   // Q fragments (B operand of S^T = K Q^T): lane (q=l31, h) holds Q[q][16ks + 8h .. +7]
+    const bf16_t* qrow = qb + (size_t)min(row, L - 1) * 96 + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
+  };
+  // per-lane LDS offsets
+  const int kswz = (l31 >> 2) & 3;   // (row>>2)&3 for row = 32*blk + l31
+  const int krow = l31 * KROW;
+  const int voff = (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+  for (int kk = 0;; ++kk) {
+  const int g = kk * p.splits + ((kk & 1) ? p.splits - 1 - sidx : sidx);   // this workgroup's next rank
+  if (g >= p.nqt) break;
+  int lane_o = lane;
+  asm volatile("" : "+v"(tid_o), "+v"(lane_o));
+  // ---- per rank: the first two K/V tiles and the Q fragments are put in flight together ----------------------
+  issue_tile(0, 0);
+  if (L > 64) issue_tile(1, 1);
+  int wq0, hi_col;
+  if (sched) {
+    hi_col = 0;
+    wq0 = L;                                      // rank past nblk (last rank of the sample): the wave idles
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const unsigned long long m = __ballot(rank_s == 4 * g + w);
+      if (m != 0ull) {
+        const int l = __builtin_ctzll(m);
+        hi_col = max(hi_col, __builtin_amdgcn_readlane(ext_s, l));
+        if (w == wave) wq0 = 32 * l;
+      }
+    }
+  } else {
+    const int q0 = (p.nqt - 1 - g) * BQ;
+    wq0 = q0 + wave * 32;
+    const int ext = block_extent(q0 + 32 * (lane & (NW - 1)));
+    hi_col = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) hi_col = max(hi_col, __builtin_amdgcn_readlane(ext, w));
+  }
+  wq0 = __builtin_amdgcn_readfirstlane(wq0);
+  hi_col = __builtin_amdgcn_readfirstlane(hi_col);
+  load_q(wq0 + l31);
   const int row = wq0 + l31;
 
   // ---- per-wave rectangle summary, per-lane unlock range -----------------------------------------
@@ -273,11 +293,6 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1e30f, l_part = 0.f;
-
-  // per-lane LDS offsets
-  const int kswz = (l31 >> 2) & 3;   // (row>>2)&3 for row = 32*blk + l31
-  const int krow = l31 * KROW;
-  const int voff = (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
   // Retire everything issued above with a wait hipcc can see (builtin) before the loop: otherwise the compiler guards
   // the Q registers with its own vmcnt(0) in front of the first MFMA of EVERY iteration, which drains the LDS-DMA
@@ -476,12 +491,14 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   bf16_t* const obase = p.o + ((size_t)b * L * p.H + head) * 96;
 #pragma unroll
   for (int it = 0; it < 6; ++it) {
-    const int ch = it * 64 + lane;                 // 16-B chunk of the wave's tile: row ch/12, chunk ch%12
+    const int ch = it * 64 + lane_o;               // 16-B chunk of the wave's tile: row ch/12, chunk ch%12
     const int r = ch / 12, c = ch - r * 12;
     const u32x4 w4 = *(const u32x4*)(sO + r * OROW + c * 16);
     if (wq0 + r < L) *(u32x4*)((char*)(obase + (size_t)(wq0 + r) * p.H * 96) + c * 16) = w4;
   }
   if (p.lse && h == 0 && row < L) p.lse[(size_t)bh * L + row] = dead ? -INFINITY : (m_run + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
+  __syncthreads();   // the staged output tiles live in the K ring: every wave has read its tile back before the next rank's DMA
+  }                  // next rank of this workgroup
 }
 
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -499,24 +516,30 @@ int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, h
   p.nqt = (a->L + NW * 32 - 1) / (NW * 32);
   p.nwords = (a->L + 63) / 64;
   {
-    // K/V of one group should stay cache resident while its ranks are walked: everything when the whole problem fits
-    // the 256 MB Infinity Cache with room to spare, else about 6 MB per XCD (8 XCDs; measured best at L = 1024 .. 4096).
-    const size_t kv_pair = (size_t)a->L * 96 * 2 * 2;
+    // workgroups per pair: enough to fill the resident slots (2 per CU) once, at most one per rank
+    static int cus = 0;                      // queried once: hipGetDeviceProperties takes milliseconds
+    if (cus == 0) {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      cus = n;
+    }
     const int nbh = a->B * a->H;
-    int grp = nbh;
-    if (kv_pair * nbh > ((size_t)128 << 20)) grp = (int)((((size_t)48 << 20) / kv_pair) & ~(size_t)7);
-#ifdef AKI_ATTN_GROUP
-    grp = AKI_ATTN_GROUP;
+    int splits = (2 * cus + nbh - 1) / nbh;
+#ifdef AKI_ATTN_SPLITS
+    splits = AKI_ATTN_SPLITS;
 #endif
-    p.group_bh = grp < 8 ? 8 : (grp > nbh ? nbh : grp);
-    if (nbh < 8) p.group_bh = nbh;
+    const int s_l2 = a->L / AKI_ATTN_L2_ROWS;   // long sequences: more splits per pair, fewer pairs in flight per L2
+    if (splits < s_l2) splits = s_l2;
+    p.splits = splits < 1 ? 1 : (splits > p.nqt ? p.nqt : splits);
+    int grp = ((2 * cus + p.splits - 1) / p.splits + 7) & ~7;     // one round of resident slots per group
+    p.group_bh = grp > nbh ? nbh : grp;
   }
   p.kvcap = a->kv_capacity > 0 ? a->kv_capacity : a->L;
   if (p.kvcap < a->L) return AKI_ERR_INVALID_ARG;
   p.scale_log2 = a->scale * 1.44269504088896340736f;
   p.dead_uniform = a->dead_rows == AKI_DEAD_ROWS_UNIFORM;
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL((mma_attn_bf16_kernel<NW>), dim3(a->B * a->H * p.nqt), dim3(NW * 64), 0, stream, p);
+  hipLaunchKernelGGL((mma_attn_bf16_kernel<NW>), dim3(a->B * a->H * p.splits), dim3(NW * 64), 0, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }
