@@ -24,9 +24,9 @@ rep("  int stage = 0;\n  for (int j = 0; j < jend; ++j) {","""  unsigned* const 
   int stage = 0;
   for (int j = 0; j < jend; ++j) {
     const unsigned ta0 = stamp();""")
-rep("  const int grp = blockIdx.x / (p.group_bh * p.nqt);","  const unsigned t_entry = stamp();\n  const int grp = blockIdx.x / (p.group_bh * p.nqt);")
-rep("  const aki_mma_rect* const rects_b =","  const unsigned t_sync1 = stamp();\n  const aki_mma_rect* const rects_b =")
-rep("  const int row = wq0 + l31;\n","  const int row = wq0 + l31;\n  const unsigned t_q = stamp();\n")
+rep("  issue_tile(0, 0);\n  if (L > 64) issue_tile(1, 1);\n  int wq0, hi_col;","  const unsigned t_entry = stamp();\n  issue_tile(0, 0);\n  if (L > 64) issue_tile(1, 1);\n  int wq0, hi_col;")
+rep("  load_q(wq0 + l31);\n  const int row = wq0 + l31;\n","  load_q(wq0 + l31);\n  const unsigned t_sync1 = stamp();\n  const int row = wq0 + l31;\n")
+rep("  const int jend = (hi_col + 63) >> 6;","  const unsigned t_q = stamp();\n  const int jend = (hi_col + 63) >> 6;")
 rep("    __builtin_amdgcn_s_barrier();\n    if (j + 2 < jend) issue_tile(","    __builtin_amdgcn_s_barrier();\n    const unsigned ta = stamp();\n    unsigned tb = ta, tc = ta, td = ta, te = ta;\n    if (j + 2 < jend) issue_tile(")
 rep("      const bool lane_covers = ","      asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n      tb = stamp();\n      const bool lane_covers = ")
 rep("      // The V^T fragments do not depend on the softmax","      { float tmp; asm volatile(\"v_add_f32 %0, %1, %2\" : \"=v\"(tmp) : \"v\"(s0[15]), \"v\"(s1[15])); asm volatile(\"s_nop 0\" :: \"v\"(tmp)); }\n      tc = stamp();\n      // The V^T fragments do not depend on the softmax")
@@ -35,6 +35,7 @@ rep("""          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_c
         }
       }
     }
+    vb_next = valid_word(j + 1);
     if (++stage == NSTAGE) stage = 0;
   }""","""          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
         }
@@ -43,6 +44,7 @@ rep("""          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_c
       te = stamp();
     }
     if (rec && j < 15) { dbg[j * 8 + 0] = ta0; dbg[j * 8 + 1] = ta; dbg[j * 8 + 2] = tb; dbg[j * 8 + 3] = tc; dbg[j * 8 + 4] = td; dbg[j * 8 + 5] = te; dbg[j * 8 + 6] = (unsigned)full_tile; }
+    vb_next = valid_word(j + 1);
     if (++stage == NSTAGE) stage = 0;
   }
   if (rec) dbg[15 * 8 + 4] = stamp();""")
