@@ -74,7 +74,7 @@ const char* aki_strerror(int status) {
 
 int aki_abi_version(void) { return AKI_ABI_VERSION; }
 
-void aki_debug_set_gemm_tile(int mode) { aki::g_force_tile = (mode == 1 || mode == 2) ? mode : 0; }
+void aki_debug_set_gemm_tile(int mode) { aki::g_force_tile = (mode >= 1 && mode <= 3) ? mode : 0; }
 
 // ---- attention core --------------------------------------------------------------------------------
 size_t aki_mma_attn_core_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype) {

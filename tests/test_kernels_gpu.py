@@ -65,7 +65,7 @@ DTYPES = [torch.bfloat16, torch.float32]
 # ------------------------------------------------------------------------------------------------
 # linear
 # ------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[0, 1, 2], ids=["tile-auto", "tile-256", "tile-128"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["tile-auto", "tile-256", "tile-128", "tile-128x96"])
 def gemm_tile(request):
     """Run the bf16 GEMM tests under the heuristic and with each tile configuration forced."""
     from aki_amd import _lib

@@ -11,7 +11,7 @@ for M, N, K, name in shapes:
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
     line = f"{name:12s} M{M} N{N} K{K}: "
-    for mode in (1, 2, 0):
+    for mode in (1, 2, 3, 0):
         lib.aki_debug_set_gemm_tile(mode)
         for _ in range(3):
             ops.linear(x, w)
