@@ -446,14 +446,27 @@ class SpliceGradFn(torch.autograd.Function):
             if ctx.needs_input_grad[2]:
                 def w_grad(out):
                     out = torch.zeros_like(ctx.w_ref) if out is None else out.zero_()
-                    return out.index_add_(0, ids[~hi], rows[~hi])
+                    return _add_rows_deterministic(out, ids[~hi], rows[~hi])
                 d_w = _deliver(ctx.w_ref, w_grad)
             if ctx.a_ref is not None and ctx.needs_input_grad[3]:
                 def a_grad(out):
                     out = torch.zeros_like(ctx.a_ref) if out is None else out.zero_()
-                    return out.index_add_(0, ids[hi] - ctx.max_id - 1, rows[hi])
+                    return _add_rows_deterministic(out, ids[hi] - ctx.max_id - 1, rows[hi])
                 d_a = _deliver(ctx.a_ref, a_grad)
         return None, d_vis, d_w, d_a, None, None, None, None
+
+
+def _add_rows_deterministic(out: torch.Tensor, idx: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+    """out[idx[i]] += rows[i] for a ZEROED `out`, reproducibly: index_add_ resolves repeated token ids with atomics, whose
+    order (and therefore the bf16 rounding of every partial sum) changes from launch to launch - the only run-to-run
+    difference tools/determinism_screen.py found in a training step.  Rows are sorted by id (stable), summed per id in f32
+    in that order, rounded once and written to distinct rows."""
+    if idx.numel() == 0:
+        return out
+    order = torch.argsort(idx, stable=True)
+    uniq, counts = torch.unique_consecutive(idx[order], return_counts=True)
+    sums = torch.segment_reduce(rows[order].float(), "sum", lengths=counts, axis=0)
+    return out.index_copy_(0, uniq, sums.to(out.dtype))
 
 
 def splice_positions(plan_h, lang_x_shape, n_img_max: int, Nv: int, L_out: int, padding_side: str, device):
