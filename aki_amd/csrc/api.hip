@@ -32,6 +32,7 @@ int mask_dense_launch(const aki_mma_rect* rects, int max_rects, const uint64_t* 
                       int64_t* out, hipStream_t s);
 int im2col_launch(const void* pix, void* out, int N, int S, int P, int Kp, int dtype, hipStream_t s);
 extern int g_force_tile;
+extern int g_deep_ring;
 size_t attn_bwd_ws_bytes(int B, int H, int Lq);
 int attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq, void* dk,
                   void* dv, const aki_mma_rect* rects, int max_rects, const uint64_t* vbits, const int* seq_lens, int masked, int B,
@@ -74,7 +75,11 @@ const char* aki_strerror(int status) {
 
 int aki_abi_version(void) { return AKI_ABI_VERSION; }
 
-void aki_debug_set_gemm_tile(int mode) { aki::g_force_tile = (mode >= 1 && mode <= 3) ? mode : 0; }
+void aki_debug_set_gemm_tile(int mode) {
+  aki::g_deep_ring = (mode & 256) ? 0 : 1;
+  mode &= 255;
+  aki::g_force_tile = (mode >= 1 && mode <= 3) ? mode : 0;
+}
 
 // ---- attention core --------------------------------------------------------------------------------
 size_t aki_mma_attn_core_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype) {

@@ -88,7 +88,7 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 // FP8: e4m3 operands through v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate).  A 128-byte
 // LDS row then holds BK = 128 k-values instead of 64, so staging, swizzle and the epilogues are byte-for-byte the same; the
 // per-row dequantisation scales (one per token, one per weight row) multiply the f32 accumulators before the epilogue.
-template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false>
+template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false, int NST = 2>
 __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int BK = FP8 ? 128 : 64, ES = FP8 ? 1 : 2, NWAVES = WN * WM;
   constexpr int WROWS = NF * 16;      // features per wave
@@ -168,11 +168,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   const int xbase = BN * 128 + (wm * WTOK + l15) * 128;
 
   const int nk = p.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();  // (vmcnt(0) + barrier): tile kt landed, the other buffer is no longer being read
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* sb = smem + (kt & 1) * STAGE_BYTES;
+  auto compute = [&](const char* sb) {
     if constexpr (FP8) {   // one k128 step per BK: the lane's 32 bytes are chunks 2kg and 2kg+1 of its row
       const int c0 = ((2 * kg) ^ swz) << 4, c1 = ((2 * kg + 1) ^ swz) << 4;
       v8i_t a[NF], b[NT];
@@ -205,6 +201,33 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
 #pragma unroll
           for (int m = 0; m < NT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], b[m], acc[n][m], 0, 0, 0);
       }
+    }
+  };
+  if constexpr (NST == 2) {
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();  // (vmcnt(0) + barrier): tile kt landed, the other buffer is no longer being read
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      compute(smem + (kt & 1) * STAGE_BYTES);
+    }
+  } else {
+    // Deep ring for weight-streaming launches (launch_small: one row of tiles, at most one workgroup per CU): nothing
+    // co-resident fills the wait and a small tile's K-step (<= 512 MFMA cycles per wave) is far shorter than the
+    // global -> LDS latency, which the 2-stage loop above pays every step.  NST - 1 tiles are in flight; the
+    // counted vmcnt retires exactly tile kt (each stage() is NLD DMA instructions per thread), the raw barrier makes it a
+    // workgroup-wide fact, and tile kt + NST - 1 then goes into the buffer tile kt - 1 was read from.
+    static_assert(NST == 4, "the counted waits below are written for four stages");
+#pragma unroll
+    for (int s_ = 0; s_ < NST - 1; ++s_)
+      if (s_ < nk) stage(s_, s_);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int rem = nk - 1 - kt;
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + NST - 1 < nk) stage((kt + NST - 1) % NST, kt + NST - 1);
+      compute(smem + (kt % NST) * STAGE_BYTES);
     }
   }
 
@@ -321,9 +344,9 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
         v[n][0] += bf16_lo(rr[0]); v[n][1] += bf16_hi(rr[0]); v[n][2] += bf16_lo(rr[1]); v[n][3] += bf16_hi(rr[1]);
       }
     }
-    if (p.wide) {
+    if (NOUT % 2 == 0 && p.wide) {   // 16-byte stores pair two feature blocks
 #pragma unroll
-      for (int n = 0; n < NOUT; n += 2) {
+      for (int n = 0; n + 1 < NOUT; n += 2) {
         const u32x4 o = pair_to_wide(pack_bf16x2(v[n][0], v[n][1]), pack_bf16x2(v[n][2], v[n][3]),
                                      pack_bf16x2(v[n + 1][0], v[n + 1][1]), pack_bf16x2(v[n + 1][2], v[n + 1][3]));
         const int f = fwave + (n + (kg & 1)) * 16 + 8 * (kg >> 1);
@@ -342,13 +365,13 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   }
 }
 
-template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false>
+template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
-  constexpr int SMEM = 2 * (BN + BM) * 128;
+  constexpr int SMEM = NST * (BN + BM) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return AKI_ERR_LAUNCH;
     attr_set = true;
   }
@@ -357,7 +380,7 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (n_out + bn_out - 1) / bn_out;
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }
@@ -400,9 +423,29 @@ static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_w
   return 0;
 }
 
+int g_deep_ring = 1;  // test hook (aki_debug_set_gemm_tile bit 8 clears it): 4-stage ring for sparse small-tile launches
+
+// 128 x 128 tiles (two workgroups per CU), except for a single row of tiles - see below
+template <int EPI, int ACT, bool FP8>
+static int launch_small(GemmParams& p, hipStream_t stream) {
+  if constexpr (!FP8) {
+    const int n_out = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N, bn_out = (EPI == EPI_SWIGLU) ? 64 : 128;
+    const long tiles = (long)((p.M + 127) / 128) * ((n_out + bn_out - 1) / bn_out);
+    // One row of tiles (an M tail of <= 128 tokens against a wide weight matrix) is a weight-streaming problem: it is
+    // bound by how many CUs pull the stream and how many loads each keeps in flight.  64-feature tiles double the
+    // workgroup count and the ring goes four stages deep: gate_up tail (120 x 16384 x 3072) 35.0 -> 23.5 us, lm_head
+    // tail 46.8 -> 37.3 us.  With several rows of tiles (B=1 prefill: 6 x 24) the deep ring measured 4 % slower.
+    if (g_deep_ring && p.M <= 128 && p.K / 64 >= 4) {
+      if (EPI != EPI_QKV_ROPE8 && tiles <= 128) return launch_gemm<2, 4, 2, 2, EPI, ACT, FP8, 4>(p, stream);
+      if (tiles <= 256) return launch_gemm<4, 4, 2, 2, EPI, ACT, FP8, 4>(p, stream);
+    }
+  }
+  return launch_gemm<4, 4, 2, 2, EPI, ACT, FP8>(p, stream);
+}
+
 template <int EPI, int ACT, bool FP8 = false>
 static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
-  if (plan == 1) return launch_gemm<4, 4, 2, 2, EPI, ACT, FP8>(p, stream);
+  if (plan == 1) return launch_small<EPI, ACT, FP8>(p, stream);
   if (plan == 0) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8>(p, stream);
   if constexpr (EPI == EPI_PLAIN && !FP8) {
     if (plan == 3) return launch_gemm<4, 3, 2, 2, EPI, ACT, FP8>(p, stream);   // 128 features x 96 tokens
@@ -418,7 +461,7 @@ static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
   if (FP8) b.sx = p.sx + m_main;
   b.y = p.y + (size_t)m_main * p.ldy;
   if (p.residual && p.res_row_mod <= 0) b.residual = p.residual + (size_t)m_main * p.ldr;
-  return launch_gemm<4, 4, 2, 2, EPI, ACT, FP8>(b, stream);
+  return launch_small<EPI, ACT, FP8>(b, stream);
 }
 
 int linear_bf16(const aki_linear_args* a, hipStream_t stream) {

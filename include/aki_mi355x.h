@@ -58,7 +58,8 @@ typedef enum {
 const char* aki_strerror(int status);
 int aki_abi_version(void);
 /* Test hook: force the bf16 GEMM tile configuration (0 = heuristic, 1 = 256x256, 2 = 128x128,
- * 3 = 128 features x 96 tokens where that tile exists - plain bf16 GEMMs - else 128x128).  Not thread safe. */
+ * 3 = 128 features x 96 tokens where that tile exists - plain bf16 GEMMs - else 128x128); adding 256 switches off
+ * the 4-stage / 64-feature variant that single-row launches (M <= 128) otherwise take.  Not thread safe. */
 void aki_debug_set_gemm_tile(int mode);
 
 /* ------------------------------------------------------------------------------------------------

@@ -76,7 +76,7 @@ def gemm_tile(request):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (256, 256, 64), (1, 768, 128), (700, 1152, 640), (513, 36, 192)])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (256, 256, 64), (1, 768, 128), (700, 1152, 640), (513, 36, 192), (120, 4096, 512), (97, 40000, 256)])
 def test_linear_plain_bias_act_residual(dtype, M, N, K, gemm_tile):
     ops = _ops()
     if dtype == torch.float32 and gemm_tile:
@@ -104,7 +104,7 @@ def test_linear_plain_bias_act_residual(dtype, M, N, K, gemm_tile):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,Nout,K", [(300, 256, 128), (130, 320, 64), (515, 128, 192)])
+@pytest.mark.parametrize("M,Nout,K", [(300, 256, 128), (130, 320, 64), (515, 128, 192), (120, 2048, 512), (64, 9000, 256)])
 def test_linear_swiglu(dtype, M, Nout, K, gemm_tile):
     ops = _ops()
     if dtype == torch.float32 and gemm_tile:
