@@ -259,15 +259,38 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   if (EPI == EPI_QKV_ROPE8) {
     constexpr int UW = NF / 2;
     const int u0 = n0 / 32 + wn * UW, nqk = 6 * p.H;
+    // cos/sin of the tile's BM token rows go through LDS (idle after the K loop): fetched from the tables every lane
+    // would issue 2 x 16 B per (token block, unit) - 32 loads per lane, 256 KB per workgroup through a 64 B/clk L1, ~6 us
+    // of the launch at the benchmark shape.  Staged, a token row's first halves (cos[d] = cos[d + 48]) are loaded once by
+    // two threads, 12 x 16 B each, and read back with ds_read_b128 (row pitch 400 B: the 16 token rows of a read land in
+    // 16 different bank groups).  v-only tiles (u0 >= nqk for the whole workgroup) skip all of it.
+    constexpr int CSROW = 400;
+    static_assert(EPI != EPI_QKV_ROPE8 || BM * CSROW <= NST * STAGE_BYTES, "cos/sin staging fits the K-loop buffers");
+    const bool tile_has_rope = n0 / 32 < nqk;                 // workgroup-uniform
+    if (tile_has_rope) {
+      __syncthreads();                                        // every wave is done reading the K-loop stages
+      for (int tk = tid >> 1; tk < BM; tk += (NWAVES * 64) >> 1) {
+        const int mr = min(m0 + tk, p.M - 1) + p.m_offset;
+        const int pos = p.position_ids ? p.position_ids[mr] : mr % p.L;
+        const int half = tid & 1;
+        const float* cp = p.cos + (size_t)pos * 96 + half * 24;
+        const float* sp = p.sin + (size_t)pos * 96 + half * 24;
+        char* dst = smem + tk * CSROW + half * 96;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          *(f32x4*)(dst + i * 16) = *(const f32x4*)(cp + 4 * i);
+          *(f32x4*)(dst + 192 + i * 16) = *(const f32x4*)(sp + 4 * i);
+        }
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
       const int mrow = m0 + wm * WTOK + m * 16 + l15;
       const bool ok = mrow < p.M;
       const int mr = min(mrow, p.M - 1) + p.m_offset;   // global token index
       const int b = mr / p.L, tt = mr - b * p.L;
-      const int pos = p.position_ids ? p.position_ids[mr] : tt;
-      const float* cp = p.cos + (size_t)pos * 96 + 4 * kg;
-      const float* sp = p.sin + (size_t)pos * 96 + 4 * kg;
+      const char* cs = smem + (wm * WTOK + m * 16 + l15) * CSROW + 16 * kg;
 #pragma unroll
       for (int q = 0; q < UW; ++q) {
         const int u = u0 + q;                           // wave-uniform
@@ -277,7 +300,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
         int d1, d2;
         if (u < nqk) {
           const int hs = u / 3, j = u - 3 * hs, which = hs / p.H, head = hs - which * p.H;
-          const f32x4 c4 = *(const f32x4*)(cp + 16 * j), s4 = *(const f32x4*)(sp + 16 * j);
+          const f32x4 c4 = *(const f32x4*)(cs + 64 * j), s4 = *(const f32x4*)(cs + 192 + 64 * j);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float x1 = acc[q][m][r], x2 = acc[q + UW][m][r];
@@ -293,10 +316,11 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
           dst = p.v_out + ((size_t)(b * p.H + vh) * p.kvcap + tt) * 96;
           d1 = 32 * j2 + 4 * kg; d2 = d1 + 16;
         }
-        if (ok) {
-          *(u32x2*)(dst + d1) = u32x2{pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
-          *(u32x2*)(dst + d2) = u32x2{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3])};
-        }
+        // the lane's two 8-byte runs (block d1 and its partner block d2) become one 16-byte run of either block:
+        // lane row kg ends up with features 8*(kg>>1) .. +7 of block (kg & 1 ? d2 : d1) - half the store instructions
+        const u32x4 o = pair_to_wide(pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3]), pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]));
+        const int dw = ((kg & 1) ? d2 : d1) - 4 * kg + 8 * (kg >> 1);
+        if (ok) *(u32x4*)(dst + dw) = o;
       }
     }
     return;
