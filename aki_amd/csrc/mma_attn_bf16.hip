@@ -3,12 +3,14 @@
 // Replaces the eager path HF:phi3/modeling_phi3.py:145-167 under the reference's dense
 // (B,1,L,L) mask (src/vlm.py:410-443) without ever forming an L x L tensor:
 //   visible(r,c) = valid(c) && r < seq_len && ( c <= r || r in rect rows && c in rect cols )
-// Tiles are classified FULL / EMPTY / PARTIAL per wave from the rectangle table; only PARTIAL tiles
-// pay for the per-element predicate.
+// The mask enters as the INITIAL VALUE of the score accumulators (0 = visible, -inf = hidden): per wave and 64-key tile the
+// rectangle table gives FULL (constant-0 C operand), ROWWISE (one bias value per lane), PARTIAL (per-lane visibility word
+// expanded to a bias) or skipped, and the softmax code is the same for all of them.
 //
-// Work decomposition.  Workgroup = NW waves = NW*32 query rows of one (batch, head); KV tiles of 64
-// keys are staged through registers into a double-buffered LDS image (K rows padded to 208 B so the
-// ds_read_b128 fragment reads are conflict-free; V rows 192 B, conflict-free for the transposed read).
+// Work decomposition.  A wave owns one 32-row block of one (batch, head); four blocks of similar column extent form a
+// "rank" that shares a K/V tile stream, and a persistent workgroup of NW = 4 waves walks a snake over the ranks of its
+// pair (kernel body: "Persistent workgroups").  KV tiles of 64 keys go global -> LDS by global_load_lds into a 3-stage
+// ring (K rows carry an XOR swizzle on the source side, V rows are read transposed with ds_read_b64_tr_b16).
 // Per wave and KV tile:
 //   S^T = K Q^T      12 x v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = Q kept in 24 VGPRs)
 //                    -> lane (q = lane&31) holds 32 of the 64 scores of ITS OWN row: the row max /
@@ -23,6 +25,10 @@
 
 #include "aki_device.h"
 
+// Lab knobs (compile-time; tools/attn_*.py build variants with -D):
+//   AKI_ATTN_L2_ROWS   sequences get L / AKI_ATTN_L2_ROWS workgroups per pair at least (fewer pairs in flight per L2)
+//   AKI_ATTN_SCHED_MAX block ranking by extent up to this many 32-row blocks (<= 64: one lane per block), 0 = position order
+//   AKI_ATTN_SPLITS    force the number of workgroups per pair
 #ifndef AKI_ATTN_L2_ROWS
 #define AKI_ATTN_L2_ROWS 256
 #endif
