@@ -19,6 +19,10 @@
 
 #include "aki_device.h"
 
+#ifndef AKI_BWD_RANK_MAJOR
+#define AKI_BWD_RANK_MAJOR 1
+#endif
+
 namespace aki {
 
 struct AttnBwdParams {
@@ -95,7 +99,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdParam
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int nkb = (p.Lk + 127) / 128;
+#if AKI_BWD_RANK_MAJOR
+  // rank-major dispatch: all first (heaviest) key blocks of every (batch, head) pair, then all second ones, ... - the
+  // hardware's in-order dispatch packs the long workgroups first and fills the tail with short ones
+  const int nbh_ = p.B * p.H;
+  const int bh = blockIdx.x % nbh_, kb0 = (blockIdx.x / nbh_) * 128;
+#else
   const int bh = blockIdx.x / nkb, kb0 = (blockIdx.x - bh * nkb) * 128;
+#endif
   const int b = bh / p.H, head = bh - b * p.H;
   const int Lb = (MASKED && p.seq_lens) ? min(p.seq_lens[b], p.Lq) : p.Lq;
   const int key = kb0 + wave * 32 + l31;
@@ -291,7 +302,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int nqb = (p.Lq + 127) / 128;
+#if AKI_BWD_RANK_MAJOR
+  const int nbh_ = p.B * p.H;
+  const int bh = blockIdx.x % nbh_, q0 = (nqb - 1 - blockIdx.x / nbh_) * 128;              // heavy (late) query blocks first, across all pairs
+#else
   const int bh = blockIdx.x / nqb, q0 = (nqb - 1 - (blockIdx.x - bh * nqb)) * 128;     // heavy (late) query blocks first
+#endif
   const int b = bh / p.H, head = bh - b * p.H;
   const int Lb = (MASKED && p.seq_lens) ? min(p.seq_lens[b], p.Lq) : p.Lq;
   const int row = q0 + wave * 32 + l31;
