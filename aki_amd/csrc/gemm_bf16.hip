@@ -58,6 +58,7 @@ struct GemmParams {
   int act;
   int tiles_m, tiles_n;
   int wide;  // 16-byte stores allowed (n_out % 8 == 0, ldy % 8 == 0, y 16-B aligned)
+  int res_wide;  // 16-byte residual loads allowed (n_out % 8 == 0, ldr % 8 == 0, residual 16-B aligned)
   // QKV + RoPE
   bf16_t* q_out;
   bf16_t* k_out;
@@ -328,6 +329,38 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
 
   constexpr int NOUT = (EPI == EPI_SWIGLU) ? NF / 2 : NF;     // output feature blocks per wave
   const int fwave = n0 + wn * (EPI == EPI_SWIGLU ? WROWS / 2 : WROWS);
+  // The residual tile goes through LDS (idle after the K loop), like cos/sin in the QKV epilogue: fetched per lane it
+  // is NT*NOUT 8-byte loads (32 on the big tile, 128 KB per workgroup through the L1); staged it is 16-byte loads of whole
+  // rows, two to sixteen per thread.  Chunk c of token row t sits at chunk c ^ (t & CMASK): the 16 token rows of a
+  // ds_read_b64 land in 16 different bank groups without padding (a padded 256 x 256 tile would not fit).
+  constexpr int RCH = BN / 8;                                  // 16-byte chunks per residual tile row
+  constexpr int CMASK = RCH >= 16 ? 15 : RCH - 1;
+  const bool res_lds = (EPI == EPI_PLAIN) && p.residual != nullptr && p.res_wide;   // workgroup-uniform
+  if (EPI == EPI_PLAIN && res_lds) {
+    static_assert(EPI != EPI_PLAIN || BM * BN * 2 <= NST * STAGE_BYTES, "residual tile fits the K-loop buffers");
+    __syncthreads();                                           // every wave is done reading the K-loop stages
+    for (int c = tid; c < BM * RCH; c += NWAVES * 64) {
+      const int tk = c / RCH, ch = c - tk * RCH;
+      const int f = n0 + 8 * ch;
+      if (f < n_out) {
+        const int mr = min(m0 + tk, p.M - 1);
+        const bf16_t* rrow = p.residual + (size_t)(p.res_row_mod > 0 ? (mr + p.m_offset) % p.res_row_mod : mr) * p.ldr;
+        *(u32x4*)(smem + (tk * RCH + (ch ^ (tk & CMASK))) * 16) = *(const u32x4*)(rrow + f);
+      }
+    }
+    __syncthreads();
+  }
+  // bias: the lane's 4 features of each block are the same for every token block - loaded once, not once per block
+  float bias4[NOUT][4];
+  if (EPI == EPI_PLAIN && p.bias) {
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+      const int f = fwave + n * 16 + 4 * kg;
+      u32x2 bb = {0u, 0u};
+      if (f < n_out) bb = *(const u32x2*)(p.bias + f);
+      bias4[n][0] = bf16_lo(bb[0]); bias4[n][1] = bf16_hi(bb[0]); bias4[n][2] = bf16_lo(bb[1]); bias4[n][3] = bf16_hi(bb[1]);
+    }
+  }
 #pragma unroll
   for (int m = 0; m < NT; ++m) {
     const int mrow = m0 + wm * WTOK + m * 16 + l15;
@@ -352,8 +385,8 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
       }
       if (EPI == EPI_PLAIN) {
         if (p.bias && fin) {
-          const u32x2 bb = *(const u32x2*)(p.bias + f);
-          v[n][0] += bf16_lo(bb[0]); v[n][1] += bf16_hi(bb[0]); v[n][2] += bf16_lo(bb[1]); v[n][3] += bf16_hi(bb[1]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[n][r] += bias4[n][r];
         }
         if (ACT == AKI_ACT_GELU_ERF) {
 #pragma unroll
@@ -364,7 +397,13 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
         }
       }
       if (rrow && fin) {
-        const u32x2 rr = *(const u32x2*)(rrow + f);
+        u32x2 rr;
+        if (res_lds) {
+          const int tk = wm * WTOK + m * 16 + l15, ch = (wn * WROWS + n * 16) / 8 + (kg >> 1);
+          rr = *(const u32x2*)(smem + (tk * RCH + (ch ^ (tk & CMASK))) * 16 + (kg & 1) * 8);
+        } else {
+          rr = *(const u32x2*)(rrow + f);
+        }
         v[n][0] += bf16_lo(rr[0]); v[n][1] += bf16_hi(rr[0]); v[n][2] += bf16_lo(rr[1]); v[n][3] += bf16_hi(rr[1]);
       }
     }
@@ -502,6 +541,7 @@ int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr;
   p.res_row_mod = a->res_row_mod; p.act = a->act;
   p.wide = (n_out % 8 == 0) && (a->ldy % 8 == 0) && (((uintptr_t)a->y & 15) == 0);
+  p.res_wide = a->residual && (n_out % 8 == 0) && (a->ldr % 8 == 0) && (((uintptr_t)a->residual & 15) == 0);
   if (a->act == AKI_ACT_SWIGLU) {
     if (a->bias) return AKI_ERR_UNSUPPORTED;
     return run_planned<EPI_SWIGLU, 0>(p, plan_tiles(a->M, n_out, 128, 64), stream);
@@ -545,6 +585,7 @@ int linear_fp8(const aki_linear_args* a, hipStream_t stream) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldr = a->ldr;
   p.res_row_mod = a->res_row_mod; p.act = a->act; p.sx = a->x_scale; p.sw = a->w_scale;
   p.wide = (n_out % 8 == 0) && (a->ldy % 8 == 0) && (((uintptr_t)a->y & 15) == 0);
+  p.res_wide = a->residual && (n_out % 8 == 0) && (a->ldr % 8 == 0) && (((uintptr_t)a->residual & 15) == 0);
   if (a->act == AKI_ACT_SWIGLU) {
     if (a->bias) return AKI_ERR_UNSUPPORTED;
     return run_planned<EPI_SWIGLU, 0, true>(p, plan_tiles(a->M, n_out, 128, 64), stream);
