@@ -98,13 +98,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdParam
   const aki_mma_rect* sR = (const aki_mma_rect*)(smem + 2 * STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const int nkb = (p.Lk + 127) / 128;
 #if AKI_BWD_RANK_MAJOR
   // rank-major dispatch: all first (heaviest) key blocks of every (batch, head) pair, then all second ones, ... - the
   // hardware's in-order dispatch packs the long workgroups first and fills the tail with short ones
   const int nbh_ = p.B * p.H;
   const int bh = blockIdx.x % nbh_, kb0 = (blockIdx.x / nbh_) * 128;
 #else
+  const int nkb = (p.Lk + 127) / 128;
   const int bh = blockIdx.x / nkb, kb0 = (blockIdx.x - bh * nkb) * 128;
 #endif
   const int b = bh / p.H, head = bh - b * p.H;

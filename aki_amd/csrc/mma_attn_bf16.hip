@@ -330,7 +330,6 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     const bool skip = !has_uniform && (!wave_alive || vb == 0ull || (causal_none && !rect_touch));
     if (!skip) {
       const char* Kb = sK + stage * KTILE;
-      const char* Vb = sV + stage * VTILE;
       // All K fragments of the tile are fetched before the first MFMA (one LDS wait instead of one in front of every
       // MFMA pair: with 2 waves per SIMD that ~128-cycle LDS latency, 24 times per tile, was the dominant stall).
       bf16x8 ka[6], kc[6];
