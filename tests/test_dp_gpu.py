@@ -71,3 +71,31 @@ def test_two_rank_training_matches_single_process(shard):
         diff = (w0 - wref).abs()
         # the compared weights are the bf16 images: one ulp at |w| in [1, 2) is 2^-7
         assert float(diff.mean()) < 2e-4 and float(diff.max()) <= 2 * 2 ** -7, (float(diff.mean()), float(diff.max()))
+
+
+def test_bench_contract_two_ranks_on_one_gpu():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per GPU): here two
+    ranks share the one GPU and gloo stands in for RCCL (AKI_BENCH_BACKEND test hook - the data path has no collective,
+    only the barrier and the max-over-ranks of the elapsed time go through the process group).  Rank 0 prints exactly one
+    JSON line that carries the contract's fields, with the whole-job token count of both ranks."""
+    import json
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AKI_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert out["unit"] == "tokens/s" and out["dtype"] == "bf16" and "workload" in out["config"] and "model" not in out["config"]
+    # whole-job throughput: both ranks' tokens over the max-over-ranks time
+    tokens = 2 * 2 * 655 * 2
+    assert abs(out["value"] - tokens / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 1e-3
+    assert out["roofline"]["bound"] in ("mfma", "hbm") and 0.0 < out["roofline"]["frac"] < 1.0
