@@ -33,6 +33,7 @@ int mask_dense_launch(const aki_mma_rect* rects, int max_rects, const uint64_t* 
 int im2col_launch(const void* pix, void* out, int N, int S, int P, int Kp, int dtype, hipStream_t s);
 extern int g_force_tile;
 extern int g_deep_ring;
+extern int g_pipe;
 size_t attn_bwd_ws_bytes(int B, int H, int Lq);
 int attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq, void* dk,
                   void* dv, const aki_mma_rect* rects, int max_rects, const uint64_t* vbits, const int* seq_lens, int masked, int B,
@@ -77,6 +78,7 @@ int aki_abi_version(void) { return AKI_ABI_VERSION; }
 
 void aki_debug_set_gemm_tile(int mode) {
   aki::g_deep_ring = (mode & 256) ? 0 : 1;
+  aki::g_pipe = (mode & 512) ? 0 : 1;
   mode &= 255;
   aki::g_force_tile = (mode >= 1 && mode <= 3) ? mode : 0;
 }

@@ -89,7 +89,7 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 // FP8: e4m3 operands through v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate).  A 128-byte
 // LDS row then holds BK = 128 k-values instead of 64, so staging, swizzle and the epilogues are byte-for-byte the same; the
 // per-row dequantisation scales (one per token, one per weight row) multiply the f32 accumulators before the epilogue.
-template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false, int NST = 2>
+template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false, int NST = 2, bool PIPE = false>
 __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int BK = FP8 ? 128 : 64, ES = FP8 ? 1 : 2, NWAVES = WN * WM;
   constexpr int WROWS = NF * 16;      // features per wave
@@ -204,7 +204,50 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
       }
     }
   };
-  if constexpr (NST == 2) {
+  if constexpr (PIPE) {
+    // Mid-step barrier pipeline (bf16, 2 stages).  In the loop below every LDS fragment read of a K-step sits between
+    // the barrier and the MFMAs that need it, and all eight waves do theirs at the same time: the LDS array (24
+    // ds_read_b128 per wave and step, ~770 array cycles per CU) and then the matrix cores (2048 cycles per SIMD) take
+    // turns.  Here the barrier moves to the MIDDLE of the step: the k32-half-1 fragments of tile kt are read under the
+    // half-0 MFMAs, and behind the barrier - which publishes tile kt+1 - its half-0 fragments are read under the half-1
+    // MFMAs of tile kt, into the registers the half-0 MFMAs have just released.  The DMA of tile kt+2 goes out right
+    // after the barrier (nobody reads that buffer any more) and has a full step to land, as before.
+    static_assert(NST == 2 && !FP8, "bf16, two stages");
+    auto load_frags = [&](const char* sb, int ks, bf16x8 (&a)[NF], bf16x8 (&b)[NT]) {
+      const int coff = ((4 * ks + kg) ^ swz) << 4;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) a[n] = *(const bf16x8*)(sb + wbase + n * 2048 + coff);
+#pragma unroll
+      for (int m = 0; m < NT; ++m) b[m] = *(const bf16x8*)(sb + xbase + m * 2048 + coff);
+    };
+    auto mma = [&](const bf16x8 (&a)[NF], const bf16x8 (&b)[NT]) {
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], b[m], acc[n][m], 0, 0, 0);
+    };
+    bf16x8 a0[NF], b0[NT], a1[NF], b1[NT];
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // tile 0 landed (tile 1 may be in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_frags(smem, 0, a0, b0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* sb = smem + (kt & 1) * STAGE_BYTES;
+      load_frags(sb, 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my pieces of tile kt+1 landed; my reads of tile kt are done
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) stage(kt & 1, kt + 2);
+      if (kt + 1 < nk) load_frags(smem + ((kt + 1) & 1) * STAGE_BYTES, 0, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (NST == 2) {
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();  // (vmcnt(0) + barrier): tile kt landed, the other buffer is no longer being read
@@ -428,13 +471,13 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   }
 }
 
-template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2>
+template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, bool PIPE = false>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
   constexpr int SMEM = NST * (BN + BM) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return AKI_ERR_LAUNCH;
     attr_set = true;
   }
@@ -443,7 +486,7 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (n_out + bn_out - 1) / bn_out;
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }
@@ -506,17 +549,27 @@ static int launch_small(GemmParams& p, hipStream_t stream) {
   return launch_gemm<4, 4, 2, 2, EPI, ACT, FP8>(p, stream);
 }
 
+int g_pipe = 1;   // test hook (aki_debug_set_gemm_tile bit 9 clears it): mid-step barrier pipeline on the 256 x 256 tile
+
+template <int EPI, int ACT, bool FP8>
+static int launch_big(GemmParams& p, hipStream_t stream) {
+  if constexpr (!FP8) {
+    if (g_pipe) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, true>(p, stream);
+  }
+  return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8>(p, stream);
+}
+
 template <int EPI, int ACT, bool FP8 = false>
 static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
   if (plan == 1) return launch_small<EPI, ACT, FP8>(p, stream);
-  if (plan == 0) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8>(p, stream);
+  if (plan == 0) return launch_big<EPI, ACT, FP8>(p, stream);
   if constexpr (EPI == EPI_PLAIN && !FP8) {
     if (plan == 3) return launch_gemm<4, 3, 2, 2, EPI, ACT, FP8>(p, stream);   // 128 features x 96 tokens
   }
   const int m_main = p.M / 256 * 256;
   GemmParams a = p, b = p;
   a.M = m_main;
-  int rc = launch_gemm<8, 4, 2, 4, EPI, ACT, FP8>(a, stream);
+  int rc = launch_big<EPI, ACT, FP8>(a, stream);
   if (rc) return rc;
   b.M = p.M - m_main;
   b.m_offset = p.m_offset + m_main;
