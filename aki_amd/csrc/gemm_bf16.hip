@@ -25,6 +25,8 @@
 // the 16x16 fragment read groups.  One vmcnt(0)+barrier per K-step; tile k+1 streams in under tile k's MFMAs.
 // (tools/gemm_lab.hip: a deeper BK=32 x 4-stage counted-vmcnt ring, interleaved LDS-DMA issue, fragment
 // double-buffering, setprio and wave staggering were all measured and bought nothing on this structure.)
+#include <type_traits>
+
 #include "aki_device.h"
 
 namespace aki {
@@ -226,6 +228,20 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
 #pragma unroll
         for (int m = 0; m < NT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], b[m], acc[n][m], 0, 0, 0);
     };
+    auto interleave_reads = [&]() {     // scheduling directives: NF + NT groups of (MFMAs, one ds_read)
+#pragma unroll
+      for (int i = 0; i < NF + NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (NF * NT) / (2 * (NF + NT)) > 0 ? (NF * NT) / (2 * (NF + NT)) : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    };
+    auto interleave_dma = [&]() {       // then NLD groups of (one MFMA, one global_load_lds)
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    };
     bf16x8 a0[NF], b0[NT], a1[NF], b1[NT];
     stage(0, 0);
     if (nk > 1) stage(1, 1);
@@ -233,20 +249,30 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     load_frags(smem, 0, a0, b0);
-    for (int kt = 0; kt < nk; ++kt) {
+    // one K-step; NEXT1 / NEXT2: tiles kt+1 / kt+2 exist (compile-time, so that the steady-state step is one basic
+    // block and the scheduling directives can spread the reads and the DMA issue between the MFMAs instead of leaving
+    // them in front: right after the barrier both waves of a SIMD would otherwise spend ~250 issue cycles on them with
+    // the matrix core idle)
+    auto step = [&](int kt, auto next1, auto next2) {
+      constexpr bool NEXT1 = decltype(next1)::value, NEXT2 = decltype(next2)::value;
       const char* sb = smem + (kt & 1) * STAGE_BYTES;
       load_frags(sb, 1, a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
+      interleave_reads();
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my pieces of tile kt+1 landed; my reads of tile kt are done
       __builtin_amdgcn_s_barrier();
-      if (kt + 2 < nk) stage(kt & 1, kt + 2);
-      if (kt + 1 < nk) load_frags(smem + ((kt + 1) & 1) * STAGE_BYTES, 0, a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NEXT1) load_frags(smem + ((kt + 1) & 1) * STAGE_BYTES, 0, a0, b0);
+      if constexpr (NEXT2) stage(kt & 1, kt + 2);
       mma(a1, b1);
+      if constexpr (NEXT1) interleave_reads();
+      if constexpr (NEXT2) interleave_dma();
       __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) step(kt, std::true_type{}, std::true_type{});
+    if (kt + 1 < nk) { step(kt, std::true_type{}, std::false_type{}); ++kt; }
+    step(kt, std::false_type{}, std::false_type{});
   } else if constexpr (NST == 2) {
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
