@@ -156,6 +156,8 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.aki_abi_version() != AKI_ABI_VERSION:
         raise AkiError("libaki_mi355x.so ABI version mismatch; rebuild it")
+    if os.environ.get("AKI_GEMM_DEBUG_MODE"):   # lab hook: A/B a GEMM variant under any driver script (see aki_debug_set_gemm_tile)
+        lib.aki_debug_set_gemm_tile(int(os.environ["AKI_GEMM_DEBUG_MODE"]))
     _lib = lib
     return lib
 
