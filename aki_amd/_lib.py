@@ -9,13 +9,14 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # AKI_MI355X_LIB: A/B hook for lab builds of the same ABI (tools/attn_*.py); the product path never sets it
 LIB_PATH = os.environ.get("AKI_MI355X_LIB") or os.path.join(_HERE, "lib", "libaki_mi355x.so")
+LAB_LIB_PATH = os.path.join(_HERE, "lib", "libaki_mi355x_lab.so")
 
 AKI_DT_BF16, AKI_DT_F32, AKI_DT_FP8_E4M3, AKI_DT_W8A16 = 0, 1, 2, 3
 AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 7
+AKI_ABI_VERSION = 8
 
 
 class AkiError(RuntimeError):
@@ -82,7 +83,6 @@ class SpliceArgs(C.Structure):
 SIGNATURES = {
     "aki_strerror": (C.c_char_p, [C.c_int]),
     "aki_abi_version": (C.c_int, []),
-    "aki_debug_set_gemm_tile": (None, [C.c_int]),
     "aki_mma_attn_core_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
     "aki_mma_attn_core_fwd": (C.c_int, [C.POINTER(MmaAttnCoreArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_mma_attn_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
@@ -129,9 +129,56 @@ SIGNATURES = {
     "aki_splice_fwd": (C.c_int, [C.POINTER(SpliceArgs), C.c_void_p]),
     "aki_mma_mask_dense": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p]),
+    "aki_mma_mask_to_table_workspace_bytes": (C.c_size_t, [C.c_int32] * 2),
+    "aki_mma_mask_to_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None
+
+
+def _bind(path: str) -> C.CDLL:
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise AkiError(f"{path} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.aki_abi_version() != AKI_ABI_VERSION:
+        raise AkiError(f"{path}: ABI version mismatch; rebuild it")
+    return lib
+
+
+def load_lab() -> C.CDLL:
+    """The lab twin of the library (same ABI + aki_lab_set_gemm_tile).  Tests / tools only: `with use_lab(mode): ...`."""
+    import torch  # noqa: F401
+    if not os.path.exists(LAB_LIB_PATH):
+        raise AkiError(f"{LAB_LIB_PATH} not found: build it with `python -m aki_amd.build`")
+    lib = _bind(LAB_LIB_PATH)
+    lib.aki_lab_set_gemm_tile.restype = None
+    lib.aki_lab_set_gemm_tile.argtypes = [C.c_int]
+    return lib
+
+
+class use_lab:
+    """Context manager for tests / tools: route every call through the lab library with GEMM tile mode `mode` forced."""
+
+    def __init__(self, mode: int):
+        self.mode = mode
+
+    def __enter__(self):
+        global _lib
+        self.saved = _lib
+        _lib = load_lab()
+        _lib.aki_lab_set_gemm_tile(self.mode)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib.aki_lab_set_gemm_tile(0)
+        _lib = self.saved
+        return False
 
 
 def load() -> C.CDLL:
@@ -146,20 +193,8 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise AkiError(f"{LIB_PATH} not found: build it with `python -m aki_amd.build` (hipcc, gfx950). "
                        "There is no CPU fallback for the AKI MMA path.")
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        try:
-            fn = getattr(lib, name)
-        except AttributeError as e:
-            raise AkiError(f"{LIB_PATH} does not export {name}; rebuild it") from e
-        fn.restype = res
-        fn.argtypes = args
-    if lib.aki_abi_version() != AKI_ABI_VERSION:
-        raise AkiError("libaki_mi355x.so ABI version mismatch; rebuild it")
-    if os.environ.get("AKI_GEMM_DEBUG_MODE"):   # lab hook: A/B a GEMM variant under any driver script (see aki_debug_set_gemm_tile)
-        lib.aki_debug_set_gemm_tile(int(os.environ["AKI_GEMM_DEBUG_MODE"]))
-    _lib = lib
-    return lib
+    _lib = _bind(LIB_PATH)
+    return _lib
 
 
 def check(rc: int, what: str = "") -> None:

@@ -34,6 +34,15 @@ class AKI(VLMWithLanguageStream):
     def _should_apply_weight_decay(self, parameter_name):
         return True
 
+    def default_eos_token_ids(self):
+        """What `lang_model.generate` would stop on by default: generation_config.eos_token_id (Phi-3.5-mini-instruct ships
+        [32007, 32001, 32000]) when the checkpoint carried one, else config.eos_token_id."""
+        for holder in (getattr(self.lang_model, "generation_config", None), getattr(self.lang_model, "config", None)):
+            eos = getattr(holder, "eos_token_id", None) if holder is not None else None
+            if eos is not None:
+                return [int(eos)] if isinstance(eos, int) else [int(e) for e in eos]
+        return []
+
     def forward(self, vision_x: Optional[torch.Tensor], lang_x: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 labels: Optional[torch.Tensor] = None, image_size: Optional[Tuple] = None,
                 past_key_values: Optional[List[Union[torch.Tensor, Tuple[torch.Tensor]]]] = None,
@@ -68,7 +77,11 @@ class AKI(VLMWithLanguageStream):
         if past_key_values is not None:
             raise NotImplementedError("generate() starts from a fresh prefill")
         max_new_tokens = int(kwargs.pop("max_new_tokens", kwargs.pop("max_length", 20)))
+        # HF `generate` stops on generation_config.eos_token_id when the caller passes none (the reference's callers pass only
+        # max_new_tokens / do_sample: local_demo.py:76-87, eval_cv_bench/eval.py:99-104); `eos_token_id=[]` switches it off.
         eos = kwargs.pop("eos_token_id", None)
+        if eos is None:
+            eos = self.default_eos_token_ids()
         eos_ids = set([eos] if isinstance(eos, int) else (eos or []))
         pad_id = kwargs.pop("pad_token_id", self.pad_token_id)
         use_graph = kwargs.pop("use_graph", None)

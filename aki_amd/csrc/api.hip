@@ -31,9 +31,14 @@ int splice_launch(const aki_splice_args* a, hipStream_t s);
 int mask_dense_launch(const aki_mma_rect* rects, int max_rects, const uint64_t* vbits, const int* seq_lens, int B, int L,
                       int64_t* out, hipStream_t s);
 int im2col_launch(const void* pix, void* out, int N, int S, int P, int Kp, int dtype, hipStream_t s);
+size_t mask_to_table_ws_bytes(int B, int L);
+int mask_to_table_launch(const int64_t* mask, int B, int L, int max_rects, aki_mma_rect* rects, uint64_t* vbits, int* seq_lens,
+                         int* status, void* ws, hipStream_t s);
+#ifdef AKI_LAB_HOOKS
 extern int g_force_tile;
 extern int g_deep_ring;
 extern int g_pipe;
+#endif
 size_t attn_bwd_ws_bytes(int B, int H, int Lq);
 int attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq, void* dk,
                   void* dv, const aki_mma_rect* rects, int max_rects, const uint64_t* vbits, const int* seq_lens, int masked, int B,
@@ -76,12 +81,18 @@ const char* aki_strerror(int status) {
 
 int aki_abi_version(void) { return AKI_ABI_VERSION; }
 
-void aki_debug_set_gemm_tile(int mode) {
+#ifdef AKI_LAB_HOOKS
+// Lab build only (libaki_mi355x_lab.so, `python -m aki_amd.build --lab`): force the bf16 GEMM tile configuration
+// (0 = heuristic, 1 = 256x256, 2 = 128x128, 3 = 128 features x 96 tokens where that tile exists, else 128x128); +256 switches
+// off the 4-stage / 64-feature variant of single-row launches, +512 the mid-step pipeline of the 256x256 tile.  Process-global,
+// not thread safe - which is why the product library does not carry it.
+void aki_lab_set_gemm_tile(int mode) {
   aki::g_deep_ring = (mode & 256) ? 0 : 1;
   aki::g_pipe = (mode & 512) ? 0 : 1;
   mode &= 255;
   aki::g_force_tile = (mode >= 1 && mode <= 3) ? mode : 0;
 }
+#endif
 
 // ---- attention core --------------------------------------------------------------------------------
 size_t aki_mma_attn_core_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype) {
@@ -472,6 +483,20 @@ int aki_mma_mask_dense(const aki_mma_rect* rects, int32_t max_rects, const uint6
   AKI_CLEAR_ERR();
   AKI_CHECK_ARG(out && B > 0 && L > 0 && max_rects >= 0 && max_rects <= AKI_MAX_RECTS && (max_rects == 0 || rects));
   return mask_dense_launch(rects, max_rects, col_valid_bits, seq_lens, B, L, out, (hipStream_t)stream);
+}
+
+size_t aki_mma_mask_to_table_workspace_bytes(int32_t B, int32_t L) {
+  return (B > 0 && L > 0) ? aki_align_up(mask_to_table_ws_bytes(B, L), 256) : 0;
+}
+
+int aki_mma_mask_to_table(const int64_t* mask, int32_t B, int32_t L, int32_t max_rects, aki_mma_rect* rects, uint64_t* col_valid_bits,
+                          int32_t* seq_lens, int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(mask && rects && col_valid_bits && seq_lens && status && B > 0 && L > 0);
+  AKI_CHECK_ARG(max_rects >= 1 && max_rects <= AKI_MAX_RECTS);
+  if (!ws || ws_bytes < aki_mma_mask_to_table_workspace_bytes(B, L)) return AKI_ERR_WORKSPACE;
+  AKI_CHECK_ALIGN16(ws);
+  return mask_to_table_launch(mask, B, L, max_rects, rects, col_valid_bits, seq_lens, status, ws, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -275,6 +275,86 @@ __global__ __launch_bounds__(256) void mask_dense_kernel(const aki_mma_rect* rec
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense (B,1,L,L) int64 0/1 mask -> table: the hand-off type of the reference (`attention_mask` of
+// src/vlm.py:589-603 as passed to lang_model at src/aki.py:125-130) converted back to rectangles + valid bits +
+// seq_lens, so a caller that still builds the dense tensor lands on the O(L) attention path.
+//   pass 1 (one block per mask row): first / one-past-last set column to the RIGHT of the diagonal, "row has a set
+//           column at all", and the column-wise OR of the whole sample as valid bits (a column nobody may see is
+//           indistinguishable from an invalid one);
+//   pass 2 (one block per sample): consecutive rows with the same right-of-diagonal interval become one rectangle
+//           (rows whose interval starts right at the diagonal, lo == r+1, are the part of a rectangle the causal
+//           triangle already covers and join the run above them); seq_len = last non-empty row + 1.
+// The candidate table is NOT trusted: the caller materialises it again (mask_dense_kernel) and compares it with the
+// input bit for bit, so anything outside the family {causal + row-interval rectangles + invalid columns} is refused.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_rows_scan_kernel(const int64_t* mask, int L, int4* rowinfo, unsigned long long* vbits) {
+  __shared__ int s_lo[4], s_hi[4], s_any[4];
+  const int b = blockIdx.y, r = blockIdx.x;
+  const int64_t* row = mask + ((size_t)b * L + r) * L;
+  const int nwords = (L + 63) / 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int lo = 0x7fffffff, hi = 0, any = 0;
+  for (int c0 = wave * 64; c0 < L; c0 += 256) {
+    const int c = c0 + lane;
+    const bool set = c < L && row[c] != 0;
+    const unsigned long long word = __ballot(set);
+    if (word) {
+      any = 1;
+      if (lane == 0) atomicOr(vbits + (size_t)b * nwords + (c0 >> 6), word);
+    }
+    if (set && c > r) { lo = min(lo, c); hi = max(hi, c + 1); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+  if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_any[wave] = any; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); any |= s_any[w]; }
+    if (hi == 0) lo = 0;
+    rowinfo[(size_t)b * L + r] = make_int4(lo, hi, any, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void mask_table_build_kernel(const int4* rowinfo, int L, int max_rects, aki_mma_rect* rects,
+                                                               int* seq_lens, int* status) {
+  constexpr int CH = 2048;
+  __shared__ int4 s_info[CH];
+  const int b = blockIdx.x;
+  int n = 0, run_lo = 0, run_hi = 0, run_start = 0, seq = 0;   // only thread 0's copies are meaningful
+  bool open = false;
+  for (int r0 = 0; r0 < L; r0 += CH) {
+    const int nr = min(CH, L - r0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr; i += 256) s_info[i] = rowinfo[(size_t)b * L + r0 + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < nr; ++i) {
+        const int r = r0 + i;
+        const int4 q = s_info[i];
+        if (q.z) seq = r + 1;
+        const bool has = q.y > q.x;
+        const bool joins = open && has && q.y == run_hi && (q.x == run_lo || (q.x == r + 1 && run_lo <= r));
+        if (open && !joins) {
+          if (n < max_rects) rects[(size_t)b * max_rects + n] = aki_mma_rect{run_start, r, run_lo, run_hi};
+          ++n;
+          open = false;
+        }
+        if (has && !open) { open = true; run_start = r; run_lo = q.x; run_hi = q.y; }
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (open) {
+      if (n < max_rects) rects[(size_t)b * max_rects + n] = aki_mma_rect{run_start, L, run_lo, run_hi};
+      ++n;
+    }
+    for (int i = n; i < max_rects; ++i) rects[(size_t)b * max_rects + i] = aki_mma_rect{0, 0, 0, 0};
+    seq_lens[b] = seq;
+    status[b] = n > max_rects ? n : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // im2col for the SigLIP patch embedding: A[n*G*G + gy*G + gx][c*P*P + py*P + px], zero padded to Kp.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -317,6 +397,20 @@ int mask_dense_launch(const aki_mma_rect* rects, int max_rects, const uint64_t* 
                       int64_t* out, hipStream_t s) {
   AKI_CLEAR_ERR();
   hipLaunchKernelGGL(mask_dense_kernel, dim3(L, B), dim3(256), 0, s, rects, rects ? max_rects : 0, vbits, seq_lens, L, out);
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
+}
+
+size_t mask_to_table_ws_bytes(int B, int L) { return (size_t)B * L * sizeof(int4); }
+
+int mask_to_table_launch(const int64_t* mask, int B, int L, int max_rects, aki_mma_rect* rects, uint64_t* vbits, int* seq_lens,
+                         int* status, void* ws, hipStream_t s) {
+  AKI_CLEAR_ERR();
+  const int nwords = (L + 63) / 64;
+  if (hipMemsetAsync(vbits, 0, (size_t)B * nwords * sizeof(uint64_t), s) != hipSuccess) return AKI_ERR_LAUNCH;
+  hipLaunchKernelGGL(mask_rows_scan_kernel, dim3(L, B), dim3(256), 0, s, mask, L, (int4*)ws, (unsigned long long*)vbits);
+  AKI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mask_table_build_kernel, dim3(B), dim3(256), 0, s, (const int4*)ws, L, max_rects, rects, seq_lens, status);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }

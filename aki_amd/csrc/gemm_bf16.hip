@@ -517,7 +517,12 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   return AKI_OK;
 }
 
-int g_force_tile = 0;  // test hook (aki_debug_set_gemm_tile): 0 = heuristic, 1 = 256^2, 2 = 128^2, 3 = 128 features x 96 tokens (plain bf16 only)
+#ifdef AKI_LAB_HOOKS
+int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;   // set by aki_lab_set_gemm_tile (lab build only)
+#else
+static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;
+#endif
+// g_force_tile: 0 = heuristic, 1 = 256^2, 2 = 128^2, 3 = 128 features x 96 tokens (plain bf16 only)
 
 // Cost model in units of one 256x256 tile's run time.  256^2 tiles: one workgroup per CU.  128-token tiles do a
 // quarter of the work; up to 256 of them run one per CU at ~75 % of the big tile's efficiency, beyond that two share a CU
@@ -555,7 +560,7 @@ static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_w
   return 0;
 }
 
-int g_deep_ring = 1;  // test hook (aki_debug_set_gemm_tile bit 8 clears it): 4-stage ring for sparse small-tile launches
+// g_deep_ring (lab bit 8 clears it): 4-stage ring for sparse small-tile launches
 
 // 128 x 128 tiles (two workgroups per CU), except for a single row of tiles - see below
 template <int EPI, int ACT, bool FP8>
@@ -575,7 +580,7 @@ static int launch_small(GemmParams& p, hipStream_t stream) {
   return launch_gemm<4, 4, 2, 2, EPI, ACT, FP8>(p, stream);
 }
 
-int g_pipe = 1;   // test hook (aki_debug_set_gemm_tile bit 9 clears it): mid-step barrier pipeline on the 256 x 256 tile
+// g_pipe (lab bit 9 clears it): mid-step barrier pipeline on the 256 x 256 tile
 
 template <int EPI, int ACT, bool FP8>
 static int launch_big(GemmParams& p, hipStream_t stream) {

@@ -407,11 +407,11 @@ int rope_bwd_merge_launch(const void* dq, const void* dk, const void* dv, const 
 //   dlogits[row][c]  = (softmax(row)[c] - [c == target]) * gscale / n_valid      (0 for ignored rows)
 // n_valid comes from a device counter written by ce_count_kernel, so nothing syncs with the host.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void ce_count_kernel(const int64_t* labels, int B, int L, int* n_valid) {
+__global__ void ce_count_kernel(const int64_t* labels, int B, int L, int V, int* n_valid) {
   int cnt = 0;
   for (int i = threadIdx.x; i < B * L; i += 256) {
     const int t = i % L;
-    if (t + 1 < L && labels[i + 1] != -100) ++cnt;
+    if (t + 1 < L && labels[i + 1] >= 0 && labels[i + 1] < V) ++cnt;
   }
   __shared__ int red[256];
   red[threadIdx.x] = cnt;
@@ -427,9 +427,14 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const bf16_t* logits, c
                                                          bf16_t* dlogits, int B, int L, int V, int ldl, int lddl, float gscale) {
   __shared__ float red[16];
   const int row = blockIdx.x, t = row % L, tid = threadIdx.x;
-  const int64_t tgt = (t + 1 < L) ? labels[row + 1] : -100;
+  int64_t tgt = (t + 1 < L) ? labels[row + 1] : -100;
+  if (tgt < 0 || tgt >= V) tgt = -100;   // out-of-range labels are ignored rows (ce_count_kernel counts the same way), never an OOB read
   const bf16_t* lr = logits + (size_t)row * ldl;
   bf16_t* dr = dlogits ? dlogits + (size_t)row * lddl : nullptr;
+  // The target logit is read BEFORE any barrier: dlogits may alias logits, and once the last __syncthreads is behind them the
+  // other waves overwrite lr[] with the gradient while thread 0 would still be reading lr[tgt] for the loss.
+  float tgt_logit = 0.f;
+  if (tid == 0 && tgt != -100) tgt_logit = bf16_bits_to_f32(lr[tgt]);
   if (tgt == -100) {
     if (tid == 0) loss_rows[row] = 0.f;
     if (dr) for (int c = tid * 2; c < V; c += 512) { if (c + 1 < V) *(unsigned*)(dr + c) = 0u; else dr[c] = 0; }
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const bf16_t* logits, c
   __syncthreads();
   const float st = red[4] + red[5] + red[6] + red[7];
   const float lse = gm + __logf(st);
-  if (tid == 0) loss_rows[row] = lse - bf16_bits_to_f32(lr[tgt]);
+  if (tid == 0) loss_rows[row] = lse - tgt_logit;
   if (dr) {
     const float k = gscale / (float)max(*n_valid, 1);
     for (int c = tid * 2; c < V; c += 512) {
@@ -475,7 +480,7 @@ int ce_launch(const void* logits, const int64_t* labels, int* n_valid, float* lo
               int lddl, float gscale, hipStream_t s) {
   if ((ldl & 1) || (dlogits && (lddl & 1))) return AKI_ERR_ALIGNMENT;
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, labels, B, L, n_valid);
+  hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, labels, B, L, V, n_valid);
   hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(B * L), dim3(256), 0, s, (const bf16_t*)logits, labels, n_valid, loss_rows, (bf16_t*)dlogits,
                      B, L, V, ldl, lddl, gscale);
   AKI_LAUNCH_CHECK();

@@ -129,12 +129,19 @@ class FlatGradReducer:
     """
 
     def __init__(self, flat_grad: torch.Tensor, spans, bucket_bytes: int = 512 << 20, group=None, shard: bool = False,
-                 breaks=()):
-        """spans: list of (param, start, stop) element ranges inside flat_grad, in buffer order."""
+                 breaks=(), exchange_when_alone: bool = False):
+        """spans: list of (param, start, stop) element ranges inside flat_grad, in buffer order.
+        exchange_when_alone: issue the collectives even in a world of one rank (they are identities there) - how the RCCL
+        entry points and the compute-stream -> communicator-stream hand-off are exercised on a single GPU."""
         self.flat, self.group, self.shard = flat_grad, group, shard
         self.enabled = True           # False during the non-final micro-batches of a gradient-accumulation window
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.active = self.world > 1 or (exchange_when_alone and dist.is_initialized())
+        # gloo (the CPU tests' transport) has neither reduce_scatter_tensor nor all_gather_into_tensor: it gets the same
+        # result from all-reduces.  Chosen by BACKEND, never by catching exceptions - a failing RCCL call must surface.
+        self.no_scatter = dist.is_initialized() and str(dist.get_backend(group)).lower() == "gloo"
+        self._delivered = set()       # ids of parameters already counted in this accumulation window
         per = max(1, bucket_bytes // flat_grad.element_size())
         brk = sorted(set(int(b) for b in breaks) | {flat_grad.numel()})
         self.buckets = []             # [start, stop, n_params, pending, work]
@@ -164,25 +171,26 @@ class FlatGradReducer:
         return b[0] + self.rank * c, b[0] + (self.rank + 1) * c
 
     def notify(self, p) -> None:
-        if not self.enabled:
+        """Called once a parameter's gradient slice is final for this window.  Idempotent per parameter: a weight used twice
+        in one backward (tied / shared modules) delivers twice, and counting it twice would launch the bucket while other
+        slices are still being written."""
+        if not self.enabled or id(p) in self._delivered:
             return
+        self._delivered.add(id(p))
         b = self.buckets[self._owner[id(p)]]
         b[3] -= 1
         if b[3] == 0:
             self._launch(b)
 
     def _launch(self, b) -> None:
-        if self.world == 1 or b[4] is not None:
+        if not self.active or b[4] is not None:
             return
         buf = self.flat[b[0]: b[1]]
-        if not self.shard:
+        if not self.shard or self.no_scatter:
             b[4] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             return
         lo, hi = self.owned(b)
-        try:
-            b[4] = dist.reduce_scatter_tensor(self.flat[lo:hi], buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        except (RuntimeError, NotImplementedError):    # gloo (CPU tests) has no reduce-scatter: same result via all-reduce
-            b[4] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b[4] = dist.reduce_scatter_tensor(self.flat[lo:hi], buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:
         for b in self.buckets:
@@ -191,17 +199,18 @@ class FlatGradReducer:
             if b[4] is not None:
                 b[4].wait()
             b[3], b[4] = b[2], None
+        self._delivered.clear()
 
     def all_gather_weights(self, flat_w: torch.Tensor) -> None:
         """After the sharded optimizer step: every rank's freshly written sub-slices -> the full flat weight buffer."""
-        if not self.shard or self.world == 1:
+        if not self.shard or not self.active:
             return
         works = []
         for b in self.buckets:
             lo, hi = self.owned(b)
-            try:
+            if not self.no_scatter:
                 works.append(dist.all_gather_into_tensor(flat_w[b[0]: b[1]], flat_w[lo:hi], group=self.group, async_op=True))
-            except (RuntimeError, NotImplementedError):    # gloo fallback: zero the foreign slices and sum
+            else:                                          # gloo: zero the foreign slices and sum
                 seg = flat_w[b[0]: b[1]]
                 keep = flat_w[lo:hi].clone()
                 seg.zero_()

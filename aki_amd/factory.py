@@ -97,6 +97,7 @@ def create_model_and_transforms(clip_vision_encoder_path: str, clip_vision_encod
                                                  cache_dir=cache_dir)
     lm = Phi3ForCausalLM(hf_lm.config)
     lm.load_state_dict(hf_lm.state_dict(), strict=True)
+    lm.generation_config = getattr(hf_lm, "generation_config", None)
     del hf_lm, hf_vis
     if text_tokenizer.pad_token is None or text_tokenizer.pad_token == text_tokenizer.eos_token:
         text_tokenizer.add_special_tokens({"pad_token": "<pad>"})

@@ -39,6 +39,7 @@ def native_language_model(lang_model_path: str, **hf_kwargs) -> Phi3ForCausalLM:
     hf_lm = AutoModelForCausalLM.from_pretrained(lang_model_path, trust_remote_code=True, **hf_kwargs)
     lm = Phi3ForCausalLM(hf_lm.config)
     lm.load_state_dict(hf_lm.state_dict(), strict=True)
+    lm.generation_config = getattr(hf_lm, "generation_config", None)
     return lm
 
 
@@ -63,6 +64,7 @@ class AKI(VLMWithLanguageStream, PyTorchModelHubMixin):
             self.set_special_token_ids({v: tokenizer.convert_tokens_to_ids(v) for v in self.special_tokens.values()})
 
     set_trainable = _TrainTimeAKI.set_trainable
+    default_eos_token_ids = _TrainTimeAKI.default_eos_token_ids
     _should_apply_weight_decay = _TrainTimeAKI._should_apply_weight_decay
     forward = _TrainTimeAKI.forward          # src/modeling_aki.py:83-151 is identical to src/aki.py:65-134
     generate = _TrainTimeAKI.generate        # MMA prefill + HIP decode steps (aki_amd/aki.py)

@@ -592,6 +592,39 @@ def splice(lang_x: torch.Tensor, attention_mask: Optional[torch.Tensor], labels:
     return embeds, labels_out, MaskTable(rects, bits, seq_lens, L_out, mask_1d), plan_h
 
 
+def mask_to_table(mask: torch.Tensor, max_rects: int = L.AKI_MAX_RECTS, verify: bool = True) -> MaskTable:
+    """The reference's LM hand-off type - `attention_mask` (B,1,L,L) 0/1 as returned by `_prepare_inputs_for_forward`
+    (src/vlm.py:589-603) - converted on the device into a MaskTable.  The kernels extract a candidate (rectangles from the
+    right-of-diagonal row intervals, valid bits from the column-wise OR, seq_lens from the last non-empty row); with
+    `verify` the candidate is materialised again and compared with the input bit for bit, so a mask outside the family
+    {causal + row-interval rectangles + invalid columns} raises instead of being approximated (one host sync)."""
+    dev = _dev(mask)
+    if mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[2] != mask.shape[3]:
+        raise AkiError(f"mask_to_table: expected (B,1,L,L), got {tuple(mask.shape)}")
+    B, _, Lq, _ = mask.shape
+    m = mask if mask.dtype == torch.int64 else (mask != 0).to(torch.int64)
+    m = m.contiguous()
+    lib = L.load()
+    rects = torch.empty((B, max_rects, 4), dtype=torch.int32, device=dev)
+    bits = torch.empty((B, (Lq + 63) // 64), dtype=torch.int64, device=dev)
+    seq_lens = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws = _ws(lib.aki_mma_mask_to_table_workspace_bytes(B, Lq), dev)
+    L.check(lib.aki_mma_mask_to_table(_ptr(m), B, Lq, max_rects, _ptr(rects), _ptr(bits), _ptr(seq_lens), _ptr(status),
+                                      _ptr(ws), ws.numel(), _stream()), "aki_mma_mask_to_table")
+    table = MaskTable(rects, bits, seq_lens, Lq)
+    if verify:
+        st = status.cpu()
+        if int(st.max()) != 0:
+            b = int(st.argmax())
+            raise AkiError(f"dense attention mask: sample {b} needs {int(st[b])} row groups, more than the {max_rects} rectangles "
+                           "the MMA kernels take; pass an ops.MaskTable or a causal/padding mask")
+        if not torch.equal(mask_dense(table, B), (m != 0).to(torch.int64)):
+            raise AkiError("dense attention mask is not of the modality-mutual family (causal triangle + per-row column "
+                           "intervals + invalid columns); the MI355X path refuses it rather than approximating it")
+    return table
+
+
 def mask_dense(table: MaskTable, B: int) -> torch.Tensor:
     """The reference's (B,1,L,L) int64 0/1 mask, materialised from the table (bit-exact)."""
     dev = table.rects.device if table.rects is not None else table.col_valid_bits.device

@@ -27,7 +27,7 @@ def make_phi3_config(**kw):
     defaults = dict(vocab_size=32064, hidden_size=3072, intermediate_size=8192, num_hidden_layers=32,
                     num_attention_heads=32, num_key_value_heads=32, rms_norm_eps=1e-5, rope_theta=10000.0,
                     max_position_embeddings=4096, original_max_position_embeddings=4096, initializer_range=0.02,
-                    pad_token_id=32000, rope_scaling=None)
+                    pad_token_id=32000, bos_token_id=1, eos_token_id=32000, rope_scaling=None)
     defaults.update(kw)
     return SimpleNamespace(**defaults)
 
@@ -142,6 +142,9 @@ class DecodeGraph:
         cache.host_len = saved_host
 
     def step(self, ids: torch.Tensor) -> torch.Tensor:
+        if self.cache.host_len + 1 > self.cache.capacity:
+            raise ops.AkiError(f"KV cache is full: {self.cache.host_len} of {self.cache.capacity} rows used; size it with "
+                               "lang_model(..., use_cache=True, cache_capacity=prompt_len + max_new_tokens)")
         rot = self.lm.model.rotary_emb
         use_long = rot.short is not None and self.cache.host_len + 1 > rot.orig_max
         if self.graph is None or use_long != self._long:
@@ -310,6 +313,11 @@ class Phi3Model(nn.Module):
 
     def decode(self, inputs_embeds, cache):
         """inputs_embeds [B, d]: the embeddings of the tokens appended at index cache.cache_len[b]."""
+        if cache.host_len + 1 > cache.capacity and not torch.cuda.is_current_stream_capturing():
+            # host_len is a host-side upper bound of max(cache_len): the guard costs no sync.  The append kernels write row
+            # cache_len[b] and read cos/sin row cache_len[b] unconditionally - one step further corrupts the next (b, h) slab.
+            raise ops.AkiError(f"KV cache is full: {cache.host_len} of {cache.capacity} rows used; size it with "
+                               "lang_model(..., use_cache=True, cache_capacity=prompt_len + max_new_tokens)")
         cache.host_len += 1                         # host-side upper bound of max(cache_len)+1: no device sync per step
         cos, sin = self.rotary_emb.tables(cache.capacity, inputs_embeds.device, cache.host_len)
         # position of the new token = its cache row = number of tokens before it (cache.cache_len, on the device)
@@ -333,6 +341,7 @@ class Phi3ForCausalLM(nn.Module):
         self.model = Phi3Model(config)
         self.vocab_size = config.vocab_size
         self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.generation_config = None     # set from the checkpoint's generation_config.json by the loaders (eos ids for generate)
 
     # --- the accessors src/vlm.py:48,80-99 relies on -----------------------------------------------------
     def get_input_embeddings(self):
@@ -407,7 +416,7 @@ class Phi3ForCausalLM(nn.Module):
         """Prefill / full forward.  With use_cache=True the returned past_key_values is an AkiKVCache holding the
         rotated keys and the values of every layer (capacity = cache_capacity or L + 256)."""
         if past_key_values is not None:
-            raise NotImplementedError("continue from an existing cache with decode_step(); chunked prefill is not implemented")
+            return self._continue(input_ids, inputs_embeds, past_key_values, labels)
         if inputs_embeds is None:
             inputs_embeds = self.model.embed_tokens(input_ids)
         B, L, _ = inputs_embeds.shape
@@ -450,6 +459,21 @@ class Phi3ForCausalLM(nn.Module):
             loss = causal_lm_loss(logits, labels)
         return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache)
 
+    def _continue(self, input_ids, inputs_embeds, cache, labels=None):
+        """Text-only continuation from an AkiKVCache - the `past_key_values is not None` call of the reference
+        (src/vlm.py:463-475 -> src/aki.py:125-130 with `input_ids` only): the new tokens attend to everything cached plus
+        their own causal prefix, i.e. T teacher-forced decode steps.  Returns logits [B, T, V'] and the same cache."""
+        if not isinstance(cache, AkiKVCache):
+            raise ops.AkiError("past_key_values must be the AkiKVCache returned by a use_cache=True forward of this model")
+        if labels is not None:
+            raise NotImplementedError("labels with past_key_values: the loss is defined on the full forward only")
+        if inputs_embeds is None:
+            inputs_embeds = self.get_input_embeddings()(input_ids)
+        if inputs_embeds.dim() == 2:
+            inputs_embeds = inputs_embeds[:, None]
+        steps = [self.decode_step(inputs_embeds=inputs_embeds[:, t], past_key_values=cache) for t in range(inputs_embeds.shape[1])]
+        return CausalLMOutputWithPast(loss=None, logits=torch.stack(steps, dim=1), past_key_values=cache)
+
     def decode_step(self, input_ids=None, inputs_embeds=None, past_key_values=None):
         """One greedy-decoding step: new token ids [B] (or their embeddings [B, d]) -> logits [B, V'].  After the prefill
         the reference's mask is all ones (src/aki_generation.py:58-62): the token attends to everything cached."""
@@ -473,9 +497,19 @@ def causal_lm_loss(logits, labels, ignore_index=-100):
 
 
 def mask_table_from_tensor(mask: torch.Tensor, L: int) -> ops.MaskTable:
-    """Accept what a reference caller would pass: a 2-D (B,L) 0/1 padding mask becomes causal + valid bits.
-    A dense 4-D (B,1,L,L) mask is refused: the whole point of this path is that it is never materialised -
-    pass the ``MaskTable`` produced by ``_prepare_inputs_for_forward`` instead."""
+    """Accept what a reference caller passes as `attention_mask`:
+      * (B, L) 0/1 padding mask            -> causal + valid bits (HF semantics);
+      * (B, 1, L, L) 0/1 dense mask        -> the hand-off type of the reference (`_prepare_inputs_for_forward`,
+        src/vlm.py:589-603, consumed at src/aki.py:125-130).  It is converted ON THE DEVICE into the rectangle table and the
+        conversion is verified bit for bit (ops.mask_to_table); masks outside the modality-mutual family raise AkiError.
+    The attention kernels never see an L x L tensor either way."""
     if mask.dim() == 2:
         return ops.MaskTable.from_host([[(0, 0, 0, 0)]] * mask.shape[0], mask.detach().cpu().numpy(), None, mask.device)
-    raise ValueError("dense 4-D attention masks are not accepted by the MI355X path; pass an ops.MaskTable")
+    if mask.dim() == 4:
+        if mask.shape[-1] != L or mask.shape[-2] != L:
+            raise ValueError(f"attention_mask {tuple(mask.shape)} does not match the sequence length {L}")
+        if mask.is_floating_point() and bool((mask < 0).any()):
+            raise ValueError("additive (already inverted) 4-D masks are not accepted: pass the 0/1 mask the reference builds "
+                             "(src/vlm.py:438-443) - the finfo.min inversion of transformers 4.41.2 is part of the kernel")
+        return ops.mask_to_table(mask.detach())
+    raise ValueError(f"attention_mask must be an ops.MaskTable, a (B,L) or a (B,1,L,L) tensor; got {tuple(mask.shape)}")

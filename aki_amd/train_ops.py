@@ -190,6 +190,10 @@ def _weight_t(w: torch.Tensor) -> torch.Tensor:
     """W [N,K] -> W^T [K, pad64(N)] (zero padded), cached until the weights change: the trainer bumps the epoch after every
     optimizer step (its kernels write through raw pointers), in-place torch updates show up in `_version`.  Temporaries (the
     lm_head's concatenated weight is a new tensor every forward) would pile up without a trainer, hence the size cap."""
+    if not (isinstance(w, torch.nn.Parameter) or hasattr(w, "_aki_grad") or getattr(w, "_aki_cacheable", False)):
+        # a temporary (slice / concatenation built inside a forward): its (data_ptr, _version) says nothing about its content -
+        # the allocator recycles the address and a fresh tensor is always version 0 - so it is transposed every time
+        return transpose(w if w.stride(1) == 1 else w.contiguous())
     key = (w.data_ptr(), tuple(w.shape), w._version, _EPOCH)
     t = _WT.get(key)
     if t is None:

@@ -21,10 +21,13 @@ from .dp import FlatGradReducer
 
 class AkiTrainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
-                 max_grad_norm: float = 1.0, bucket_bytes: int = 512 << 20, group=None, shard_optimizer: bool = False):
+                 max_grad_norm: float = 1.0, bucket_bytes: int = 512 << 20, group=None, shard_optimizer: bool = False,
+                 exchange_when_alone: bool = False):
         """shard_optimizer: keep fp32 master weights and moments only for this rank's 1/world slice of every gradient
         bucket (reduce-scatter + all-gather instead of all-reduce) - the memory behaviour of the reference's FSDP launch
-        configs (train/distributed.py:170-243, scripts/run_train.sh:23) for the optimizer state."""
+        configs (train/distributed.py:170-243, scripts/run_train.sh:23) for the optimizer state.
+        exchange_when_alone: run the collectives even when the process group has a single rank (identities) - a one-GPU
+        box then exercises the real RCCL reduce-scatter / all-gather / all-reduce entry points and stream hand-off."""
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
@@ -33,7 +36,8 @@ class AkiTrainer:
             [p for p in model.parameters() if p.requires_grad], [])
         groups = [(list(wd), weight_decay), (list(nwd), 0.0)]
         dev = next(model.parameters()).device
-        self.shard = bool(shard_optimizer) and self.world > 1
+        alone = bool(exchange_when_alone) and dist.is_initialized()
+        self.shard = bool(shard_optimizer) and (self.world > 1 or alone)
         self.group = group
         # flat layout: [decay params | no-decay params], every parameter 16-byte aligned; when sharding, bucket ends (and
         # therefore segment ends) are padded to multiples of 8*world so every bucket splits evenly over the ranks
@@ -58,7 +62,8 @@ class AkiTrainer:
         self.w16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
         self.g16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
         self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.reducer = FlatGradReducer(self.g16, spans, bucket_bytes, group, shard=self.shard, breaks=breaks)
+        self.reducer = FlatGradReducer(self.g16, spans, bucket_bytes, group, shard=self.shard, breaks=breaks,
+                                       exchange_when_alone=alone)
         self.params = []
         self.span_of = {id(p): (lo, hi) for p, lo, hi in spans}
         for p, lo, hi in spans:

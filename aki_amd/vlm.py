@@ -150,7 +150,15 @@ class VLMWithLanguageStream(VLM):
                                     padding_side: str = "left", num_beams: int = 1):
         """src/vlm.py:445-603.  ``attention_mask`` in the returned dict is an ``ops.MaskTable``."""
         if past_key_values is not None:
-            raise NotImplementedError("KV-cache decode is SURVEY 8(f) item 1 (next)")
+            # src/vlm.py:463-468: the caller's mask must span the cached tokens (incl. image tokens) + the new ids
+            past_len = past_key_values.get_seq_length()
+            assert attention_mask is None or attention_mask.shape[1] == past_len + lang_x.shape[1], (
+                "Attention_mask must be as long as the entire past len (including image tokens) and current input IDs. "
+                "Check that you've expanded the attention mask to account for past image tokens.")
+            if vision_tokens is not None:
+                raise NotImplementedError("new images on top of an existing KV cache: the reference cannot do it either "
+                                          "(its mask for the new chunk would not cover the cached columns); start a new prefill")
+            return {"input_ids": lang_x, "attention_mask": None, "labels": labels}
         if vision_tokens is None:
             return {"input_ids": lang_x, "attention_mask": attention_mask, "labels": labels}
         emb = self.lang_model.get_input_embeddings()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 7
+#define AKI_ABI_VERSION 8
 
 typedef enum {
   AKI_OK = 0,
@@ -57,10 +57,6 @@ typedef enum {
 
 const char* aki_strerror(int status);
 int aki_abi_version(void);
-/* Test hook: force the bf16 GEMM tile configuration (0 = heuristic, 1 = 256x256, 2 = 128x128,
- * 3 = 128 features x 96 tokens where that tile exists - plain bf16 GEMMs - else 128x128); adding 256 switches off
- * the 4-stage / 64-feature variant that single-row launches (M <= 128) otherwise take.  Not thread safe. */
-void aki_debug_set_gemm_tile(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * Mask description.  The reference materialises a dense (B,1,L,L) int64 0/1 tensor
@@ -398,6 +394,20 @@ int aki_quant_rows_fp8(const void* x, const void* rms_weight, float rms_eps, voi
  * callers that still want it (bit-exact vs src/vlm.py:410-443 + src/utils.py:99-108). */
 int aki_mma_mask_dense(const aki_mma_rect* rects, int32_t max_rects, const uint64_t* col_valid_bits,
                        const int32_t* seq_lens, int32_t B, int32_t L, int64_t* out, void* stream);
+
+/* aki_mma_mask_to_table - the inverse: the reference's LM hand-off type, `attention_mask` (B,1,L,L) int64 0/1 as returned
+ * by `_prepare_inputs_for_forward` (src/vlm.py:589-603) and passed to `lang_model(...)` (src/aki.py:125-130), converted on
+ * the device into the table the attention kernels consume.
+ *   mask [B,1,L,L] int64 (non-zero = visible) -> rects [B][max_rects], col_valid_bits [B][ceil(L/64)], seq_lens [B],
+ *   status [B] device int32: 0 = ok, n > max_rects = the sample needs n row groups (its rects are then incomplete).
+ *   workspace: aki_mma_mask_to_table_workspace_bytes(B, L) bytes.
+ * The result is a CANDIDATE: only masks of the family {causal triangle + row-interval rectangles + invalid columns +
+ * empty bottom rows} are representable.  The caller proves it by materialising the table again with aki_mma_mask_dense
+ * and comparing with the input bit for bit (aki_amd/phi3.py does; anything else is refused, never approximated). */
+size_t aki_mma_mask_to_table_workspace_bytes(int32_t B, int32_t L);
+int aki_mma_mask_to_table(const int64_t* mask, int32_t B, int32_t L, int32_t max_rects, aki_mma_rect* rects,
+                          uint64_t* col_valid_bits, int32_t* seq_lens, int32_t* status, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 #ifdef __cplusplus
 }

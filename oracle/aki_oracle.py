@@ -154,6 +154,38 @@ def clamp_span(n: int, image_start: int, text_start: int, text_end: int) -> Tupl
     return (rs, re_, cs, ce)
 
 
+def mask_to_table(mask01: np.ndarray, max_rects: int = 8):
+    """Inverse of :func:`mask_from_spans` for the reference's LM hand-off type: one sample's dense (L, L) 0/1 mask
+    (what `_prepare_inputs_for_forward` returns, src/vlm.py:589-603, after stacking, src/utils.py:99-108) ->
+    (rects [(row_lo,row_hi,col_lo,col_hi)...], valid_cols bool [L], seq_len).  Build-defined helper (the reference has no
+    such function): it is pinned by the round trip through the reference's own masks - `mask_from_spans(valid, rects)`
+    restricted to rows < seq_len must give back `mask01` for every golden mask case (tests/test_oracle_golden.py).
+    Rules: valid(c) = any row sees c; seq_len = last non-empty row + 1; consecutive rows with the same right-of-diagonal
+    interval [lo, hi) form one rectangle, a row whose interval starts at r+1 (clipped by the diagonal) joins the run
+    above it.  Returns None when more than max_rects rectangles would be needed."""
+    m = np.asarray(mask01) != 0
+    L = m.shape[0]
+    valid = m.any(axis=0)
+    rows_any = m.any(axis=1)
+    seq_len = int(np.nonzero(rows_any)[0].max()) + 1 if rows_any.any() else 0
+    rects, run = [], None      # run = [start, lo, hi]
+    for r in range(L):
+        right = np.nonzero(m[r, r + 1:])[0]
+        has = len(right) > 0
+        lo, hi = (int(right[0]) + r + 1, int(right[-1]) + r + 2) if has else (0, 0)
+        joins = run is not None and has and hi == run[2] and (lo == run[1] or (lo == r + 1 and run[1] <= r))
+        if run is not None and not joins:
+            rects.append((run[0], r, run[1], run[2]))
+            run = None
+        if has and run is None:
+            run = [r, lo, hi]
+    if run is not None:
+        rects.append((run[0], L, run[1], run[2]))
+    if len(rects) > max_rects:
+        return None
+    return rects, valid, seq_len
+
+
 # ----------------------------------------------------------------------------------------------
 # a8: padding / stacking
 # ----------------------------------------------------------------------------------------------

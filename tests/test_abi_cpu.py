@@ -34,8 +34,93 @@ def test_library_exports_every_declared_symbol(lib):
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/aki_mi355x.h but not exported"
-    assert lib.aki_abi_version() == 7
+    assert lib.aki_abi_version() == 8
+    exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "debug" not in exported and "aki_lab_" not in exported, "lab / debug hooks must not ship in the product library"
     assert b"aligned" in lib.aki_strerror(-3)
+
+
+STRUCTS = {"aki_mma_rect": "MmaRect", "aki_mma_attn_core_args": "MmaAttnCoreArgs", "aki_mma_attn_args": "MmaAttnArgs",
+           "aki_attn_args": "AttnArgs", "aki_linear_args": "LinearArgs", "aki_splice_args": "SpliceArgs",
+           "aki_attn_bwd_args": "AttnBwdArgs"}
+
+
+def header_structs():
+    """{struct name: [field names in declaration order]} parsed out of include/aki_mi355x.h."""
+    src = open(os.path.join(ROOT, "include", "aki_mi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                fields.append(re.findall(r"(\w+)\s*$", part.strip())[0])
+        out[name] = fields
+    return out
+
+
+def c_layouts(tmp_path):
+    """sizeof / offsetof of every args struct as the C compiler sees the header: {struct: (size, {field: (offset, size)})}."""
+    structs = header_structs()
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "aki_mi355x.h"', "int main(void) {"]
+    for sname, fields in structs.items():
+        lines.append(f'  printf("S {sname} %zu\\n", sizeof({sname}));')
+        for f in fields:
+            lines.append(f'  printf("F {sname} {f} %zu %zu\\n", offsetof({sname}, {f}), sizeof((({sname}*)0)->{f}));')
+    lines += ["  return 0;", "}"]
+    csrc = tmp_path / "layout.c"
+    csrc.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(csrc), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    lay = {}
+    for ln in out.splitlines():
+        t = ln.split()
+        if t[0] == "S":
+            lay[t[1]] = (int(t[2]), {})
+        else:
+            lay[t[1]][1][t[2]] = (int(t[3]), int(t[4]))
+    return structs, lay
+
+
+def assert_same_layout(cls, sname, fields, lay):
+    size, offs = lay[sname]
+    assert [f for f, _ in cls._fields_] == fields, f"{cls.__name__}: field names / order differ from {sname}"
+    assert C.sizeof(cls) == size, f"{cls.__name__}: {C.sizeof(cls)} bytes, header says {size}"
+    for f, ct in cls._fields_:
+        d = getattr(cls, f)
+        assert (d.offset, d.size) == offs[f], f"{cls.__name__}.{f}: ctypes (offset, size) {(d.offset, d.size)} vs C {offs[f]}"
+
+
+def integration_md_binding():
+    """The python block of INTEGRATION.md section B, verbatim."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blk = md[md.index("<!-- BEGIN mi355x_binding.py -->"):md.index("<!-- END mi355x_binding.py -->")]
+    return blk[blk.index("```python") + len("```python"):blk.rindex("```")]
+
+
+def test_struct_layouts_match_the_header(lib, tmp_path, monkeypatch):
+    """Every args struct: the ctypes mirror in aki_amd/_lib.py AND the one a maintainer would paste from INTEGRATION.md
+    against sizeof/offsetof of a C program compiled from the header (round-1 shipped a stale 128-byte MmaAttnArgs in the
+    document while the library read kv_capacity at offset 128)."""
+    from aki_amd import _lib
+    structs, lay = c_layouts(tmp_path)
+    assert set(structs) == set(STRUCTS), "a struct was added to the header: mirror it in _lib.py and list it here"
+    for sname, cname in STRUCTS.items():
+        assert_same_layout(getattr(_lib, cname), sname, structs[sname], lay)
+    assert lay["aki_mma_attn_args"][0] == 152 and lay["aki_mma_attn_args"][1]["kv_capacity"][0] == 128
+    monkeypatch.setenv("AKI_MI355X_SO", _lib.LIB_PATH)
+    ns = {}
+    exec(compile(integration_md_binding(), "INTEGRATION.md#B", "exec"), ns)     # loads the library, binds the prototypes
+    assert_same_layout(ns["MmaAttnArgs"], "aki_mma_attn_args", structs["aki_mma_attn_args"], lay)
+    for fn, (res, args) in _lib.SIGNATURES.items():          # prototypes the document binds must agree with _lib.py
+        bound = getattr(ns["_lib"], fn)
+        if bound.argtypes is not None:
+            assert len(bound.argtypes) == len(args), fn
+            assert [C.sizeof(a) for a in bound.argtypes] == [C.sizeof(a) for a in args], fn
 
 
 def test_host_side_validation_without_gpu(lib):

@@ -136,6 +136,74 @@ def test_generate_stops_at_eos_and_pads():
         m.generate(vx, lx, attention_mask=am, num_beams=4)
 
 
+def test_generate_default_eos_comes_from_the_language_model_config():
+    """The reference's callers pass only max_new_tokens / do_sample (local_demo.py:76-87, eval_cv_bench/eval.py:99-104) and
+    HF `generate` stops on generation_config.eos_token_id: so must the drop-in, without an eos_token_id argument."""
+    from types import SimpleNamespace
+    m, g = build_tiny(torch.float32)
+    vx, lx, am, _ = batch(g, torch.float32)
+    pad = gen.TINY["pad_token_id"]
+    free = m.generate(vx, lx, attention_mask=am, max_new_tokens=6, eos_token_id=[])       # explicit "no EOS": all 6 tokens
+    assert free.shape[1] == 6
+    m.lang_model.config.eos_token_id = int(free[0, 1])         # config.json style (one id)
+    assert m.default_eos_token_ids() == [int(free[0, 1])]
+    toks = m.generate(vx, lx, attention_mask=am, max_new_tokens=6)
+    assert toks[0, :2].tolist() == free[0, :2].tolist() and bool((toks[0, 2:] == pad).all())
+    # generation_config.json style (a list) takes precedence, like HF
+    m.lang_model.generation_config = SimpleNamespace(eos_token_id=sorted(set(free[:, 0].tolist())))
+    toks = m.generate(vx, lx, attention_mask=am, max_new_tokens=6)
+    assert toks.shape[1] == 1 and toks[:, 0].tolist() == free[:, 0].tolist()
+
+
+def test_decode_past_cache_capacity_raises():
+    """decoding past the cache capacity used to write into the next (batch, head) slab silently."""
+    from aki_amd import AkiError
+    from aki_amd.phi3 import DecodeGraph
+    m, g = build_tiny(torch.float32)
+    vx, lx, am, _ = batch(g, torch.float32)
+    with torch.no_grad():
+        prep = m._prepare_inputs_for_forward(vision_tokens=m.vision_tokenizer(m._encode_vision_x(vx)), lang_x=lx, attention_mask=am,
+                                             padding_side="right")
+        L = prep["inputs_embeds"].shape[1]
+        out = m.lang_model(inputs_embeds=prep["inputs_embeds"], attention_mask=prep["attention_mask"], use_cache=True, cache_capacity=L + 2)
+        cache = out.past_key_values
+        nxt = out.logits[:, -1].argmax(-1)
+        for _ in range(2):
+            nxt = m.lang_model.decode_step(input_ids=nxt, past_key_values=cache).argmax(-1)
+        guard = cache.k[0].clone()
+        with pytest.raises(AkiError, match="KV cache is full"):
+            m.lang_model.decode_step(input_ids=nxt, past_key_values=cache)
+        with pytest.raises(AkiError, match="KV cache is full"):
+            DecodeGraph(m.lang_model, cache).step(nxt)
+        assert torch.equal(guard, cache.k[0]) and cache.host_len == L + 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_forward_continues_from_past_key_values(dtype):
+    """`model(vision_x=None, lang_x=new_ids, past_key_values=cache)` - the continuation call of the reference
+    (src/vlm.py:463-475, src/aki.py:125-130): logits of the new tokens == a fresh full forward over prompt + new tokens."""
+    m, g = build_tiny(dtype)
+    vx, lx, am, _ = batch(g, dtype)
+    b = 0
+    nreal = int(am[b].sum())
+    ids = lx[b:b + 1, :nreal]
+    new = torch.tensor([[17, 93, 5]], device=DEV)
+    with torch.no_grad():
+        first = m(vx[b:b + 1], ids, attention_mask=torch.ones_like(ids), use_cache=True)
+        cache = first.past_key_values
+        past_len = cache.get_seq_length()
+        mask = torch.ones((1, past_len + new.shape[1]), dtype=torch.long, device=DEV)
+        cont = m(None, new, attention_mask=mask, past_key_values=cache)
+        full = m(vx[b:b + 1], torch.cat([ids, new], 1), attention_mask=torch.ones((1, nreal + 3), dtype=torch.long, device=DEV))
+        with pytest.raises(AssertionError):
+            m(None, new, attention_mask=mask[:, :-1], past_key_values=cache)
+    assert cont.logits.shape == (1, 3, full.logits.shape[-1]) and cont.past_key_values is cache
+    assert cache.get_seq_length() == past_len + 3
+    err = (cont.logits.float() - full.logits[:, -3:].float()).abs().max().item()
+    tol = (2e-4 if dtype == torch.float32 else 3e-2) * max(1.0, full.logits.float().abs().max().item())
+    assert err <= tol, f"continuation vs full forward: {err:.3g} > {tol:.3g}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_generate_graph_replay_equals_eager(dtype):
     """hipGraph replay of the decode step must give exactly the tokens of eager launches (same kernels, same order)."""

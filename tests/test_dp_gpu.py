@@ -45,9 +45,55 @@ def _worker(rank, world, port, shard, ret):
     assert len(tr.reducer.buckets) >= 3 and tr.shard == shard
     sl = slice(2 * rank, 2 * rank + 2)
     losses = [float(tr.train_step(vx[sl], lx[sl], attention_mask=am[sl], labels=lab[sl])) for _ in range(2)]
-    ret[rank] = (tr.w16.float().cpu(), losses, float(tr.grad_norm()))
+    ret[rank] = (_weights_in_param_order(tr), losses, float(tr.grad_norm()))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _weights_in_param_order(tr):
+    """The bf16 weights as one vector in the trainer's parameter order (the flat buffers of a sharded and an unsharded
+    trainer differ by alignment padding, the parameters do not)."""
+    return torch.cat([p.detach().float().reshape(-1).cpu() for p in tr.params])
+
+
+def _rccl_alone_worker(rank, port, shard, ret):
+    """One rank, backend "nccl" (= RCCL): the collectives are identities but they are the REAL entry points -
+    reduce_scatter_tensor / all_gather_into_tensor / all_reduce on slices that HIP kernels wrote on the compute stream."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from aki_amd.trainer import AkiTrainer
+    m, vx, lx, am, lab = _setup()
+    tr = AkiTrainer(m, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1, bucket_bytes=1 << 20, shard_optimizer=shard, exchange_when_alone=True)
+    assert tr.reducer.active and not tr.reducer.no_scatter and tr.shard == shard and len(tr.reducer.buckets) >= 3
+    launched = []
+    orig = tr.reducer._launch
+    tr.reducer._launch = lambda b: (launched.append(torch.cuda.current_stream().query()), orig(b))[1]
+    losses = [float(tr.train_step(vx, lx, attention_mask=am, labels=lab)) for _ in range(2)]
+    torch.cuda.synchronize()
+    ret["rccl"] = (_weights_in_param_order(tr), losses, float(tr.grad_norm()), len(launched))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("shard", [False, True], ids=["allreduce", "sharded"])
+def test_rccl_entry_points_on_one_gpu(shard):
+    """The exchange through backend "nccl" (RCCL) with a world of one: same weights, bit for bit, as a trainer that runs
+    no collective at all.  This is the stream hand-off gloo cannot test: RCCL reads the gradient slices on its own stream
+    right after the wgrad GEMMs wrote them on the compute stream."""
+    from aki_amd.trainer import AkiTrainer
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_alone_worker, args=(_free_port(), shard, ret), nprocs=1, join=True)
+    w, losses, gnorm, n_launch = ret["rccl"]
+    m, vx, lx, am, lab = _setup()
+    tr = AkiTrainer(m, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1, bucket_bytes=1 << 20)   # same buckets -> same summation order of the norm
+    ref_losses = [float(tr.train_step(vx, lx, attention_mask=am, labels=lab)) for _ in range(2)]
+    assert n_launch >= 2 * 3, "the buckets were not exchanged"
+    assert losses == ref_losses and gnorm == float(tr.grad_norm())
+    assert torch.equal(w, _weights_in_param_order(tr))
 
 
 @pytest.mark.timeout(300)
@@ -63,14 +109,12 @@ def test_two_rank_training_matches_single_process(shard):
     m, vx, lx, am, lab = _setup()
     tr = AkiTrainer(m, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1)
     ref_losses = [float(tr.train_step(vx, lx, attention_mask=am, labels=lab)) for _ in range(2)]
-    wref = tr.w16.float().cpu()
-    # same flat layout only without sharding padding: compare through the parameters' own order
+    wref = _weights_in_param_order(tr)
     assert abs(sum(l0) / 2 + sum(l1) / 2 - sum(ref_losses)) < 2e-2 * abs(sum(ref_losses))
     assert abs(g0 - float(tr.grad_norm())) < 0.05 * float(tr.grad_norm()) + 1e-3
-    if not shard:
-        diff = (w0 - wref).abs()
-        # the compared weights are the bf16 images: one ulp at |w| in [1, 2) is 2^-7
-        assert float(diff.mean()) < 2e-4 and float(diff.max()) <= 2 * 2 ** -7, (float(diff.mean()), float(diff.max()))
+    diff = (w0 - wref).abs()      # both exchange modes, compared in parameter order
+    # the compared weights are the bf16 images: one ulp at |w| in [1, 2) is 2^-7
+    assert float(diff.mean()) < 2e-4 and float(diff.max()) <= 2 * 2 ** -7, (float(diff.mean()), float(diff.max()))
 
 
 def test_bench_contract_two_ranks_on_one_gpu():

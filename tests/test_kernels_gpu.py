@@ -67,12 +67,15 @@ DTYPES = [torch.bfloat16, torch.float32]
 # ------------------------------------------------------------------------------------------------
 @pytest.fixture(params=[0, 1, 2, 3], ids=["tile-auto", "tile-256", "tile-128", "tile-128x96"])
 def gemm_tile(request):
-    """Run the bf16 GEMM tests under the heuristic and with each tile configuration forced."""
+    """Run the bf16 GEMM tests under the heuristic (product library) and with each tile configuration forced - the forcing
+    switch exists only in the lab twin of the library (libaki_mi355x_lab.so: same sources + aki_lab_set_gemm_tile)."""
     from aki_amd import _lib
-    lib = _lib.load()
-    lib.aki_debug_set_gemm_tile(request.param)
-    yield request.param
-    lib.aki_debug_set_gemm_tile(0)
+    if request.param == 0:
+        _lib.load()
+        yield 0
+        return
+    with _lib.use_lab(request.param):
+        yield request.param
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -465,6 +468,103 @@ def test_mask_dense_all_reference_cases():
         table = ops.MaskTable.from_host([[O.clamp_span(nn, s, tt, e)]], am[None], None, DEV)
         dense = ops.mask_dense(table, 1).cpu().numpy()
         assert np.array_equal(dense[0], gen.unpack_mask_bits(g[f"bits_{i}"], (1, nn, nn))), f"mask case {i}"
+
+
+def test_mask_to_table_all_reference_cases():
+    """The reference's hand-off type (dense (B,1,L,L) int64 0/1, src/vlm.py:589-603) -> table -> dense is the identity
+    on every mask the reference itself generated (31 golden cases), alone and stacked into padded batches the way
+    stack_with_padding_2D_attention does (zero rows / columns at the bottom / right)."""
+    ops = _ops()
+    g = load_golden("mask_cases.npz")
+    cases = gen.mask_cases()
+    dense = [gen.unpack_mask_bits(g[f"bits_{i}"], (1, len(c[0]), len(c[0])))[0].astype(np.int64) for i, c in enumerate(cases)]
+    for i, d in enumerate(dense):
+        m = torch.from_numpy(d)[None, None].to(DEV)
+        table = ops.mask_to_table(m)
+        assert torch.equal(ops.mask_dense(table, 1), m), f"mask case {i}"
+        rects, valid, seq_len = O.mask_to_table(d)                      # the oracle's restatement of the conversion
+        assert [r for r in table.rects[0].tolist() if r != [0, 0, 0, 0]] == [list(r) for r in rects], f"mask case {i}"
+        assert int(table.seq_lens[0]) == seq_len
+        want_bits = ops.MaskTable.from_host([[]], valid[None], None, DEV).col_valid_bits
+        assert torch.equal(table.col_valid_bits, want_bits), f"mask case {i}"
+    Lmax = max(d.shape[0] for d in dense)
+    stacked = np.zeros((len(dense), 1, Lmax, Lmax), dtype=np.int64)
+    for i, d in enumerate(dense):
+        stacked[i, 0, :d.shape[0], :d.shape[0]] = d
+    m = torch.from_numpy(stacked).to(DEV)
+    table = ops.mask_to_table(m, max_rects=1)              # the reference's masks need exactly one rectangle
+    assert torch.equal(ops.mask_dense(table, len(dense)), m)
+    # other dtypes a caller may hold the same mask in
+    for dt in (torch.bool, torch.int32, torch.float32, torch.bfloat16):
+        assert torch.equal(ops.mask_dense(ops.mask_to_table(m.to(dt)), len(dense)), m)
+
+
+def test_mask_to_table_multi_image_and_rejections():
+    ops = _ops()
+    L = 200
+    am = np.ones((2, L), dtype=bool)
+    am[1, 150:] = False
+    rects = [[(4, 20, 20, 120), (30, 46, 46, 120), (60, 76, 76, 120)], [(0, 16, 16, 90)]]
+    t0 = ops.MaskTable.from_host(rects, am, [L, 170], DEV)
+    dense = ops.mask_dense(t0, 2)
+    t1 = ops.mask_to_table(dense)
+    assert torch.equal(ops.mask_dense(t1, 2), dense)
+    assert t1.rects[0, :3].tolist() == [list(r) for r in rects[0]] and t1.seq_lens.tolist() == [L, 170]
+    # a rectangle that dips below the diagonal (col_lo < row_hi) is still one rectangle
+    t2 = ops.MaskTable.from_host([[(10, 40, 20, 100)]], np.ones((1, L), dtype=bool), None, DEV)
+    d2 = ops.mask_dense(t2, 1)
+    assert torch.equal(ops.mask_dense(ops.mask_to_table(d2, max_rects=1), 1), d2)
+    # outside the family: a hole in the causal triangle, a two-interval row, too many row groups
+    bad = dense.clone(); bad[0, 0, 100, 50] = 0
+    with pytest.raises(ops.AkiError):
+        ops.mask_to_table(bad)
+    bad = dense.clone(); bad[0, 0, 10, 130:140] = 1
+    with pytest.raises(ops.AkiError):
+        ops.mask_to_table(bad)
+    with pytest.raises(ops.AkiError):
+        ops.mask_to_table(dense, max_rects=2)
+    full = torch.ones((1, 1, 64, 64), dtype=torch.int64, device=DEV)      # bidirectional = one rectangle under the diagonal rule
+    tf = ops.mask_to_table(full, max_rects=1)
+    assert tf.rects[0, 0].tolist() == [0, 63, 1, 64] and torch.equal(ops.mask_dense(tf, 1), full)
+    stair = torch.tril(torch.ones((64, 64), dtype=torch.int64, device=DEV))
+    for r in range(0, 30, 2):
+        stair[r, r + 1:r + 3 + r] = 1                                       # one row group per row: 15 > 8
+    with pytest.raises(ops.AkiError):
+        ops.mask_to_table(stair[None, None])
+
+
+def test_integration_md_binding_runs_verbatim(monkeypatch):
+    """INTEGRATION.md section B, executed as written: the dense mask of the reference -> table, then the fused MMA op
+    through the document's own ctypes structure; must equal aki_amd.ops on the same inputs bit for bit."""
+    from test_abi_cpu import integration_md_binding
+    from aki_amd import _lib
+    from types import SimpleNamespace
+    ops = _ops()
+    _lib.load()
+    monkeypatch.setenv("AKI_MI355X_SO", _lib.LIB_PATH)
+    ns = {}
+    exec(compile(integration_md_binding(), "INTEGRATION.md#B", "exec"), ns)
+    rng = gen.rng_for("integration_md")
+    B, L, H, Dh = 2, 150, 4, 96
+    d = H * Dh
+    am = np.ones((B, L), dtype=bool); am[1, 130:] = False
+    t0 = ops.MaskTable.from_host([[(5, 21, 21, 100)], [(3, 19, 19, 80)]], am, [L, 140], DEV)
+    dense = ops.mask_dense(t0, B)
+    x = t(rng.standard_normal((B, L, d), dtype=np.float32), torch.bfloat16)
+    wqkv = t(rng.standard_normal((3 * d, d), dtype=np.float32) * 0.05, torch.bfloat16)
+    wo = t(rng.standard_normal((d, d), dtype=np.float32) * 0.05, torch.bfloat16)
+    cos, sin = O.rope_cos_sin(np.arange(L)[None], Dh)
+    tc, ts = torch.from_numpy(cos).to(DEV), torch.from_numpy(sin).to(DEV)
+    module = SimpleNamespace(config=SimpleNamespace(num_attention_heads=H), head_dim=Dh, qkv_proj=SimpleNamespace(weight=wqkv),
+                             o_proj=lambda o: ops.linear(o, wo))
+    rects, bits, seq_lens = ns["mask_table"](dense)
+    got = ns["mma_attention"](module, x, tc, ts, rects, bits, seq_lens)
+    want = ops.linear(ops.mma_attn(x, wqkv, tc[0], ts[0], t0, H), wo)
+    assert torch.equal(got, want)
+    holed = dense.clone()
+    holed[0, 0, 60, 30] = 0                       # a hole inside the causal triangle: not an MMA mask
+    with pytest.raises(ValueError):
+        ns["mask_table"](holed)
 
 
 def test_splice_multi_image_build_defined():

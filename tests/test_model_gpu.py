@@ -84,6 +84,41 @@ def test_tiny_aki_forward_bf16_vs_reference():
     assert abs(float(out.loss) - float(g["loss"])) < 2e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lang_model_accepts_the_reference_dense_mask_bit_exact(dtype):
+    """The reference hands `attention_mask (B,1,L,L) int64 0/1` to lang_model (src/vlm.py:589-603 -> src/aki.py:125-130).
+    Passing that dense tensor - here the reference's OWN mask from the golden file - must give exactly the logits of the
+    MaskTable path: it is converted on the device (aki_mma_mask_to_table), verified, and runs the same kernels."""
+    from aki_amd import ops
+    m, g = build_tiny(dtype)
+    vx, lx, am, lab = batch(g, dtype)
+    B = lx.shape[0]
+    with torch.no_grad():
+        prep = m._prepare_inputs_for_forward(vision_tokens=m.vision_tokenizer(m._encode_vision_x(vx)), lang_x=lx,
+                                             attention_mask=am, labels=lab, padding_side="right")
+        dense = torch.from_numpy(gen.unpack_mask_bits(g["mask_bits"], tuple(g["mask_shape"])).astype(np.int64)).to(DEV)
+        assert dense.shape == (B, 1, prep["inputs_embeds"].shape[1], prep["inputs_embeds"].shape[1])
+        via_table = m.lang_model(inputs_embeds=prep["inputs_embeds"], attention_mask=prep["attention_mask"], labels=prep["labels"])
+        via_dense = m.lang_model(inputs_embeds=prep["inputs_embeds"], attention_mask=dense, labels=prep["labels"])
+    assert torch.equal(via_table.logits, via_dense.logits)
+    assert torch.equal(via_table.loss, via_dense.loss)
+    got = ops.mask_to_table(dense)
+    want = prep["attention_mask"]
+    assert torch.equal(got.col_valid_bits, want.col_valid_bits) and torch.equal(got.seq_lens, want.seq_lens)
+    # KV-cache prefill through the dense mask, too
+    with torch.no_grad():
+        c1 = m.lang_model(inputs_embeds=prep["inputs_embeds"], attention_mask=dense, use_cache=True).past_key_values
+        c2 = m.lang_model(inputs_embeds=prep["inputs_embeds"], attention_mask=want, use_cache=True).past_key_values
+    assert torch.equal(c1.cache_len, c2.cache_len) and torch.equal(c1.k[1][:, :, :4], c2.k[1][:, :, :4])
+    # what the family does not contain is refused, never approximated
+    bad = dense.clone()
+    bad[0, 0, 5, 2] = 0
+    with torch.no_grad(), pytest.raises(ops.AkiError):
+        m.lang_model(inputs_embeds=prep["inputs_embeds"], attention_mask=bad)
+    with torch.no_grad(), pytest.raises(ValueError):
+        m.lang_model(inputs_embeds=prep["inputs_embeds"], attention_mask=(1.0 - dense.float()) * -1e9)
+
+
 def test_reference_api_behaviour():
     m, g = build_tiny(torch.float32)
     vx, lx, am, lab = batch(g, torch.float32)

@@ -200,3 +200,36 @@ def test_torch_oracle_gradients_match_reference_backward():
         scale = max(float(gg["abss"][i]) / gr.numel(), 1e-8)
         np.testing.assert_allclose(got, want, atol=2e-3 * scale + 1e-9, rtol=2e-3, err_msg=n_)
         assert abs(float(gr.double().abs().sum()) - float(gg["abss"][i])) <= 1e-3 * float(gg["abss"][i]) + 1e-9, n_
+
+
+def test_mask_to_table_round_trips_every_reference_mask():
+    """oracle.mask_to_table (the restatement the HIP converter aki_mma_mask_to_table is checked against) inverts the
+    reference's `_make_modality_mutual_mask` on all golden cases: table -> dense gives the reference's mask back."""
+    g = load_golden("mask_cases.npz")
+    for i, (am, s, t, e) in enumerate(gen.mask_cases()):
+        n = len(am)
+        dense = gen.unpack_mask_bits(g[f"bits_{i}"], (1, n, n))[0]
+        out = O.mask_to_table(dense, max_rects=1)
+        assert out is not None, i
+        rects, valid, seq_len = out
+        back = O.mask_from_spans(valid.astype(np.int64), rects)[0].copy()
+        back[seq_len:] = 0
+        assert np.array_equal(back, dense), i
+        want = O.clamp_span(n, s, t, e)
+        if rects:      # the rectangle covers the reference's slice assignment up to columns nobody can see / the diagonal
+            (r0, r1, c0, c1), = rects
+            assert want[0] <= r0 and r1 <= want[1] and c1 <= want[3], (i, rects, want)
+    # multi-image (build-defined) and a rectangle dipping below the diagonal
+    am = np.ones(60, dtype=np.int64)
+    for rr in ([(2, 10, 10, 40), (12, 20, 20, 40)], [(5, 30, 12, 50)]):
+        dense = O.mask_from_spans(am, rr)[0]
+        rects, valid, seq_len = O.mask_to_table(dense)
+        assert np.array_equal(O.mask_from_spans(valid.astype(np.int64), rects)[0], dense) and seq_len == 60
+    # a bidirectional mask is ONE rectangle whose lower part the causal triangle already covers
+    rects, valid, seq_len = O.mask_to_table(np.ones((40, 40), dtype=np.int64), max_rects=1)
+    assert rects == [(0, 39, 1, 40)] and valid.all() and seq_len == 40
+    # lookahead windows of different widths: one row group per row -> not representable
+    stair = np.tril(np.ones((40, 40), dtype=np.int64))
+    for r in range(0, 20, 2):
+        stair[r, r + 1:r + 3 + r] = 1
+    assert O.mask_to_table(stair, max_rects=8) is None
