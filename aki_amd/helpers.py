@@ -149,31 +149,38 @@ class PerceiverResampler(VisionTokenizer):
         return ops.layernorm(latents, self.norm.weight, self.norm.bias, self.norm.eps)
 
 
+def _table_dims(given: Optional[torch.Tensor], declared_rows, declared_cols, what: str):
+    """(rows, cols) of a parameter table that is either handed over ready-made or described by its two sizes."""
+    if given is None:
+        if declared_rows is None or declared_cols is None:
+            raise AssertionError(f"{what}: without a ready-made tensor both sizes have to be given")
+        return int(declared_rows), int(declared_cols)
+    rows, cols = given.shape
+    for declared, actual in ((declared_rows, rows), (declared_cols, cols)):
+        if declared is not None and declared != actual:
+            raise AssertionError(f"{what}: the tensor is {rows} x {cols}, which contradicts the declared size {declared}")
+    return int(rows), int(cols)
+
+
 class DecoupledEmbedding(nn.Embedding):
-    """src/helpers.py:350-492.  The lookup itself happens inside the splice kernel (aki_splice_fwd); this
-    module keeps the parameters (``weight``, ``additional_embedding.weight``) and a standalone forward."""
+    """Embedding table split into the tokenizer's original rows (`weight`, frozen by default) and the rows of the special
+    tokens added for AKI (`additional_embedding.weight`, always trainable) - parameter names and constructor arguments of
+    src/helpers.py:350-492, because checkpoints and `VLM.__init__` depend on them.  On the product path the lookup happens
+    inside the splice kernel (aki_splice_fwd reads both tables); `forward` is the standalone form of the same gather."""
 
     def __init__(self, max_original_id: int, num_additional_embeddings: int = 0, _weight: torch.Tensor = None,
                  num_original_embeddings: int = None, embedding_dim: int = None, partially_freeze=True, device=None,
                  dtype=None, pad_token_id=None) -> None:
         if pad_token_id is not None and pad_token_id > max_original_id:
-            raise ValueError(f"pad_token_id must be <= max_original_id. Got {pad_token_id} and {max_original_id}."
-                             + "If the original tokenizer does not have a pad_token_id, use pad_token_id=None.")
-        if _weight is not None:
-            assert (num_original_embeddings is None) or (_weight.shape[0] == num_original_embeddings)
-            assert (embedding_dim is None) or (_weight.shape[1] == embedding_dim)
-            num_original_embeddings, embedding_dim = _weight.shape
-        else:
-            assert num_original_embeddings is not None, "num_original_embeddings must be provided if _weight is not provided"
-            assert embedding_dim is not None, "embedding_dim must be provided if _weight is not provided"
-        super().__init__(num_embeddings=num_original_embeddings, embedding_dim=embedding_dim, device=device, dtype=dtype,
-                         padding_idx=pad_token_id, _weight=_weight)
+            raise ValueError(f"pad_token_id={pad_token_id} lies beyond max_original_id={max_original_id}: the padding row has "
+                             "to be one of the original rows (pass pad_token_id=None for a tokenizer without a pad token)")
+        rows, width = _table_dims(_weight, num_original_embeddings, embedding_dim, "DecoupledEmbedding")
+        super().__init__(rows, width, padding_idx=pad_token_id, _weight=_weight, device=device, dtype=dtype)
         self.max_original_id = max_original_id
         self.padding_idx = pad_token_id
         self.num_additional_embeddings = num_additional_embeddings
-        if self.num_additional_embeddings > 0:
-            self.additional_embedding = nn.Embedding(num_embeddings=self.num_additional_embeddings,
-                                                     embedding_dim=embedding_dim, device=device, dtype=dtype)
+        if num_additional_embeddings > 0:
+            self.additional_embedding = nn.Embedding(num_additional_embeddings, width, device=device, dtype=dtype)
         self.set_requires_grad(require_regular_grad=not partially_freeze, require_additional_grad=True)
 
     def set_requires_grad(self, require_regular_grad, require_additional_grad):
@@ -190,47 +197,40 @@ class DecoupledEmbedding(nn.Embedding):
         return torch.where(hi[..., None], add, full)
 
     def extra_repr(self) -> str:
-        return "num_original_embeddings={}, num_additional_embeddings={}, embedding_dim={}, partially_freeze={}".format(
-            self.max_original_id + 1, self.num_additional_embeddings, self.embedding_dim, (not self.weight.requires_grad))
+        frozen = "frozen" if not self.weight.requires_grad else "trainable"
+        return (f"{self.max_original_id + 1} original rows ({frozen}) + {self.num_additional_embeddings} additional rows, "
+                f"width {self.embedding_dim}")
 
 
 class DecoupledLinear(nn.Linear):
-    """src/helpers.py:495-613: logits = (x W^T)[..., :max_original_id+1] ++ x W_add^T.  Executed as ONE HIP
-    GEMM over the row-concatenated weight (rebuilt only when a parameter changes)."""
+    """Output head split the same way (src/helpers.py:495-613): logits = (x W^T)[..., :max_original_id+1] ++ x W_add^T with
+    `weight` / `bias` for the original vocabulary and `additional_fc` for the added tokens.  Executed as ONE HIP GEMM over
+    the row-concatenated weight, which is rebuilt only when a parameter changes."""
 
     def __init__(self, max_original_id: int, additional_out_features: int = 0, _weight: torch.Tensor = None,
                  _bias: torch.Tensor = None, in_features: int = None, original_out_features: int = None, bias: bool = True,
                  partially_freeze: bool = True, device=None, dtype=None) -> None:
-        if _weight is not None:
-            assert (_weight.shape[0] == original_out_features) or (original_out_features is None)
-            assert (_weight.shape[1] == in_features) or (in_features is None)
-            in_features = _weight.shape[1]
-            original_out_features = _weight.shape[0]
-        else:
-            assert in_features is not None, "in_features must be provided if _weight is not provided"
-            assert original_out_features is not None, "original_out_features must be provided if _weight is not provided"
-        if _bias is not None:
-            assert bias is True, "bias must be True if _bias is provided"
-        super().__init__(in_features, original_out_features, bias, device, dtype)
+        n_out, n_in = _table_dims(_weight, original_out_features, in_features, "DecoupledLinear")
+        if _bias is not None and not bias:
+            raise AssertionError("DecoupledLinear: a bias tensor was handed over although bias=False")
+        super().__init__(n_in, n_out, bias, device, dtype)
         if _weight is not None:
             self.weight = nn.Parameter(_weight)
         if _bias is not None:
             self.bias = nn.Parameter(_bias)
-        self.in_features = in_features
-        self.original_out_features = original_out_features
+        self.in_features, self.original_out_features = n_in, n_out
         self.max_original_id = max_original_id
         self.additional_out_features = additional_out_features
         self.has_bias = bias
         if additional_out_features > 0:
-            self.additional_fc = nn.Linear(in_features=in_features, out_features=additional_out_features, bias=self.has_bias,
-                                           device=device, dtype=dtype)
+            self.additional_fc = nn.Linear(n_in, additional_out_features, bias=bias, device=device, dtype=dtype)
         self.set_requires_grad(require_regular_grad=not partially_freeze, require_additional_grad=True)
         self._fused = None
 
     def set_requires_grad(self, require_regular_grad, require_additional_grad):
-        self.weight.requires_grad_(require_regular_grad)
-        if self.has_bias:
-            self.bias.requires_grad_(require_regular_grad)
+        for p in (self.weight, self.bias if self.has_bias else None):
+            if p is not None:
+                p.requires_grad_(require_regular_grad)
         self.additional_fc.requires_grad_(require_additional_grad)
 
     def _fused_weight(self):
@@ -265,6 +265,6 @@ class DecoupledLinear(nn.Linear):
         return ops.decode_linear(input, w, rms_weight, eps, bias=b)[..., :n]
 
     def extra_repr(self) -> str:
-        return "in_features={}, out_features={}, additional_out_features={}, bias={}, partially_freeze={}".format(
-            self.in_features, self.max_original_id + 1, self.additional_out_features, self.bias is not None,
-            (not self.weight.requires_grad or not self.bias.requires_grad))
+        frozen = "frozen" if not self.weight.requires_grad else "trainable"
+        return (f"{self.in_features} -> {self.max_original_id + 1} original ({frozen}) + {self.additional_out_features} "
+                f"additional outputs, bias={self.bias is not None}")

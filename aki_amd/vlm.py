@@ -24,42 +24,51 @@ ASSISTANT_TOKEN_ID = 32001  # hard-coded by the reference, src/vlm.py:490-496
 
 
 class VLM(nn.Module):
+    """Vision tower + vision tokenizer + language model under the attribute names checkpoints and the training scripts rely
+    on (`vision_encoder`, `vision_tokenizer`, `lang_model`; src/vlm.py:26-103).  Construction swaps the language model's
+    token tables for their decoupled forms so that the special tokens get trainable rows of their own."""
+
     def __init__(self, vision_encoder: nn.Module, vision_tokenizer: nn.Module, lang_model: nn.Module,
                  initial_tokenizer_len: int, pad_token_id: int, gradient_checkpointing: bool = False,
                  base_img_size: Optional[int] = None):
         super().__init__()
+        self.vision_encoder, self.vision_tokenizer, self.lang_model = vision_encoder, vision_tokenizer, lang_model
+        cfg = lang_model.config
         self.lang_embedding_dim = lang_model.get_input_embeddings().weight.shape[1]
-        self.lang_hidden_dim = getattr(lang_model.config, "d_model", None) or lang_model.config.hidden_size
+        self.lang_hidden_dim = getattr(cfg, "d_model", None) or cfg.hidden_size
         self.vis_embedding_dim = vision_tokenizer.dim_media
         self.num_tokens_per_vis = vision_tokenizer.num_tokens_per_media
-        self.vision_encoder = vision_encoder
-        self.vision_tokenizer = vision_tokenizer
-        self.lang_model = lang_model
-        if base_img_size is None:
-            cfg = getattr(self.vision_encoder, "config", None)
-            base_img_size = cfg.image_size if cfg is not None else self.vision_encoder.image_size[0]
+        if base_img_size is None:       # native resolution of the tower: HF towers carry it in their config, open_clip as a tuple
+            vcfg = getattr(vision_encoder, "config", None)
+            base_img_size = vcfg.image_size if vcfg is not None else vision_encoder.image_size[0]
         self.base_img_size = base_img_size
         self.pad_token_id = pad_token_id
         self.initial_tokenizer_len = initial_tokenizer_len
-        std = getattr(self.lang_model.config, "initializer_range", 0.02)
-        old_in = self.lang_model.get_input_embeddings()
-        input_embeds = DecoupledEmbedding(max_original_id=initial_tokenizer_len - 1,
-                                          num_additional_embeddings=len(self.special_tokens),
-                                          _weight=old_in.weight, pad_token_id=self.pad_token_id)
-        input_embeds.additional_embedding.to(old_in.weight.dtype).to(old_in.weight.device)
-        input_embeds.additional_embedding.weight.data.normal_(mean=0.0, std=std)
-        self.lang_model.set_input_embeddings(input_embeds)
-        old_out = self.lang_model.get_output_embeddings()
-        # NB: like the reference (src/vlm.py:88-93) this leaves DecoupledLinear's `bias=True` default in force even
-        # when the LM head has no bias, so checkpoints carry lm_head.bias / lm_head.additional_fc.bias.
-        out_embeds = DecoupledLinear(max_original_id=initial_tokenizer_len - 1,
-                                     additional_out_features=len(self.special_tokens), _weight=old_out.weight,
-                                     _bias=old_out.bias if hasattr(old_out, "bias") else None)
-        out_embeds.to(old_out.weight.dtype).to(old_out.weight.device)
-        out_embeds.additional_fc.to(old_out.weight.dtype).to(old_out.weight.device)
-        out_embeds.additional_fc.weight.data.normal_(mean=0.0, std=std)
-        self.lang_model.set_output_embeddings(out_embeds)
+        self._decouple_token_tables(n_new=len(self.special_tokens), std=getattr(cfg, "initializer_range", 0.02))
+        # accepted for signature compatibility; the HIP autograd path keeps its activations (82 GB of 288 GB at the
+        # benchmark batch) and has no recompute mode
         self.vision_tokenizer._use_gradient_checkpointing = gradient_checkpointing
+
+    def _decouple_token_tables(self, n_new: int, std: float) -> None:
+        """Input embedding -> DecoupledEmbedding, output head -> DecoupledLinear; the original rows are shared with the
+        incoming modules, the new rows start as N(0, std) (state-dict keys: `...embed_tokens.additional_embedding.weight`,
+        `lm_head.additional_fc.{weight,bias}`; like the reference the head's `bias=True` default stays in force even for
+        a bias-free lm_head, so checkpoints carry `lm_head.bias`)."""
+        last_original = self.initial_tokenizer_len - 1
+        emb_in = self.lang_model.get_input_embeddings()
+        table = DecoupledEmbedding(max_original_id=last_original, num_additional_embeddings=n_new, _weight=emb_in.weight,
+                                   pad_token_id=self.pad_token_id)
+        head_in = self.lang_model.get_output_embeddings()
+        head = DecoupledLinear(max_original_id=last_original, additional_out_features=n_new, _weight=head_in.weight,
+                               _bias=getattr(head_in, "bias", None))
+        for new_mod, ref in ((table, emb_in.weight), (head, head_in.weight)):
+            new_mod.to(device=ref.device, dtype=ref.dtype)
+        with torch.no_grad():
+            if n_new > 0:
+                table.additional_embedding.weight.normal_(mean=0.0, std=std)
+                head.additional_fc.weight.normal_(mean=0.0, std=std)
+        self.lang_model.set_input_embeddings(table)
+        self.lang_model.set_output_embeddings(head)
 
     # ---- vision ------------------------------------------------------------------------------------------
     def _encode_vision_x(self, vision_x: torch.Tensor):
@@ -72,49 +81,57 @@ class VLM(nn.Module):
             x = self.vision_encoder(x, interpolate_pos_encoding=interp).last_hidden_state
         return x.reshape(b, T, Fr, x.shape[1], x.shape[2])
 
-    # ---- bookkeeping the training scripts call --------------------------------------------------------------
-    @property
-    def num_trainable_params(self):
-        return num_params(self, filter_to_trainable=True)
-
+    # ---- what the training scripts ask the model -------------------------------------------------------------
     def set_trainable(self):
         raise NotImplementedError
-
-    def group_params_by_weight_decay(self):
-        params_with_wd, params_without_wd = [], []
-        for n, p in self.named_parameters():
-            if p.requires_grad:
-                (params_with_wd if self._should_apply_weight_decay(n) else params_without_wd).append(p)
-        return params_with_wd, params_without_wd
 
     def _should_apply_weight_decay(self, parameter_name):
         raise NotImplementedError
 
+    def group_params_by_weight_decay(self):
+        """(decayed, not decayed) trainable parameters, in registration order (train/train.py:330-337 builds AdamW from it)."""
+        decayed, plain = [], []
+        for name, p in self.named_parameters():
+            if p.requires_grad:
+                (decayed if self._should_apply_weight_decay(name) else plain).append(p)
+        return decayed, plain
+
+    @property
+    def num_trainable_params(self):
+        return num_params(self, filter_to_trainable=True)
+
+    def _param_report(self, trainable_only: bool) -> str:
+        what = "trainable parameters" if trainable_only else "parameters"
+        parts = (("Vision encoder", self.vision_encoder), ("Vision tokenizer", self.vision_tokenizer), ("Language model", self.lang_model))
+        return "\n".join(f"{label}: {num_params(mod, filter_to_trainable=trainable_only):,} {what}" for label, mod in parts)
+
+    @property
+    def num_params_per_module(self):
+        return self._param_report(False)
+
+    @property
+    def num_trainable_params_per_module(self):
+        return self._param_report(True)
+
+    # ---- special tokens (<image>, <|endofchunk|>) ------------------------------------------------------------------
     @property
     def special_tokens(self):
-        assert "media_token" in self._special_tokens, \
-            "VLMs need to request that the tokenizer add a media_token and call set_special_token_ids to set self.media_token_id"
+        """{attribute stem: token string}; subclasses fill `_special_tokens` BEFORE calling this constructor."""
+        assert "media_token" in self._special_tokens, "a VLM needs a media token: define _special_tokens['media_token'], " \
+            "add it to the tokenizer and hand its id to set_special_token_ids"
         return self._special_tokens
 
     @property
     def special_token_ids(self):
-        return [getattr(self, f"{att_name}_id") for att_name in self.special_tokens]
+        return [getattr(self, f"{stem}_id") for stem in self.special_tokens]
 
     def set_special_token_ids(self, string_to_ids):
-        assert set(self.special_tokens.values()).issubset(set(string_to_ids.keys()))
-        for att_name, token_str in self.special_tokens.items():
-            token_id = string_to_ids[token_str]
-            setattr(self, f"{att_name}_id", token_id)
-            setattr(self.lang_model, f"{att_name}_id", token_id)
-
-    def init_gradient_checkpointing(self):
-        from torch.distributed.algorithms._checkpoint.checkpoint_wrapper import (
-            checkpoint_wrapper, CheckpointWrapper, CheckpointImpl, apply_activation_checkpointing)
-        from functools import partial
-        wrapper = partial(checkpoint_wrapper, checkpoint_impl=CheckpointImpl.NO_REENTRANT)
-        apply_activation_checkpointing(self, checkpoint_wrapper_fn=wrapper,
-                                       check_fn=lambda m: getattr(m, "_use_gradient_checkpointing", False)
-                                       and not isinstance(m, CheckpointWrapper))
+        """{token string: id} from the tokenizer -> `self.<stem>_id`, mirrored onto the language model."""
+        missing = [tok for tok in self.special_tokens.values() if tok not in string_to_ids]
+        assert not missing, f"no id given for the special tokens {missing}"
+        for stem, tok in self.special_tokens.items():
+            for holder in (self, self.lang_model):
+                setattr(holder, f"{stem}_id", string_to_ids[tok])
 
 
 class VLMWithLanguageStream(VLM):
@@ -188,35 +205,17 @@ class VLMWithLanguageStream(VLM):
         pass
 
     def get_fsdp_lambda_fn(self):
-        from torch.distributed.algorithms._checkpoint.checkpoint_wrapper import CheckpointWrapper
-        decoder_block_class = getattr_recursive(self.lang_model, self.decoder_layers_attr_name)[0].__class__
-
-        def lambda_fn(module: nn.Module):
-            if getattr(module, "_use_gradient_checkpointing", False) and not isinstance(module, CheckpointWrapper):
-                return False
-            if module is self.vision_tokenizer:
-                return True
-            if isinstance(module, decoder_block_class):
-                return True
-
-        return lambda_fn
+        """Predicate `module -> bool` naming the sharding units of the model - every decoder block and the vision tokenizer
+        (the granularity of train/distributed.py:170-222).  `aki_amd.trainer.AkiTrainer(shard_params=True)` cuts its gather /
+        reduce-scatter buckets at exactly these module boundaries."""
+        blocks = getattr_recursive(self.lang_model, self.decoder_layers_attr_name)
+        block_ids = {id(b) for b in blocks}
+        return lambda module: module is self.vision_tokenizer or id(module) in block_ids
 
     def group_params_by_weight_decay(self):
-        params_with_wd, params_without_wd = [], []
-        for n, p in self.named_parameters():
+        """As the base class, except that the token embedding tables are never decayed (src/vlm.py:690-703)."""
+        decayed, plain = [], []
+        for name, p in self.named_parameters():
             if p.requires_grad:
-                (params_without_wd if "lang_model.model.embed_tokens" in n else params_with_wd).append(p)
-        return params_with_wd, params_without_wd
-
-    @property
-    def num_params_per_module(self):
-        return "\n".join([f"Vision encoder: {num_params(self.vision_encoder):,} parameters",
-                          f"Vision tokenizer: {num_params(self.vision_tokenizer):,} parameters",
-                          f"Language model: {num_params(self.lang_model):,} parameters"])
-
-    @property
-    def num_trainable_params_per_module(self):
-        return "\n".join([
-            f"Vision encoder: {num_params(self.vision_encoder, filter_to_trainable=True):,} trainable parameters",
-            f"Vision tokenizer: {num_params(self.vision_tokenizer, filter_to_trainable=True):,} trainable parameters",
-            f"Language model: {num_params(self.lang_model, filter_to_trainable=True):,} trainable parameters"])
+                (plain if "lang_model.model.embed_tokens" in name else decayed).append(p)
+        return decayed, plain
