@@ -223,9 +223,23 @@ def siglip_encoder_layer(h, p, n_heads, eps=1e-6):
     return h + x
 
 
+def siglip_interpolate_pos(pos_emb, grid):
+    """HF:siglip/modeling_siglip.py `interpolate_pos_encoding`: the learned (g0*g0, E) table resampled bicubically
+    (align_corners=False) to grid x grid.  The reference never takes this path (it only runs the tower's native 384 px,
+    src/vlm.py:202-203); BASELINE's 336 px metric resolution does - pinned against transformers' own method in
+    tests/test_model_gpu.py::test_full_width_siglip_tower_vs_transformers."""
+    g0 = int(round(pos_emb.shape[0] ** 0.5))
+    if grid == g0:
+        return pos_emb
+    t = pos_emb.float().reshape(1, g0, g0, -1).permute(0, 3, 1, 2)
+    t = F.interpolate(t, size=(grid, grid), mode="bicubic", align_corners=False)
+    return t.permute(0, 2, 3, 1).reshape(grid * grid, -1).to(pos_emb.dtype)
+
+
 def siglip_vision_forward(pixels, p, n_layers, n_heads, eps=1e-6):
-    h = siglip_patch_embed(pixels, p["embeddings.patch_embedding.weight"], p["embeddings.patch_embedding.bias"],
-                           p["embeddings.position_embedding.weight"])
+    w = p["embeddings.patch_embedding.weight"]
+    pos = siglip_interpolate_pos(p["embeddings.position_embedding.weight"], pixels.shape[-1] // w.shape[-1])
+    h = siglip_patch_embed(pixels, w, p["embeddings.patch_embedding.bias"], pos)
     for l in range(n_layers):
         h = siglip_encoder_layer(h, _sub(p, f"encoder.layers.{l}."), n_heads, eps)
     return layer_norm(h, p["post_layernorm.weight"], p["post_layernorm.bias"], eps)

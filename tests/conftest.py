@@ -17,6 +17,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+PARITY_LOG = []      # (test, what, dtype, max |err|, mean |err|, max |ref|, bar) of every parity comparison of the session
+
+
+def record_parity(what, dtype, err_max, err_mean, ref_max, bar):
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    PARITY_LOG.append(dict(test=test, what=str(what), dtype=str(dtype).replace("torch.", ""), max_err=float(err_max),
+                           mean_err=float(err_mean), max_ref=float(ref_max), bar=str(bar)))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Measured errors of every parity comparison -> gpurun_out/parity_errors.json (the table in DESIGN.md section 2 is made
+    from it by tools/parity_table.py), so that every tolerance in the tests is justified by a number."""
+    if not PARITY_LOG:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_errors.json"), "w") as f:
+        json.dump(PARITY_LOG, f, indent=0)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
 
