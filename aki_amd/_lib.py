@@ -158,6 +158,8 @@ def load_lab() -> C.CDLL:
     lib = _bind(LAB_LIB_PATH)
     lib.aki_lab_set_gemm_tile.restype = None
     lib.aki_lab_set_gemm_tile.argtypes = [C.c_int]
+    lib.aki_lab_set_attn_variant.restype = None
+    lib.aki_lab_set_attn_variant.argtypes = [C.c_int]
     return lib
 
 

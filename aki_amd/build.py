@@ -22,7 +22,8 @@ LIB = os.path.join(LIBDIR, "libaki_mi355x.so")
 # Lab twin: the same sources with -DAKI_LAB_HOOKS (adds aki_lab_set_gemm_tile, a process-global tile-forcing switch that the
 # product library must not carry).  Used by the forced-tile GEMM tests and tools/siglip_gemm_bench.py only.
 LAB_LIB = os.path.join(LIBDIR, "libaki_mi355x_lab.so")
-LAB_SOURCES = ["api.hip", "gemm_bf16.hip"]
+LAB_SOURCES = ["api.hip", "gemm_bf16.hip", "mma_attn_bf16.hip"]
+LAB_ONLY_SOURCES = ["mma_attn64_bf16.hip"]     # experiments that exist in the lab library only
 SOURCES = ["api.hip", "gemm_bf16.hip", "mma_attn_bf16.hip", "attn_nc_bf16.hip", "decode.hip", "train_kernels.hip", "attn_bwd_bf16.hip", "fp8_quant.hip", "simple_f32.hip", "aux_kernels.hip"]
 ARCH = "gfx950"
 
@@ -45,9 +46,10 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True, l
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "aki_device.h"), os.path.join(ROOT, "include", "aki_mi355x.h")]
+    headers = [os.path.join(CSRC, "aki_device.h"), os.path.join(CSRC, "attn_mma_common.h"), os.path.join(ROOT, "include", "aki_mi355x.h")]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    if not force and _newer(LIB, srcs + headers) and (not lab or _newer(LAB_LIB, srcs + headers)):
+    lab_only = [os.path.join(CSRC, s_) for s_ in LAB_ONLY_SOURCES]
+    if not force and _newer(LIB, srcs + headers) and (not lab or _newer(LAB_LIB, srcs + lab_only + headers)):
         return LIB
     flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
              "-Wno-unused-result", "-ffp-contract=off"]
@@ -65,7 +67,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True, l
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         return obj, r.stderr
 
-    jobs = [(s_, False) for s_ in srcs] + ([(os.path.join(CSRC, s_), True) for s_ in LAB_SOURCES] if lab else [])
+    jobs = [(s_, False) for s_ in srcs] + ([(os.path.join(CSRC, s_), True) for s_ in LAB_SOURCES + LAB_ONLY_SOURCES] if lab else [])
     with cf.ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
         results = list(ex.map(cc, jobs))
     objs = [o for o, _ in results[:len(srcs)]]
@@ -79,7 +81,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True, l
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if lab:
         swapped = {os.path.basename(o).replace(".lab.o", ".o"): o for o in lab_objs}
-        mix = [swapped.get(os.path.basename(o), o) for o in objs]
+        mix = [swapped.pop(os.path.basename(o), o) for o in objs] + list(swapped.values())   # + the lab-only objects
         r = subprocess.run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LAB_LIB] + mix, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link (lab) failed:\n{r.stdout}\n{r.stderr}")

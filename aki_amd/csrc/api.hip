@@ -38,6 +38,7 @@ int mask_to_table_launch(const int64_t* mask, int B, int L, int max_rects, aki_m
 extern int g_force_tile;
 extern int g_deep_ring;
 extern int g_pipe;
+extern int g_attn_variant;
 #endif
 size_t attn_bwd_ws_bytes(int B, int H, int Lq);
 int attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq, void* dk,
@@ -92,6 +93,8 @@ void aki_lab_set_gemm_tile(int mode) {
   mode &= 255;
   aki::g_force_tile = (mode >= 1 && mode <= 3) ? mode : 0;
 }
+// 0 = product choice, 1 = 32-row attention core (two waves per SIMD), 2 = 64-row core (one wave per SIMD)
+void aki_lab_set_attn_variant(int v) { aki::g_attn_variant = v; }
 #endif
 
 // ---- attention core --------------------------------------------------------------------------------

@@ -124,6 +124,19 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   const int n_out = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
 
   // ---- per-thread staging sources ----------------------------------------------------------------------------
+  auto weight_row = [&](int row) {    // tile row (0 .. BN-1, wave-local feature blocks) -> row of the weight matrix
+    if (EPI == EPI_SWIGLU) {  // wave-local blocks [0,NF/2) = gate rows, [NF/2,NF) = up rows of the same features
+      const int w_ = row / WROWS, within = row % WROWS, nb = within >> 4, i = within & 15;
+      const int f = min(n0 + w_ * (WROWS / 2) + (nb % (NF / 2)) * 16 + i, n_out - 1);
+      return (nb < NF / 2) ? f : n_out + f;
+    } else if (EPI == EPI_QKV_ROPE8) {
+      const int w_ = row / WROWS, within = row % WROWS, nb = within >> 4, i = within & 15;
+      const int u = n0 / 32 + w_ * (NF / 2) + (nb % (NF / 2));
+      return min(qkv_unit_row(min(u, 9 * p.H - 1), nb / (NF / 2), p.H) + i, p.N - 1);
+    } else {
+      return min(n0 + row, p.N - 1);
+    }
+  };
   const char* src[NLD];
 #pragma unroll
   for (int j = 0; j < NLD; ++j) {
@@ -131,19 +144,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     const int row = rowgroup * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     if (rowgroup * 8 < BN) {
-      int wrow;
-      if (EPI == EPI_SWIGLU) {  // wave-local blocks [0,NF/2) = gate rows, [NF/2,NF) = up rows of the same features
-        const int w_ = row / WROWS, within = row % WROWS, nb = within >> 4, i = within & 15;
-        const int f = min(n0 + w_ * (WROWS / 2) + (nb % (NF / 2)) * 16 + i, n_out - 1);
-        wrow = (nb < NF / 2) ? f : n_out + f;
-      } else if (EPI == EPI_QKV_ROPE8) {
-        const int w_ = row / WROWS, within = row % WROWS, nb = within >> 4, i = within & 15;
-        const int u = n0 / 32 + w_ * (NF / 2) + (nb % (NF / 2));
-        wrow = min(qkv_unit_row(min(u, 9 * p.H - 1), nb / (NF / 2), p.H) + i, p.N - 1);
-      } else {
-        wrow = min(n0 + row, p.N - 1);
-      }
-      src[j] = (const char*)p.w + (size_t)wrow * p.ldw * ES + chunk * 16;
+      src[j] = (const char*)p.w + (size_t)weight_row(row) * p.ldw * ES + chunk * 16;
     } else {
       const int xrow = min(m0 + row - BN, p.M - 1);
       src[j] = (const char*)p.x + (size_t)xrow * p.ldx * ES + chunk * 16;
@@ -497,6 +498,12 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   }
 }
 
+#ifdef AKI_LAB_HOOKS
+int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;   // set by aki_lab_set_gemm_tile (lab build only)
+#else
+static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;
+#endif
+
 template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, bool PIPE = false>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
@@ -517,11 +524,6 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   return AKI_OK;
 }
 
-#ifdef AKI_LAB_HOOKS
-int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;   // set by aki_lab_set_gemm_tile (lab build only)
-#else
-static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;
-#endif
 // g_force_tile: 0 = heuristic, 1 = 256^2, 2 = 128^2, 3 = 128 features x 96 tokens (plain bf16 only)
 
 // Cost model in units of one 256x256 tile's run time.  256^2 tiles: one workgroup per CU.  128-token tiles do a

@@ -21,9 +21,7 @@
 //                    operand": element j of lane-half h <-> key 16s + 8(j>>2) + 4h + (j&3)); the
 //                    matching V^T A-operand comes from two ds_read_b64_tr_b16 per fragment.
 // O^T keeps the query on the lane, so the rescale factor and the final 1/l are lane-local.
-#include <type_traits>
-
-#include "aki_device.h"
+#include "attn_mma_common.h"
 
 // Lab knobs (compile-time; tools/attn_*.py build variants with -D):
 //   AKI_ATTN_L2_ROWS   sequences get L / AKI_ATTN_L2_ROWS workgroups per pair at least (fewer pairs in flight per L2)
@@ -37,81 +35,6 @@
 #endif
 
 namespace aki {
-
-struct AttnParams {
-  const bf16_t* q;
-  const bf16_t* k;
-  const bf16_t* v;
-  bf16_t* o;
-  float* lse;
-  const aki_mma_rect* rects;
-  const uint64_t* vbits;
-  const int* seq_lens;
-  int max_rects;
-  int B, H, L;
-  int nqt, nwords;
-  int splits;    // workgroups per (batch, head) pair
-  int group_bh;  // pairs per dispatch group
-  int kvcap;  // rows per (batch, head) of k / v (>= L when they are a KV cache)
-  float scale_log2;  // scale * log2(e)
-  int dead_uniform;
-};
-
-constexpr int KROW = 192;   // K rows unpadded: bank conflicts are removed by chunk ^= (row>>2)&3 (low 2 bits of the 16-B chunk)
-constexpr int VROW = 192;
-constexpr int KTILE = 64 * KROW;
-constexpr int VTILE = 64 * VROW;
-constexpr int NSTAGE = 3;   // LDS ring: tile j computing, j+1 landed or landing, j+2 being issued
-
-constexpr int MAX_VB_WORDS = 256;  // L <= 16384
-
-// v_max3_f32 without the canonicalising v_max hipcc inserts in front of fmaxf on MFMA results
-__device__ __forceinline__ float max3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-
-// A lane's 32 score columns of a 64-key tile, in register order i = 16*kb + r, are
-//   col(i) = c0 + 4h + (i&3) + 8*((i&15)>>2) + 32*(i>>4)      (strictly increasing in i)
-// so "col <= y" is a PREFIX of the register order.  count_le(x) = number of i with col(i) - (c0+4h) <= x.
-__device__ __forceinline__ int count_le(int x) {
-  const int n = 4 * (x >> 3) + min((x & 7) + 1, 4);
-  return x < 0 ? 0 : min(n, 32);
-}
-
-// the n lowest bits set, n in [0, 32]
-__device__ __forceinline__ unsigned low_bits(int n) { return n >= 32 ? ~0u : ((1u << n) - 1u); }
-
-// bit BIT of hid -> -inf (hidden) or 0 (visible), two VALU ops and no VCC round trip (hipcc turns the C form into
-// v_and / v_cmp / v_cndmask with hazard nops)
-template <int BIT>
-__device__ __forceinline__ float mask_bias(int hid, int ninf) {
-  int t;
-  float b;
-  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t) : "v"(hid), "n"(BIT));
-  asm("v_and_b32 %0, %1, %2" : "=v"(b) : "s"(ninf), "v"(t));
-  return b;
-}
-
-// compile-time loop (the tr-read offsets below must be immediates of an inline-asm statement)
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
-// ds_read_b64_tr_b16 through inline asm: the builtin form is treated by hipcc as "may alias any LDS-DMA in flight" and
-// gets an s_waitcnt vmcnt(0) in front, which would drain the K/V ring.  The asm form is invisible to that analysis
-// (and to the compiler's lgkmcnt bookkeeping: the data is only touched after wait_tr_reads below; cdna guide 5.7).
-template <int OFF>
-__device__ __forceinline__ u32x2 ds_read_tr(unsigned lds_addr) {
-  u32x2 r;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
-  return r;
-}
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnParams p) {
@@ -506,12 +429,23 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   }                  // next rank of this workgroup
 }
 
+#ifdef AKI_LAB_HOOKS
+// Lab library only: the experimental 64-rows-per-wave core (mma_attn64_bf16.hip, one wave per SIMD) can be switched in for
+// an A/B in one process (tools/attn_ab.py).  It is not part of the product library: as compiled by hipcc it is 1.7x SLOWER
+// than this kernel ("64-row attention core").
+int attn_core64_bf16(const aki_mma_attn_core_args* a, hipStream_t stream);
+int g_attn_variant = 0;   // 0 / 1 = this kernel, 2 = the 64-row kernel
+#endif
+
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (a->Dh != 96) return AKI_ERR_UNSUPPORTED;
   if (a->max_rects < 0 || a->max_rects > AKI_MAX_RECTS) return AKI_ERR_INVALID_ARG;
   if ((a->L + 63) / 64 > MAX_VB_WORDS) return AKI_ERR_UNSUPPORTED;
   AKI_CHECK_ALIGN16(a->q); AKI_CHECK_ALIGN16(a->k); AKI_CHECK_ALIGN16(a->v); AKI_CHECK_ALIGN16(a->o);
   (void)ws; (void)ws_bytes;  // the bf16 path needs no scratch (kept in the signature for the f32 path)
+#ifdef AKI_LAB_HOOKS
+  if (g_attn_variant == 2) return attn_core64_bf16(a, stream);
+#endif
   constexpr int NW = 4;
   AttnParams p = {};
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.o = (bf16_t*)a->o; p.lse = a->lse;
