@@ -16,7 +16,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 8
+AKI_ABI_VERSION = 9
 
 
 class AkiError(RuntimeError):
@@ -65,7 +65,8 @@ class LinearArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldx", C.c_int32), ("ldw", C.c_int32),
                 ("ldy", C.c_int32), ("ldr", C.c_int32), ("res_row_mod", C.c_int32), ("act", C.c_int32),
-                ("dtype", C.c_int32), ("x_scale", C.c_void_p), ("w_scale", C.c_void_p)]
+                ("dtype", C.c_int32), ("x_scale", C.c_void_p), ("w_scale", C.c_void_p),
+                ("w2", C.c_void_p), ("w2_row0", C.c_int32), ("w2_rows", C.c_int32)]
 
 
 class SpliceArgs(C.Structure):
@@ -121,6 +122,7 @@ SIGNATURES = {
     "aki_gelu_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_size_t, C.c_int32, C.c_void_p]),
     "aki_rope_bwd_merge": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p]),
     "aki_ce_loss_fwd_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_float, C.c_int32, C.c_void_p]),
+    "aki_ce_rows_fwd_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_float, C.c_int32, C.c_void_p]),
     "aki_grad_sqnorm_workspace_bytes": (C.c_size_t, []),
     "aki_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_adamw_step": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p] + [C.c_float] * 7 + [C.c_int32, C.c_void_p]),

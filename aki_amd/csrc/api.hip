@@ -56,6 +56,8 @@ int rope_bwd_merge_launch(const void* dq, const void* dk, const void* dv, const 
                           int B, int H, int L, int Dh, hipStream_t s);
 int ce_launch(const void* logits, const int64_t* labels, int* n_valid, float* loss_rows, void* dlogits, int B, int L, int V, int ldl,
               int lddl, float gscale, hipStream_t s);
+int ce_rows_launch(const void* logits, const int64_t* targets, const int* n_valid, float* loss_rows, void* dlogits, int rows, int V,
+                   int ldl, int lddl, float gscale, hipStream_t s);
 size_t grad_sqnorm_ws_bytes();
 int grad_sqnorm_launch(const void* g, size_t n, float* out, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int adamw_launch(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
@@ -202,6 +204,11 @@ int aki_linear_fwd(const aki_linear_args* a, void* stream) {
   AKI_CHECK_ARG(a->act >= AKI_ACT_NONE && a->act <= AKI_ACT_SWIGLU);
   const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
   AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));
+  if (a->w2) {   // two-segment weight: the bf16 MFMA GEMM only
+    AKI_CHECK_ARG(a->w2_row0 > 0 && a->w2_rows > 0 && a->w2_row0 < a->N);
+    if (a->dtype != AKI_DT_BF16 || a->act != AKI_ACT_NONE) return AKI_ERR_UNSUPPORTED;
+    return linear_bf16(a, (hipStream_t)stream);
+  }
   if (a->dtype == AKI_DT_FP8_E4M3) return linear_fp8(a, (hipStream_t)stream);
   if (a->dtype == AKI_DT_W8A16) return gemv_bf16(a, nullptr, 0.f, (hipStream_t)stream);
   if (a->dtype == AKI_DT_BF16) {
@@ -442,6 +449,14 @@ int aki_ce_loss_fwd_bwd(const void* logits, const int64_t* labels, int32_t* n_va
   AKI_CHECK_ARG(logits && labels && n_valid && loss_rows && B > 0 && L > 0 && V > 0 && ldl >= V && (!dlogits || lddl >= V));
   AKI_BF16_ONLY(dtype);
   return ce_launch(logits, labels, n_valid, loss_rows, dlogits, B, L, V, ldl, lddl, gscale, (hipStream_t)stream);
+}
+
+int aki_ce_rows_fwd_bwd(const void* logits, const int64_t* targets, const int32_t* n_valid, float* loss_rows, void* dlogits, int32_t rows,
+                        int32_t V, int32_t ldl, int32_t lddl, float gscale, int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(logits && targets && n_valid && loss_rows && rows > 0 && V > 0 && ldl >= V && (!dlogits || lddl >= V));
+  AKI_BF16_ONLY(dtype);
+  return ce_rows_launch(logits, targets, n_valid, loss_rows, dlogits, rows, V, ldl, lddl, gscale, (hipStream_t)stream);
 }
 
 size_t aki_grad_sqnorm_workspace_bytes(void) { return grad_sqnorm_ws_bytes(); }

@@ -73,6 +73,9 @@ struct GemmParams {
   // fp8 (e4m3) operands: x and w point at bytes, ldx / ldw count bytes, one f32 scale per token row / weight row
   const float* sx;
   const float* sw;
+  // two-segment weight (EPI_PLAIN): logical rows >= w2_row0 come from w2 (aki_linear_args)
+  const bf16_t* w2;
+  int w2_row0, w2_rows;
 };
 
 // Two feature blocks (P = block n, Q = block n+1), each 4 consecutive features per lane as 2 packed dwords.
@@ -144,7 +147,12 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     const int row = rowgroup * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     if (rowgroup * 8 < BN) {
-      src[j] = (const char*)p.w + (size_t)weight_row(row) * p.ldw * ES + chunk * 16;
+      const int wr = weight_row(row);
+      const char* wp = (const char*)p.w + (size_t)wr * p.ldw * ES;
+      if (EPI == EPI_PLAIN && !FP8) {
+        if (p.w2 != nullptr && wr >= p.w2_row0) wp = (const char*)p.w2 + (size_t)min(wr - p.w2_row0, p.w2_rows - 1) * p.ldw * ES;
+      }
+      src[j] = wp + chunk * 16;
     } else {
       const int xrow = min(m0 + row - BN, p.M - 1);
       src[j] = (const char*)p.x + (size_t)xrow * p.ldx * ES + chunk * 16;
@@ -628,6 +636,10 @@ int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
   p.res_row_mod = a->res_row_mod; p.act = a->act;
   p.wide = (n_out % 8 == 0) && (a->ldy % 8 == 0) && (((uintptr_t)a->y & 15) == 0);
   p.res_wide = a->residual && (n_out % 8 == 0) && (a->ldr % 8 == 0) && (((uintptr_t)a->residual & 15) == 0);
+  if (a->w2) {
+    AKI_CHECK_ALIGN16(a->w2);
+    p.w2 = (const bf16_t*)a->w2; p.w2_row0 = a->w2_row0; p.w2_rows = a->w2_rows;
+  }
   if (a->act == AKI_ACT_SWIGLU) {
     if (a->bias) return AKI_ERR_UNSUPPORTED;
     return run_planned<EPI_SWIGLU, 0>(p, plan_tiles(a->M, n_out, 128, 64), stream);

@@ -423,11 +423,13 @@ __global__ void ce_count_kernel(const int64_t* labels, int B, int L, int V, int*
   if (threadIdx.x == 0) *n_valid = red[0];
 }
 
+// ROWS = true: `labels` holds one already-shifted target per row of an arbitrary chunk of rows (aki_ce_rows_fwd_bwd)
+template <bool ROWS>
 __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const bf16_t* logits, const int64_t* labels, const int* n_valid, float* loss_rows,
                                                          bf16_t* dlogits, int B, int L, int V, int ldl, int lddl, float gscale) {
   __shared__ float red[16];
-  const int row = blockIdx.x, t = row % L, tid = threadIdx.x;
-  int64_t tgt = (t + 1 < L) ? labels[row + 1] : -100;
+  const int row = blockIdx.x, t = ROWS ? 0 : row % L, tid = threadIdx.x;
+  int64_t tgt = ROWS ? labels[row] : ((t + 1 < L) ? labels[row + 1] : -100);
   if (tgt < 0 || tgt >= V) tgt = -100;   // out-of-range labels are ignored rows (ce_count_kernel counts the same way), never an OOB read
   const bf16_t* lr = logits + (size_t)row * ldl;
   bf16_t* dr = dlogits ? dlogits + (size_t)row * lddl : nullptr;
@@ -481,8 +483,18 @@ int ce_launch(const void* logits, const int64_t* labels, int* n_valid, float* lo
   if ((ldl & 1) || (dlogits && (lddl & 1))) return AKI_ERR_ALIGNMENT;
   AKI_CLEAR_ERR();
   hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, labels, B, L, V, n_valid);
-  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(B * L), dim3(256), 0, s, (const bf16_t*)logits, labels, n_valid, loss_rows, (bf16_t*)dlogits,
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel<false>, dim3(B * L), dim3(256), 0, s, (const bf16_t*)logits, labels, n_valid, loss_rows, (bf16_t*)dlogits,
                      B, L, V, ldl, lddl, gscale);
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
+}
+
+int ce_rows_launch(const void* logits, const int64_t* targets, const int* n_valid, float* loss_rows, void* dlogits, int rows, int V,
+                   int ldl, int lddl, float gscale, hipStream_t s) {
+  if ((ldl & 1) || (dlogits && (lddl & 1))) return AKI_ERR_ALIGNMENT;
+  AKI_CLEAR_ERR();
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel<true>, dim3(rows), dim3(256), 0, s, (const bf16_t*)logits, targets, n_valid, loss_rows,
+                     (bf16_t*)dlogits, 1, rows, V, ldl, lddl, gscale);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }

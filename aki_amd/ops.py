@@ -146,13 +146,18 @@ class MaskTable:
 
 # ------------------------------------------------------------------------------------------------
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           act: int = ACT_NONE, res_row_mod: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = act(x W^T + bias) [+ residual]; W is an nn.Linear weight [N,K] (K a multiple of 64 for bf16)."""
-    dev = _dev(x, w, bias, residual, out)
+           act: int = ACT_NONE, res_row_mod: int = 0, out: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
+           w2_row0: int = 0, n_rows: Optional[int] = None) -> torch.Tensor:
+    """y = act(x W^T + bias) [+ residual]; W is an nn.Linear weight [N,K] (K a multiple of 64 for bf16).
+    Two-segment weight (DecoupledLinear, src/helpers.py:594-603): with `w2`, logical weight row r is w[r] for r < w2_row0 and
+    w2[r - w2_row0] beyond; `n_rows` = logical rows (output width, may include padding columns that repeat w2's last row)."""
+    dev = _dev(x, w, bias, residual, out, w2)
     lib = L.load()
     x2 = _rows2d(x)
     M, K = x2.shape
-    N = w.shape[0]
+    N = w.shape[0] if w2 is None else int(n_rows if n_rows is not None else w2_row0 + w2.shape[0])
+    if w2 is not None and (w2.shape[1] != K or w2.stride(1) != 1 or w2.stride(0) != w.stride(0) or not 0 < w2_row0 <= w.shape[0]):
+        raise AkiError("linear: the second weight segment must have the layout of the first")
     if w.shape[1] != K or w.stride(1) != 1:
         raise AkiError(f"linear: weight {tuple(w.shape)} does not match input K={K}")
     n_out = N // 2 if act == ACT_SWIGLU else N
@@ -165,7 +170,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if residual is not None:
         r2 = _rows2d(residual)
     a = L.LinearArgs(_ptr(x2), _ptr(w), _ptr(bias), _ptr(r2), _ptr(o2), M, N, K, x2.stride(0), w.stride(0), o2.stride(0),
-                     0 if r2 is None else r2.stride(0), res_row_mod, act, _dt(x))
+                     0 if r2 is None else r2.stride(0), res_row_mod, act, _dt(x), None, None,
+                     _ptr(w2), int(w2_row0) if w2 is not None else 0, int(w2.shape[0]) if w2 is not None else 0)
     end = _TAP.begin(("linear", M, N, K, act)) if (_TAP is not None and _TAP.want(("linear", M, N, K, act))) else None
     L.check(lib.aki_linear_fwd(C.byref(a), _stream()), "aki_linear_fwd")
     if end is not None:

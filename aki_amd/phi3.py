@@ -386,31 +386,6 @@ class Phi3ForCausalLM(nn.Module):
             return ops.linear(h, self.lm_head.weight, bias=self.lm_head.bias)
         return self.lm_head(h)   # DecoupledLinear (src/vlm.py:88-99): one HIP GEMM / GEMV over the fused weight
 
-    def _head_train(self, h):
-        """lm_head on the autograd path: one GEMM over the row-concatenated weight, rows padded to a multiple of 64 (the
-        dgrad GEMM contracts over them) -> (logits [B, L, pad64(n)], n)."""
-        head = self.lm_head
-        if type(head) is nn.Linear:
-            ws, bs = [head.weight], ([head.bias] if head.bias is not None else None)
-        else:   # DecoupledLinear (src/helpers.py:594-603)
-            n0 = head.max_original_id + 1
-            ws = [head.weight[:n0]] + ([head.additional_fc.weight] if head.additional_out_features else [])
-            bs = None
-            if head.has_bias and head.bias is not None:
-                bs = [head.bias[:n0]]
-                if head.additional_out_features:
-                    ab = head.additional_fc.bias
-                    bs.append(ab if ab is not None else torch.zeros(head.additional_out_features, dtype=h.dtype, device=h.device))
-        n = sum(w.shape[0] for w in ws)
-        pad = (n + 63) // 64 * 64 - n
-        if pad:
-            ws = ws + [torch.zeros((pad, ws[0].shape[1]), dtype=h.dtype, device=h.device)]
-            if bs is not None:
-                bs = bs + [torch.zeros((pad,), dtype=h.dtype, device=h.device)]
-        w = torch.cat(ws, 0) if len(ws) > 1 else ws[0]
-        b = None if bs is None else (torch.cat(bs, 0) if len(bs) > 1 else bs[0])
-        return T.linear(h, w, b, None), n
-
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, labels=None, position_ids=None,
                 use_cache=False, past_key_values=None, cache_capacity=None, **kwargs):
         """Prefill / full forward.  With use_cache=True the returned past_key_values is an AkiKVCache holding the
@@ -438,10 +413,9 @@ class Phi3ForCausalLM(nn.Module):
         self.model.skip_final_norm = False
         self._pre_norm_h = h if fp8_head else None
         if labels is not None and cache is None and _ag(h, *self.lm_head.parameters()):
-            # training: padded logits -> fused shifted cross-entropy whose kernel also leaves d(loss)/d(logits) in the
-            # logits buffer (so the output carries no logits; train/losses.py:110-115 only reads [0] = loss)
-            logits_pad, n_cols = self._head_train(h)
-            loss = T.CELossFn.apply(logits_pad, labels, n_cols)
+            # training: lm_head + shifted cross-entropy chunk by chunk - no [B, L, V] logits tensor, no concatenated head
+            # weight (so the output carries no logits; train/losses.py:110-115 only reads [0] = loss)
+            loss = T.fused_head_ce(h, self.lm_head, labels, chunk=getattr(self, "head_chunk_rows", 2048))
             return CausalLMOutputWithPast(loss=loss, logits=None, past_key_values=None)
         logits = self._head(h)
         if cache is not None:
@@ -490,7 +464,15 @@ class Phi3ForCausalLM(nn.Module):
 
 
 def causal_lm_loss(logits, labels, ignore_index=-100):
-    """HF ForCausalLMLoss: shift by one, mean cross entropy over non-ignored targets, computed in f32."""
+    """HF ForCausalLMLoss: shift by one, mean cross entropy over non-ignored targets, computed in f32.  bf16 logits on the
+    GPU go through the HIP cross-entropy kernel (forward only, read in place through their row stride); the exact-f32 parity
+    path keeps torch's."""
+    if (logits.is_cuda and logits.dtype == torch.bfloat16 and ignore_index == -100 and logits.dim() == 3 and logits.stride(2) == 1
+            and logits.stride(0) == logits.shape[1] * logits.stride(1) and logits.stride(1) % 2 == 0):
+        B, L, n = logits.shape
+        ld = logits.stride(1)
+        rows = torch.as_strided(logits, (B, L, ld), (L * ld, ld, 1)) if ld != n else logits
+        return T.ce_loss(rows, labels.to(logits.device), n, want_grad=False)[0]
     lg = logits[:, :-1].float()
     tg = labels[:, 1:].to(lg.device)
     return F.cross_entropy(lg.reshape(-1, lg.shape[-1]), tg.reshape(-1), ignore_index=ignore_index)

@@ -141,6 +141,19 @@ def ce_loss(logits: torch.Tensor, labels: torch.Tensor, n_cols: int, gscale: flo
     return rows.sum() / nv.clamp(min=1).to(torch.float32)[0], nv
 
 
+def ce_rows(logits: torch.Tensor, targets: torch.Tensor, n_valid: torch.Tensor, n_cols: int, want_grad: bool) -> torch.Tensor:
+    """Cross-entropy of a CHUNK of rows: logits [rows, ld >= n_cols] bf16, targets [rows] int64 (already shifted; < 0 = ignored),
+    n_valid: device int32 [1] = scored rows of the whole batch.  Returns loss_rows f32 [rows] (their sum / n_valid is the chunk's
+    share of the mean loss); with want_grad the logits buffer is overwritten by d(mean loss)/d(logits)."""
+    _need_bf16(logits)
+    _dev(logits, targets, n_valid)
+    rows = torch.empty((logits.shape[0],), dtype=torch.float32, device=logits.device)
+    L.check(L.load().aki_ce_rows_fwd_bwd(_ptr(logits), _ptr(targets), _ptr(n_valid), _ptr(rows), _ptr(logits) if want_grad else None,
+                                         logits.shape[0], n_cols, logits.stride(0), logits.stride(0), 1.0, _BF16, _stream()),
+            "aki_ce_rows_fwd_bwd")
+    return rows
+
+
 def attn_bwd(q, k, v, o, d_o, lse, table: Optional[ops.MaskTable], scale: float):
     """q,k,v [B,H,L,Dh]; o, d_o [B,Lq,H*Dh]; lse [B,H,Lq] -> dq, dk, dv.  table=None: plain (non-causal) attention."""
     _need_bf16(q, k, v, o, d_o)
@@ -420,6 +433,147 @@ class CELossFn(torch.autograd.Function):
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
         return dl * g.to(dl.dtype), None, None
+
+
+class FusedHeadCEFn(torch.autograd.Function):
+    """lm_head (DecoupledLinear, src/helpers.py:594-603) + HF shifted cross-entropy (train/losses.py:83-116) WITHOUT the
+    [B, L, V] logits tensor: the rows are processed in chunks of `chunk` tokens - logits chunk (one two-segment GEMM straight
+    off `weight[:n0]` and `additional_fc.weight`, no concatenated copy), loss rows; in the backward the chunk is recomputed,
+    turned into d(logits) in place and consumed at once by the dgrad GEMM (d h) and the wgrad GEMMs, which accumulate into
+    the two weights' gradient buffers.  Peak extra memory: one chunk (chunk x pad64(V) bf16) instead of B*L x V.
+    Inputs: h [B, L, K] (after the final norm), weight [V0, K] (rows [:n0] used), add_w [n_add, K] or None, bias [V0] or
+    None, add_b [n_add] or None, labels [B, L]."""
+
+    @staticmethod
+    def forward(ctx, h, weight, add_w, bias, add_b, labels, n0, chunk):
+        _need_bf16(h, weight, add_w)
+        B, Lq, K = h.shape
+        n_add = 0 if add_w is None else add_w.shape[0]
+        V = n0 + n_add
+        Vp = _pad64(V)
+        h2 = _rows2d(h)
+        M = h2.shape[0]
+        tgt = torch.full((B, Lq), -100, dtype=torch.int64, device=h.device)
+        tgt[:, :-1] = labels[:, 1:].to(torch.int64)
+        tgt = tgt.reshape(-1)
+        nv = ((tgt >= 0) & (tgt < V)).sum().to(torch.int32).reshape(1)
+        fb = None
+        if bias is not None:                          # fused bias vector (64 KB - not the 197 MB weight)
+            fb = torch.zeros((Vp,), dtype=h.dtype, device=h.device)
+            fb[:n0] = bias.detach()[:n0]
+            if add_b is not None:
+                fb[n0:V] = add_b.detach()
+        total = torch.zeros((), dtype=torch.float32, device=h.device)
+        buf = torch.empty((min(chunk, M), Vp), dtype=h.dtype, device=h.device)
+        for r0 in range(0, M, chunk):
+            r1 = min(M, r0 + chunk)
+            lg = buf[: r1 - r0]
+            FusedHeadCEFn._logits(h2[r0:r1], weight, add_w, fb, n0, Vp, lg)
+            total = total + ce_rows(lg, tgt[r0:r1], nv, V, want_grad=False).sum()
+        ctx.save_for_backward(h, weight, add_w, tgt, nv)
+        ctx.fb, ctx.n0, ctx.chunk = fb, n0, chunk
+        ctx.refs = (weight, add_w, bias, add_b)
+        return total / nv.clamp(min=1).to(torch.float32)[0]
+
+    @staticmethod
+    def _logits(hc, weight, add_w, fb, n0, Vp, out):
+        if add_w is None:           # plain nn.Linear head: columns [n0, Vp) of the chunk buffer stay unwritten (never read below V)
+            return ops.linear(hc, weight, bias=fb, out=out[:, :n0])
+        return ops.linear(hc, weight, bias=fb, out=out, w2=add_w, w2_row0=n0, n_rows=Vp)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, weight, add_w, tgt, nv = ctx.saved_tensors
+        w_ref, a_ref, b_ref, ab_ref = ctx.refs
+        n0, chunk = ctx.n0, ctx.chunk
+        n_add = 0 if add_w is None else add_w.shape[0]
+        V = n0 + n_add
+        Vp = _pad64(V)
+        h2 = _rows2d(h)
+        M, K = h2.shape
+        need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_a = add_w is not None and ctx.needs_input_grad[2]
+        need_b = b_ref is not None and ctx.needs_input_grad[3]
+        need_ab = ab_ref is not None and ctx.needs_input_grad[4]
+        # transposed two-segment weight for the dgrad GEMM: [K, Vp], padding columns zero
+        wt = None
+        if need_h:
+            wt = torch.zeros((K, Vp), dtype=h.dtype, device=h.device)
+            transpose(weight[:n0], out=wt)                          # columns [0, pad64(n0)): rows n0.. of that range are zero-filled
+            if n_add:
+                wt[:, n0:V] = add_w.detach().t()
+                if _pad64(n0) > V:
+                    wt[:, V:_pad64(n0)] = 0
+        # gradient destinations: the trainer's flat-buffer views when there are any (written in place, first chunk overwrites)
+        def dest(param, rows):
+            tgt_ = _fresh_target(param)
+            live = param is not None and getattr(param, "_aki_grad_live", False)
+            if tgt_ is None and not live:
+                return torch.zeros_like(param), False, False          # plain autograd: a fresh tensor goes back
+            return (param._aki_grad, True, live)
+        gw = ga = gb = gab = None
+        if need_w:
+            gw, w_flat, w_live = dest(w_ref, n0)
+            if not w_live and weight.shape[0] > n0:
+                gw[n0:].zero_()                                      # rows of the original table the head never reads
+        if need_a:
+            ga, a_flat, a_live = dest(a_ref, n_add)
+        dh = torch.empty_like(h2) if need_h else None
+        dbias = torch.zeros((Vp,), dtype=torch.float32, device=h.device) if (need_b or need_ab) else None
+        gs = g.to(h.dtype)
+        buf = torch.empty((min(chunk, M), Vp), dtype=h.dtype, device=h.device)
+        first = True
+        for r0 in range(0, M, chunk):
+            r1 = min(M, r0 + chunk)
+            lg = buf[: r1 - r0]
+            FusedHeadCEFn._logits(h2[r0:r1], weight, add_w, ctx.fb, n0, Vp, lg)
+            ce_rows(lg, tgt[r0:r1], nv, V, want_grad=True)            # lg is now d(mean loss)/d(logits) on columns < V
+            if Vp > V:
+                lg[:, V:].zero_()
+            lg.mul_(gs)
+            if need_h:
+                ops.linear(lg, wt, out=dh[r0:r1])
+            if need_w or need_a:
+                dT, xT = transpose(lg), transpose(h2[r0:r1])          # [Vp, pad64(rows)], [K, pad64(rows)]
+                if need_w:
+                    acc = (not first) or w_live
+                    ops.linear(dT[:n0], xT, out=gw[:n0], residual=gw[:n0] if acc else None)
+                if need_a:
+                    acc = (not first) or a_live
+                    ops.linear(dT[n0:V], xT, out=ga, residual=ga if acc else None)
+            if dbias is not None:
+                dbias += colsum(lg).float()
+            first = False
+        def finish(param, grad, flat):
+            if not flat:
+                return grad
+            param._aki_grad_live = True
+            hook = getattr(param, "_aki_grad_hook", None)
+            if hook is not None:
+                hook(param)
+            return None
+        out_w = finish(w_ref, gw, w_flat) if need_w else None
+        out_a = finish(a_ref, ga, a_flat) if need_a else None
+        out_b = out_ab = None
+        if need_b:
+            full = torch.zeros_like(b_ref)
+            full[:n0] = dbias[:n0].to(full.dtype)
+            out_b = _deliver(b_ref, lambda out: full if out is None else out.copy_(full))
+        if need_ab:
+            part = dbias[n0:V].to(ab_ref.dtype)
+            out_ab = _deliver(ab_ref, lambda out: part if out is None else out.copy_(part))
+        return (dh.view(h.shape) if need_h else None), out_w, out_a, out_b, out_ab, None, None, None
+
+
+def fused_head_ce(h, head, labels, chunk: int = 2048):
+    """Loss of `head` (nn.Linear or DecoupledLinear) on the final hidden states h [B, L, K] against labels [B, L], chunked."""
+    if type(head) is torch.nn.Linear:
+        return FusedHeadCEFn.apply(h, head.weight, None, head.bias, None, labels, head.weight.shape[0], chunk)
+    n0 = head.max_original_id + 1
+    add = head.additional_fc if head.additional_out_features else None
+    bias = head.bias if (head.has_bias and head.bias is not None) else None
+    return FusedHeadCEFn.apply(h, head.weight, None if add is None else add.weight, bias,
+                               None if (add is None or bias is None) else add.bias, labels, n0, chunk)
 
 
 class SpliceGradFn(torch.autograd.Function):

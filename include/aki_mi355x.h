@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 8
+#define AKI_ABI_VERSION 9
 
 typedef enum {
   AKI_OK = 0,
@@ -206,6 +206,13 @@ typedef struct {
    * y stay bf16.  act: NONE or SWIGLU.  Ignored for the other dtypes. */
   const float* x_scale;
   const float* w_scale;
+  /* Two-segment weight (bf16 MFMA GEMM, act NONE): logical weight row r comes from w[r] for r < w2_row0 and from
+   * w2[min(r - w2_row0, w2_rows - 1)] beyond it (same ldw) - `DecoupledLinear` (src/helpers.py:594-603: the original
+   * vocabulary rows ++ the rows of the added tokens) as ONE GEMM without a concatenated copy of the 197 MB head weight.
+   * N counts logical rows and may exceed w2_row0 + w2_rows (padding columns repeat the last w2 row).  w2 = NULL: plain. */
+  const void* w2;
+  int32_t w2_row0;
+  int32_t w2_rows;
 } aki_linear_args;
 
 int aki_linear_fwd(const aki_linear_args* args, void* stream);
@@ -339,6 +346,10 @@ int aki_decode_linear_fwd(const aki_linear_args* args, const void* rms_weight, f
  * aki_ce_loss_fwd_bwd   HF shifted cross-entropy: row (b,t) against labels[b][t+1], ignore_index -100;
  *                       loss_rows [B*L] f32 (sum / *n_valid = loss), n_valid: device int32 (written),
  *                       dlogits (may alias logits, may be NULL) = d(mean loss)/d(logits) * gscale
+ * aki_ce_rows_fwd_bwd   the same arithmetic for an arbitrary CHUNK of rows: targets[r] is the (already shifted) class of row r
+ *                       (< 0 or >= V: ignored row), *n_valid (device int32) is an INPUT - the number of scored rows of the
+ *                       whole batch.  With it the lm_head and the loss run chunk by chunk and the [B, L, V] logits tensor
+ *                       is never formed (src/helpers.py:594-603 + train/losses.py:83-116).
  * aki_grad_sqnorm       *out (+)= sum g^2 over a bf16 gradient buffer (n % 8 == 0)
  * aki_adamw_step        fp32 master weights p, moments m, v; bf16 gradients g -> updated p/m/v and bf16 weights w16.
  *                       g is scaled by gscale (1/world, 1/grad_accum) and, when sqnorm != NULL and max_norm > 0, clipped by
@@ -377,6 +388,8 @@ int aki_rope_bwd_merge(const void* dq, const void* dk, const void* dv, const flo
                        void* dqkv, int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype, void* stream);
 int aki_ce_loss_fwd_bwd(const void* logits, const int64_t* labels, int32_t* n_valid, float* loss_rows, void* dlogits, int32_t B,
                         int32_t L, int32_t V, int32_t ldl, int32_t lddl, float gscale, int32_t dtype, void* stream);
+int aki_ce_rows_fwd_bwd(const void* logits, const int64_t* targets, const int32_t* n_valid, float* loss_rows, void* dlogits,
+                        int32_t rows, int32_t V, int32_t ldl, int32_t lddl, float gscale, int32_t dtype, void* stream);
 size_t aki_grad_sqnorm_workspace_bytes(void);
 int aki_grad_sqnorm(const void* g, size_t n, float* out, int32_t accumulate, int32_t dtype, void* workspace, size_t workspace_bytes,
                     void* stream);

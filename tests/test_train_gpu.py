@@ -125,6 +125,92 @@ def _dense_attention(q, k, v, mask01, scale):
     return (p @ v).transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
 
 
+@pytest.mark.parametrize("M,K,V0,n0,n_add", [(300, 256, 1100, 1001, 2), (700, 512, 3100, 3001, 2), (120, 192, 70, 66, 3), (1380, 3072, 32064, 32011, 2)])
+def test_linear_two_segment_weight(M, K, V0, n0, n_add):
+    """aki_linear_fwd with w2 / w2_row0 / w2_rows = DecoupledLinear (src/helpers.py:594-603) as one GEMM: columns < n0 from
+    weight[:n0], the next n_add from additional_fc.weight, padding columns repeat its last row; against torch on the host."""
+    from aki_amd import ops
+    x, w, w2 = rt(M, K, seed=1), rt(V0, K, seed=2, scale=0.05), rt(n_add, K, seed=3, scale=0.05)
+    V = n0 + n_add
+    Vp = (V + 63) // 64 * 64
+    b = rt(Vp, seed=4, scale=0.1)
+    y = ops.linear(x, w, bias=b, w2=w2, w2_row0=n0, n_rows=Vp)
+    assert y.shape == (M, Vp)
+    wf = torch.cat([w[:n0], w2, w2[-1:].expand(Vp - V, K)], 0).float().cpu()
+    rows = torch.arange(0, M, max(1, M // 97))
+    want = x.float().cpu()[rows] @ wf.t() + b.float().cpu()
+    close(y[rows.to(DEV)], want.to(DEV), tol=1e-2, what="two-segment GEMM")
+    fused = ops.linear(x, torch.cat([w[:n0], w2, w2[-1:].expand(Vp - V, K)], 0).contiguous(), bias=b)
+    assert torch.equal(y, fused), "must be the same arithmetic as the GEMM over a concatenated copy"
+
+
+def test_ce_rows_chunks_equal_whole_batch_kernel():
+    from aki_amd import train_ops as T
+    B, L, V, ld = 3, 50, 1003, 1024
+    logits = rt(B, L, ld, seed=5, scale=2.0)
+    labels = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(6)).to(DEV)
+    labels[0, 10:14] = -100
+    labels[2, 1] = V + 5                                       # out of range -> ignored, not an out-of-bounds read
+    whole = logits.clone()
+    loss, nv = T.ce_loss(whole, labels, V, want_grad=True)
+    tgt = torch.full((B, L), -100, dtype=torch.int64, device=DEV)
+    tgt[:, :-1] = labels[:, 1:]
+    tgt = tgt.reshape(-1)
+    nv2 = ((tgt >= 0) & (tgt < V)).sum().to(torch.int32).reshape(1)
+    assert int(nv2) == int(nv)
+    flat = logits.reshape(B * L, ld).clone()
+    total = 0.0
+    for r0 in range(0, B * L, 64):
+        total = total + T.ce_rows(flat[r0:r0 + 64], tgt[r0:r0 + 64], nv2, V, want_grad=True).sum()
+    assert abs(float(total / nv2[0]) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    assert torch.equal(flat[:, :V], whole.reshape(B * L, ld)[:, :V])
+    lg = logits.float()[:, :-1, :V].reshape(-1, V)
+    tg = labels[:, 1:].reshape(-1).clone()
+    tg[tg >= V] = -100
+    want = F.cross_entropy(lg, tg, ignore_index=-100)
+    assert abs(float(loss) - float(want)) < 2e-3 * max(1.0, abs(float(want)))
+
+
+@pytest.mark.parametrize("decoupled,bias", [(True, True), (True, False), (False, False)])
+def test_fused_head_ce_matches_autograd_without_logits_tensor(decoupled, bias):
+    """lm_head + shifted cross-entropy chunk by chunk (three chunks here) against fp32 torch autograd over
+    DecoupledLinear.forward + F.cross_entropy on the same bf16-rounded tensors: loss, d h, both weight gradients, both
+    bias gradients; rows of the original table beyond max_original_id get a zero gradient."""
+    from aki_amd import train_ops as T
+    B, L, K, V0, n0, n_add = 2, 70, 128, 900, 811 if decoupled else 896, 2 if decoupled else 0
+    if not decoupled:
+        V0 = n0
+    h = rt(B, L, K, seed=1).requires_grad_()
+    w = rt(V0, K, seed=2, scale=0.08).requires_grad_()
+    aw = rt(n_add, K, seed=3, scale=0.08).requires_grad_() if decoupled else None
+    bb = rt(V0, seed=4, scale=0.1).requires_grad_() if bias else None
+    ab = rt(n_add, seed=5, scale=0.1).requires_grad_() if (bias and decoupled) else None
+    labels = torch.randint(0, n0 + n_add, (B, L), generator=torch.Generator().manual_seed(7)).to(DEV)
+    labels[1, 40:] = -100
+    loss = T.FusedHeadCEFn.apply(h, w, aw, bb, ab, labels, n0, 48)
+    loss.backward()
+    hr, wr = h.detach().float().requires_grad_(), w.detach().float().requires_grad_()
+    awr = aw.detach().float().requires_grad_() if decoupled else None
+    bbr = bb.detach().float().requires_grad_() if bias else None
+    abr = ab.detach().float().requires_grad_() if ab is not None else None
+    lg = F.linear(hr, wr, bbr)[..., :n0]
+    if decoupled:
+        lg = torch.cat((lg, F.linear(hr, awr, abr)), -1)
+    want = F.cross_entropy(lg[:, :-1].reshape(-1, lg.shape[-1]), labels[:, 1:].reshape(-1), ignore_index=-100)
+    want.backward()
+    assert abs(float(loss) - float(want)) < 2e-3 * max(1.0, abs(float(want)))
+    close(h.grad, hr.grad, tol=3e-2, what="d h")
+    close(w.grad[:n0], wr.grad[:n0], tol=3e-2, what="d weight")
+    assert bool((w.grad[n0:] == 0).all())
+    if decoupled:
+        close(aw.grad, awr.grad, tol=3e-2, what="d additional_fc.weight")
+    if bias:
+        close(bb.grad[:n0], bbr.grad[:n0], tol=3e-2, what="d bias")
+        assert bool((bb.grad[n0:] == 0).all())
+        if ab is not None:
+            close(ab.grad, abr.grad, tol=3e-2, what="d additional_fc.bias")
+
+
 @pytest.mark.parametrize("case", ["single_image", "multi_image_padded", "long"])
 def test_mma_attention_backward(case):
     """dq/dk/dv of the MMA attention core vs autograd over a dense-mask fp32 attention on the same bf16 inputs."""
