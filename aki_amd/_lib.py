@@ -131,6 +131,7 @@ SIGNATURES = {
     "aki_splice_fwd": (C.c_int, [C.POINTER(SpliceArgs), C.c_void_p]),
     "aki_mma_mask_dense": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p]),
+    "aki_sft_collate_pad": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32] + [C.c_void_p] * 4),
     "aki_mma_mask_to_table_workspace_bytes": (C.c_size_t, [C.c_int32] * 2),
     "aki_mma_mask_to_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
 }

@@ -31,6 +31,9 @@ int splice_launch(const aki_splice_args* a, hipStream_t s);
 int mask_dense_launch(const aki_mma_rect* rects, int max_rects, const uint64_t* vbits, const int* seq_lens, int B, int L,
                       int64_t* out, hipStream_t s);
 int im2col_launch(const void* pix, void* out, int N, int S, int P, int Kp, int dtype, hipStream_t s);
+int sft_collate_launch(const int64_t* ids, const int64_t* labels, const int64_t* mask, const int* offsets, int B, int T_out,
+                       int64_t pad_id, int64_t ignore_index, int left, int64_t* out_ids, int64_t* out_labels, int64_t* out_mask,
+                       hipStream_t s);
 size_t mask_to_table_ws_bytes(int B, int L);
 int mask_to_table_launch(const int64_t* mask, int B, int L, int max_rects, aki_mma_rect* rects, uint64_t* vbits, int* seq_lens,
                          int* status, void* ws, hipStream_t s);
@@ -501,6 +504,16 @@ int aki_mma_mask_dense(const aki_mma_rect* rects, int32_t max_rects, const uint6
   AKI_CLEAR_ERR();
   AKI_CHECK_ARG(out && B > 0 && L > 0 && max_rects >= 0 && max_rects <= AKI_MAX_RECTS && (max_rects == 0 || rects));
   return mask_dense_launch(rects, max_rects, col_valid_bits, seq_lens, B, L, out, (hipStream_t)stream);
+}
+
+int aki_sft_collate_pad(const int64_t* ids, const int64_t* labels, const int64_t* attention_mask, const int32_t* offsets, int32_t B,
+                        int32_t T_out, int64_t pad_token_id, int64_t ignore_index, int32_t padding_side, int64_t* out_ids,
+                        int64_t* out_labels, int64_t* out_mask, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(ids && offsets && out_ids && B > 0 && T_out > 0 && (padding_side == 0 || padding_side == 1));
+  AKI_CHECK_ARG((!out_labels || labels) && (!out_mask || attention_mask));
+  return sft_collate_launch(ids, labels, attention_mask, offsets, B, T_out, pad_token_id, ignore_index, padding_side, out_ids, out_labels,
+                            out_mask, (hipStream_t)stream);
 }
 
 size_t aki_mma_mask_to_table_workspace_bytes(int32_t B, int32_t L) {

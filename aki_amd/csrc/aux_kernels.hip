@@ -355,6 +355,27 @@ __global__ __launch_bounds__(256) void mask_table_build_kernel(const int4* rowin
 }
 
 // ------------------------------------------------------------------------------------------------
+// SFT collate (train/sft_data_utils/loader_utils.py:11-91 `_pad_trunc` / `batch_collate_pad`): B ragged token sequences,
+// concatenated (`offsets[b] .. offsets[b+1]`), become [B, T_out] arrays - truncated to their first T_out tokens, or padded
+// on the right / left with pad_token_id (ids), ignore_index (labels) and 0 (attention mask).  One block per sample.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sft_collate_kernel(const int64_t* ids, const int64_t* labels, const int64_t* mask,
+                                                          const int* offsets, int T_out, int64_t pad_id, int64_t ignore_index,
+                                                          int left, int64_t* out_ids, int64_t* out_labels, int64_t* out_mask) {
+  const int b = blockIdx.x;
+  const int o0 = offsets[b], len = offsets[b + 1] - o0;
+  const int shift = (left && len < T_out) ? T_out - len : 0;     // left padding moves the sequence to the end of the row
+  for (int t = threadIdx.x; t < T_out; t += 256) {
+    const int s = t - shift;
+    const bool tok = s >= 0 && s < len;                           // len >= T_out: the first T_out tokens survive
+    const size_t o = (size_t)b * T_out + t;
+    out_ids[o] = tok ? ids[o0 + s] : pad_id;
+    if (out_labels) out_labels[o] = tok ? labels[o0 + s] : ignore_index;
+    if (out_mask) out_mask[o] = tok ? mask[o0 + s] : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // im2col for the SigLIP patch embedding: A[n*G*G + gy*G + gx][c*P*P + py*P + px], zero padded to Kp.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -411,6 +432,16 @@ int mask_to_table_launch(const int64_t* mask, int B, int L, int max_rects, aki_m
   hipLaunchKernelGGL(mask_rows_scan_kernel, dim3(L, B), dim3(256), 0, s, mask, L, (int4*)ws, (unsigned long long*)vbits);
   AKI_LAUNCH_CHECK();
   hipLaunchKernelGGL(mask_table_build_kernel, dim3(B), dim3(256), 0, s, (const int4*)ws, L, max_rects, rects, seq_lens, status);
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
+}
+
+int sft_collate_launch(const int64_t* ids, const int64_t* labels, const int64_t* mask, const int* offsets, int B, int T_out,
+                       int64_t pad_id, int64_t ignore_index, int left, int64_t* out_ids, int64_t* out_labels, int64_t* out_mask,
+                       hipStream_t s) {
+  AKI_CLEAR_ERR();
+  hipLaunchKernelGGL(sft_collate_kernel, dim3(B), dim3(256), 0, s, ids, labels, mask, offsets, T_out, pad_id, ignore_index, left,
+                     out_ids, out_labels, out_mask);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }

@@ -415,7 +415,7 @@ class Phi3ForCausalLM(nn.Module):
         if labels is not None and cache is None and _ag(h, *self.lm_head.parameters()):
             # training: lm_head + shifted cross-entropy chunk by chunk - no [B, L, V] logits tensor, no concatenated head
             # weight (so the output carries no logits; train/losses.py:110-115 only reads [0] = loss)
-            loss = T.fused_head_ce(h, self.lm_head, labels, chunk=getattr(self, "head_chunk_rows", 2048))
+            loss = T.fused_head_ce(h, self.lm_head, labels, chunk=getattr(self, "head_chunk_rows", 2688))
             return CausalLMOutputWithPast(loss=loss, logits=None, past_key_values=None)
         logits = self._head(h)
         if cache is not None:

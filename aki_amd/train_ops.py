@@ -565,7 +565,7 @@ class FusedHeadCEFn(torch.autograd.Function):
         return (dh.view(h.shape) if need_h else None), out_w, out_a, out_b, out_ab, None, None, None
 
 
-def fused_head_ce(h, head, labels, chunk: int = 2048):
+def fused_head_ce(h, head, labels, chunk: int = 2688):
     """Loss of `head` (nn.Linear or DecoupledLinear) on the final hidden states h [B, L, K] against labels [B, L], chunked."""
     if type(head) is torch.nn.Linear:
         return FusedHeadCEFn.apply(h, head.weight, None, head.bias, None, labels, head.weight.shape[0], chunk)

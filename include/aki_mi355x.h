@@ -422,6 +422,16 @@ int aki_mma_mask_to_table(const int64_t* mask, int32_t B, int32_t L, int32_t max
                           uint64_t* col_valid_bits, int32_t* seq_lens, int32_t* status, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* aki_sft_collate_pad - the SFT collate (train/sft_data_utils/loader_utils.py:11-91 `_pad_trunc` + `batch_collate_pad`) on the
+ * device: B ragged samples, concatenated (sample b = elements offsets[b] .. offsets[b+1]-1 of ids / labels / attention_mask),
+ * -> [B, T_out] int64 arrays.  A sample of T_out tokens or more keeps its FIRST T_out tokens; a shorter one is padded on the
+ * right (padding_side 0) or left (1) with pad_token_id / ignore_index / 0.  T_out is the caller's: `max_length + 1` for
+ * padding="max_length" (loader_utils.py:78-82), the longest sample for "longest" (:30-31).  labels / attention_mask and their
+ * outputs may be NULL together. */
+int aki_sft_collate_pad(const int64_t* ids, const int64_t* labels, const int64_t* attention_mask, const int32_t* offsets, int32_t B,
+                        int32_t T_out, int64_t pad_token_id, int64_t ignore_index, int32_t padding_side, int64_t* out_ids,
+                        int64_t* out_labels, int64_t* out_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,6 +211,38 @@ def stack_with_padding_2d_attention(tensors: List[np.ndarray]) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------------------------
+# 8(f) #4: SFT collate (train/sft_data_utils/loader_utils.py)
+# ----------------------------------------------------------------------------------------------
+SFT_IGNORE_INDEX = -100   # train/sft_data_utils/templates/templates.py IGNORE_INDEX
+
+
+def sft_pad_trunc(x, padding: str, padding_side: str, pad_value: int, max_length) -> np.ndarray:
+    """`_pad_trunc`, loader_utils.py:11-50: every sample to one length - "longest": the longest sample's; "max_length": the
+    given one; longer samples keep their FIRST max_length tokens, shorter ones are padded left or right."""
+    lengths = [len(s) for s in x]
+    if padding == "longest":
+        max_length = max(lengths)                                   # :30-31 (the caller's limit is dropped here, as in the reference)
+    rows = []
+    for s, n in zip(x, lengths):
+        s = [int(v) for v in (s.tolist() if hasattr(s, "tolist") else s)]
+        if n >= max_length:
+            rows.append(s[:max_length])                             # :38-40
+        else:
+            pads = [pad_value] * (max_length - n)
+            rows.append(s + pads if padding_side == "right" else pads + s)   # :42-47
+    return np.asarray(rows, dtype=np.int64)
+
+
+def sft_batch_collate_pad(batch, padding: str, padding_side: str, pad_token_id: int, max_length):
+    """`batch_collate_pad`, loader_utils.py:53-91 (note `max_length + 1` for the BOS token, :78-82)."""
+    if padding != "max_length":
+        max_length = max_length or int(1e12)
+    cols = {k: [s[k] for s in batch] for k in ("input_ids", "labels", "attention_mask")}
+    pads = {"input_ids": pad_token_id, "labels": SFT_IGNORE_INDEX, "attention_mask": 0}
+    return {k: sft_pad_trunc(v, padding, padding_side, pads[k], max_length + 1) for k, v in cols.items()}
+
+
+# ----------------------------------------------------------------------------------------------
 # a5 / a12: decoupled embedding + lm_head
 # ----------------------------------------------------------------------------------------------
 def decoupled_embedding(ids: np.ndarray, weight: np.ndarray, additional_weight: Optional[np.ndarray],

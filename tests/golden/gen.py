@@ -97,3 +97,20 @@ def grad_sample_idx(numel: int, k: int = 48) -> np.ndarray:
     if numel <= k:
         return np.arange(numel, dtype=np.int64)
     return (np.arange(k, dtype=np.int64) * 2654435761 + 12345) % numel
+
+
+def sft_cases():
+    """Seeded ragged batches + collate arguments for the SFT collate (train/sft_data_utils/loader_utils.py)."""
+    rng = rng_for("sft_collate")
+    cases = []
+    for (B, lo, hi, padding, side, max_length) in [(4, 3, 40, "max_length", "right", 24), (5, 1, 30, "longest", "right", 16), (3, 10, 60, "max_length", "left", 63),
+                                                    (6, 2, 90, "longest", "left", None), (1, 7, 8, "max_length", "right", 4), (8, 400, 700, "max_length", "right", 512),
+                                                    (2, 5, 6, "longest", "right", 2)]:
+        batch = []
+        for _ in range(B):
+            n = int(rng.integers(lo, hi + 1))
+            ids = rng.integers(0, 32064, n).astype(np.int64)
+            lab = np.where(rng.random(n) < 0.4, -100, ids)
+            batch.append({"input_ids": ids.tolist(), "labels": lab.tolist(), "attention_mask": [1] * n})
+        cases.append((batch, padding, side, 32000, max_length))
+    return cases

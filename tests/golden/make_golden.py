@@ -281,8 +281,22 @@ def g_patch_embed():
          y_sum=np.array(float(y.astype(np.float64).sum())), y_abs=np.array(float(np.abs(y.astype(np.float64)).sum())))
 
 
+def g_sft_collate():
+    """8(f) #4: `batch_collate_pad` of the reference's SFT data pipeline on seeded ragged batches (inputs are regenerated from the
+    seed by the tests; only the reference's outputs are stored)."""
+    lu = R.load_sft_loader_utils()
+    out = {}
+    for i, (batch, padding, side, pad_id, max_length) in enumerate(gen.sft_cases()):
+        res = lu.batch_collate_pad([{k: (torch.tensor(v) if (i % 2 and k == "input_ids") else v) for k, v in s.items()} for s in batch],
+                                   padding, side, pad_id, max_length)
+        for k, v in res.items():
+            out[f"{k}_{i}"] = v.numpy()
+    save("sft_collate.npz", n_cases=np.array(len(gen.sft_cases())), **out)
+
+
 def main():
     ref = R.load_reference()
+    g_sft_collate()
     g_mask(ref)
     g_decoupled(ref)
     g_rope()

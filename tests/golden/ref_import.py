@@ -74,6 +74,27 @@ def load_reference():
     return pkg
 
 
+def load_sft_loader_utils():
+    """train/sft_data_utils/loader_utils.py (imports only its sibling templates/templates.py) loaded by file path."""
+    root = os.path.join(REF_ROOT, "train", "sft_data_utils")
+    if not os.path.isdir(root):
+        raise RuntimeError("reference tree not present; goldens can only be regenerated in the build container")
+    for name, path in (("aki_ref_sft", root), ("aki_ref_sft.templates", os.path.join(root, "templates"))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [path]
+            sys.modules[name] = m
+    mods = {}
+    for full, path in (("aki_ref_sft.templates.templates", os.path.join(root, "templates", "templates.py")),
+                       ("aki_ref_sft.loader_utils", os.path.join(root, "loader_utils.py"))):
+        spec = importlib.util.spec_from_file_location(full, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[full] = mod
+        spec.loader.exec_module(mod)
+        mods[full] = mod
+    return mods["aki_ref_sft.loader_utils"]
+
+
 def invert_mask_441(mask01: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """transformers==4.41.2 ``_prepare_4d_causal_attention_mask`` for a 4-D input:
     ``inverted = 1.0 - mask; inverted.masked_fill(inverted.bool(), finfo(dtype).min)``."""

@@ -233,3 +233,17 @@ def test_mask_to_table_round_trips_every_reference_mask():
     for r in range(0, 20, 2):
         stair[r, r + 1:r + 3 + r] = 1
     assert O.mask_to_table(stair, max_rects=8) is None
+
+
+def test_sft_collate_restatement_vs_reference():
+    """oracle.sft_batch_collate_pad against the reference's `batch_collate_pad` (train/sft_data_utils/loader_utils.py:53-91) on
+    seeded ragged batches: both padding modes, both sides, truncation, tensors as samples."""
+    g = load_golden("sft_collate.npz")
+    cases = gen.sft_cases()
+    assert int(g["n_cases"]) == len(cases) >= 6
+    for i, (batch, padding, side, pad_id, max_length) in enumerate(cases):
+        got = O.sft_batch_collate_pad(batch, padding, side, pad_id, max_length)
+        for k in ("input_ids", "labels", "attention_mask"):
+            assert got[k].dtype == np.int64 and np.array_equal(got[k], g[f"{k}_{i}"]), (i, k)
+        longest = max(len(s["input_ids"]) for s in batch)
+        assert got["input_ids"].shape[1] == (longest if padding == "longest" else max_length + 1)

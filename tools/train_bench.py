@@ -1,9 +1,15 @@
 """Pre-training step of BASELINE configs[2] on real hardware: AKI-4B, bf16 compute / fp32 master weights, 8 samples per
 GPU (336 px image + 512-token prompt, L = 655), forward + backward + gradient all-reduce (RCCL) + clip 1.0 + AdamW.
-    python tools/train_bench.py [--steps 5] [--warmup 2] [--batch 8] [--layers 32]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py
-Prints one JSON line (rank 0): training tokens/s, ms per step, split into forward / backward(+all-reduce) / optimizer,
-model FLOP utilisation against the dense bf16 MFMA peak, and peak HBM use."""
+    python tools/train_bench.py [--gpus 1] [--steps 5] [--warmup 2] [--batch 8] [--layers 32] [--bucket-mb 512] [--shard-optimizer]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/train_bench.py --gpus N ...
+Prints ONE JSON line (rank 0) with the fields of bench.py's contract (value = whole-job training tokens/s over the
+max-over-ranks time of exactly K steps bracketed by barrier + synchronize) plus the split into forward / backward (+ overlapped
+exchange) / optimizer, `exchange_ms` = all gradient buckets exchanged back to back with nothing else running, `exchange_exposed_ms`
+= what of it the step actually waits for after the backward pass, `overlap_frac` = 1 - exposed / total, model FLOP utilisation and
+peak HBM use.  The gradients are exchanged in bf16 (they are produced in bf16 into the flat buffer; there is no fp32 gradient copy
+to reduce), the sum is exact in fp32 inside RCCL's reduction only per element pair - see DESIGN.md section 6.
+--exchange-when-alone runs the collectives in a world of one (identities through RCCL): the single-GPU box then measures the
+software path of the exchange; real scaling needs the 8-GPU node (none has been available to this build: no scaling curve exists)."""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +22,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--shard-optimizer", action="store_true", help="ZeRO/FSDP-style: reduce-scatter grads, 1/world optimizer state")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks of the job (informational; the launcher sets WORLD_SIZE)")
+    ap.add_argument("--bucket-mb", type=int, default=512, help="gradient bucket size; xGMI is point-to-point, few large messages")
+    ap.add_argument("--exchange-when-alone", action="store_true", help="world of one: still issue the RCCL collectives")
+    ap.add_argument("--head-chunk", type=int, default=0, help="rows per chunk of the fused lm_head + cross-entropy (0 = default 2688: two chunks at the benchmark batch)")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -23,22 +33,35 @@ def main():
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or a.exchange_when_alone:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(os.environ.get("AKI_BENCH_BACKEND", "nccl"), rank=rank, world_size=world, device_id=dev)
     from aki_amd.factory import build_aki
     from aki_amd.trainer import AkiTrainer
     from aki_amd.phi3 import make_phi3_config
     model = build_aki(make_phi3_config(num_hidden_layers=a.layers), dtype=torch.bfloat16, device=dev, seed=0)   # same seed: replicas start identical
     model.train()
+    if a.head_chunk:
+        model.lang_model.head_chunk_rows = a.head_chunk
     model.set_trainable()
-    tr = AkiTrainer(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=1.0, shard_optimizer=a.shard_optimizer)
+    tr = AkiTrainer(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=1.0, shard_optimizer=a.shard_optimizer,
+                    bucket_bytes=a.bucket_mb << 20, exchange_when_alone=a.exchange_when_alone)
     B, L = a.batch, bench.N_TXT - 1 + bench.NV
     vx, ids, am = bench.synth_batch(B, dev, torch.bfloat16, model.media_token_id, seed=1000 + rank)
     labels = ids.clone()
     labels[labels == model.media_token_id] = -100          # train/losses.py:88-116: labels = input ids, special tokens masked
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    parts = {"forward": 0.0, "backward": 0.0, "optimizer": 0.0}
+    parts = {"forward": 0.0, "backward": 0.0, "optimizer": 0.0, "exchange_exposed": 0.0}
+    # exposed exchange: from the end of the backward COMPUTE (autograd returned, last kernel queued) to the end of reducer.finish()
+    orig_finish = tr.reducer.finish
+    marks = {}
+    def timed_finish():
+        marks["a"] = ev(); marks["a"].record()
+        orig_finish()
+        marks["b"] = ev(); marks["b"].record()
+    tr.reducer.finish = timed_finish
     losses = []
     torch.cuda.reset_peak_memory_stats()
     for it in range(a.warmup + a.steps):
@@ -60,6 +83,7 @@ def main():
             torch.cuda.synchronize()
             for k, i in (("forward", 0), ("backward", 1), ("optimizer", 2)):
                 parts[k] += e[i].elapsed_time(e[i + 1])
+            parts["exchange_exposed"] += marks["a"].elapsed_time(marks["b"])
             losses.append(float(out.loss))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -67,6 +91,18 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # the whole exchange on its own: every bucket back to back, nothing else on the GPU
+    exch_ms = 0.0
+    if tr.reducer.active:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            tr.reducer.finish = orig_finish
+            tr.reducer.finish()
+            torch.cuda.synchronize()
+        exch_ms = (time.perf_counter() - t1) / 3 * 1e3
     if rank == 0:
         n_lm = sum(p.numel() for n_, p in model.named_parameters() if n_.startswith("lang_model.") and "embed_tokens" not in n_)
         # 6 FLOP per parameter per token (fwd 2 + bwd 4) for the decoder + head, + the frozen tower's forward and the connector
@@ -74,11 +110,20 @@ def main():
         ms = elapsed / a.steps * 1e3
         print(json.dumps({
             "metric": "training tokens/s, AKI-4B pre-training step (fwd+bwd+all-reduce+clip+AdamW)", "value": round(B * world * L * a.steps / elapsed, 1),
-            "unit": "tokens/s", "n_gpus": world, "ms_per_step": round(ms, 2), "global_batch": B * world, "seq_len": L,
+            "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "AKI-4B pre-training step, BASELINE configs[2]: 336px image + 512-token prompt per sample, batch 8 per GPU, "
+                                   "bf16 compute / fp32 master weights; random-init weights", "global_batch": B * world, "seq_len": L,
+                       "parallelism": f"dp{world}" + ("+sharded-optimizer" if a.shard_optimizer else ""), "bucket_mb": a.bucket_mb,
+                       "gradient_exchange": ("reduce-scatter + all-gather" if tr.shard else "all-reduce") + " of bf16 gradients, in place in the flat buffer",
+                       "layers": a.layers},
+            "exchange_ms": round(exch_ms, 3), "exchange_exposed_ms": round(parts["exchange_exposed"] / a.steps, 3),
+            "overlap_frac": (round(1.0 - min(1.0, (parts["exchange_exposed"] / a.steps) / exch_ms), 3) if exch_ms > 0 else None),
+            "buckets": len(tr.reducer.buckets),
             "parts_ms": {k: round(v / a.steps, 2) for k, v in parts.items()}, "losses": [round(x, 4) for x in losses],
             "trainable_params": tr.numel, "lm_mfu_vs_2500TF": round(flops / (ms * 1e-3) / 2.5e15, 4),
-            "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1), "dtype": "bf16 compute, fp32 master/moments, bf16 grads"}))
-    if world > 1:
+            "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1), "precision": "bf16 compute, fp32 master/moments, bf16 grads", "head_chunk_rows": getattr(model.lang_model, "head_chunk_rows", 2688)}))
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
