@@ -191,6 +191,7 @@ def adamw_step(p32, m, v, g16, w16, sqnorm, max_norm, gscale, lr, beta1, beta2, 
 # ---- transposed-weight cache -------------------------------------------------------------------------------------
 _EPOCH = 0            # bumped by the trainer after every optimizer step (the kernels write weights through raw pointers)
 _WT = {}
+CACHE_WT = True       # False under sharded parameters: a cache of transposed weights would re-materialise what sharding released
 
 
 def bump_weight_epoch() -> None:
@@ -203,7 +204,7 @@ def _weight_t(w: torch.Tensor) -> torch.Tensor:
     """W [N,K] -> W^T [K, pad64(N)] (zero padded), cached until the weights change: the trainer bumps the epoch after every
     optimizer step (its kernels write through raw pointers), in-place torch updates show up in `_version`.  Temporaries (the
     lm_head's concatenated weight is a new tensor every forward) would pile up without a trainer, hence the size cap."""
-    if not (isinstance(w, torch.nn.Parameter) or hasattr(w, "_aki_grad") or getattr(w, "_aki_cacheable", False)):
+    if not CACHE_WT or not (isinstance(w, torch.nn.Parameter) or hasattr(w, "_aki_grad") or getattr(w, "_aki_cacheable", False)):
         # a temporary (slice / concatenation built inside a forward): its (data_ptr, _version) says nothing about its content -
         # the allocator recycles the address and a fresh tensor is always version 0 - so it is transposed every time
         return transpose(w if w.stride(1) == 1 else w.contiguous())
@@ -250,7 +251,10 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, residual):
         _need_bf16(x, w)
         y = ops.linear(x, w, bias=bias, residual=residual)
-        ctx.save_for_backward(x, w)
+        # Weights are NOT handed to save_for_backward: the backward reads the parameter as it is THEN (ctx.w_ref).  With
+        # sharded parameters (trainer.AkiShardedTrainer) its storage is released after the forward and gathered again -
+        # in place - before the backward, which autograd's saved-tensor version check would refuse.
+        ctx.save_for_backward(x)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.bias_ref = bias
         ctx.w_ref = w
@@ -258,7 +262,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        (x,), w = ctx.saved_tensors, ctx.w_ref
         N, K = w.shape
         dy2 = _rows2d(dy)
         M = dy2.shape[0]
@@ -288,13 +292,13 @@ class NormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps, rms):
         y = ops.rmsnorm(x, w, eps) if rms else ops.layernorm(x, w, b, eps)
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x)
         ctx.eps, ctx.rms, ctx.w_ref, ctx.b_ref = eps, rms, w, b
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        (x,), w = ctx.saved_tensors, ctx.w_ref
         need_db = not ctx.rms and ctx.b_ref is not None
         wt = _fresh_target(ctx.w_ref) if ctx.needs_input_grad[1] else None
         bt = _fresh_target(ctx.b_ref) if (need_db and ctx.needs_input_grad[2]) else None
@@ -314,13 +318,13 @@ class NormResidualFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, eps):
         y = ops.rmsnorm(x, w, eps)
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x)
         ctx.eps, ctx.w_ref = eps, w
         return y, x.view_as(x)
 
     @staticmethod
     def backward(ctx, dy, dres):
-        x, w = ctx.saved_tensors
+        (x,), w = ctx.saved_tensors, ctx.w_ref
         wt = _fresh_target(ctx.w_ref) if ctx.needs_input_grad[1] else None
         dx, dw, _ = norm_bwd(True, x, w, dy, ctx.eps, dw_out=wt, dres=dres)
         gw = _deliver(ctx.w_ref, lambda out: dw if (out is None or out is wt) else out.copy_(dw)) if ctx.needs_input_grad[1] else None
@@ -370,13 +374,13 @@ class QkvRopeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, cos, sin, num_heads, position_ids):
         q, k, v = ops.qkv_rope(x, w, cos, sin, num_heads, position_ids)
-        ctx.save_for_backward(x, w, cos, sin)
+        ctx.save_for_backward(x, cos, sin)
         ctx.pos, ctx.w_ref = position_ids, w
         return q, k, v
 
     @staticmethod
     def backward(ctx, dq, dk, dv):
-        x, w, cos, sin = ctx.saved_tensors
+        (x, cos, sin), w = ctx.saved_tensors, ctx.w_ref
         dqkv = rope_bwd_merge(dq, dk, dv, cos, sin, ctx.pos)          # [B, L, 3*H*Dh]
         d2 = dqkv.view(-1, dqkv.shape[-1])
         dx = ops.linear(d2, _weight_t(w)).view(x.shape) if ctx.needs_input_grad[0] else None
@@ -470,7 +474,7 @@ class FusedHeadCEFn(torch.autograd.Function):
             lg = buf[: r1 - r0]
             FusedHeadCEFn._logits(h2[r0:r1], weight, add_w, fb, n0, Vp, lg)
             total = total + ce_rows(lg, tgt[r0:r1], nv, V, want_grad=False).sum()
-        ctx.save_for_backward(h, weight, add_w, tgt, nv)
+        ctx.save_for_backward(h, tgt, nv)
         ctx.fb, ctx.n0, ctx.chunk = fb, n0, chunk
         ctx.refs = (weight, add_w, bias, add_b)
         return total / nv.clamp(min=1).to(torch.float32)[0]
@@ -483,8 +487,9 @@ class FusedHeadCEFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        h, weight, add_w, tgt, nv = ctx.saved_tensors
+        h, tgt, nv = ctx.saved_tensors
         w_ref, a_ref, b_ref, ab_ref = ctx.refs
+        weight, add_w = w_ref, a_ref
         n0, chunk = ctx.n0, ctx.chunk
         n_add = 0 if add_w is None else add_w.shape[0]
         V = n0 + n_add

@@ -185,3 +185,295 @@ class AkiTrainer:
         self.backward(loss)
         self.optimizer_step()
         return loss.detach()
+
+
+# ======================================================================================================================
+# Parameter-sharded data parallelism: the FSDP FULL_SHARD exchange of the reference's shipped launch
+# configurations (train/distributed.py:170-243, wrap units from `get_fsdp_lambda_fn`, scripts/run_train.sh:23).
+# ======================================================================================================================
+def _storage_bytes(t: torch.Tensor) -> int:
+    return t.untyped_storage().size()
+
+
+class _PreBackward(torch.autograd.Function):
+    """Identity placed on a unit's output: its backward runs before anything inside the unit does, which is where the unit's
+    parameters are gathered again and its gradient buffer is allocated."""
+
+    @staticmethod
+    def forward(ctx, y, unit):
+        ctx.unit = unit
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ctx.unit.materialize()
+        ctx.unit.alloc_grads()
+        return dy, None
+
+
+class _Unit:
+    """One sharding unit: the trainable parameters of a decoder block / the vision tokenizer / the root remainder as ONE flat
+    bf16 buffer whose storage only exists while the unit computes.  Each rank keeps 1/world of it (bf16 shard, fp32 master
+    weights and moments of that shard) - weights, gradients and optimizer state are all sharded."""
+
+    def __init__(self, name, params, decay, world, rank, group, device, no_scatter):
+        self.name, self.params, self.decay = name, params, decay
+        self.world, self.rank, self.group, self.no_scatter = world, rank, group, no_scatter
+        offs, off = [], 0
+        for p in params:
+            offs.append(off)
+            off = (off + p.numel() + 7) // 8 * 8
+        align = 8 * world
+        self.numel = (off + align - 1) // align * align
+        self.n_shard = self.numel // world
+        self.lo = rank * self.n_shard
+        self.w_full = torch.zeros(self.numel, dtype=torch.bfloat16, device=device)
+        self.g_full = torch.zeros(self.numel, dtype=torch.bfloat16, device=device)
+        self.nbytes = self.numel * 2
+        for p, o in zip(params, offs):
+            self.w_full[o:o + p.numel()].copy_(p.detach().reshape(-1))
+        self.w_shard = self.w_full[self.lo:self.lo + self.n_shard].clone()
+        self.g_shard = torch.zeros(self.n_shard, dtype=torch.bfloat16, device=device)
+        self.master = self.w_shard.float()
+        self.m = torch.zeros_like(self.master)
+        self.v = torch.zeros_like(self.master)
+        for p, o in zip(params, offs):
+            p.data = self.w_full[o:o + p.numel()].view(p.shape)
+            p._aki_grad = self.g_full[o:o + p.numel()].view(p.shape)
+            p._aki_grad_live = False
+            p._aki_unit = self
+            p.grad = None
+        self.pending = len(params)
+        self.delivered = set()
+        self.inflight = None               # (work, tmp shard) of the reduce-scatter in flight
+        self.fresh = True                  # g_shard holds nothing of this accumulation window yet
+        self.release()
+        self.release_grads()
+
+    # -- weights -------------------------------------------------------------------------------------------------------
+    def live(self) -> bool:
+        return _storage_bytes(self.w_full) != 0
+
+    def materialize(self) -> None:
+        """All-gather the unit's bf16 weights from the ranks' shards (no-op while the storage is alive)."""
+        if self.live():
+            return
+        self.w_full.untyped_storage().resize_(self.nbytes)
+        mine = self.w_full[self.lo:self.lo + self.n_shard]
+        if self.world == 1 and not dist.is_initialized():
+            mine.copy_(self.w_shard)
+        elif not self.no_scatter:
+            dist.all_gather_into_tensor(self.w_full, self.w_shard, group=self.group)
+        else:                              # gloo: zero the foreign slices and sum
+            self.w_full.zero_()
+            mine.copy_(self.w_shard)
+            dist.all_reduce(self.w_full, op=dist.ReduceOp.SUM, group=self.group)
+
+    def release(self) -> None:
+        if self.live():
+            self.w_full.untyped_storage().resize_(0)
+
+    # -- gradients ---------------------------------------------------------------------------------------------------------
+    def alloc_grads(self) -> None:
+        if _storage_bytes(self.g_full) == 0:
+            self.g_full.untyped_storage().resize_(self.nbytes)
+            self.g_full.zero_()            # padding between parameters and parameters nobody writes must contribute zeros
+            for p in self.params:
+                p._aki_grad_live = False
+
+    def release_grads(self) -> None:
+        if _storage_bytes(self.g_full) != 0:
+            self.g_full.untyped_storage().resize_(0)
+
+    def reduce_grads(self) -> None:
+        """Reduce-scatter the unit's gradients: rank r receives the SUM of slice r, added to its gradient shard."""
+        tmp = torch.empty_like(self.g_shard)
+        if self.world == 1 and not dist.is_initialized():
+            tmp.copy_(self.g_full[self.lo:self.lo + self.n_shard])
+            work = None
+        elif not self.no_scatter:
+            work = dist.reduce_scatter_tensor(tmp, self.g_full, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(self.g_full, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.inflight = (work, tmp)
+
+    def finish_reduce(self) -> None:
+        """Wait for the reduce-scatter in flight (the compute stream waits, not the host), fold it into the shard, free the
+        unit's full gradient buffer and - when nothing else needs them - its weights."""
+        if self.inflight is None:
+            return
+        work, tmp = self.inflight
+        if work is not None:
+            work.wait()
+        if self.no_scatter and dist.is_initialized():
+            tmp.copy_(self.g_full[self.lo:self.lo + self.n_shard])
+        if self.fresh:
+            self.g_shard.copy_(tmp)
+            self.fresh = False
+        else:
+            self.g_shard += tmp
+        self.inflight = None
+        self.release_grads()
+        self.release()
+
+
+class AkiShardedTrainer:
+    """AkiTrainer's step (forward, backward, clip, AdamW; train/train_utils.py:242-266) with PARAMETERS sharded as well -
+    what FSDP(FULL_SHARD) does for the reference (train/distributed.py:193-222): every rank stores 1/world of each unit's
+    bf16 weights, gradients, fp32 master weights and moments; a unit's weights are all-gathered right before its forward,
+    released after it, gathered again right before its backward, and its gradients are reduce-scattered as soon as its
+    last wgrad GEMM has written them (overlapping the next unit's backward; the wait is deferred by one unit).
+    Units = the modules `model.get_fsdp_lambda_fn()` selects (decoder blocks, vision tokenizer) + the remaining trainable
+    parameters as root units (alive for the whole step, one per weight-decay group)."""
+
+    def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
+                 max_grad_norm: float = 1.0, group=None):
+        self.model, self.group = model, group
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.step_count = 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        no_scatter = dist.is_initialized() and str(dist.get_backend(group)).lower() == "gloo"
+        dev = next(model.parameters()).device
+        decayed, plain = model.group_params_by_weight_decay()
+        plain_ids = {id(p) for p in plain}
+        is_unit = model.get_fsdp_lambda_fn()
+        self.units, taken = [], set()
+        self._hooks = []
+        for name, mod in model.named_modules():
+            if not is_unit(mod):
+                continue
+            ps = [p for p in mod.parameters() if p.requires_grad and id(p) not in taken]
+            if not ps:
+                continue
+            assert not any(id(p) in plain_ids for p in ps), "a sharding unit with mixed weight decay"
+            taken.update(id(p) for p in ps)
+            u = _Unit(name, ps, weight_decay, self.world, self.rank, group, dev, no_scatter)
+            self.units.append(u)
+            self._hooks.append(mod.register_forward_pre_hook(lambda m, a, u=u: u.materialize()))
+            self._hooks.append(mod.register_forward_hook(lambda m, a, out, u=u: self._after_forward(u, out)))
+        self.roots = []
+        for nm, ps, dec in (("root", [p for p in decayed if id(p) not in taken], weight_decay), ("root.embeddings", list(plain), 0.0)):
+            ps = [p for p in ps if p.requires_grad]
+            if ps:
+                self.roots.append(_Unit(nm, ps, dec, self.world, self.rank, group, dev, no_scatter))
+        self.all_units = self.units + self.roots
+        self.params = [p for u in self.all_units for p in u.params]
+        for p in self.params:
+            p._aki_grad_hook = self.notify
+        for p in model.parameters():
+            if not p.requires_grad and p.dtype != torch.bfloat16:
+                p.data = p.data.to(torch.bfloat16)
+        self._hooks.append(model.register_forward_pre_hook(self._before_model_forward))
+        self._hooks.append(model.register_forward_hook(self._after_model_forward))
+        self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.numel = sum(u.numel for u in self.all_units)
+        self._last = None                  # unit whose reduce-scatter is in flight
+        self.enabled = True
+        T.CACHE_WT = False
+        T.bump_weight_epoch()
+
+    # ---- hooks ---------------------------------------------------------------------------------------------------------
+    def _after_forward(self, u, out):
+        if torch.is_grad_enabled() and isinstance(out, torch.Tensor) and out.requires_grad:
+            out = _PreBackward.apply(out, u)
+        u.release()
+        return out
+
+    def _before_model_forward(self, module, args):
+        for r in self.roots:
+            r.materialize()
+        return None
+
+    def _after_model_forward(self, module, args, out):
+        if not torch.is_grad_enabled():
+            for r in self.roots:
+                r.release()
+        return None
+
+    def notify(self, p) -> None:
+        """A parameter's gradient slice is final for this backward pass."""
+        u = p._aki_unit
+        if id(p) in u.delivered:
+            return
+        u.delivered.add(id(p))
+        u.pending -= 1
+        if u.pending == 0 and self.enabled:
+            self._launch(u)
+
+    def _launch(self, u) -> None:
+        if self._last is not None:
+            self._last.finish_reduce()     # deferred by one unit: that exchange ran under this unit's backward
+        u.reduce_grads()
+        self._last = u
+
+    # ---- one step ------------------------------------------------------------------------------------------------------
+    def zero_grad(self) -> None:
+        for u in self.all_units:
+            u.fresh = True
+            for p in u.params:
+                p._aki_grad_live = False
+                p.grad = None
+
+    def backward(self, loss: torch.Tensor) -> None:
+        for r in self.roots:
+            r.materialize()
+            r.alloc_grads()
+        for u in self.all_units:
+            u.pending, u.delivered = len(u.params), set()
+        loss.backward()
+        for u in self.all_units:
+            if u.pending == 0:
+                continue
+            u.alloc_grads()                # a unit nothing flowed through (or whose gradients come from autograd itself)
+            for p in u.params:
+                if p.grad is not None:
+                    if p._aki_grad_live:
+                        p._aki_grad += p.grad.to(torch.bfloat16)
+                    else:
+                        p._aki_grad.copy_(p.grad)
+                        p._aki_grad_live = True
+                    p.grad = None
+                self.notify(p)
+        if self._last is not None:
+            self._last.finish_reduce()
+            self._last = None
+        for u in self.all_units:
+            u.release_grads()
+            u.release()
+
+    def optimizer_step(self) -> None:
+        self.step_count += 1
+        for i, u in enumerate(self.all_units):
+            T.grad_sqnorm(u.g_shard, self.sqnorm, accumulate=i > 0)
+        if dist.is_initialized():
+            dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
+        for u in self.all_units:
+            T.adamw_step(u.master, u.m, u.v, u.g_shard, u.w_shard, self.sqnorm, self.max_grad_norm, 1.0 / self.world, self.lr,
+                         self.betas[0], self.betas[1], self.eps, u.decay, self.step_count)
+        T.bump_weight_epoch()
+
+    def grad_norm(self) -> torch.Tensor:
+        return self.sqnorm.sqrt() / self.world
+
+    def train_step(self, vision_x, lang_x, attention_mask=None, labels=None) -> torch.Tensor:
+        self.zero_grad()
+        out = self.model(vision_x, lang_x, attention_mask=attention_mask, labels=labels)
+        loss = out[0] if not hasattr(out, "loss") else out.loss
+        self.backward(loss)
+        self.optimizer_step()
+        return loss.detach()
+
+    # ---- inspection ----------------------------------------------------------------------------------------------------
+    def full_weights(self) -> torch.Tensor:
+        """All trainable bf16 weights as one f32 vector in parameter order (gathers every unit once; tests, checkpoints)."""
+        out = []
+        for u in self.all_units:
+            u.materialize()
+            out.extend(p.detach().float().reshape(-1).cpu() for p in u.params)
+            u.release()
+        return torch.cat(out)
+
+    def resident_bytes(self) -> int:
+        """Bytes of weights, gradients and optimizer state this rank holds between steps."""
+        return sum(u.n_shard * (2 + 2 + 12) for u in self.all_units)

@@ -14,6 +14,8 @@ the only collectives are the timing barrier and the max-over-ranks of the elapse
 Prints ONE JSON line (rank 0) with the contract's fields plus
   "roofline"     for the dominant kernel (by time in the timed region), timed live with HIP events on the launch stream
   "mma_kernel"   the same object for the north-star's MMA op (QKV projection + RoPE + span-driven attention)
+  "mma_core"     the attention core alone (the op's second launch), timed live on the benchmark's own mask table and shapes
+                 right after the timed region: algorithmic bytes / flops per launch against the HBM and MFMA peaks
   "cpu_baseline" the oracle (numpy port of the reference's eager path) timed on this box's host cores (N=1 only)
 """
 import argparse
@@ -146,7 +148,7 @@ def cpu_baseline(budget_s=25.0):
         t["lm_head"] = time.perf_counter() - t0
     total = t["patch_embed"] + 27 * t["siglip_layer"] + t["perceiver"] + t["splice_mask"] + 32 * t["decoder_layer"] + t["lm_head"]
     return {"value": round(B * L / total, 2), "unit": "tokens/s", "cores": int(cores), "cores_visible": int(avail),
-            "cpu_gemm_gflops": round(best[0] / 1e9, 1), "kind": "port",
+            "cpu_gemm_gflops": round(best[0] / 1e9, 1), "kind": "port", "estimated": True,
             "sample": f"one batch of the benchmark workload ({B} x (336px image + 512-token prompt), L=655), torch fp32 eager "
                       "restatement of the reference forward on the host cores (thread count = best measured GEMM rate): 2/32 decoder layers and 2/27 SigLIP layers "
                       "timed and scaled by layer count, patch embed, connector, splice + dense mask + inversion and lm_head "
@@ -229,6 +231,26 @@ def main():
         elapsed = float(tt.item())
     assert torch.isfinite(out.logits.float()).all()
 
+    # the attention core on its own (second launch of the fused MMA op): same shapes, the batch's own mask table
+    core = None
+    if rank == 0:
+        with torch.no_grad():
+            prep = model._prepare_inputs_for_forward(vision_tokens=model.vision_tokenizer(model._encode_vision_x(vx)), lang_x=ids,
+                                                     attention_mask=am, padding_side="right")
+            table = prep["attention_mask"]
+            gq = torch.Generator(device=dev).manual_seed(7)
+            q, k, v = (torch.randn(B, 32, L, 96, device=dev, generator=gq).to(torch.bfloat16) for _ in range(3))
+            for _ in range(3):
+                ops.mma_attn_core(q, k, v, table, 96 ** -0.5)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.mma_attn_core(q, k, v, table, 96 ** -0.5)
+            e1.record()
+            torch.cuda.synchronize()
+            core = e0.elapsed_time(e1) / 20
+            del q, k, v, prep
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         tokens = B * world * L
@@ -254,18 +276,23 @@ def main():
                       f"{r['total_ms_per_step']:8.3f} ms/step", file=sys.stderr)
         dom = rows[0]
 
-        def pmc_traffic(kernel_sig):
-            """HBM-side bytes per launch of one kernel from the committed rocprofv3 --pmc passes of THIS command
-            (profiles/*_pmc_summary.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE; counters cannot be read from
-            inside the process).  None when no profile of the same configuration is committed."""
+        def pmc_traffic(*kernel_sigs):
+            """HBM-side bytes per launch of one kernel (or the sum over the kernels of one op) from the committed rocprofv3
+            --pmc passes of THIS command (profiles/*_pmc_summary.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE;
+            counters cannot be read from inside the process).  None when no profile of the same configuration is committed."""
             if fp8 or world != 1 or B != BATCH:
                 return None, None
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
                 try:
-                    for e in json.load(open(f)):
-                        if kernel_sig in e["kernel"] and "hbm_read_bytes_corrected_x2" in e and "hbm_write_bytes" in e:
-                            return int(e["hbm_read_bytes_corrected_x2"] + e["hbm_write_bytes"]), os.path.relpath(f, ROOT)
+                    entries = json.load(open(f))
+                    tot = 0
+                    for sig in kernel_sigs:
+                        hit = [e for e in entries if sig in e["kernel"] and "hbm_read_bytes_corrected_x2" in e and "hbm_write_bytes" in e]
+                        if not hit:
+                            raise KeyError(sig)
+                        tot += int(hit[0]["hbm_read_bytes_corrected_x2"] + hit[0]["hbm_write_bytes"])
+                    return tot, os.path.relpath(f, ROOT)
                 except Exception:
                     continue
             return None, None
@@ -292,8 +319,25 @@ def main():
                 res["roofline"]["traffic_source"] = src
                 res["roofline"]["algorithmic_bytes_per_launch"] = int(2 * (dom["flops"] / 2 / 16384 / 3072 * 3072 + 16384 * 3072 + dom["flops"] / 2 / 16384 / 3072 * 8192))
         mma = [r for r in rows if r["tag"].startswith("mma_attn")]
+        TUNIT = "bytes per launch (L2<->fabric: FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache hits)"
         if mma:
             res["mma_kernel"] = mk(mma[0])
+            tr, src = pmc_traffic("gemm_bf16_kernel<8, 4, 2, 4, 3, 0", "mma_attn_bf16_kernel")
+            if tr is not None:     # QKV+RoPE GEMM main launch + attention core (the 120-row tail launch of the GEMM is not in the sum)
+                res["mma_kernel"].update(traffic=tr, traffic_unit=TUNIT, traffic_source=src,
+                                         algorithmic_bytes_per_launch=int(2 * (B * L * 3072 + 9216 * 3072 + 3 * B * L * 3072) + 4 * B * L * 3072 * 2))
+        if core is not None:
+            pairs = L * (L + 1) // 2 + NV * max(0, (N_TXT - 17 + NV) - (6 + NV))
+            cfl, cby = 4.0 * 96 * pairs * B * 32, 4.0 * B * L * 3072 * 2
+            tr, src = pmc_traffic("mma_attn_bf16_kernel")
+            res["mma_core"] = {"kernel": f"mma_attn_core (span-driven softmax(QK^T)V) B{B} H32 L{L}", "bound": "hbm",
+                               "achieved": round(cby / core / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(cby / core / 1e6 / PEAK_HBM_GBS, 4), "traffic": tr, "avg_launch_ms": round(core, 4),
+                               "algorithmic_bytes_per_launch": int(cby), "algorithmic_flops_per_launch": cfl,
+                               "mfma_tflops": round(cfl / core / 1e9, 1), "mfma_frac": round(cfl / core / 1e9 / PEAK_BF16_TFLOPS, 4),
+                               "note": "219 FLOP/B: just on the HBM side of the ridge (312 FLOP/B); both fractions are given"}
+            if src:
+                res["mma_core"].update(traffic_unit=TUNIT, traffic_source=src)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["cpu_baseline"]["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)

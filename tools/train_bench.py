@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--shard-optimizer", action="store_true", help="ZeRO/FSDP-style: reduce-scatter grads, 1/world optimizer state")
+    ap.add_argument("--shard-params", action="store_true", help="FSDP FULL_SHARD equivalent: weights, gradients and optimizer state sharded (AkiShardedTrainer)")
     ap.add_argument("--gpus", type=int, default=1, help="ranks of the job (informational; the launcher sets WORLD_SIZE)")
     ap.add_argument("--bucket-mb", type=int, default=512, help="gradient bucket size; xGMI is point-to-point, few large messages")
     ap.add_argument("--exchange-when-alone", action="store_true", help="world of one: still issue the RCCL collectives")
@@ -39,15 +40,20 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(os.environ.get("AKI_BENCH_BACKEND", "nccl"), rank=rank, world_size=world, device_id=dev)
     from aki_amd.factory import build_aki
-    from aki_amd.trainer import AkiTrainer
+    from aki_amd.trainer import AkiShardedTrainer, AkiTrainer
     from aki_amd.phi3 import make_phi3_config
     model = build_aki(make_phi3_config(num_hidden_layers=a.layers), dtype=torch.bfloat16, device=dev, seed=0)   # same seed: replicas start identical
     model.train()
     if a.head_chunk:
         model.lang_model.head_chunk_rows = a.head_chunk
     model.set_trainable()
-    tr = AkiTrainer(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=1.0, shard_optimizer=a.shard_optimizer,
-                    bucket_bytes=a.bucket_mb << 20, exchange_when_alone=a.exchange_when_alone)
+    if a.shard_params:
+        tr = AkiShardedTrainer(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=1.0)
+        tr.shard = True
+        tr.reducer = type("R", (), {"finish": staticmethod(lambda: None), "active": False, "buckets": tr.all_units})()
+    else:
+        tr = AkiTrainer(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=1.0, shard_optimizer=a.shard_optimizer,
+                        bucket_bytes=a.bucket_mb << 20, exchange_when_alone=a.exchange_when_alone)
     B, L = a.batch, bench.N_TXT - 1 + bench.NV
     vx, ids, am = bench.synth_batch(B, dev, torch.bfloat16, model.media_token_id, seed=1000 + rank)
     labels = ids.clone()
@@ -76,6 +82,8 @@ def main():
         out = model(vx, ids, attention_mask=am, labels=labels)
         e[1].record()
         tr.backward(out.loss)
+        if a.shard_params and "a" not in marks:
+            marks["a"] = marks["b"] = e[1]
         e[2].record()
         tr.optimizer_step()
         e[3].record()
@@ -114,8 +122,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "AKI-4B pre-training step, BASELINE configs[2]: 336px image + 512-token prompt per sample, batch 8 per GPU, "
                                    "bf16 compute / fp32 master weights; random-init weights", "global_batch": B * world, "seq_len": L,
-                       "parallelism": f"dp{world}" + ("+sharded-optimizer" if a.shard_optimizer else ""), "bucket_mb": a.bucket_mb,
-                       "gradient_exchange": ("reduce-scatter + all-gather" if tr.shard else "all-reduce") + " of bf16 gradients, in place in the flat buffer",
+                       "parallelism": f"dp{world}" + ("+sharded-params" if a.shard_params else "+sharded-optimizer" if a.shard_optimizer else ""), "bucket_mb": a.bucket_mb,
+                       "gradient_exchange": ("per-unit all-gather of weights (x2) + reduce-scatter of gradients" if a.shard_params else ("reduce-scatter + all-gather" if tr.shard else "all-reduce") + " of bf16 gradients, in place in the flat buffer"),
                        "layers": a.layers},
             "exchange_ms": round(exch_ms, 3), "exchange_exposed_ms": round(parts["exchange_exposed"] / a.steps, 3),
             "overlap_frac": (round(1.0 - min(1.0, (parts["exchange_exposed"] / a.steps) / exch_ms), 3) if exch_ms > 0 else None),
