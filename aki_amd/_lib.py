@@ -16,7 +16,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 9
+AKI_ABI_VERSION = 10
 
 
 class AkiError(RuntimeError):
@@ -41,7 +41,7 @@ class MmaAttnArgs(C.Structure):
                 ("B", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("Dh", C.c_int32), ("d_model", C.c_int32),
                 ("ldx", C.c_int32), ("ldw", C.c_int32), ("pos_rows", C.c_int32), ("scale", C.c_float),
                 ("dtype", C.c_int32), ("dead_rows", C.c_int32), ("kv_capacity", C.c_int32),
-                ("x_scale", C.c_void_p), ("w_scale", C.c_void_p)]
+                ("x_scale", C.c_void_p), ("w_scale", C.c_void_p), ("row_scale", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -66,7 +66,10 @@ class LinearArgs(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldx", C.c_int32), ("ldw", C.c_int32),
                 ("ldy", C.c_int32), ("ldr", C.c_int32), ("res_row_mod", C.c_int32), ("act", C.c_int32),
                 ("dtype", C.c_int32), ("x_scale", C.c_void_p), ("w_scale", C.c_void_p),
-                ("w2", C.c_void_p), ("w2_row0", C.c_int32), ("w2_rows", C.c_int32)]
+                ("w2", C.c_void_p), ("w2_row0", C.c_int32), ("w2_rows", C.c_int32),
+                ("row_scale", C.c_void_p), ("row_shift", C.c_void_p), ("col_shift", C.c_void_p), ("stats_rstd", C.c_void_p),
+                ("stats_mean", C.c_void_p), ("stats_eps", C.c_float), ("stats_workspace", C.c_void_p),
+                ("stats_workspace_bytes", C.c_size_t)]
 
 
 class SpliceArgs(C.Structure):
@@ -91,6 +94,8 @@ SIGNATURES = {
     "aki_qkv_rope_fwd": (C.c_int, [C.POINTER(MmaAttnArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    "aki_linear_stats_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "aki_row_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "aki_rmsnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_float, C.c_int32, C.c_void_p]),
     "aki_layernorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

@@ -53,13 +53,14 @@ class AKI(VLMWithLanguageStream):
         assert not (past_vision_tokens is None) ^ (past_media_locations is None), \
             "past_vision_tokens and past_media_locations must both be None or both be not None"
         if vision_x is not None:
+            plan = self._start_splice_plan(lang_x) if past_key_values is None else None   # ahead of the vision side's launches
             vision_tokens = self.vision_tokenizer(self._encode_vision_x(vision_x=vision_x))
         else:
-            vision_tokens = None
+            vision_tokens, plan = None, None
         new_inputs = self._prepare_inputs_for_forward(
             vision_tokens=vision_tokens, lang_x=lang_x, attention_mask=attention_mask, vision_attention_mask=None,
             labels=labels, past_key_values=past_key_values, past_media_locations=past_media_locations,
-            padding_side="right", past_vision_tokens=past_vision_tokens)
+            padding_side="right", past_vision_tokens=past_vision_tokens, splice_plan=plan)
         output = self.lang_model(**new_inputs, use_cache=use_cache, past_key_values=past_key_values, **kwargs)
         self._post_forward_hook()
         return output
@@ -87,11 +88,12 @@ class AKI(VLMWithLanguageStream):
         use_graph = kwargs.pop("use_graph", None)
         if use_graph is None:
             use_graph = max_new_tokens >= 8          # capture costs about two eager steps
-        vision_tokens = self.vision_tokenizer(self._encode_vision_x(vision_x=vision_x)) if vision_x is not None else None
-        if vision_tokens is None:
+        if vision_x is None:
             raise NotImplementedError("text-only generation is outside the AKI hot path")
+        plan = self._start_splice_plan(lang_x)
+        vision_tokens = self.vision_tokenizer(self._encode_vision_x(vision_x=vision_x))
         new_inputs = self._prepare_inputs_for_forward(vision_tokens=vision_tokens, lang_x=lang_x, attention_mask=attention_mask,
-                                                      padding_side="right")
+                                                      padding_side="right", splice_plan=plan)
         table = new_inputs["attention_mask"]
         L = new_inputs["inputs_embeds"].shape[1]
         out = self.lang_model(inputs_embeds=new_inputs["inputs_embeds"], attention_mask=table, use_cache=True,

@@ -4,6 +4,8 @@
 
 namespace aki {
 int linear_bf16(const aki_linear_args* a, hipStream_t stream);
+size_t linear_stats_ws_bytes(int M, int n_out);
+int row_stats_launch(const void* x, int rows, int cols, int ldx, float eps, float* rstd, float* mean, hipStream_t s);
 int linear_f32(const aki_linear_args* a, hipStream_t stream);
 int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStream_t stream);
 int qkv_rope_fp8(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStream_t stream);
@@ -153,6 +155,7 @@ static int check_fused(const aki_mma_attn_args* a) {
   AKI_CHECK_ARG(a->ldx >= a->d_model && a->ldw >= a->d_model && a->pos_rows > 0);
   AKI_CHECK_ARG(a->position_ids || a->pos_rows >= a->L);
   AKI_CHECK_ARG(dtype_ok(a->dtype) || (a->dtype == AKI_DT_FP8_E4M3 && a->x_scale && a->w_scale));
+  AKI_CHECK_ARG(!a->row_scale || a->dtype == AKI_DT_BF16);
   return AKI_OK;
 }
 
@@ -199,6 +202,15 @@ int aki_mma_attn_fwd(const aki_mma_attn_args* a, void* ws, size_t ws_bytes, void
 }
 
 // ---- linear ------------------------------------------------------------------------------------------
+size_t aki_linear_stats_workspace_bytes(int32_t M, int32_t N_out) { return (M > 0 && N_out > 0) ? aki_align_up(linear_stats_ws_bytes(M, N_out), 256) : 0; }
+
+int aki_row_stats(const void* x, int32_t rows, int32_t cols, int32_t ldx, float eps, float* rstd, float* mean, int32_t dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(x && rstd && rows > 0 && cols > 0 && ldx >= cols && eps > 0.f);
+  if (dtype != AKI_DT_BF16) return AKI_ERR_UNSUPPORTED;
+  return row_stats_launch(x, rows, cols, ldx, eps, rstd, mean, (hipStream_t)stream);
+}
+
 int aki_linear_fwd(const aki_linear_args* a, void* stream) {
   AKI_CLEAR_ERR();
   AKI_CHECK_ARG(a && a->x && a->w && a->y);
@@ -207,6 +219,10 @@ int aki_linear_fwd(const aki_linear_args* a, void* stream) {
   AKI_CHECK_ARG(a->act >= AKI_ACT_NONE && a->act <= AKI_ACT_SWIGLU);
   const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
   AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));
+  if (a->row_scale || a->row_shift || a->stats_rstd) {   // folded normalisation: the bf16 MFMA GEMM only
+    if (a->dtype != AKI_DT_BF16) return AKI_ERR_UNSUPPORTED;
+    return linear_bf16(a, (hipStream_t)stream);
+  }
   if (a->w2) {   // two-segment weight: the bf16 MFMA GEMM only
     AKI_CHECK_ARG(a->w2_row0 > 0 && a->w2_rows > 0 && a->w2_row0 < a->N);
     if (a->dtype != AKI_DT_BF16 || a->act != AKI_ACT_NONE) return AKI_ERR_UNSUPPORTED;

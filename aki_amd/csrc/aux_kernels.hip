@@ -106,6 +106,43 @@ __global__ __launch_bounds__(256) void norm_f32_kernel(const float* x, const flo
   }
 }
 
+// Row statistics on their own (input of the first block when the normalisation is folded into the GEMMs): one block per row,
+// rstd = 1/sqrt(mean(x^2) + eps), or with `mean`: mean and 1/sqrt(var + eps) (two-pass variance, as the LayerNorm kernel).
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* x, int cols, int ldx, float eps, float* rstd, float* mean) {
+  __shared__ float red[16];
+  const int row = blockIdx.x;
+  const bf16_t* xr = x + (size_t)row * ldx;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+    const u32x4 v = *(const u32x4*)(xr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float a = bf16_lo(v[e]), b = bf16_hi(v[e]); s1 += a + b; s2 += a * a + b * b; }
+  }
+  block_sum2<256>(s1, s2, red);
+  if (mean == nullptr) {
+    if (threadIdx.x == 0) rstd[row] = rsqrtf(s2 / cols + eps);
+    return;
+  }
+  const float mu = s1 / cols;
+  float d2 = 0.f, dummy = 0.f;
+  for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+    const u32x4 v = *(const u32x4*)(xr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float a = bf16_lo(v[e]) - mu, b = bf16_hi(v[e]) - mu; d2 += a * a + b * b; }
+  }
+  block_sum2<256>(d2, dummy, red);
+  if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rsqrtf(d2 / cols + eps); }
+}
+
+int row_stats_launch(const void* x, int rows, int cols, int ldx, float eps, float* rstd, float* mean, hipStream_t s) {
+  if (cols % 8 || ldx % 8) return AKI_ERR_UNSUPPORTED;
+  AKI_CHECK_ALIGN16(x);
+  AKI_CLEAR_ERR();
+  hipLaunchKernelGGL(row_stats_kernel, dim3(rows), dim3(256), 0, s, (const bf16_t*)x, cols, ldx, eps, rstd, mean);
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
+}
+
 int norm_launch(bool rms, const void* x, const void* w, const void* b, void* y, int rows, int cols, int ldx, int ldy,
                 float eps, int dtype, hipStream_t stream) {
   if (rows <= 0 || cols <= 0) return AKI_ERR_INVALID_ARG;

@@ -76,6 +76,16 @@ struct GemmParams {
   // two-segment weight (EPI_PLAIN): logical rows >= w2_row0 come from w2 (aki_linear_args)
   const bf16_t* w2;
   int w2_row0, w2_rows;
+  // Normalisation folded into the GEMMs (aki_linear_args).  Consumer: y = row_scale[m] * (acc - row_shift[m] * col_c[n]) ...
+  const float* row_scale;
+  const float* row_shift;
+  const float* col_c;
+  // Producer (EPI_PLAIN): per-row statistics of the tile's bf16 OUTPUT, reduced over the row by the last tile of the row panel
+  float* st_rstd;
+  float* st_mean;
+  float* st_part;      // [slots][2][M] partial sums (sum of squares, sum), slot = tile column * WN + wave column
+  unsigned* st_cnt;    // [tiles_m] arrival counters, zero between launches
+  float st_eps;
 };
 
 // Two feature blocks (P = block n, Q = block n+1), each 4 consecutive features per lane as 2 packed dwords.
@@ -180,6 +190,38 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   const int xbase = BN * 128 + (wm * WTOK + l15) * 128;
 
   const int nk = p.K / BK;
+  // ---- epilogue operands (bias, folded-norm scale / shift / column sums).  Their fetch is a DRAM-latency round trip that
+  // nothing in the epilogue can hide; small tiles (several short launches per layer, spare registers) issue it here, under
+  // the first K-step's DMA wait, the big pipelined tile (at the register limit) right after the K loop, ahead of the
+  // residual staging, whose own round trip then covers it.
+  constexpr int NOUT = (EPI == EPI_SWIGLU) ? NF / 2 : NF;     // output feature blocks per wave
+  const int fwave = n0 + wn * (EPI == EPI_SWIGLU ? WROWS / 2 : WROWS);
+  // folded LayerNorm (consumer), kernel-uniform.  Not on the pipelined 256^2 tile: its epilogue has no registers left for
+  // the column sums (they spilled - and a launch that touches scratch costs ~6 us of dispatch gap on either side); the
+  // host routes row_shift launches to the 128-token tiles, which is where SigLIP's shapes go anyway.
+  const bool shifted = !PIPE && (EPI == EPI_PLAIN) && p.row_shift != nullptr;
+  u32x2 biasp[NOUT];
+  f32x4 colc4[NOUT];
+  float rsv[NT], muv[NT];
+  auto fetch_epilogue_operands = [&]() {
+    if (EPI == EPI_QKV_ROPE8) return;
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+      const int f = fwave + n * 16 + 4 * kg;
+      biasp[n] = u32x2{0u, 0u};
+      colc4[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (EPI == EPI_PLAIN && p.bias && f < n_out) biasp[n] = *(const u32x2*)(p.bias + f);
+      if (EPI == EPI_PLAIN && shifted && f < n_out) colc4[n] = *(const f32x4*)(p.col_c + f);
+    }
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      const int mr = min(m0 + wm * WTOK + m * 16 + l15, p.M - 1);
+      rsv[m] = p.row_scale ? p.row_scale[mr] : 1.0f;
+      muv[m] = (EPI == EPI_PLAIN && shifted) ? p.row_shift[mr] : 0.0f;
+    }
+  };
+  constexpr bool EARLY_OPERANDS = !PIPE && !FP8;
+  if constexpr (EARLY_OPERANDS) fetch_epilogue_operands();
   auto compute = [&](const char* sb) {
     if constexpr (FP8) {   // one k128 step per BK: the lane's 32 bytes are chunks 2kg and 2kg+1 of its row
       const int c0 = ((2 * kg) ^ swz) << 4, c1 = ((2 * kg + 1) ^ swz) << 4;
@@ -370,6 +412,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
       const int mr = min(mrow, p.M - 1) + p.m_offset;   // global token index
       const int b = mr / p.L, tt = mr - b * p.L;
       const char* cs = smem + (wm * WTOK + m * 16 + l15) * CSROW + 16 * kg;
+      const float rs = p.row_scale ? p.row_scale[min(mrow, p.M - 1)] : 1.0f;   // folded RMSNorm: 1 / rms of the token's hidden state
 #pragma unroll
       for (int q = 0; q < UW; ++q) {
         const int u = u0 + q;                           // wave-uniform
@@ -382,7 +425,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
           const f32x4 c4 = *(const f32x4*)(cs + 64 * j), s4 = *(const f32x4*)(cs + 192 + 64 * j);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float x1 = acc[q][m][r], x2 = acc[q + UW][m][r];
+            const float x1 = acc[q][m][r] * rs, x2 = acc[q + UW][m][r] * rs;
             v1[r] = x1 * c4[r] - x2 * s4[r];
             v2[r] = x2 * c4[r] + x1 * s4[r];
           }
@@ -391,7 +434,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
         } else {
           const int u2 = u - nqk, vh = u2 / 3, j2 = u2 - 3 * vh;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { v1[r] = acc[q][m][r]; v2[r] = acc[q + UW][m][r]; }
+          for (int r = 0; r < 4; ++r) { v1[r] = acc[q][m][r] * rs; v2[r] = acc[q + UW][m][r] * rs; }
           dst = p.v_out + ((size_t)(b * p.H + vh) * p.kvcap + tt) * 96;
           d1 = 32 * j2 + 4 * kg; d2 = d1 + 16;
         }
@@ -405,8 +448,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     return;
   }
 
-  constexpr int NOUT = (EPI == EPI_SWIGLU) ? NF / 2 : NF;     // output feature blocks per wave
-  const int fwave = n0 + wn * (EPI == EPI_SWIGLU ? WROWS / 2 : WROWS);
+  if constexpr (!EARLY_OPERANDS) fetch_epilogue_operands();
   // The residual tile goes through LDS (idle after the K loop), like cos/sin in the QKV epilogue: fetched per lane it
   // is NT*NOUT 8-byte loads (32 on the big tile, 128 KB per workgroup through the L1); staged it is 16-byte loads of whole
   // rows, two to sixteen per thread.  Chunk c of token row t sits at chunk c ^ (t & CMASK): the 16 token rows of a
@@ -428,17 +470,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     }
     __syncthreads();
   }
-  // bias: the lane's 4 features of each block are the same for every token block - loaded once, not once per block
-  float bias4[NOUT][4];
-  if (EPI == EPI_PLAIN && p.bias) {
-#pragma unroll
-    for (int n = 0; n < NOUT; ++n) {
-      const int f = fwave + n * 16 + 4 * kg;
-      u32x2 bb = {0u, 0u};
-      if (f < n_out) bb = *(const u32x2*)(p.bias + f);
-      bias4[n][0] = bf16_lo(bb[0]); bias4[n][1] = bf16_hi(bb[0]); bias4[n][2] = bf16_lo(bb[1]); bias4[n][3] = bf16_hi(bb[1]);
-    }
-  }
+  const bool stats = (EPI == EPI_PLAIN) && p.st_part != nullptr;         // kernel-uniform
 #pragma unroll
   for (int m = 0; m < NT; ++m) {
     const int mrow = m0 + wm * WTOK + m * 16 + l15;
@@ -447,6 +479,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     bf16_t* yrow = p.y + (size_t)mr * p.ldy;
     const bf16_t* rrow = nullptr;
     if (p.residual) rrow = p.residual + (size_t)(p.res_row_mod > 0 ? (mr + p.m_offset) % p.res_row_mod : mr) * p.ldr;
+    const float rs = rsv[m], mu = muv[m];
     float v[NOUT][4];
 #pragma unroll
     for (int n = 0; n < NOUT; ++n) {
@@ -455,16 +488,17 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (EPI == EPI_SWIGLU) {
-          const float g = acc[n][m][r], u = acc[n + NF / 2][m][r];
+          const float g = acc[n][m][r] * rs, u = acc[n + NF / 2][m][r] * rs;
           v[n][r] = u * silu_fast(g);
+        } else if (EPI == EPI_PLAIN && shifted) {
+          v[n][r] = (acc[n][m][r] - mu * colc4[n][r]) * rs;
         } else {
-          v[n][r] = acc[n][m][r];
+          v[n][r] = acc[n][m][r] * rs;
         }
       }
       if (EPI == EPI_PLAIN) {
         if (p.bias && fin) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[n][r] += bias4[n][r];
+          v[n][0] += bf16_lo(biasp[n][0]); v[n][1] += bf16_hi(biasp[n][0]); v[n][2] += bf16_lo(biasp[n][1]); v[n][3] += bf16_hi(biasp[n][1]);
         }
         if (ACT == AKI_ACT_GELU_ERF) {
 #pragma unroll
@@ -485,6 +519,28 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
         v[n][0] += bf16_lo(rr[0]); v[n][1] += bf16_hi(rr[0]); v[n][2] += bf16_lo(rr[1]); v[n][3] += bf16_hi(rr[1]);
       }
     }
+    if (EPI == EPI_PLAIN && stats) {
+      // producer: this wave's share of the token's sum / sum of squares over the tile's features, of the values AS STORED
+      // (bf16); the four lanes that hold a token (kg = 0..3) fold theirs, lane kg == 0 writes through (sc1) for the reducer
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int n = 0; n < NOUT; ++n) {
+        const bool fin = fwave + n * 16 + 4 * kg < n_out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float vb = fin ? round_bf16(v[n][r]) : 0.f;
+          s1 += vb;
+          s2 += vb * vb;
+        }
+      }
+      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      if (kg == 0 && ok) {   // one 8-byte write-through store: {sum of squares, sum}
+        unsigned long long* pp = (unsigned long long*)p.st_part + (size_t)(tn * WN + wn) * p.M + mrow;
+        const unsigned long long both = (unsigned long long)__float_as_uint(s2) | ((unsigned long long)__float_as_uint(s1) << 32);
+        __hip_atomic_store(pp, both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     if (NOUT % 2 == 0 && p.wide) {   // 16-byte stores pair two feature blocks
 #pragma unroll
       for (int n = 0; n + 1 < NOUT; n += 2) {
@@ -502,6 +558,72 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
           *(u32x2*)(yrow + f) = o;
         }
       }
+    }
+  }
+  if (EPI == EPI_PLAIN && stats) {
+    // Row statistics: the LAST tile of a row panel to get here folds the panel's partial sums in a fixed order (the result
+    // does not depend on which tile that is) and writes 1/rms (and the mean) of the panel's rows.  Hand-off as in
+    // cdna_hip_programming.md Guideline 16 (R1 / ticket form): write-through partials, every storing wave drains them,
+    // barrier, one lane draws a ticket; the reducer reads the partials with agent-scope loads.  It puts the counter back
+    // to zero - the counters are zero again when the launch ends.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* const flag = (unsigned*)smem;
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(p.st_cnt + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = (old == (unsigned)p.tiles_n - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag != 0u) {
+      // All (slot, row) pairs of the panel are fetched in parallel (agent-scope loads: the writers sit behind other L2s) and
+      // parked in the K-loop buffers, which nobody reads any more; then one thread per row adds its column top to bottom.
+      const int slots = p.tiles_n * WN;
+      constexpr int NTHR = NWAVES * 64;
+      constexpr int CH = (NST * STAGE_BYTES - 16) / (BM * 8);          // slots per pass through LDS
+      static_assert(CH >= 8, "statistics staging");
+      unsigned long long* const park = (unsigned long long*)(smem + 16);
+      const unsigned long long* const part = (const unsigned long long*)p.st_part;
+      float s1 = 0.f, s2 = 0.f;
+      for (int sl0 = 0; sl0 < slots; sl0 += CH) {
+        const int total = min(CH, slots - sl0) * BM;
+        for (int it0 = tid; it0 < total; it0 += 8 * NTHR) {
+          unsigned long long got[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int it = it0 + u * NTHR;
+            const int sl = it / BM, row = it - sl * BM;
+            got[u] = 0ull;
+            if (it < total && m0 + row < p.M)
+              got[u] = __hip_atomic_load(part + (size_t)(sl0 + sl) * p.M + m0 + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int it = it0 + u * NTHR;
+            if (it < total) park[it] = got[u];
+          }
+        }
+        __syncthreads();
+        if (tid < BM) {
+          for (int sl = 0; sl < total / BM; ++sl) {
+            const unsigned long long both = park[sl * BM + tid];
+            s2 += __uint_as_float((unsigned)both);
+            s1 += __uint_as_float((unsigned)(both >> 32));
+          }
+        }
+        __syncthreads();
+      }
+      if (tid < BM && m0 + tid < p.M) {
+        const int mrow = m0 + tid;
+        const float inv_n = 1.0f / (float)n_out;
+        const float mean = s1 * inv_n;
+        if (p.st_mean) {        // LayerNorm statistics
+          p.st_mean[mrow] = mean;
+          p.st_rstd[mrow] = rsqrtf(fmaxf(s2 * inv_n - mean * mean, 0.f) + p.st_eps);
+        } else {                // RMSNorm
+          p.st_rstd[mrow] = rsqrtf(s2 * inv_n + p.st_eps);
+        }
+      }
+      if (tid == 0) __hip_atomic_store(p.st_cnt + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -550,7 +672,13 @@ static double cost_small(long tiles, double work) {
 // plan 3 (plain bf16 GEMMs only, `mid_ok`): 128-feature x 96-token tiles when they fit ONE round of the 2-per-CU slots and
 // the 128^2 tiling would leave that round partly empty - SigLIP out-proj / fc2 (N = 1152: 324 -> 432 tiles, 21.7 -> 17.9 us
 // and 61.6 -> 50.5 us), Perceiver kv (360 -> 480 tiles, 20.4 -> 17.2 us).  Same K order per output element: bit-identical.
-static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_work = 0.25, bool mid_ok = false) {
+static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_work = 0.25, bool mid_ok = false, bool big_ok = true) {
+  if (!big_ok) {     // folded LayerNorm: small or mid tiles only
+    const long ns_ = (n_out + bn_small - 1) / bn_small, nm_ = (long)((M + 95) / 96) * ns_;
+    if (g_force_tile == 3 && mid_ok) return 3;
+    if (!g_force_tile && mid_ok && nm_ <= 512 && cost_small(nm_, 0.75 * small_work) < cost_small((long)((M + 127) / 128) * ns_, small_work)) return 3;
+    return 1;
+  }
   if (g_force_tile) return g_force_tile == 2 ? 1 : (g_force_tile == 3 ? (mid_ok ? 3 : 1) : 0);
   const long nb = (n_out + bn_big - 1) / bn_big, ns = (n_out + bn_small - 1) / bn_small;
   const double all_big = cost_big((long)((M + 255) / 256) * nb);
@@ -618,7 +746,16 @@ static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
   if (FP8) b.sx = p.sx + m_main;
   b.y = p.y + (size_t)m_main * p.ldy;
   if (p.residual && p.res_row_mod <= 0) b.residual = p.residual + (size_t)m_main * p.ldr;
+  if (p.row_scale) b.row_scale = p.row_scale + m_main;
+  if (p.row_shift) b.row_shift = p.row_shift + m_main;
+  if (p.st_rstd) b.st_rstd = p.st_rstd + m_main;
+  if (p.st_mean) b.st_mean = p.st_mean + m_main;
   return launch_small<EPI, ACT, FP8>(b, stream);
+}
+
+constexpr size_t STATS_CNT_BYTES = 4096;     // arrival counters of up to 1024 row panels (zero-filled once by the caller)
+size_t linear_stats_ws_bytes(int M, int n_out) {
+  return STATS_CNT_BYTES + (size_t)(2 * ((n_out + 63) / 64) + 2) * 2 * (size_t)M * sizeof(float);   // <= 2 waves x N/64 tile columns
 }
 
 int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
@@ -640,11 +777,20 @@ int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
     AKI_CHECK_ALIGN16(a->w2);
     p.w2 = (const bf16_t*)a->w2; p.w2_row0 = a->w2_row0; p.w2_rows = a->w2_rows;
   }
+  p.row_scale = a->row_scale; p.row_shift = a->row_shift; p.col_c = a->col_shift;
+  if (a->row_shift && (!a->col_shift || !a->row_scale || (((uintptr_t)a->col_shift) & 15) || a->act == AKI_ACT_SWIGLU)) return AKI_ERR_INVALID_ARG;
+  if (a->stats_rstd) {
+    if (a->act == AKI_ACT_SWIGLU || a->M > 64 * (int)(STATS_CNT_BYTES / sizeof(unsigned))) return AKI_ERR_UNSUPPORTED;   // one counter per row panel (>= 64 rows)
+    if (!a->stats_workspace || a->stats_workspace_bytes < linear_stats_ws_bytes(a->M, n_out) || (((uintptr_t)a->stats_workspace) & 15)) return AKI_ERR_WORKSPACE;
+    p.st_rstd = a->stats_rstd; p.st_mean = a->stats_mean; p.st_eps = a->stats_eps;
+    p.st_cnt = (unsigned*)a->stats_workspace;
+    p.st_part = (float*)((char*)a->stats_workspace + STATS_CNT_BYTES);
+  }
   if (a->act == AKI_ACT_SWIGLU) {
     if (a->bias) return AKI_ERR_UNSUPPORTED;
     return run_planned<EPI_SWIGLU, 0>(p, plan_tiles(a->M, n_out, 128, 64), stream);
   }
-  const int plan = plan_tiles(a->M, n_out, 256, 128, 0.25, true);
+  const int plan = plan_tiles(a->M, n_out, 256, 128, 0.25, true, a->row_shift == nullptr);
   switch (a->act) {
     case AKI_ACT_GELU_ERF: return run_planned<EPI_PLAIN, AKI_ACT_GELU_ERF>(p, plan, stream);
     case AKI_ACT_GELU_TANH: return run_planned<EPI_PLAIN, AKI_ACT_GELU_TANH>(p, plan, stream);
@@ -664,6 +810,7 @@ int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStre
   p.q_out = (bf16_t*)q; p.k_out = (bf16_t*)k; p.v_out = (bf16_t*)v;
   p.cos = a->cos; p.sin = a->sin; p.position_ids = a->position_ids; p.H = a->H; p.L = a->L;
   p.kvcap = a->kv_capacity > 0 ? a->kv_capacity : a->L;
+  p.row_scale = a->row_scale;
   return run_planned<EPI_QKV_ROPE8, 0>(p, plan_tiles(p.M, p.N, 256, 128), stream);
 }
 

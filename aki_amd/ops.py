@@ -64,10 +64,12 @@ class EventTap:
     """Optional per-kernel timing with HIP events on the stream the kernels are launched on (torch's current
     stream).  bench.py installs one for the timed region; when no tap is installed the cost is one `is None` test."""
 
-    def __init__(self, tags=None, select=None):
+    def __init__(self, tags=None, select=None, every=1):
         self.tags = tags          # None = every tagged launch
         self.select = select      # optional predicate on the full tag (e.g. only one GEMM shape): every bracketed launch
-        self.events = {}          # costs two event records on the stream, so time only what is reported
+        self.events = {}          # costs two event records on the stream (~6 us of dispatch gap each on MI355X, see
+        self.every = every        # tools/trace_gaps.py), so time only what is reported - and only every `every`-th launch of it
+        self.calls = {}
 
     def want(self, tag) -> bool:
         if self.tags is not None and tag[0] not in self.tags:
@@ -75,6 +77,9 @@ class EventTap:
         return self.select is None or bool(self.select(tag))
 
     def begin(self, tag):
+        n = self.calls[tag] = self.calls.get(tag, 0) + 1
+        if (n - 1) % self.every:
+            return None
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         self.events.setdefault(tag, []).append((a, b))
@@ -83,7 +88,63 @@ class EventTap:
 
     def summary(self):
         torch.cuda.synchronize()
-        return {tag: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / len(ev)) for tag, ev in self.events.items()}
+        return {tag: (self.calls[tag], sum(a.elapsed_time(b) for a, b in ev) / len(ev)) for tag, ev in self.events.items()}
+
+
+class Prepared:
+    """Cache of one-time weight transforms (K padding, QKV concatenation, folded norm gains), rebuilt when a parameter changes
+    (version counter, storage, dtype, device) or when the trainer announces raw-pointer weight writes (`epoch`)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, name, params, fn, epoch=0):
+        key = (epoch,) + tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+        hit = self._c.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                self._c[name] = (key, fn())
+        return self._c[name][1]
+
+
+def fold_gain(w: torch.Tensor, gain: torch.Tensor) -> torch.Tensor:
+    """W' = W * diag(gain), rounded once to W's dtype: x_normed(gain) @ W^T == (x * rstd) @ W'^T up to that rounding."""
+    return (w.detach().float() * gain.detach().float()[None, :]).to(w.dtype).contiguous()
+
+
+@dataclass
+class RowStats:
+    """Per-row statistics of an activation [M, N], produced by the epilogue of the GEMM that wrote it (or by `row_stats`) and
+    consumed by the next GEMM as `row_scale` / `row_shift`: the block's pre-norm then costs no launch of its own."""
+    rstd: torch.Tensor                      # f32 [M]: 1/sqrt(mean(y^2) + eps) (RMSNorm) or 1/sqrt(var(y) + eps) (LayerNorm)
+    mean: Optional[torch.Tensor] = None     # f32 [M] (LayerNorm only)
+
+
+_STATS_WS = {}
+
+
+def _stats_ws(M: int, n_out: int, dev) -> torch.Tensor:
+    """Workspace of the producer side (arrival counters + partial sums): zero-filled once per (device, stream, size class)."""
+    need = int(L.load().aki_linear_stats_workspace_bytes(M, n_out))
+    key = (torch.device(dev).index, torch.cuda.current_stream().cuda_stream)
+    ws = _STATS_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _STATS_WS[key] = torch.zeros(max(need, 8 << 20), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def new_stats(M: int, dev, ln: bool = False) -> RowStats:
+    return RowStats(torch.empty((M,), dtype=torch.float32, device=dev), torch.empty((M,), dtype=torch.float32, device=dev) if ln else None)
+
+
+def row_stats(x: torch.Tensor, eps: float, ln: bool = False) -> RowStats:
+    """Statistics of a tensor no GEMM of this library produced (the first block's input): one HBM pass, no output tensor."""
+    dev = _dev(x)
+    x2 = _rows2d(x)
+    st = new_stats(x2.shape[0], dev, ln)
+    L.check(L.load().aki_row_stats(_ptr(x2), x2.shape[0], x2.shape[1], x2.stride(0), float(eps), _ptr(st.rstd), _ptr(st.mean), _dt(x),
+                                   _stream()), "aki_row_stats")
+    return st
 
 
 _TAP: Optional[EventTap] = None
@@ -147,11 +208,16 @@ class MaskTable:
 # ------------------------------------------------------------------------------------------------
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            act: int = ACT_NONE, res_row_mod: int = 0, out: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
-           w2_row0: int = 0, n_rows: Optional[int] = None) -> torch.Tensor:
+           w2_row0: int = 0, n_rows: Optional[int] = None, row_scale: Optional[torch.Tensor] = None,
+           row_shift: Optional[torch.Tensor] = None, col_shift: Optional[torch.Tensor] = None,
+           stats_out: Optional[RowStats] = None, stats_eps: float = 0.0) -> torch.Tensor:
     """y = act(x W^T + bias) [+ residual]; W is an nn.Linear weight [N,K] (K a multiple of 64 for bf16).
     Two-segment weight (DecoupledLinear, src/helpers.py:594-603): with `w2`, logical weight row r is w[r] for r < w2_row0 and
-    w2[r - w2_row0] beyond; `n_rows` = logical rows (output width, may include padding columns that repeat w2's last row)."""
-    dev = _dev(x, w, bias, residual, out, w2)
+    w2[r - w2_row0] beyond; `n_rows` = logical rows (output width, may include padding columns that repeat w2's last row).
+    Folded normalisation (see include/aki_mi355x.h, aki_linear_args): `row_scale` / `row_shift` / `col_shift` apply the input's
+    RMSNorm / LayerNorm in the epilogue (w then carries the gain), `stats_out` makes this GEMM produce the statistics of ITS
+    output for the next one."""
+    dev = _dev(x, w, bias, residual, out, w2, row_scale, row_shift, col_shift)
     lib = L.load()
     x2 = _rows2d(x)
     M, K = x2.shape
@@ -172,6 +238,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     a = L.LinearArgs(_ptr(x2), _ptr(w), _ptr(bias), _ptr(r2), _ptr(o2), M, N, K, x2.stride(0), w.stride(0), o2.stride(0),
                      0 if r2 is None else r2.stride(0), res_row_mod, act, _dt(x), None, None,
                      _ptr(w2), int(w2_row0) if w2 is not None else 0, int(w2.shape[0]) if w2 is not None else 0)
+    a.row_scale, a.row_shift, a.col_shift = _ptr(row_scale), _ptr(row_shift), _ptr(col_shift)
+    if stats_out is not None:
+        sws = _stats_ws(M, n_out, dev)
+        a.stats_rstd, a.stats_mean, a.stats_eps = _ptr(stats_out.rstd), _ptr(stats_out.mean), float(stats_eps)
+        a.stats_workspace, a.stats_workspace_bytes = sws.data_ptr(), sws.numel()
     end = _TAP.begin(("linear", M, N, K, act)) if (_TAP is not None and _TAP.want(("linear", M, N, K, act))) else None
     L.check(lib.aki_linear_fwd(C.byref(a), _stream()), "aki_linear_fwd")
     if end is not None:
@@ -253,19 +324,19 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, r
     return (o, lse) if return_lse else o
 
 
-def _fused_args(x2, w_qkv, cos, sin, position_ids, o, lse, table, B, H, Lq, Dh, scale, dead_rows, kv_capacity=0):
+def _fused_args(x2, w_qkv, cos, sin, position_ids, o, lse, table, B, H, Lq, Dh, scale, dead_rows, kv_capacity=0, row_scale=None):
     return L.MmaAttnArgs(_ptr(x2), _ptr(w_qkv), _ptr(cos), _ptr(sin), _ptr(position_ids), _ptr(o), _ptr(lse),
                          _ptr(table.rects), _ptr(table.col_valid_bits), _ptr(table.seq_lens), table.max_rects,
                          B, H, Lq, Dh, x2.shape[1], x2.stride(0), w_qkv.stride(0), cos.shape[0], float(scale),
-                         _dt(x2), dead_rows, kv_capacity)
+                         _dt(x2), dead_rows, kv_capacity, None, None, _ptr(row_scale))
 
 
 def mma_attn(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, table: MaskTable, num_heads: int,
              scale: Optional[float] = None, position_ids: Optional[torch.Tensor] = None,
-             dead_rows: int = DEAD_ROWS_UNIFORM) -> torch.Tensor:
+             dead_rows: int = DEAD_ROWS_UNIFORM, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused QKV projection + RoPE + span-driven attention.  x [B,L,d] -> o [B,L,H*Dh] (before o_proj).
-    cos/sin: f32 [pos_rows, Dh]."""
-    dev = _dev(x, w_qkv, cos, sin, position_ids)
+    cos/sin: f32 [pos_rows, Dh].  row_scale: folded input RMSNorm (x raw, w_qkv carries the gain)."""
+    dev = _dev(x, w_qkv, cos, sin, position_ids, row_scale)
     B, Lq, d = x.shape
     Dh = w_qkv.shape[0] // (3 * num_heads)
     x2 = _rows2d(x)
@@ -277,7 +348,7 @@ def mma_attn(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch
     lib = L.load()
     ws = _ws(lib.aki_mma_attn_workspace_bytes(B, num_heads, Lq, Dh, _dt(x)), dev)
     a = _fused_args(x2, w_qkv, cos, sin, position_ids, o, None, table, B, num_heads, Lq, Dh,
-                    scale if scale is not None else Dh ** -0.5, dead_rows)
+                    scale if scale is not None else Dh ** -0.5, dead_rows, row_scale=row_scale)
     end = _TAP.begin(("mma_attn", B, num_heads, Lq, Dh)) if (_TAP is not None and _TAP.want(("mma_attn",))) else None
     L.check(lib.aki_mma_attn_fwd(C.byref(a), _ptr(ws), ws.numel(), _stream()), "aki_mma_attn_fwd")
     if end is not None:
@@ -287,7 +358,7 @@ def mma_attn(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch
 
 def qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, num_heads: int,
              position_ids: Optional[torch.Tensor] = None, k_out: Optional[torch.Tensor] = None,
-             v_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+             v_out: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Stage 1 of the fused op: rotated q [B,H,L,Dh], rotated k and v.  With k_out / v_out ([B,H,cap,Dh], cap >= L)
     the keys/values are written straight into a KV cache (prefill)."""
     dev = _dev(x, w_qkv, cos, sin, k_out, v_out)
@@ -306,7 +377,7 @@ def qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, cos: torch.Tensor, sin: torch
     if not (k_out.is_contiguous() and v_out.is_contiguous()) or v_out.shape != k_out.shape or cap < Lq:
         raise AkiError("qkv_rope: bad KV output buffers")
     a = _fused_args(x2, w_qkv, cos, sin, position_ids, None, None, MaskTable(None, None, None, Lq), B, num_heads, Lq, Dh,
-                    Dh ** -0.5, 0, 0 if cap == Lq else cap)
+                    Dh ** -0.5, 0, 0 if cap == Lq else cap, row_scale=row_scale)
     ws = _ws(B * Lq * 3 * num_heads * Dh * 4 if x.dtype == torch.float32 else 256, dev)
     L.check(L.load().aki_qkv_rope_fwd(C.byref(a), _ptr(q), _ptr(k_out), _ptr(v_out), _ptr(ws), ws.numel(), _stream()),
             "aki_qkv_rope_fwd")
@@ -556,26 +627,70 @@ def connector_proj(x: torch.Tensor, ln_w, ln_b, w, b, eps: float = 1e-5) -> torc
     return out.reshape(*x.shape[:-1], d_out)
 
 
+@dataclass
+class SplicePlan:
+    """The per-sample splice plan (image count, text span, output length ...) on its way to the host: started early by
+    `splice_plan_async`, collected by `splice`."""
+    plan: torch.Tensor           # int32 [B, AKI_PLAN_STRIDE] on the device
+    host: torch.Tensor           # the same, pinned host memory, valid once `ready` has passed
+    ready: "torch.cuda.Event"
+    lang_x: torch.Tensor         # the int64 ids the plan was made from
+    key: tuple
+
+
+_PLAN_PINNED = {}
+
+
+def splice_plan_async(lang_x: torch.Tensor, media_token_id: int, assistant_token_id: int, n_vis_tokens: int) -> SplicePlan:
+    """The plan depends on the token ids only, while the splice itself needs the vision tokens - the last thing the vision
+    side produces.  Sizing the outputs needs the plan on the HOST: called before the vision tower is issued, the plan kernel and
+    its 100-byte copy run ahead of ~8 ms of queued GPU work, and `splice` later waits on an event that has long passed instead
+    of draining the stream (0.35 ms of idle GPU per forward at the benchmark shape)."""
+    dev = _dev(lang_x)
+    B, T = lang_x.shape
+    ids = lang_x.to(torch.int64).contiguous()
+    plan = torch.empty((B, L.AKI_PLAN_STRIDE), dtype=torch.int32, device=dev)
+    L.check(L.load().aki_splice_plan(_ptr(ids), B, T, media_token_id, assistant_token_id, n_vis_tokens, _ptr(plan), _stream()),
+            "aki_splice_plan")
+    ring = _PLAN_PINNED.setdefault((B, torch.device(dev).index), [[], 0])
+    if len(ring[0]) < 4:
+        ring[0].append(torch.empty((B, L.AKI_PLAN_STRIDE), dtype=torch.int32).pin_memory())
+    host = ring[0][ring[1] % len(ring[0])]
+    ring[1] += 1
+    host.copy_(plan, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return SplicePlan(plan, host, ev, ids, (lang_x.data_ptr(), lang_x._version, tuple(lang_x.shape), media_token_id, assistant_token_id, n_vis_tokens))
+
+
 def splice(lang_x: torch.Tensor, attention_mask: Optional[torch.Tensor], labels: Optional[torch.Tensor],
            embed_weight: torch.Tensor, embed_additional: Optional[torch.Tensor], max_original_id: int,
            vision_tokens: torch.Tensor, media_token_id: int, pad_token_id: int, assistant_token_id: int = 32001,
-           padding_side: str = "right", max_rects: int = 1):
+           padding_side: str = "right", max_rects: int = 1, plan: Optional[SplicePlan] = None):
     """Language-stream fusion (src/vlm.py:445-603).  Returns (inputs_embeds, labels_out, MaskTable, plan_host).
-    One small device->host copy (the per-sample plan) is needed to size the outputs."""
+    One small device->host copy (the per-sample plan) is needed to size the outputs; `plan` = the result of an earlier
+    `splice_plan_async` on the same ids makes that copy free."""
     dev = _dev(lang_x, attention_mask, labels, embed_weight, embed_additional, vision_tokens)
     lib = L.load()
     B, T = lang_x.shape
-    lang_x = lang_x.to(torch.int64).contiguous()
+    if plan is not None and plan.key != (lang_x.data_ptr(), lang_x._version, tuple(lang_x.shape), media_token_id, assistant_token_id,
+                                         vision_tokens.shape[2]):
+        plan = None                     # made from other ids: plan again
+    lang_x = plan.lang_x if plan is not None else lang_x.to(torch.int64).contiguous()
     if attention_mask is not None:
         attention_mask = attention_mask.to(torch.int64).contiguous()
     if labels is not None:
         labels = labels.to(torch.int64).contiguous()
     vision_tokens = vision_tokens.to(embed_weight.dtype).contiguous()
     _, T_img, Nv, d = vision_tokens.shape
-    plan = torch.empty((B, L.AKI_PLAN_STRIDE), dtype=torch.int32, device=dev)
-    L.check(lib.aki_splice_plan(_ptr(lang_x), B, T, media_token_id, assistant_token_id, Nv, _ptr(plan), _stream()),
-            "aki_splice_plan")
-    plan_h = plan.cpu()
+    if plan is not None:
+        plan.ready.synchronize()
+        plan, plan_h = plan.plan, plan.host.clone()
+    else:
+        plan = torch.empty((B, L.AKI_PLAN_STRIDE), dtype=torch.int32, device=dev)
+        L.check(lib.aki_splice_plan(_ptr(lang_x), B, T, media_token_id, assistant_token_id, Nv, _ptr(plan), _stream()),
+                "aki_splice_plan")
+        plan_h = plan.cpu()
     n_img = plan_h[:, 0]
     if int(n_img.max()) > T_img:
         raise AkiError(f"a sample has {int(n_img.max())} <image> placeholders but vision_x carries only {T_img} images")

@@ -231,8 +231,39 @@ class Phi3DecoderLayer(nn.Module):
         self.input_layernorm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self._fp8 = None
+        self._prep = ops.Prepared()
 
-    def forward(self, h, cos, sin, table, position_ids=None, cache=None):
+    def folds(self, h) -> bool:
+        """Inference in bf16: both RMSNorms are folded into the GEMMs around them (forward_folded)."""
+        return h.dtype == torch.bfloat16 and self._fp8 is None and not _ag(h, *self.parameters())
+
+    def forward_folded(self, h, st, cos, sin, table, position_ids=None, cache=None):
+        """The inference layer without norm launches: h is the raw residual stream and `st` its per-token 1/rms, produced by the
+        epilogue of the GEMM that wrote h (o_proj / down_proj, `stats_out`).  RMSNorm(h) @ W^T = rstd * (h @ (W diag(gamma))^T), so
+        the QKV and gate_up GEMMs read h itself against gain-folded weights and scale their accumulators per token.  Returns
+        (h_out, stats of h_out); 4 launches per layer instead of 6."""
+        at, mlp, n1, n2 = self.self_attn, self.mlp, self.input_layernorm, self.post_attention_layernorm
+        wq = self._prep.get("qkv", [at.qkv_proj.weight, n1.weight], lambda: ops.fold_gain(at.qkv_proj.weight, n1.weight), T._EPOCH)
+        wg = self._prep.get("gate_up", [mlp.gate_up_proj.weight, n2.weight],
+                            lambda: ops.fold_gain(mlp.gate_up_proj.weight, n2.weight), T._EPOCH)
+        M = h.numel() // h.shape[-1]
+        if cache is None:
+            o = ops.mma_attn(h, wq, cos, sin, table, at.num_heads, at.scaling, position_ids, row_scale=st.rstd)
+        else:
+            q, k, v = ops.qkv_rope(h, wq, cos, sin, at.num_heads, position_ids, k_out=cache.k[at.layer_idx],
+                                   v_out=cache.v[at.layer_idx], row_scale=st.rstd)
+            o = ops.mma_attn_core(q, k, v, table, at.scaling)
+        st2 = ops.new_stats(M, h.device)
+        h = ops.linear(o, at.o_proj.weight, residual=h, stats_out=st2, stats_eps=n2.variance_epsilon)
+        a = ops.linear(h, wg, act=ops.ACT_SWIGLU, row_scale=st2.rstd)
+        st3 = ops.new_stats(M, h.device)
+        h = ops.linear(a, mlp.down_proj.weight, residual=h, stats_out=st3, stats_eps=n1.variance_epsilon)
+        return h, st3
+
+    def forward(self, h, cos, sin, table, position_ids=None, cache=None, stats=None):
+        """-> h_out; with `stats` (ops.RowStats of h, see forward_folded) -> (h_out, stats of h_out)."""
+        if stats is not None:
+            return self.forward_folded(h, stats, cos, sin, table, position_ids, cache)
         if self._fp8 is not None and not torch.is_grad_enabled():
             return self._forward_fp8(h, cos, sin, table, position_ids, cache)
         if cache is None and _ag(h, *self.parameters()):
@@ -296,6 +327,9 @@ class Phi3Model(nn.Module):
         self.norm = Phi3RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.rotary_emb = Phi3RotaryTables(config)
         self.skip_final_norm = False
+        self.defer_final_norm = False            # set by Phi3ForCausalLM around its own call: the lm_head takes the raw stream
+        self.fold_norms = True                   # bf16 inference: RMSNorms folded into the neighbouring GEMMs
+        self.final_stats = None
 
     def forward(self, inputs_embeds, table, position_ids=None, cache=None):
         B, L, _ = inputs_embeds.shape
@@ -305,6 +339,17 @@ class Phi3Model(nn.Module):
         if cache is not None:
             cache.host_len = seq_len
         h = inputs_embeds
+        self.final_stats = None
+        if self.fold_norms and all(layer.folds(h) for layer in self.layers) and not _ag(h, self.norm.weight):
+            # every RMSNorm of the stack rides on the GEMM before it (statistics) and after it (gain, scale): the only pass over
+            # the residual stream that is not a GEMM is this one, for the embeddings no kernel of ours produced
+            st = ops.row_stats(h, self.norm.variance_epsilon)
+            for layer in self.layers:
+                h, st = layer(h, cos, sin, table, position_ids, cache, stats=st)     # through __call__: module hooks (weight gathering) run
+            if self.defer_final_norm:
+                self.final_stats = st            # the head folds the final norm the same way
+                return h
+            return ops.rmsnorm(h, self.norm.weight, self.norm.variance_epsilon)
         for layer in self.layers:
             h = layer(h, cos, sin, table, position_ids, cache)
         if self.skip_final_norm:                 # the fp8 head fuses the final RMSNorm into its quantiser
@@ -342,6 +387,7 @@ class Phi3ForCausalLM(nn.Module):
         self.vocab_size = config.vocab_size
         self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
         self.generation_config = None     # set from the checkpoint's generation_config.json by the loaders (eos ids for generate)
+        self._prep = ops.Prepared()
 
     # --- the accessors src/vlm.py:48,80-99 relies on -----------------------------------------------------
     def get_input_embeddings(self):
@@ -386,6 +432,16 @@ class Phi3ForCausalLM(nn.Module):
             return ops.linear(h, self.lm_head.weight, bias=self.lm_head.bias)
         return self.lm_head(h)   # DecoupledLinear (src/vlm.py:88-99): one HIP GEMM / GEMV over the fused weight
 
+    def _head_folded(self, h, st):
+        """lm_head(norm(h)) with the final RMSNorm folded: gain into a cached copy of the head weight, 1/rms into the epilogue."""
+        norm, head = self.model.norm, self.lm_head
+        if type(head) is nn.Linear:
+            w = self._prep.get("head", [head.weight, norm.weight], lambda: ops.fold_gain(head.weight, norm.weight), T._EPOCH)
+            return ops.linear(h, w, bias=head.bias, row_scale=st.rstd)
+        w0, b, n = head._fused_weight()
+        w = self._prep.get("head", [w0, norm.weight], lambda: ops.fold_gain(w0, norm.weight), (T._EPOCH, head._fused[0]))
+        return ops.linear(h, w, bias=b, row_scale=st.rstd)[..., :n]
+
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, labels=None, position_ids=None,
                 use_cache=False, past_key_values=None, cache_capacity=None, **kwargs):
         """Prefill / full forward.  With use_cache=True the returned past_key_values is an AkiKVCache holding the
@@ -409,15 +465,20 @@ class Phi3ForCausalLM(nn.Module):
                                inputs_embeds.device)
         fp8_head = getattr(self, "_fp8_head", None) is not None and not torch.is_grad_enabled()
         self.model.skip_final_norm = fp8_head
+        self.model.defer_final_norm = True
         h = self.model(inputs_embeds, table, position_ids, cache)
-        self.model.skip_final_norm = False
+        self.model.skip_final_norm = self.model.defer_final_norm = False
+        head_stats, self.model.final_stats = self.model.final_stats, None     # not None: h is the raw stream, norm folded into the head
         self._pre_norm_h = h if fp8_head else None
+        if head_stats is not None and _ag(h, *self.lm_head.parameters()):
+            # frozen decoder under a trainable head: the head's autograd path wants the normalised stream itself
+            h, head_stats = ops.rmsnorm(h, self.model.norm.weight, self.model.norm.variance_epsilon), None
         if labels is not None and cache is None and _ag(h, *self.lm_head.parameters()):
             # training: lm_head + shifted cross-entropy chunk by chunk - no [B, L, V] logits tensor, no concatenated head
             # weight (so the output carries no logits; train/losses.py:110-115 only reads [0] = loss)
             loss = T.fused_head_ce(h, self.lm_head, labels, chunk=getattr(self, "head_chunk_rows", 2688))
             return CausalLMOutputWithPast(loss=loss, logits=None, past_key_values=None)
-        logits = self._head(h)
+        logits = self._head(h) if head_stats is None else self._head_folded(h, head_stats)
         if cache is not None:
             cache.cache_len.copy_(table.token_counts(B, h.device))
             if table.col_valid_bits is not None:

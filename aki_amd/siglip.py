@@ -25,19 +25,17 @@ def make_siglip_config(**kw):
     return SimpleNamespace(**d)
 
 
-class _Prepared:
-    """Cache of one-time weight transforms (K padding, QKV concatenation), invalidated when a parameter changes."""
+_Prepared = ops.Prepared
 
-    def __init__(self):
-        self._c = {}
 
-    def get(self, name, params, fn):
-        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
-        hit = self._c.get(name)
-        if hit is None or hit[0] != key:
-            with torch.no_grad():
-                self._c[name] = (key, fn())
-        return self._c[name][1]
+def fold_layernorm(w: torch.Tensor, b: torch.Tensor, ln: nn.LayerNorm):
+    """LayerNorm(x) @ W^T + b = rstd * (x @ W'^T - mean * c) + b'  with  W' = W diag(gamma) (rounded to W's dtype),
+    c[n] = sum_k W'[n][k] (f32, of the ROUNDED W' - that is what the MFMA multiplies) and b' = W beta + b."""
+    wf = ops.fold_gain(w, ln.weight)
+    c = torch.zeros(((w.shape[0] + 3) // 4 * 4,), dtype=torch.float32, device=w.device)
+    c[: w.shape[0]] = wf.float().sum(1)
+    bf = (w.float() @ ln.bias.detach().float() + (b.float() if b is not None else 0.0)).to(w.dtype).contiguous()
+    return wf, bf, c
 
 
 class SiglipVisionEmbeddings(nn.Module):
@@ -89,6 +87,20 @@ class SiglipAttention(nn.Module):
         self.out_proj = nn.Linear(self.embed_dim, self.embed_dim)
         self._prep = _Prepared()
 
+    def forward_folded(self, h, st, ln, stats_out, stats_eps):
+        """out_proj(attention(qkv(LayerNorm(h)))) + h without the LayerNorm launch: `st` = (1/std, mean) per token of h; the gain
+        sits in the cached qkv weight, the shift in its bias, the mean's share mu[m] * sum_k W'[n][k] comes off in the epilogue.
+        The out-projection leaves the statistics of its own output in `stats_out` for the next LayerNorm."""
+        N, L, E = h.shape
+        ps = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.q_proj.bias, self.k_proj.bias, self.v_proj.bias,
+              ln.weight, ln.bias]
+        wqkv, bqkv, cqkv = self._prep.get("qkv_ln", ps, lambda: fold_layernorm(torch.cat([p.detach() for p in ps[:3]], 0),
+                                                                                torch.cat([p.detach() for p in ps[3:6]], 0), ln))
+        qkv = ops.linear(h, wqkv, bias=bqkv, row_scale=st.rstd, row_shift=st.mean, col_shift=cqkv)
+        qkv = qkv.view(N, L, 3, self.num_heads, self.head_dim)
+        a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], self.scale)
+        return ops.linear(a, self.out_proj.weight, bias=self.out_proj.bias, residual=h, stats_out=stats_out, stats_eps=stats_eps)
+
     def forward(self, x, residual):
         N, L, E = x.shape
         ps = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]
@@ -110,7 +122,9 @@ class SiglipMLP(nn.Module):
         self.act = ops.ACT_GELU_TANH if "tanh" in config.hidden_act else ops.ACT_GELU_ERF
         self._prep = _Prepared()
 
-    def forward(self, x, residual):
+    def forward(self, x, residual, st=None, ln=None, stats_out=None, stats_eps=0.0):
+        """fc2(act(fc1(x))) + residual.  With `st`/`ln`: x is the raw stream and LayerNorm `ln` is folded into fc1 (see
+        SiglipAttention.forward_folded); `stats_out` receives the statistics of the result."""
         inter = self.fc1.weight.shape[0]
         Kp = (inter + 63) // 64 * 64
         w2 = self._prep.get("w2", [self.fc2.weight], lambda: ops.pad_k(self.fc2.weight.detach()))
@@ -124,8 +138,13 @@ class SiglipMLP(nn.Module):
             if len(_HBUF) > 8:
                 _HBUF.clear()
             hbuf = _HBUF[key] = torch.zeros((*lead, Kp), dtype=x.dtype, device=x.device)
-        ops.linear(x, self.fc1.weight, bias=self.fc1.bias, act=self.act, out=hbuf[..., :inter])
-        return ops.linear(hbuf, w2, bias=self.fc2.bias, residual=residual)
+        if st is None:
+            ops.linear(x, self.fc1.weight, bias=self.fc1.bias, act=self.act, out=hbuf[..., :inter])
+        else:
+            w1, b1, c1 = self._prep.get("fc1_ln", [self.fc1.weight, self.fc1.bias, ln.weight, ln.bias],
+                                        lambda: fold_layernorm(self.fc1.weight.detach(), self.fc1.bias.detach(), ln))
+            ops.linear(x, w1, bias=b1, act=self.act, out=hbuf[..., :inter], row_scale=st.rstd, row_shift=st.mean, col_shift=c1)
+        return ops.linear(hbuf, w2, bias=self.fc2.bias, residual=residual, stats_out=stats_out, stats_eps=stats_eps)
 
 
 class SiglipEncoderLayer(nn.Module):
@@ -136,7 +155,19 @@ class SiglipEncoderLayer(nn.Module):
         self.layer_norm2 = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self.mlp = SiglipMLP(config)
 
-    def forward(self, h):
+    def forward_folded(self, h, st, want_stats=True):
+        """Inference layer in 5 launches (qkv, attention, out, fc1, fc2): both LayerNorms ride on the GEMMs around them.
+        Returns (h_out, statistics of h_out for the next layer's layer_norm1 - every layer shares config.layer_norm_eps)."""
+        M = h.numel() // h.shape[-1]
+        st2 = ops.new_stats(M, h.device, ln=True)
+        h = self.self_attn.forward_folded(h, st, self.layer_norm1, st2, self.layer_norm2.eps)
+        st3 = ops.new_stats(M, h.device, ln=True) if want_stats else None
+        return self.mlp(h, h, st=st2, ln=self.layer_norm2, stats_out=st3, stats_eps=self.layer_norm1.eps), st3
+
+    def forward(self, h, stats=None, want_stats=True):
+        """-> h_out; with `stats` (ops.RowStats of h) -> forward_folded's (h_out, stats of h_out)."""
+        if stats is not None:
+            return self.forward_folded(h, stats, want_stats)
         h = self.self_attn(ops.layernorm(h, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps), h)
         return self.mlp(ops.layernorm(h, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps), h)
 
@@ -146,7 +177,15 @@ class SiglipEncoder(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([SiglipEncoderLayer(config) for _ in range(config.num_hidden_layers)])
 
+    fold_norms = True      # bf16 inference: LayerNorms folded into the neighbouring GEMMs
+
     def forward(self, h):
+        if self.fold_norms and h.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (
+                h.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            st = ops.row_stats(h, self.layers[0].layer_norm1.eps, ln=True)      # the embeddings' statistics: the one extra pass
+            for i, layer in enumerate(self.layers):
+                h, st = layer(h, stats=st, want_stats=i + 1 < len(self.layers))
+            return h
         for layer in self.layers:
             h = layer(h)
         return h

@@ -164,8 +164,9 @@ class VLMWithLanguageStream(VLM):
                                     labels: torch.Tensor = None, past_key_values=None,
                                     vision_attention_mask: Optional[torch.Tensor] = None,
                                     past_media_locations: torch.Tensor = None, past_vision_tokens: torch.Tensor = None,
-                                    padding_side: str = "left", num_beams: int = 1):
-        """src/vlm.py:445-603.  ``attention_mask`` in the returned dict is an ``ops.MaskTable``."""
+                                    padding_side: str = "left", num_beams: int = 1, splice_plan=None):
+        """src/vlm.py:445-603.  ``attention_mask`` in the returned dict is an ``ops.MaskTable``.  ``splice_plan``: the result of
+        `_start_splice_plan(lang_x)` issued before the vision side (saves the stream drain that sizing the outputs costs)."""
         if past_key_values is not None:
             # src/vlm.py:463-468: the caller's mask must span the cached tokens (incl. image tokens) + the new ids
             past_len = past_key_values.get_seq_length()
@@ -185,7 +186,8 @@ class VLMWithLanguageStream(VLM):
         try:
             embeds, new_labels, table, plan = ops.splice(
                 lang_x, attention_mask, labels, emb.weight, emb.additional_embedding.weight, emb.max_original_id,
-                vision_tokens, self.media_token_id, self.pad_token_id, ASSISTANT_TOKEN_ID, padding_side, max_rects)
+                vision_tokens, self.media_token_id, self.pad_token_id, ASSISTANT_TOKEN_ID, padding_side, max_rects,
+                plan=splice_plan)
         except ops.AkiError as e:
             if "max_rects" in str(e):
                 raise RuntimeError("Tensors must have same number of dimensions: got 3 and 1 - the reference cannot "
@@ -200,6 +202,12 @@ class VLMWithLanguageStream(VLM):
             embeds = T.SpliceGradFn.apply(embeds, vision_tokens, emb.weight, emb.additional_embedding.weight,
                                           lang_x.to(torch.int64), pos_lang, pos_vis, emb.max_original_id)
         return {"inputs_embeds": embeds, "attention_mask": table, "labels": new_labels}
+
+    def _start_splice_plan(self, lang_x: torch.Tensor):
+        """Issue the splice's planning kernel and its device->host copy now (see ops.splice_plan_async); None off the GPU path."""
+        if not lang_x.is_cuda:
+            return None
+        return ops.splice_plan_async(lang_x, self.media_token_id, ASSISTANT_TOKEN_ID, self.num_tokens_per_vis)
 
     def _post_forward_hook(self):
         pass

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 9
+#define AKI_ABI_VERSION 10
 
 typedef enum {
   AKI_OK = 0,
@@ -146,6 +146,7 @@ typedef struct {
    * the attention core runs exactly as in the bf16 path. */
   const float* x_scale;
   const float* w_scale;
+  const float* row_scale;  /* folded input RMSNorm (see aki_linear_args): x is the RAW hidden state, w_qkv = W diag(gain); NULL = none */
 } aki_mma_attn_args;
 
 size_t aki_mma_attn_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t dtype);
@@ -213,9 +214,33 @@ typedef struct {
   const void* w2;
   int32_t w2_row0;
   int32_t w2_rows;
+  /* Normalisation folded into the GEMMs (bf16 MFMA path; HF:phi3/modeling_phi3.py:266-284 RMSNorm, torch.nn.LayerNorm of
+   * HF:siglip/modeling_siglip.py:329-354) - the pre-norm of a block costs no launch and no pass over the activations:
+   *   consumer   y = act( row_scale[m] * (x W'^T - row_shift[m] * col_shift[n]) + bias ) [+ residual]
+   *              RMSNorm: W' = W diag(gain), row_scale = 1/rms(x_m), row_shift = NULL.
+   *              LayerNorm: W' = W diag(gain), row_scale = 1/std(x_m), row_shift = mean(x_m), col_shift[n] = sum_k W'[n][k] (f32),
+   *              bias = W beta + b.  (W', col_shift and that bias are prepared once per weight by the caller.)
+   *   producer   stats_rstd != NULL: while writing y, the GEMM also computes the row statistics of y AS STORED (bf16):
+   *              stats_rstd[m] = 1/sqrt(mean(y_m^2) + eps)                      (stats_mean == NULL: RMSNorm of the next block)
+   *              stats_mean[m] = mean(y_m), stats_rstd[m] = 1/sqrt(var(y_m) + eps)   (stats_mean != NULL: LayerNorm)
+   *              stats_workspace: aki_linear_stats_workspace_bytes(M, N_out) bytes, 16-byte aligned, ZERO-FILLED ONCE (arrival
+   *              counters the kernel puts back to zero; launches sharing it must be stream-ordered).  act must not be SWIGLU.
+   * All NULL: plain GEMM. */
+  const float* row_scale;
+  const float* row_shift;
+  const float* col_shift;
+  float* stats_rstd;
+  float* stats_mean;
+  float stats_eps;
+  void* stats_workspace;
+  size_t stats_workspace_bytes;
 } aki_linear_args;
 
 int aki_linear_fwd(const aki_linear_args* args, void* stream);
+size_t aki_linear_stats_workspace_bytes(int32_t M, int32_t N_out);
+/* aki_row_stats - the same statistics for a tensor no GEMM of this library produced (the first block's input): rstd[m] (and,
+ * when mean != NULL, mean[m]) of x [rows, cols] bf16. */
+int aki_row_stats(const void* x, int32_t rows, int32_t cols, int32_t ldx, float eps, float* rstd, float* mean, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Normalisation.  rmsnorm: HF:phi3/modeling_phi3.py:266-284 (fp32 statistics, result cast to the

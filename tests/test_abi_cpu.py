@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/aki_mi355x.h but not exported"
-    assert lib.aki_abi_version() == 9
+    assert lib.aki_abi_version() == 10
     exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "debug" not in exported and "aki_lab_" not in exported, "lab / debug hooks must not ship in the product library"
     assert b"aligned" in lib.aki_strerror(-3)
@@ -111,7 +111,7 @@ def test_struct_layouts_match_the_header(lib, tmp_path, monkeypatch):
     assert set(structs) == set(STRUCTS), "a struct was added to the header: mirror it in _lib.py and list it here"
     for sname, cname in STRUCTS.items():
         assert_same_layout(getattr(_lib, cname), sname, structs[sname], lay)
-    assert lay["aki_mma_attn_args"][0] == 152 and lay["aki_mma_attn_args"][1]["kv_capacity"][0] == 128
+    assert lay["aki_mma_attn_args"][0] == 160 and lay["aki_mma_attn_args"][1]["kv_capacity"][0] == 128
     monkeypatch.setenv("AKI_MI355X_SO", _lib.LIB_PATH)
     ns = {}
     exec(compile(integration_md_binding(), "INTEGRATION.md#B", "exec"), ns)     # loads the library, binds the prototypes

@@ -1,0 +1,186 @@
+"""GPU parity tests of the folded normalisation (ABI v10: aki_linear_args.row_scale / row_shift / col_shift / stats_*,
+aki_mma_attn_args.row_scale, aki_row_stats): a block's pre-norm rides on the GEMM before it (which leaves the per-token
+statistics of its output) and on the GEMM after it (gain folded into the weight, 1/rms - and the mean's share - applied to the
+accumulator).  Oracle: norm-then-linear in f32 numpy on the bf16-rounded inputs (oracle/aki_oracle.py rms_norm / layer_norm /
+linear), i.e. Phi3RMSNorm -> qkv_proj / gate_up_proj (HF:phi3/modeling_phi3.py:266-284) and nn.LayerNorm -> q/k/v / fc1
+(HF:siglip/modeling_siglip.py).  Tolerance as in test_kernels_gpu.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden import gen
+import aki_oracle as O
+from test_kernels_gpu import DEV, check, gemm_tile, n, rnd, t, _ops  # noqa: F401  (gemm_tile is a fixture)
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _stats_np(y, eps, ln):
+    y = y.astype(np.float64)
+    if ln:
+        mu = y.mean(-1)
+        return 1.0 / np.sqrt(((y - mu[:, None]) ** 2).mean(-1) + eps), mu
+    return 1.0 / np.sqrt((y * y).mean(-1) + eps), None
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 64), (37, 1152), (300, 3072), (5, 200)])
+@pytest.mark.parametrize("ln", [False, True])
+def test_row_stats(rows, cols, ln):
+    ops = _ops()
+    dtype = BF
+    x = gen.rng_for(f"rowstats{rows}{cols}").standard_normal((rows, cols), dtype=np.float32) * 3 + (1.5 if ln else 0.0)
+    st = ops.row_stats(t(x, dtype), 1e-5, ln=ln)
+    rstd, mu = _stats_np(rnd(x, dtype), 1e-5, ln)
+    np.testing.assert_allclose(n(st.rstd), rstd, rtol=2e-5)
+    if ln:
+        np.testing.assert_allclose(n(st.mean), mu, rtol=2e-5, atol=1e-6)
+    else:
+        assert st.mean is None
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (37, 1152, 640), (1380, 3072, 256), (700, 1152, 4352), (17, 192, 64), (513, 72, 192)])
+@pytest.mark.parametrize("ln", [False, True])
+def test_linear_producer_statistics(M, N, K, ln, gemm_tile):
+    """`stats_out`: the output is bit-identical to the plain launch, and the statistics are those of the bf16 values stored -
+    what a norm kernel reading y back would compute.  Twice in a row: the arrival counters must be back at zero."""
+    ops = _ops()
+    rng = gen.rng_for(f"prod{M}{N}{K}")
+    x = t(rng.standard_normal((M, K), dtype=np.float32), BF)
+    w = t(rng.standard_normal((N, K), dtype=np.float32) * 0.05, BF)
+    b = t(rng.standard_normal((N,), dtype=np.float32) * 0.1 + (0.7 if ln else 0.0), BF)
+    r = t(rng.standard_normal((M, N), dtype=np.float32) * 2, BF)
+    y0 = ops.linear(x, w, bias=b, residual=r)
+    for rep in range(2):
+        st = ops.new_stats(M, DEV, ln=ln)
+        st.rstd.fill_(float("nan"))
+        y = ops.linear(x, w, bias=b, residual=r, stats_out=st, stats_eps=1e-6)
+        assert torch.equal(y, y0), "the statistics epilogue changed the GEMM's output"
+        rstd, mu = _stats_np(n(y), 1e-6, ln)
+        np.testing.assert_allclose(n(st.rstd), rstd, rtol=3e-5, err_msg=f"rstd, repetition {rep}")
+        if ln:
+            np.testing.assert_allclose(n(st.mean), mu, rtol=3e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (37, 1152, 640), (1380, 2048, 256), (64, 9000, 192)])
+def test_linear_folded_rmsnorm(M, N, K, gemm_tile):
+    """RMSNorm(x) @ W^T  ==  rstd[m] * (x @ (W diag(gamma))^T), plain and SwiGLU epilogues."""
+    ops = _ops()
+    rng = gen.rng_for(f"foldrms{M}{N}{K}")
+    x = rng.standard_normal((M, K), dtype=np.float32) * rng.uniform(0.2, 6.0, (M, 1)).astype(np.float32)
+    g = 1.0 + 0.3 * rng.standard_normal((K,), dtype=np.float32)
+    w = rng.standard_normal((2 * N, K), dtype=np.float32) * 0.06
+    xr, gr, wr = rnd(x, BF), rnd(g, BF), rnd(w, BF)
+    xd, wd = t(x, BF), t(w, BF)
+    st = ops.row_stats(xd, 1e-5)
+    wf = ops.fold_gain(wd, t(g, BF))
+    normed = O.rms_norm(xr, gr, 1e-5)
+    # The oracle keeps the normalised activation in f32.  Either HIP path rounds once more on the way into the MFMA (the
+    # unfused one the normalised activation, the folded one the gain-scaled weight - same 2^-9 relative step, K terms): 2x
+    # the single-kernel tolerance, and the folded path must not be further from the oracle than the unfused one.
+    y = ops.linear(xd, wf[:N], row_scale=st.rstd)
+    want = normed @ wr[:N].T
+    check(n(y), want, BF, "folded RMSNorm -> linear", scale_atol=2.0)
+    y0 = ops.linear(ops.rmsnorm(xd, t(g, BF), 1e-5), wd[:N])
+    e_fold, e_unf = np.abs(n(y) - want).mean(), np.abs(n(y0) - want).mean()
+    assert e_fold <= 1.15 * e_unf + 1e-6, f"folded path mean error {e_fold:.3g} vs norm-then-linear {e_unf:.3g}"
+    y = ops.linear(xd, wf, act=ops.ACT_SWIGLU, row_scale=st.rstd)
+    up = normed @ wr.T
+    check(n(y), up[:, N:] * O.silu(up[:, :N]), BF, "folded RMSNorm -> gate_up + SwiGLU", scale_atol=2.0)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (37, 3456, 1152), (1380, 4304, 1152), (513, 72, 192)])
+def test_linear_folded_layernorm(M, N, K, gemm_tile):
+    """LayerNorm(x) @ W^T + b == rstd * (x @ W'^T - mean * c) + (W beta + b), with bias / GELU / residual epilogues, on
+    rows whose mean is several standard deviations off zero (the term that cancels)."""
+    ops = _ops()
+    from aki_amd.siglip import fold_layernorm
+    rng = gen.rng_for(f"foldln{M}{N}{K}")
+    x = rng.standard_normal((M, K), dtype=np.float32) * rng.uniform(0.3, 4.0, (M, 1)).astype(np.float32) \
+        + rng.uniform(-6.0, 6.0, (M, 1)).astype(np.float32)
+    g = 1.0 + 0.3 * rng.standard_normal((K,), dtype=np.float32)
+    beta = 0.2 * rng.standard_normal((K,), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) * 0.05
+    b = rng.standard_normal((N,), dtype=np.float32) * 0.1
+    r = rng.standard_normal((M, N), dtype=np.float32)
+    xr, gr, betar, wr, br, rr = (rnd(a, BF) for a in (x, g, beta, w, b, r))
+    ln = torch.nn.LayerNorm(K, eps=1e-6).to(DEV).to(BF)
+    with torch.no_grad():
+        ln.weight.copy_(t(g, BF))
+        ln.bias.copy_(t(beta, BF))
+    xd = t(x, BF)
+    wf, bf, c = fold_layernorm(t(w, BF), t(b, BF), ln)
+    st = ops.row_stats(xd, 1e-6, ln=True)
+    base = O.layer_norm(xr, gr, betar, 1e-6) @ wr.T + br
+    kw = dict(bias=bf, row_scale=st.rstd, row_shift=st.mean, col_shift=c)
+    check(n(ops.linear(xd, wf, **kw)), base, BF, "folded LayerNorm -> linear + bias", scale_atol=2.0)
+    check(n(ops.linear(xd, wf, act=ops.ACT_GELU_TANH, **kw)), O.gelu_tanh(base.astype(np.float32)), BF, "folded LayerNorm -> fc1 + GELU",
+          scale_atol=2.0)
+    check(n(ops.linear(xd, wf, residual=t(r, BF), **kw)), base + rr, BF, "folded LayerNorm -> linear + residual", scale_atol=2.0)
+
+
+def test_folded_chain_full_width_rows():
+    """AKI-4B widths at the benchmark's token count (8 x 661 = 5288 rows, with the M-tail launch): o_proj leaves 1/rms of the new
+    residual stream, gate_up consumes it - against norm-then-linear on a sample of rows."""
+    ops = _ops()
+    M, d, inter = 5288, 3072, 8192
+    gq = torch.Generator(device="cpu").manual_seed(11)
+    o = torch.randn(M, d, generator=gq).to(BF).to(DEV)
+    h = (torch.randn(M, d, generator=gq) * 3).to(BF).to(DEV)
+    wo = (torch.randn(d, d, generator=gq) * 0.02).to(BF).to(DEV)
+    wg = (torch.randn(2 * inter, d, generator=gq) * 0.02).to(BF).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(d, generator=gq)).to(BF).to(DEV)
+    st = ops.new_stats(M, DEV)
+    h2 = ops.linear(o, wo, residual=h, stats_out=st, stats_eps=1e-5)
+    a = ops.linear(h2, ops.fold_gain(wg, gamma), act=ops.ACT_SWIGLU, row_scale=st.rstd)
+    rows = np.r_[0:4, 255:258, 2643:2647, 5118:5124, 5284:5288]
+    rstd, _ = _stats_np(n(h2), 1e-5, False)
+    np.testing.assert_allclose(n(st.rstd), rstd, rtol=3e-5)
+    normed = O.rms_norm(n(h2)[rows], n(gamma), 1e-5)
+    up = normed @ n(wg).T
+    check(n(a)[rows], up[:, inter:] * O.silu(up[:, :inter]), BF, "o_proj statistics -> folded gate_up, full width", scale_atol=4.0)
+    # and the unfused HIP chain lands in the same place (4x: norm rounding, GEMM output rounding, and the gate * up product)
+    a0 = ops.linear(ops.rmsnorm(h2, gamma, 1e-5), wg, act=ops.ACT_SWIGLU)
+    check(n(a0)[rows], up[:, inter:] * O.silu(up[:, :inter]), BF, "unfused chain, full width", scale_atol=4.0)
+
+
+@pytest.mark.parametrize("B,L,H", [(2, 300, 4), (2, 690, 32)])
+def test_qkv_rope_and_mma_attn_folded_rmsnorm(B, L, H):
+    """The QKV + RoPE stage with row_scale (both the cache-prefill entry and the fused attention entry)."""
+    ops = _ops()
+    d = 96 * H
+    rng = gen.rng_for(f"foldqkv{B}{L}{H}")
+    x = rng.standard_normal((B, L, d), dtype=np.float32) * rng.uniform(0.3, 5.0, (B, L, 1)).astype(np.float32)
+    g = 1.0 + 0.3 * rng.standard_normal((d,), dtype=np.float32)
+    w = rng.standard_normal((3 * d, d), dtype=np.float32) * 0.03
+    cos, sin = O.rope_cos_sin(np.arange(L)[None], 96)
+    cosd, sind = torch.from_numpy(cos[0]).to(DEV), torch.from_numpy(sin[0]).to(DEV)
+    xd = t(x, BF)
+    st = ops.row_stats(xd, 1e-5)
+    wf = ops.fold_gain(t(w, BF), t(g, BF))
+    q, k, v = ops.qkv_rope(xd, wf, cosd, sind, H, row_scale=st.rstd)
+    qkv = O.rms_norm(rnd(x, BF), rnd(g, BF), 1e-5).reshape(B * L, d) @ rnd(w, BF).T
+    qkv = qkv.reshape(B, L, 3 * d)
+    hd = lambda a: a.reshape(B, L, H, 96).transpose(0, 2, 1, 3)
+    qw, kw = O.apply_rope(hd(qkv[..., :d]), hd(qkv[..., d:2 * d]), cos, sin)
+    check(n(q), qw, BF, "q (folded norm)", scale_atol=2.0)
+    check(n(k), kw, BF, "k (folded norm)", scale_atol=2.0)
+    check(n(v), hd(qkv[..., 2 * d:]), BF, "v (folded norm)", scale_atol=2.0)
+    table = ops.MaskTable.causal(B, L, DEV)
+    o_fold = ops.mma_attn(xd, wf, cosd, sind, table, H, row_scale=st.rstd)
+    o_core = ops.mma_attn_core(q, k, v, table, 96 ** -0.5)
+    assert torch.equal(o_fold, o_core), "fused entry and two-stage entry disagree under row_scale"
+
+
+def test_folded_arguments_are_validated():
+    ops = _ops()
+    x = torch.randn(64, 128, device=DEV).to(BF)
+    w = torch.randn(256, 128, device=DEV).to(BF)
+    st = ops.row_stats(x, 1e-5, ln=True)
+    with pytest.raises(ops.AkiError):          # a mean without the weight's column sums
+        ops.linear(x, w, row_scale=st.rstd, row_shift=st.mean)
+    with pytest.raises(ops.AkiError):          # LayerNorm folding has no SwiGLU form
+        ops.linear(x, w, act=ops.ACT_SWIGLU, row_scale=st.rstd, row_shift=st.mean, col_shift=torch.zeros(256, device=DEV))
+    with pytest.raises(ops.AkiError):          # f32 GEMM: not on the folded path
+        ops.linear(x.float(), w.float(), row_scale=st.rstd)
