@@ -44,6 +44,7 @@ extern int g_force_tile;
 extern int g_deep_ring;
 extern int g_pipe;
 extern int g_attn_variant;
+extern long long* g_clock_probe;
 #endif
 size_t attn_bwd_ws_bytes(int B, int H, int Lq);
 int attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq, void* dk,
@@ -102,6 +103,8 @@ void aki_lab_set_gemm_tile(int mode) {
 }
 // 0 = product choice, 1 = 32-row attention core (two waves per SIMD), 2 = 64-row core (one wave per SIMD)
 void aki_lab_set_attn_variant(int v) { aki::g_attn_variant = v; }
+// device pointer to two int64: every bf16 GEMM launch then leaves {shader cycles, 100 MHz wall ticks} of its workgroup 0 there
+void aki_lab_set_clock_probe(void* two_int64) { aki::g_clock_probe = (long long*)two_int64; }
 #endif
 
 // ---- attention core --------------------------------------------------------------------------------

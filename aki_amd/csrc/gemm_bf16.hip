@@ -85,6 +85,9 @@ struct GemmParams {
   float* st_mean;
   float* st_part;      // [slots][2][M] partial sums (sum of squares, sum), slot = tile column * WN + wave column
   unsigned* st_cnt;    // [tiles_m] arrival counters, zero between launches
+#ifdef AKI_LAB_HOOKS
+  long long* clock_probe;   // lab: {shader cycles, 100 MHz ticks} of workgroup 0
+#endif
   float st_eps;
 };
 
@@ -122,6 +125,12 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wm = wave / WN;
   const int l15 = lane & 15, kg = lane >> 4;
+#ifdef AKI_LAB_HOOKS
+  // clock probe (lab build): shader cycles and the 100 MHz wall clock over workgroup 0's lifetime -> the engine clock the
+  // kernel actually ran at (tools/gemm_clock.py)
+  long long probe_c0 = 0, probe_w0 = 0;
+  if (blockIdx.x == 0 && tid == 0 && p.clock_probe) { probe_c0 = clock64(); probe_w0 = wall_clock64(); }
+#endif
 
   // ---- tile id: XCD-contiguous chunks, grouped so concurrently running tiles of an XCD share operand panels ----
   const int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -626,10 +635,17 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
       if (tid == 0) __hip_atomic_store(p.st_cnt + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+#ifdef AKI_LAB_HOOKS
+  if (blockIdx.x == 0 && tid == 0 && p.clock_probe) {
+    p.clock_probe[0] = clock64() - probe_c0;
+    p.clock_probe[1] = wall_clock64() - probe_w0;
+  }
+#endif
 }
 
 #ifdef AKI_LAB_HOOKS
 int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;   // set by aki_lab_set_gemm_tile (lab build only)
+long long* g_clock_probe = nullptr;                  // set by aki_lab_set_clock_probe
 #else
 static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;
 #endif
@@ -649,6 +665,9 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (n_out + bn_out - 1) / bn_out;
   AKI_CLEAR_ERR();
+#ifdef AKI_LAB_HOOKS
+  p.clock_probe = g_clock_probe;
+#endif
   hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
