@@ -201,13 +201,12 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   const int nk = p.K / BK;
   // ---- epilogue operands (bias, folded-norm scale / shift / column sums).  Their fetch is a DRAM-latency round trip that
   // nothing in the epilogue can hide; small tiles (several short launches per layer, spare registers) issue it here, under
-  // the first K-step's DMA wait, the big pipelined tile (at the register limit) right after the K loop, ahead of the
-  // residual staging, whose own round trip then covers it.
+  // the first K-step's DMA wait, the 256^2 tiles (at the register limit) right after the K loop, ahead of the residual
+  // staging, whose own round trip then covers it.
   constexpr int NOUT = (EPI == EPI_SWIGLU) ? NF / 2 : NF;     // output feature blocks per wave
   const int fwave = n0 + wn * (EPI == EPI_SWIGLU ? WROWS / 2 : WROWS);
-  // folded LayerNorm (consumer), kernel-uniform.  Not on the pipelined 256^2 tile: its epilogue has no registers left for
-  // the column sums (they spilled - and a launch that touches scratch costs ~6 us of dispatch gap on either side); the
-  // host routes row_shift launches to the 128-token tiles, which is where SigLIP's shapes go anyway.
+  // folded LayerNorm (consumer), kernel-uniform.  Not on the PIPELINED 256^2 tile: its epilogue has no registers left for the
+  // column sums (they spilled); the host sends row_shift launches that want the big tile to its unpipelined twin.
   const bool shifted = !PIPE && (EPI == EPI_PLAIN) && p.row_shift != nullptr;
   u32x2 biasp[NOUT];
   f32x4 colc4[NOUT];
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
       muv[m] = (EPI == EPI_PLAIN && shifted) ? p.row_shift[mr] : 0.0f;
     }
   };
-  constexpr bool EARLY_OPERANDS = !PIPE && !FP8;
+  constexpr bool EARLY_OPERANDS = !PIPE && !FP8 && NF * NT <= 16;
   if constexpr (EARLY_OPERANDS) fetch_epilogue_operands();
   auto compute = [&](const char* sb) {
     if constexpr (FP8) {   // one k128 step per BK: the lane's 32 bytes are chunks 2kg and 2kg+1 of its row
@@ -691,13 +690,7 @@ static double cost_small(long tiles, double work) {
 // plan 3 (plain bf16 GEMMs only, `mid_ok`): 128-feature x 96-token tiles when they fit ONE round of the 2-per-CU slots and
 // the 128^2 tiling would leave that round partly empty - SigLIP out-proj / fc2 (N = 1152: 324 -> 432 tiles, 21.7 -> 17.9 us
 // and 61.6 -> 50.5 us), Perceiver kv (360 -> 480 tiles, 20.4 -> 17.2 us).  Same K order per output element: bit-identical.
-static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_work = 0.25, bool mid_ok = false, bool big_ok = true) {
-  if (!big_ok) {     // folded LayerNorm: small or mid tiles only
-    const long ns_ = (n_out + bn_small - 1) / bn_small, nm_ = (long)((M + 95) / 96) * ns_;
-    if (g_force_tile == 3 && mid_ok) return 3;
-    if (!g_force_tile && mid_ok && nm_ <= 512 && cost_small(nm_, 0.75 * small_work) < cost_small((long)((M + 127) / 128) * ns_, small_work)) return 3;
-    return 1;
-  }
+static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_work = 0.25, bool mid_ok = false) {
   if (g_force_tile) return g_force_tile == 2 ? 1 : (g_force_tile == 3 ? (mid_ok ? 3 : 1) : 0);
   const long nb = (n_out + bn_big - 1) / bn_big, ns = (n_out + bn_small - 1) / bn_small;
   const double all_big = cost_big((long)((M + 255) / 256) * nb);
@@ -742,7 +735,7 @@ static int launch_small(GemmParams& p, hipStream_t stream) {
 template <int EPI, int ACT, bool FP8>
 static int launch_big(GemmParams& p, hipStream_t stream) {
   if constexpr (!FP8) {
-    if (g_pipe) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, true>(p, stream);
+    if (g_pipe && p.row_shift == nullptr) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, true>(p, stream);
   }
   return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8>(p, stream);
 }
@@ -809,7 +802,7 @@ int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
     if (a->bias) return AKI_ERR_UNSUPPORTED;
     return run_planned<EPI_SWIGLU, 0>(p, plan_tiles(a->M, n_out, 128, 64), stream);
   }
-  const int plan = plan_tiles(a->M, n_out, 256, 128, 0.25, true, a->row_shift == nullptr);
+  const int plan = plan_tiles(a->M, n_out, 256, 128, 0.25, true);
   switch (a->act) {
     case AKI_ACT_GELU_ERF: return run_planned<EPI_PLAIN, AKI_ACT_GELU_ERF>(p, plan, stream);
     case AKI_ACT_GELU_TANH: return run_planned<EPI_PLAIN, AKI_ACT_GELU_TANH>(p, plan, stream);
