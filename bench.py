@@ -212,8 +212,9 @@ def main():
     # HIP events on the launch stream around the kernels that are reported: the dominant GEMM (gate_up + SwiGLU, known
     # from profiles/) and the MMA op.  --kernel-table brackets every GEMM instead (costs ~4 % of the step).
     # An event record is not free (a barrier packet: ~6 us of dispatch gap each, tools/trace_gaps.py): the reported kernels
-    # are bracketed on every 4th launch (8 of the 32 layers, every step), which keeps the probe under 0.5 % of the step.
-    tap = ops.EventTap(tags={"linear", "mma_attn", "linear_fp8", "mma_attn_fp8"}, every=1 if args.kernel_table else 4,
+    # are bracketed on every 8th launch (4 of the 32 layers, every step: 40 samples per kernel in a default run), which keeps the probe
+    # under 0.3 % of the step.
+    tap = ops.EventTap(tags={"linear", "mma_attn", "linear_fp8", "mma_attn_fp8"}, every=1 if args.kernel_table else 8,
                        select=None if args.kernel_table else (lambda tag: tag[0].startswith("mma_attn") or
                                                               (tag[4] == ops.ACT_SWIGLU and tag[0] == ("linear_fp8" if fp8 else "linear"))))
     if world > 1:
