@@ -40,7 +40,7 @@ def test_row_stats(rows, cols, ln):
         assert st.mean is None
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (37, 1152, 640), (1380, 3072, 256), (700, 1152, 4352), (17, 192, 64), (513, 72, 192)])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (37, 1152, 640), (1380, 3072, 256), (700, 1152, 4352), (17, 192, 64), (513, 72, 192), (3, 256, 128), (1, 3072, 3072)])
 @pytest.mark.parametrize("ln", [False, True])
 def test_linear_producer_statistics(M, N, K, ln, gemm_tile):
     """`stats_out`: the output is bit-identical to the plain launch, and the statistics are those of the bf16 values stored -
@@ -56,14 +56,17 @@ def test_linear_producer_statistics(M, N, K, ln, gemm_tile):
         st = ops.new_stats(M, DEV, ln=ln)
         st.rstd.fill_(float("nan"))
         y = ops.linear(x, w, bias=b, residual=r, stats_out=st, stats_eps=1e-6)
-        assert torch.equal(y, y0), "the statistics epilogue changed the GEMM's output"
+        if M > 16:
+            assert torch.equal(y, y0), "the statistics epilogue changed the GEMM's output"
+        else:   # <= 16 rows: the plain launch is the weight-streaming GEMV / skinny kernel (another summation order)
+            check(n(y), n(y0), BF, "producer launch vs GEMV path")
         rstd, mu = _stats_np(n(y), 1e-6, ln)
         np.testing.assert_allclose(n(st.rstd), rstd, rtol=3e-5, err_msg=f"rstd, repetition {rep}")
         if ln:
             np.testing.assert_allclose(n(st.mean), mu, rtol=3e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (37, 1152, 640), (1380, 2048, 256), (64, 9000, 192)])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (37, 1152, 640), (1380, 2048, 256), (64, 9000, 192), (2, 512, 128), (1, 3072, 3072)])
 def test_linear_folded_rmsnorm(M, N, K, gemm_tile):
     """RMSNorm(x) @ W^T  ==  rstd[m] * (x @ (W diag(gamma))^T), plain and SwiGLU epilogues."""
     ops = _ops()
