@@ -35,12 +35,21 @@ def close(got, want, tol=2e-2, what=""):
 
 def test_transpose_pads_with_zeros():
     from aki_amd import train_ops as T
-    for R, C in [(5240, 3072), (100, 72), (333, 1000)]:
+    # aligned shapes take the DMA + transposed-LDS-read kernel, (333, 1001)-like ones the element-wise fallback
+    for R, C in [(5240, 3072), (100, 72), (333, 1000), (5240, 16384), (64, 64), (129, 8), (1, 8), (5240, 1152), (200, 4304), (77, 1001)]:
         x = rt(R, C, seed=R)
         y = T.transpose(x)
         Rp = (R + 63) // 64 * 64
         assert y.shape == (C, Rp)
-        assert torch.equal(y[:, :R], x.t()) and bool((y[:, R:] == 0).all())
+        assert torch.equal(y[:, :R], x.t()), (R, C)
+        assert bool((y[:, R:] == 0).all()), (R, C)
+    # a column slice of a wider buffer (row pitch > columns), into a preallocated output that must stay untouched outside
+    big = rt(700, 512, seed=3)
+    x = big[:, 64:64 + 256]
+    out = torch.full((256 + 2, 704), 7.0, dtype=BF, device=DEV)
+    y = T.transpose(x, out=out[1:257])
+    assert torch.equal(y[:, :700], x.t()) and bool((y[:, 700:] == 0).all())
+    assert bool((out[0] == 7).all()) and bool((out[257] == 7).all())
 
 
 @pytest.mark.parametrize("rms", [True, False])
