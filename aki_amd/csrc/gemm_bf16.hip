@@ -678,7 +678,15 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
 // quarter of the work; up to 256 of them run one per CU at ~75 % of the big tile's efficiency, beyond that two share a CU
 // and overlap each other's prologue / epilogue (~90 %: tools/siglip_gemm_bench.py - SigLIP fc1, 1224 small tiles in three
 // half-rounds, 903 TF/s vs 696 for 306 big tiles in two rounds at 60 % occupancy).
-static double cost_big(long tiles) { return (double)((tiles + 255) / 256); }
+// A last round that fills at most half the CUs runs faster than a full one - the part is power-bound on these tiles, and the
+// busy half gets the clock and the fabric of the idle half: 384 tiles of a K = 5248 weight-gradient GEMM take 1.65 full rounds,
+// not 2 (209 us against 127 us per round and 239 us for the 128^2 tiling the whole-round model preferred).  Only claimed for
+// long K loops (>= 64 steps): with SigLIP's 18 steps the fixed costs of a round dominate and the discount is not there.
+static double cost_big(long tiles, int ksteps = 0) {
+  const long full = tiles / 256, rem = tiles % 256;
+  if (rem == 0) return (double)full;
+  return (double)full + ((ksteps >= 64 && full >= 1 && rem <= 128) ? 0.65 : 1.0);
+}
 // `work` = small-tile work relative to the big tile (0.25 for 128x128 vs 256x256, 0.5 for the 192x128 QKV tile).
 static double cost_small(long tiles, double work) {
   return tiles <= 256 ? (tiles ? work / 0.75 : 0.0) : (double)((tiles + 511) / 512) * (2.0 * work / 0.9);
@@ -690,10 +698,10 @@ static double cost_small(long tiles, double work) {
 // plan 3 (plain bf16 GEMMs only, `mid_ok`): 128-feature x 96-token tiles when they fit ONE round of the 2-per-CU slots and
 // the 128^2 tiling would leave that round partly empty - SigLIP out-proj / fc2 (N = 1152: 324 -> 432 tiles, 21.7 -> 17.9 us
 // and 61.6 -> 50.5 us), Perceiver kv (360 -> 480 tiles, 20.4 -> 17.2 us).  Same K order per output element: bit-identical.
-static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_work = 0.25, bool mid_ok = false) {
+static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_work = 0.25, bool mid_ok = false, int ksteps = 0) {
   if (g_force_tile) return g_force_tile == 2 ? 1 : (g_force_tile == 3 ? (mid_ok ? 3 : 1) : 0);
   const long nb = (n_out + bn_big - 1) / bn_big, ns = (n_out + bn_small - 1) / bn_small;
-  const double all_big = cost_big((long)((M + 255) / 256) * nb);
+  const double all_big = cost_big((long)((M + 255) / 256) * nb, ksteps);
   const double all_small = cost_small((long)((M + 127) / 128) * ns, small_work);
   const int m_main = M / 256 * 256, tail = M - m_main;
   double split = 1e30;
@@ -802,7 +810,7 @@ int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
     if (a->bias) return AKI_ERR_UNSUPPORTED;
     return run_planned<EPI_SWIGLU, 0>(p, plan_tiles(a->M, n_out, 128, 64), stream);
   }
-  const int plan = plan_tiles(a->M, n_out, 256, 128, 0.25, true);
+  const int plan = plan_tiles(a->M, n_out, 256, 128, 0.25, true, a->K / 64);
   switch (a->act) {
     case AKI_ACT_GELU_ERF: return run_planned<EPI_PLAIN, AKI_ACT_GELU_ERF>(p, plan, stream);
     case AKI_ACT_GELU_TANH: return run_planned<EPI_PLAIN, AKI_ACT_GELU_TANH>(p, plan, stream);
