@@ -109,7 +109,8 @@ class Prepared:
 
 def fold_gain(w: torch.Tensor, gain: torch.Tensor) -> torch.Tensor:
     """W' = W * diag(gain), rounded once to W's dtype: x_normed(gain) @ W^T == (x * rstd) @ W'^T up to that rounding."""
-    return (w.detach().float() * gain.detach().float()[None, :]).to(w.dtype).contiguous()
+    ct = torch.float64 if w.dtype == torch.float64 else torch.float32          # computed in f32 (f64 stays f64), rounded once
+    return (w.detach().to(ct) * gain.detach().to(ct)[None, :]).to(w.dtype).contiguous()
 
 
 @dataclass

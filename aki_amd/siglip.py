@@ -34,7 +34,8 @@ def fold_layernorm(w: torch.Tensor, b: torch.Tensor, ln: nn.LayerNorm):
     wf = ops.fold_gain(w, ln.weight)
     c = torch.zeros(((w.shape[0] + 3) // 4 * 4,), dtype=torch.float32, device=w.device)
     c[: w.shape[0]] = wf.float().sum(1)
-    bf = (w.float() @ ln.bias.detach().float() + (b.float() if b is not None else 0.0)).to(w.dtype).contiguous()
+    ct = torch.float64 if w.dtype == torch.float64 else torch.float32
+    bf = (w.to(ct) @ ln.bias.detach().to(ct) + (b.to(ct) if b is not None else 0.0)).to(w.dtype).contiguous()
     return wf, bf, c
 
 
