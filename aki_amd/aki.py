@@ -14,6 +14,22 @@ from .helpers import PerceiverResampler
 from .vlm import VLMWithLanguageStream
 
 
+def sample_next(logits: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, generator=None) -> torch.Tensor:
+    """One sampling step on [B, V] logits, in HF's processor order: temperature, top-k, top-p (nucleus), multinomial."""
+    x = logits.float() / temperature
+    V = x.shape[-1]
+    if 0 < top_k < V:
+        kth = x.topk(top_k, dim=-1).values[:, -1:]
+        x = x.masked_fill(x < kth, float("-inf"))
+    if top_p < 1.0:
+        sx, si = x.sort(dim=-1, descending=True)
+        cum = sx.softmax(dim=-1).cumsum(dim=-1)
+        drop = cum - sx.softmax(dim=-1) >= top_p            # keep the smallest prefix whose mass reaches top_p (always >= 1 token)
+        sx = sx.masked_fill(drop, float("-inf"))
+        x = torch.full_like(x, float("-inf")).scatter(-1, si, sx)
+    return torch.multinomial(x.softmax(dim=-1), 1, generator=generator).squeeze(-1)
+
+
 class AKI(VLMWithLanguageStream):
     def __init__(self, vision_encoder: nn.Module, lang_model: nn.Module, vis_feature_dim: int, initial_tokenizer_len: int,
                  pad_token_id: int, decoder_layers_attr_name: str = None, gradient_checkpointing: bool = False,
@@ -65,16 +81,107 @@ class AKI(VLMWithLanguageStream):
         self._post_forward_hook()
         return output
 
+    def _beam_search(self, cache, logits, K: int, max_new_tokens: int, eos_ids, pad_id: int, length_penalty: float, early_stopping):
+        """Beam search over the decode path (the algorithm of HF `GenerationMixin` beam search with a `BeamSearchScorer`:
+        2K candidates per step, hypotheses normalised by generated_length ** length_penalty, one sequence returned per sample).
+        The prompt's cache rows are expanded to K beams and re-ordered in place every step (AkiKVCache.select_rows)."""
+        dev = logits.device
+        B = logits.shape[0]
+        cache.select_rows(torch.arange(B, device=dev).repeat_interleave(K))
+        logp = torch.log_softmax(logits.float(), dim=-1).repeat_interleave(K, dim=0)             # [B*K, V]
+        V = logp.shape[-1]
+        scores = torch.zeros((B, K), dtype=torch.float32, device=dev)
+        scores[:, 1:] = -1e9                                                                      # all beams start identical: keep one
+        seqs = torch.zeros((B * K, 0), dtype=torch.long, device=dev)
+        hyps = [[] for _ in range(B)]                                                             # per sample: (score, tokens)
+        done = [False] * B
+        eos_set = set(int(e) for e in eos_ids)
+
+        def worst(b):
+            return min(h[0] for h in hyps[b]) if len(hyps[b]) >= K else -float("inf")
+
+        def add(b, score_sum, toks, gen_len):
+            sc = score_sum / (max(gen_len, 1) ** length_penalty)
+            if len(hyps[b]) < K or sc > worst(b):
+                hyps[b].append((sc, toks))
+                if len(hyps[b]) > K:
+                    hyps[b].remove(min(hyps[b], key=lambda h: h[0]))
+
+        for t in range(max_new_tokens):
+            cand = (logp.view(B, K, V) + scores[:, :, None]).view(B, K * V)
+            top_s, top_i = cand.topk(2 * K, dim=-1)
+            top_s_h, top_i_h = top_s.tolist(), top_i.tolist()
+            nxt_tok = torch.full((B, K), pad_id, dtype=torch.long)
+            nxt_beam = torch.zeros((B, K), dtype=torch.long)
+            nxt_score = torch.full((B, K), -1e9, dtype=torch.float32)
+            seqs_h = seqs.tolist() if eos_set else None
+            for b in range(B):
+                if done[b]:
+                    nxt_beam[b] = torch.arange(K)
+                    continue
+                n = 0
+                for rank, (sc, idx) in enumerate(zip(top_s_h[b], top_i_h[b])):
+                    beam, tok = divmod(idx, V)
+                    if tok in eos_set:
+                        if rank < K:                                                              # HF: EOS beyond the K best is ignored
+                            add(b, sc, seqs_h[b * K + beam] + [tok], t + 1)
+                        continue
+                    nxt_tok[b, n], nxt_beam[b, n], nxt_score[b, n] = tok, beam, sc
+                    n += 1
+                    if n == K:
+                        break
+                if len(hyps[b]) >= K:
+                    best_running = float(nxt_score[b].max()) / ((t + 1) ** length_penalty)
+                    if early_stopping is True or (early_stopping is False and worst(b) >= best_running):
+                        done[b] = True
+            if all(done) or t + 1 == max_new_tokens:
+                # close the books: running beams become hypotheses (with the token chosen at this step)
+                for b in range(B):
+                    if done[b]:
+                        continue
+                    for n in range(K):
+                        if float(nxt_score[b, n]) > -1e8:
+                            base = seqs[b * K + int(nxt_beam[b, n])].tolist()
+                            add(b, float(nxt_score[b, n]), base + [int(nxt_tok[b, n])], t + 1)
+                break
+            gather = (torch.arange(B)[:, None] * K + nxt_beam).view(-1).to(dev)
+            seqs = torch.cat([seqs.index_select(0, gather), nxt_tok.view(-1, 1).to(dev)], dim=1)
+            scores = nxt_score.to(dev)
+            cache.select_rows(gather)
+            step_logits = self.lang_model.decode_step(input_ids=nxt_tok.view(-1).to(dev), past_key_values=cache)
+            logp = torch.log_softmax(step_logits.float(), dim=-1)
+        best = [max(h, key=lambda x: x[0])[1] for h in hyps]
+        width = max(len(x) for x in best)
+        out = torch.full((B, width), pad_id, dtype=torch.long)
+        for b, x in enumerate(best):
+            out[b, : len(x)] = torch.tensor(x, dtype=torch.long)
+        return out.to(dev)
+
     @torch.no_grad()
     def generate(self, vision_x, lang_x, image_size=None, attention_mask=None, past_key_values=None,
                  past_media_locations=None, past_vision_tokens=None, **kwargs):
-        """Greedy generation (src/aki.py:136-209 + src/aki_generation.py:36-86 as used by local_demo.py / eval.py with
+        """Generation (src/aki.py:136-209 + src/aki_generation.py:36-86; local_demo.py / eval.py call it with
         do_sample=False): MMA prefill into a KV cache, then one HIP decode step per token.  Like HF `generate` called with
         `inputs_embeds` only, the return value holds just the NEW tokens [B, <= max_new_tokens]; finished rows are padded
-        with pad_token_id.  Differences from the reference, both only visible for B > 1 (where the reference is
-        inconsistent): the prompt batch is right-padded and every sample continues from its own length."""
-        if kwargs.pop("num_beams", 1) != 1 or kwargs.pop("do_sample", False):
-            raise NotImplementedError("only greedy decoding (num_beams=1, do_sample=False) is implemented on the MI355X path")
+        with pad_token_id.  Decoding modes, selected by the HF keyword arguments the reference forwards (`**kwargs`,
+        src/aki.py:160-207): greedy (default), sampling (`do_sample=True` with `temperature`, `top_k`, `top_p`, optional
+        `generator`), beam search (`num_beams=K`, `length_penalty`, `early_stopping`; one returned sequence per sample).
+        Differences from the reference, both only visible for B > 1 (where the reference is inconsistent): the
+        prompt batch is right-padded and every sample continues from its own length."""
+        num_beams = int(kwargs.pop("num_beams", 1))
+        do_sample = bool(kwargs.pop("do_sample", False))
+        temperature = float(kwargs.pop("temperature", 1.0))
+        top_k = int(kwargs.pop("top_k", 0) or 0)
+        top_p = float(kwargs.pop("top_p", 1.0))
+        rng = kwargs.pop("generator", None)
+        length_penalty = float(kwargs.pop("length_penalty", 1.0))
+        early_stopping = kwargs.pop("early_stopping", False)
+        if int(kwargs.pop("num_return_sequences", 1)) != 1:
+            raise NotImplementedError("num_return_sequences > 1")
+        if num_beams < 1 or (num_beams > 1 and do_sample):
+            raise NotImplementedError("beam-sample decoding (num_beams > 1 with do_sample=True)")
+        if do_sample and temperature <= 0:
+            raise ValueError("temperature must be positive")
         if past_key_values is not None:
             raise NotImplementedError("generate() starts from a fresh prefill")
         max_new_tokens = int(kwargs.pop("max_new_tokens", kwargs.pop("max_length", 20)))
@@ -102,6 +209,10 @@ class AKI(VLMWithLanguageStream):
         B = lang_x.shape[0]
         last = (cache.cache_len.long() - 1).clamp_(min=0)
         logits = out.logits[torch.arange(B, device=lang_x.device), last]          # logits of each sample's last real token
+        if num_beams > 1:
+            tokens = self._beam_search(cache, logits, num_beams, max_new_tokens, eos_ids, pad_id, length_penalty, early_stopping)
+            self._post_forward_hook()
+            return tokens
         tokens = torch.full((B, max_new_tokens), pad_id, dtype=torch.long, device=lang_x.device)
         done = torch.zeros(B, dtype=torch.bool, device=lang_x.device)
         eos_t = torch.tensor(sorted(eos_ids), dtype=torch.long, device=lang_x.device) if eos_ids else None
@@ -110,7 +221,7 @@ class AKI(VLMWithLanguageStream):
             from .phi3 import DecodeGraph
             stepper = DecodeGraph(self.lang_model, cache)
         for t in range(max_new_tokens):
-            nxt = logits.float().argmax(dim=-1)
+            nxt = sample_next(logits, temperature, top_k, top_p, rng) if do_sample else logits.float().argmax(dim=-1)
             nxt = torch.where(done, torch.full_like(nxt, pad_id), nxt)
             tokens[:, t] = nxt
             if eos_t is not None:

@@ -68,3 +68,4 @@ class AKI(VLMWithLanguageStream, PyTorchModelHubMixin):
     _should_apply_weight_decay = _TrainTimeAKI._should_apply_weight_decay
     forward = _TrainTimeAKI.forward          # src/modeling_aki.py:83-151 is identical to src/aki.py:65-134
     generate = _TrainTimeAKI.generate        # MMA prefill + HIP decode steps (aki_amd/aki.py)
+    _beam_search = _TrainTimeAKI._beam_search

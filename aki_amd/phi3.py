@@ -99,9 +99,22 @@ class AkiKVCache:
         self.host_len = 0                                                       # host copy of max(cache_len)
         self.attn_ws = None                                                     # split-KV attention workspace (zeroed once)
         self.grid_keys = capacity                                               # host bound of n_keys sizing the decode grid
+        self.attn_ws_rows = B
 
     def get_seq_length(self, layer_idx=0):
         return int(self.cache_len.max())
+
+    def select_rows(self, index: torch.Tensor) -> None:
+        """Rows (sequences) of every per-sequence buffer gathered by `index` (int64 [B']): beam search's cache re-ordering
+        (HF `_reorder_cache`) and, with repeated indices, the expansion of a prompt batch to its beams."""
+        self.k = [t.index_select(0, index) for t in self.k]
+        self.v = [t.index_select(0, index) for t in self.v]
+        self.cache_len = self.cache_len.index_select(0, index)
+        if self.valid_bits is not None:
+            self.valid_bits = self.valid_bits.index_select(0, index).contiguous()
+        if self.attn_ws is not None and index.numel() != self.attn_ws_rows:
+            self.attn_ws = None                       # sized per sequence: rebuilt (zero-filled) by the next decode step
+        self.attn_ws_rows = index.numel()
 
     def __getitem__(self, i):   # HF-style past_key_values[layer] -> (k, v)
         return self.k[i], self.v[i]

@@ -136,7 +136,7 @@ def test_generate_stops_at_eos_and_pads():
     toks = m.generate(vx, lx, attention_mask=am, max_new_tokens=6, eos_token_id=eos, pad_token_id=gen.TINY["pad_token_id"])
     assert int(toks[0, 0]) == eos and bool((toks[0, 1:] == gen.TINY["pad_token_id"]).all())
     with pytest.raises(NotImplementedError):
-        m.generate(vx, lx, attention_mask=am, num_beams=4)
+        m.generate(vx, lx, attention_mask=am, num_beams=4, num_return_sequences=2)
 
 
 def test_generate_default_eos_comes_from_the_language_model_config():
@@ -265,3 +265,93 @@ def test_decode_attn_fused_vs_two_kernels(B, H, cap, lens):
         assert torch.equal(fin, torch.isfinite(k2.float())) and torch.equal(k1[fin], k2[fin]) and torch.equal(v1[fin], v2[fin]), "appended rows differ"
         check(n(got), n(want).astype(np.float32), dt, f"fused decode attention (pass {rep})", scale_atol=2.0)
     assert int(ws[: B * H].abs().sum()) == 0
+
+
+# ---- sampling and beam search (HF keyword arguments the reference forwards through **kwargs, src/aki.py:160-207) --------------
+def _seq_logprob(m, vx_b, prompt_ids, new_tokens):
+    """Sum of log-probabilities of `new_tokens` after `prompt_ids`, from FULL forwards (fp32) - the yardstick the decode path
+    (KV cache, cache re-ordering) is checked against."""
+    ids = prompt_ids
+    total = 0.0
+    for tok in new_tokens:
+        with torch.no_grad():
+            lg = m(vx_b, ids[None], attention_mask=torch.ones_like(ids)[None]).logits[0, -1].float()
+        total += float(torch.log_softmax(lg, -1)[tok])
+        ids = torch.cat([ids, torch.tensor([tok], device=ids.device)])
+    return total
+
+
+def test_sampling_modes():
+    from aki_amd.aki import sample_next
+    m, g = build_tiny(torch.float32)
+    vx, lx, am, _ = batch(g, torch.float32)
+    greedy = m.generate(vx, lx, attention_mask=am, max_new_tokens=4, eos_token_id=[])
+    # top_k = 1 is greedy, whatever the temperature
+    tk1 = m.generate(vx, lx, attention_mask=am, max_new_tokens=4, eos_token_id=[], do_sample=True, top_k=1, temperature=0.7)
+    assert torch.equal(tk1, greedy)
+    # a vanishing nucleus keeps only the most probable token
+    tp = m.generate(vx, lx, attention_mask=am, max_new_tokens=4, eos_token_id=[], do_sample=True, top_p=1e-6)
+    assert torch.equal(tp, greedy)
+    # same generator state -> same draw; the draw respects top_k
+    g1 = torch.Generator(device=DEV).manual_seed(5)
+    g2 = torch.Generator(device=DEV).manual_seed(5)
+    a = m.generate(vx, lx, attention_mask=am, max_new_tokens=6, eos_token_id=[], do_sample=True, top_k=5, generator=g1)
+    b = m.generate(vx, lx, attention_mask=am, max_new_tokens=6, eos_token_id=[], do_sample=True, top_k=5, generator=g2)
+    assert torch.equal(a, b) and a.shape == (lx.shape[0], 6)
+    # the step itself: frequencies follow the filtered softmax
+    logits = torch.tensor([[2.0, 1.0, 0.0, -1.0, -5.0]], device=DEV).repeat(20000, 1)
+    draws = sample_next(logits, temperature=1.0, top_k=3, generator=torch.Generator(device=DEV).manual_seed(0))
+    freq = torch.bincount(draws, minlength=5).float() / draws.numel()
+    want = torch.softmax(torch.tensor([2.0, 1.0, 0.0]), -1)
+    assert float(freq[3:].sum()) == 0.0 and torch.allclose(freq[:3].cpu(), want, atol=0.015)
+    draws = sample_next(logits, top_p=0.7, generator=torch.Generator(device=DEV).manual_seed(1))       # mass 0.63 + 0.23: two tokens
+    assert set(draws.unique().tolist()) == {0, 1}
+    with pytest.raises(NotImplementedError):
+        m.generate(vx, lx, attention_mask=am, max_new_tokens=2, num_beams=2, do_sample=True)
+
+
+@pytest.mark.parametrize("K", [2, 3])
+def test_beam_search_against_full_forward_scores(K):
+    """The returned hypothesis must (a) score, by full forwards, what beam search says; (b) score at least as well as the greedy
+    continuation of the same length; (c) equal an independent beam search that uses full forwards only (no KV cache, no
+    re-ordering) - which pins AkiKVCache.select_rows and the expansion of the prompt rows to beams."""
+    m, g = build_tiny(torch.float32)
+    vx, lx, am, _ = batch(g, torch.float32)
+    n_new = 4
+    got = m.generate(vx, lx, attention_mask=am, max_new_tokens=n_new, num_beams=K, eos_token_id=[])
+    greedy = m.generate(vx, lx, attention_mask=am, max_new_tokens=n_new, eos_token_id=[])
+    assert got.shape == (lx.shape[0], n_new)
+    for b in range(lx.shape[0]):
+        prompt = lx[b, : int(am[b].sum())]
+        # reference beam search on full forwards
+        beams = [(0.0, [])]
+        for t in range(n_new):
+            cand = []
+            for sc, toks in beams:
+                ids = torch.cat([prompt, torch.tensor(toks, dtype=torch.long, device=DEV)])
+                with torch.no_grad():
+                    lg = m(vx[b:b + 1], ids[None], attention_mask=torch.ones_like(ids)[None]).logits[0, -1].float()
+                lp = torch.log_softmax(lg, -1)
+                top = lp.topk(2 * K)
+                cand += [(sc + float(v), toks + [int(i)]) for v, i in zip(top.values, top.indices)]
+            cand.sort(key=lambda c: -c[0])
+            beams = cand[:K]
+        want = beams[0][1]
+        assert got[b].tolist() == want, f"sample {b}: beam search {got[b].tolist()} vs full-forward beam search {want}"
+        s_beam = _seq_logprob(m, vx[b:b + 1], prompt, got[b].tolist())
+        s_greedy = _seq_logprob(m, vx[b:b + 1], prompt, greedy[b].tolist())
+        assert abs(s_beam - beams[0][0]) < 1e-3 and s_beam >= s_greedy - 1e-4
+
+
+def test_beam_search_stops_on_eos_and_pads():
+    m, g = build_tiny(torch.float32)
+    vx, lx, am, _ = batch(g, torch.float32)
+    free = m.generate(vx, lx, attention_mask=am, max_new_tokens=3, num_beams=2, eos_token_id=[])
+    eos = sorted(set(free[:, 1].tolist()))                    # the second token of every sample's best beam ends it
+    out = m.generate(vx, lx, attention_mask=am, max_new_tokens=6, num_beams=2, eos_token_id=eos, pad_token_id=0)
+    assert out.shape[1] <= 6
+    for b in range(lx.shape[0]):
+        row = out[b].tolist()
+        hits = [i for i, t_ in enumerate(row) if t_ in eos]
+        if hits:                                              # everything behind the first EOS is padding
+            assert all(t_ == 0 for t_ in row[hits[0] + 1:])
