@@ -146,7 +146,7 @@ def test_reference_api_behaviour():
     wd, nwd = m.group_params_by_weight_decay()
     assert len(nwd) >= 1 and len(wd) > len(nwd)
     with pytest.raises(NotImplementedError):
-        m.generate(vx, lx, do_sample=True)          # only greedy decoding is implemented
+        m.generate(vx, lx, do_sample=True, num_beams=2)          # beam-sample decoding is not implemented
 
 
 def test_cpu_tensors_fail_loudly():
