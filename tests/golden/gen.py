@@ -114,3 +114,21 @@ def sft_cases():
             batch.append({"input_ids": ids.tolist(), "labels": lab.tolist(), "attention_mask": [1] * n})
         cases.append((batch, padding, side, 32000, max_length))
     return cases
+
+
+def loss_cases():
+    """Inputs of the loss-callable / LR-schedule fixtures (tests/golden/train_losses.npz): schedule settings and the steps at which the
+    multiplier is sampled; seeded id / label batches with padding and special tokens sprinkled in."""
+    scheds = [dict(lr=1e-4, min_lr=1e-5, num_warmup_steps=10, num_training_steps=100, num_cycles=0.5),
+              dict(lr=3e-5, min_lr=0.0, num_warmup_steps=0, num_training_steps=37, num_cycles=0.5),
+              dict(lr=2e-4, min_lr=2e-5, num_warmup_steps=25, num_training_steps=40, num_cycles=1.0)]
+    steps = [0, 1, 2, 5, 9, 10, 11, 17, 25, 36, 37, 39, 40, 50, 99, 100, 150]
+    rng = rng_for("loss_cases")
+    pad, specials = 7, [11, 12]
+    ids = rng.integers(13, 60, size=(3, 12)).astype(np.int64)
+    ids[0, 9:] = pad
+    ids[1, 4] = specials[0]
+    ids[2, [2, 7]] = specials
+    labels = ids.copy()
+    labels[:, :3] = -100                                   # prompt positions already ignored by the collator
+    return scheds, steps, pad, specials, ids, labels

@@ -294,8 +294,39 @@ def g_sft_collate():
     save("sft_collate.npz", n_cases=np.array(len(gen.sft_cases())), **out)
 
 
+def g_train_losses():
+    """a13 callers: the reference's LR schedule multipliers and the labels its two loss callables hand to the model (a stub model
+    records them) - train/losses.py:10-40,83-151."""
+    tl = R.load_train_losses()
+    scheds, steps, pad, specials, ids, labels = gen.loss_cases()
+    out = {}
+    for i, sc in enumerate(scheds):
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=sc["lr"])
+        sched = tl.get_cosine_schedule_with_warmup(opt, sc["lr"], sc["min_lr"], sc["num_warmup_steps"], sc["num_training_steps"], sc["num_cycles"])
+        out[f"mult_{i}"] = np.array([sched.lr_lambdas[0](st) for st in steps], dtype=np.float64)
+    seen = {}
+
+    class Stub:
+        special_token_ids = specials
+
+        def __call__(self, **kw):
+            seen.update(kw)
+            return (torch.tensor(1.5),)
+
+    import contextlib
+    tok = type("Tok", (), {"pad_token_id": pad})()
+    tl.NextTokenPrediction()(Stub(), tok, None, torch.from_numpy(ids.copy()), torch.ones_like(torch.from_numpy(ids)), contextlib.nullcontext)
+    out["ntp_labels"] = seen["labels"].numpy().copy()
+    seen.clear()
+    tl.SupervisedPrediction()(Stub(), tok, None, torch.from_numpy(ids.copy()), torch.from_numpy(labels.copy()),
+                              torch.ones_like(torch.from_numpy(ids)), contextlib.nullcontext)
+    out["sft_labels"] = seen["labels"].numpy().copy()
+    save("train_losses.npz", **out)
+
+
 def main():
     ref = R.load_reference()
+    g_train_losses()
     g_sft_collate()
     g_mask(ref)
     g_decoupled(ref)

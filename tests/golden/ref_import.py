@@ -95,6 +95,17 @@ def load_sft_loader_utils():
     return mods["aki_ref_sft.loader_utils"]
 
 
+def load_train_losses():
+    """train/losses.py (imports torch only) loaded by file path."""
+    path = os.path.join(REF_ROOT, "train", "losses.py")
+    if not os.path.isfile(path):
+        raise RuntimeError("reference tree not present; goldens can only be regenerated in the build container")
+    spec = importlib.util.spec_from_file_location("aki_ref_train_losses", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def invert_mask_441(mask01: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """transformers==4.41.2 ``_prepare_4d_causal_attention_mask`` for a 4-D input:
     ``inverted = 1.0 - mask; inverted.masked_fill(inverted.bool(), finfo(dtype).min)``."""

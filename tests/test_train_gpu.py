@@ -429,6 +429,42 @@ def test_gradient_accumulation_matches_full_batch():
     assert rel < 2e-2, rel
 
 
+def test_reference_training_loop_pieces_run_on_this_stack():
+    """train/train_utils.py:230-266 as the reference writes it - loss_fn(model, tokenizer, images, input_ids, attention_mask,
+    autocast), backward, clip + AdamW, scheduler step - with aki_amd.losses standing in for train/losses.py."""
+    import contextlib
+    from aki_amd import losses as LS
+    from aki_amd.trainer import AkiTrainer
+    OT, cfg, m, p, (vx, lx, am, lab) = _tiny_train_setup()
+    tok = type("Tok", (), {"pad_token_id": int(m.pad_token_id)})()
+    loss_fn = LS.get_loss_fn("next_token_prediction")
+    # the callable's loss is the model's loss on labels = ids with padding ignored
+    want_labels = torch.where(lx == tok.pad_token_id, torch.full_like(lx, -100), lx)
+    with torch.no_grad():
+        direct = m(vx, lx, attention_mask=am, labels=want_labels).loss
+        via = loss_fn(m, tok, vx, lx, am, contextlib.nullcontext)
+    assert torch.equal(direct, via)
+    tr = AkiTrainer(m, lr=0.0, max_grad_norm=1.0)
+    sched = LS.TrainerSchedule(tr, lr=2e-3, min_lr=2e-4, num_warmup_steps=2, num_training_steps=6)
+    seen_lr, losses = [], []
+    for step in range(4):
+        tr.zero_grad()
+        loss = loss_fn(m, tok, vx, lx, am, contextlib.nullcontext)
+        tr.backward(loss)
+        seen_lr.append(tr.lr)
+        tr.optimizer_step()
+        sched.step()
+        losses.append(float(loss.detach()))
+    assert seen_lr == [2e-3 * LS.lr_multiplier(i, 2e-3, 2e-4, 2, 6) for i in range(4)]
+    assert losses[-1] < losses[0], losses
+    # supervised objective: special tokens of the model are ignored on top of the collator's labels
+    sft = LS.get_loss_fn("supervised_finetune")
+    lab2 = lab.clone()
+    with torch.no_grad():
+        l_sft = sft(m, tok, vx, lx, lab2, am, contextlib.nullcontext)
+    assert bool((lab2[torch.isin(lab, torch.tensor(m.special_token_ids, device=lab.device))] == -100).all()) and torch.isfinite(l_sft)
+
+
 def test_trainer_checkpoint_resume():
     """state_dict() after 2 steps -> a fresh model + trainer -> load_state_dict() -> step 3 gives the same loss and the same
     weights as the uninterrupted run, bit for bit: every kernel on the path is run-to-run deterministic (the embedding gradient
