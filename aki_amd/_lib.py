@@ -16,7 +16,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 10
+AKI_ABI_VERSION = 11
 
 
 class AkiError(RuntimeError):
@@ -95,6 +95,7 @@ SIGNATURES = {
     "aki_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "aki_linear_stats_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "aki_linear_stats_counter_bytes": (C.c_size_t, [C.c_int32]),
     "aki_row_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "aki_rmsnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_float, C.c_int32, C.c_void_p]),

@@ -5,6 +5,7 @@
 namespace aki {
 int linear_bf16(const aki_linear_args* a, hipStream_t stream);
 size_t linear_stats_ws_bytes(int M, int n_out);
+size_t linear_stats_cnt_bytes(int M);
 int row_stats_launch(const void* x, int rows, int cols, int ldx, float eps, float* rstd, float* mean, hipStream_t s);
 int linear_f32(const aki_linear_args* a, hipStream_t stream);
 int qkv_rope_bf16(const aki_mma_attn_args* a, void* q, void* k, void* v, hipStream_t stream);
@@ -205,6 +206,7 @@ int aki_mma_attn_fwd(const aki_mma_attn_args* a, void* ws, size_t ws_bytes, void
 }
 
 // ---- linear ------------------------------------------------------------------------------------------
+size_t aki_linear_stats_counter_bytes(int32_t M) { return M > 0 ? linear_stats_cnt_bytes(M) : 0; }
 size_t aki_linear_stats_workspace_bytes(int32_t M, int32_t N_out) { return (M > 0 && N_out > 0) ? aki_align_up(linear_stats_ws_bytes(M, N_out), 256) : 0; }
 
 int aki_row_stats(const void* x, int32_t rows, int32_t cols, int32_t ldx, float eps, float* rstd, float* mean, int32_t dtype, void* stream) {

@@ -773,9 +773,15 @@ static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
   return launch_small<EPI, ACT, FP8>(b, stream);
 }
 
-constexpr size_t STATS_CNT_BYTES = 4096;     // arrival counters of up to 1024 row panels (zero-filled once by the caller)
+// Arrival counters: one per row panel (>= 64 rows), at the front of the statistics workspace; the partial sums follow.  The
+// area grows with M in 4 KB steps (4 KB serves M <= 65536, every size the models launch today) - a caller that re-uses one
+// workspace for a LARGER M than before zero-fills the (then larger) counter area again (include/aki_mi355x.h).
+size_t linear_stats_cnt_bytes(int M) {
+  const size_t panels = ((size_t)(M > 0 ? M : 1) + 63) / 64;
+  return (panels * sizeof(unsigned) + 4095) / 4096 * 4096;
+}
 size_t linear_stats_ws_bytes(int M, int n_out) {
-  return STATS_CNT_BYTES + (size_t)(2 * ((n_out + 63) / 64) + 2) * 2 * (size_t)M * sizeof(float);   // <= 2 waves x N/64 tile columns
+  return linear_stats_cnt_bytes(M) + (size_t)(2 * ((n_out + 63) / 64) + 2) * 2 * (size_t)M * sizeof(float);   // <= 2 waves x N/64 tile columns
 }
 
 int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
@@ -800,11 +806,11 @@ int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
   p.row_scale = a->row_scale; p.row_shift = a->row_shift; p.col_c = a->col_shift;
   if (a->row_shift && (!a->col_shift || !a->row_scale || (((uintptr_t)a->col_shift) & 15) || a->act == AKI_ACT_SWIGLU)) return AKI_ERR_INVALID_ARG;
   if (a->stats_rstd) {
-    if (a->act == AKI_ACT_SWIGLU || a->M > 64 * (int)(STATS_CNT_BYTES / sizeof(unsigned))) return AKI_ERR_UNSUPPORTED;   // one counter per row panel (>= 64 rows)
+    if (a->act == AKI_ACT_SWIGLU) return AKI_ERR_UNSUPPORTED;
     if (!a->stats_workspace || a->stats_workspace_bytes < linear_stats_ws_bytes(a->M, n_out) || (((uintptr_t)a->stats_workspace) & 15)) return AKI_ERR_WORKSPACE;
     p.st_rstd = a->stats_rstd; p.st_mean = a->stats_mean; p.st_eps = a->stats_eps;
     p.st_cnt = (unsigned*)a->stats_workspace;
-    p.st_part = (float*)((char*)a->stats_workspace + STATS_CNT_BYTES);
+    p.st_part = (float*)((char*)a->stats_workspace + linear_stats_cnt_bytes(a->M));
   }
   if (a->act == AKI_ACT_SWIGLU) {
     if (a->bias) return AKI_ERR_UNSUPPORTED;

@@ -125,13 +125,20 @@ _STATS_WS = {}
 
 
 def _stats_ws(M: int, n_out: int, dev) -> torch.Tensor:
-    """Workspace of the producer side (arrival counters + partial sums): zero-filled once per (device, stream, size class)."""
-    need = int(L.load().aki_linear_stats_workspace_bytes(M, n_out))
+    """Workspace of the producer side (arrival counters + partial sums): zero-filled once per (device, stream, size class).
+    The counter area at its front grows with M (include/aki_mi355x.h): when a launch needs a larger one than this buffer has
+    served so far, the new area is zero-filled again - partial sums of earlier, smaller launches lie there."""
+    lib = L.load()
+    need = int(lib.aki_linear_stats_workspace_bytes(M, n_out))
+    cnt = int(lib.aki_linear_stats_counter_bytes(M))
     key = (torch.device(dev).index, torch.cuda.current_stream().cuda_stream)
-    ws = _STATS_WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _STATS_WS[key] = torch.zeros(max(need, 8 << 20), dtype=torch.uint8, device=dev)
-    return ws
+    hit = _STATS_WS.get(key)
+    if hit is None or hit[0].numel() < need:
+        hit = _STATS_WS[key] = [torch.zeros(max(need, 8 << 20), dtype=torch.uint8, device=dev), cnt]
+    elif cnt > hit[1]:
+        hit[0][:cnt].zero_()          # stream-ordered behind the launches that used the smaller layout
+        hit[1] = cnt
+    return hit[0]
 
 
 def new_stats(M: int, dev, ln: bool = False) -> RowStats:

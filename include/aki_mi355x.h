@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 10
+#define AKI_ABI_VERSION 11
 
 typedef enum {
   AKI_OK = 0,
@@ -238,6 +238,7 @@ typedef struct {
 
 int aki_linear_fwd(const aki_linear_args* args, void* stream);
 size_t aki_linear_stats_workspace_bytes(int32_t M, int32_t N_out);
+size_t aki_linear_stats_counter_bytes(int32_t M);
 /* aki_row_stats - the same statistics for a tensor no GEMM of this library produced (the first block's input): rstd[m] (and,
  * when mean != NULL, mean[m]) of x [rows, cols] bf16. */
 int aki_row_stats(const void* x, int32_t rows, int32_t cols, int32_t ldx, float eps, float* rstd, float* mean, int32_t dtype, void* stream);

@@ -324,6 +324,39 @@ def g_train_losses():
     save("train_losses.npz", **out)
 
 
+def g_tiny_generate(ref, n_new=8):
+    """f1: greedy continuation produced by the REFERENCE (src/aki.py:136-209 + src/aki_generation.py:36-86).  The patched
+    `_update_model_kwargs_for_generation` needs private API of transformers 4.41.2, so the reference's `generate` cannot be driven
+    under the installed 5.x; its semantics can: after the MMA prefill every new token attends to all earlier positions (the
+    all-ones mask of aki_generation.py:58-62) at position = its index, and the prompt's rows keep the MMA mask they were cached
+    under.  A full `AKI.forward` of the reference over prompt + tokens-so-far computes exactly that last row (the mask of the
+    prompt part is unchanged as long as no generated token is <image> / <|assistant|>, asserted below), so the continuation is
+    produced by repeated full forwards of the imported reference, one sample at a time - the reference's generate is batch-1
+    in effect.  Stored: token ids, the top-1 / top-2 margin per step (near-ties are data, not failures), and the
+    chosen-row logits on a column subset."""
+    model, _ = build_tiny(ref)
+    lang_x, am, _, vision_x = tiny_batch()
+    T = gen.TINY
+    cols = np.unique(np.concatenate((np.arange(0, 32013, 997), [1, 2, 32000, 32001, 32007, 32010, 32011, 32012])))
+    B = lang_x.shape[0]
+    toks = np.zeros((B, n_new), dtype=np.int64)
+    margin = np.zeros((B, n_new), dtype=np.float32)
+    rows = np.zeros((B, n_new, len(cols)), dtype=np.float32)
+    for b in range(B):
+        ids = torch.from_numpy(lang_x[b, : int(am[b].sum())])[None]
+        vx = torch.from_numpy(vision_x[b:b + 1])
+        for t in range(n_new):
+            logits = model(vx, ids, attention_mask=torch.ones_like(ids)).logits[0, -1]
+            top2 = logits.topk(2)
+            nxt = int(top2.indices[0])
+            assert nxt not in (T["media_token_id"], 32001), "a generated special token would change the reference's mask"
+            toks[b, t], margin[b, t] = nxt, float(top2.values[0] - top2.values[1])
+            rows[b, t] = logits[cols].numpy()
+            ids = torch.cat([ids, torch.tensor([[nxt]])], dim=1)
+    print("generate margins (top1 - top2):", np.round(margin, 5).tolist())
+    save("tiny_generate.npz", tokens=toks, margin=margin, logit_cols=cols, logits=rows)
+
+
 def main():
     ref = R.load_reference()
     g_train_losses()
@@ -336,6 +369,7 @@ def main():
     g_patch_embed()
     g_tiny_e2e(ref)
     g_tiny_grads(ref)
+    g_tiny_generate(ref)
 
 
 if __name__ == "__main__":

@@ -205,3 +205,28 @@ def test_bench_contract_two_ranks_on_one_gpu():
     tokens = 2 * 2 * 655 * 2
     assert abs(out["value"] - tokens / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 1e-3
     assert out["roofline"]["bound"] in ("mfma", "hbm") and 0.0 < out["roofline"]["frac"] < 1.0
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver starts `--gpus 1`): bench.py must start the two
+    ranks itself - as a child `torch.distributed.run` - and report n_gpus = 2 with both ranks in the process group; it must never
+    run one rank and print a one-GPU line.  The gloo hook lets the two ranks share this box's single GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["AKI_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    # and with RCCL as the transport it refuses instead of falling back: this box has one GPU
+    if torch.cuda.device_count() < 2:
+        env.pop("AKI_BENCH_BACKEND")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                           capture_output=True, text=True, env=env, timeout=300, cwd=root)
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], (r.returncode, r.stdout[-500:])

@@ -187,3 +187,21 @@ def test_folded_arguments_are_validated():
         ops.linear(x, w, act=ops.ACT_SWIGLU, row_scale=st.rstd, row_shift=st.mean, col_shift=torch.zeros(256, device=DEV))
     with pytest.raises(ops.AkiError):          # f32 GEMM: not on the folded path
         ops.linear(x.float(), w.float(), row_scale=st.rstd)
+
+
+def test_stats_producer_beyond_65536_rows_and_growing_counter_area():
+    """the statistics-producing GEMM refused M > 65536 (a fixed 4 KB counter area).  The area now grows with
+    M; a workspace that served a smaller M first (its partial sums lie where the larger counter area will be) is re-zeroed by
+    the host wrapper.  Statistics of a 70 000-row launch are checked against torch on the stored bf16 output."""
+    from aki_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    K, N = 128, 256
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.2).to(torch.bfloat16)
+    for M in (3000, 70000, 131073):          # ascending: every step enlarges the counter area of the SAME workspace
+        x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+        st = ops.new_stats(M, DEV)
+        y = ops.linear(x, w, stats_out=st, stats_eps=1e-5)
+        want = torch.rsqrt(y.float().pow(2).mean(-1) + 1e-5)
+        err = ((st.rstd - want).abs() / want).max().item()
+        assert err < 1e-5, (M, err)
+        assert torch.equal(y, ops.linear(x, w))                                  # the producer epilogue does not change y

@@ -247,3 +247,20 @@ def test_sft_collate_restatement_vs_reference():
             assert got[k].dtype == np.int64 and np.array_equal(got[k], g[f"{k}_{i}"]), (i, k)
         longest = max(len(s["input_ids"]) for s in batch)
         assert got["input_ids"].shape[1] == (longest if padding == "longest" else max_length + 1)
+
+
+def test_torch_oracle_greedy_continuation_matches_the_reference():
+    """f1 (generate): the oracle's repeated full forwards reproduce the continuation the REFERENCE produced
+    (tests/golden/tiny_generate.npz, made by make_golden.py::g_tiny_generate from the imported reference)."""
+    import torch
+    OT, g, p, vision_x = _tiny_torch()
+    gg = load_golden("tiny_generate.npz")
+    cols = torch.from_numpy(gg["logit_cols"])
+    with torch.no_grad():
+        for b in range(g["lang_x"].shape[0]):
+            ids = torch.from_numpy(g["lang_x"][b, : int(g["attention_mask"][b].sum())])[None]
+            for t in range(gg["tokens"].shape[1]):
+                logits = OT.aki_forward(p, tiny_cfg(), vision_x[b:b + 1], ids, torch.ones_like(ids))["logits"][0, -1]
+                np.testing.assert_allclose(logits[cols].numpy(), gg["logits"][b, t], atol=2e-4, rtol=1e-3)
+                assert int(logits.argmax()) == int(gg["tokens"][b, t]), (b, t)
+                ids = torch.cat([ids, torch.tensor([[int(gg["tokens"][b, t])]])], dim=1)

@@ -23,22 +23,36 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--shard-optimizer", action="store_true", help="ZeRO/FSDP-style: reduce-scatter grads, 1/world optimizer state")
     ap.add_argument("--shard-params", action="store_true", help="FSDP FULL_SHARD equivalent: weights, gradients and optimizer state sharded (AkiShardedTrainer)")
-    ap.add_argument("--gpus", type=int, default=1, help="ranks of the job (informational; the launcher sets WORLD_SIZE)")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks of the job; without a launcher (WORLD_SIZE unset) --gpus N > 1 starts the N ranks itself")
     ap.add_argument("--bucket-mb", type=int, default=512, help="gradient bucket size; xGMI is point-to-point, few large messages")
     ap.add_argument("--exchange-when-alone", action="store_true", help="world of one: still issue the RCCL collectives")
     ap.add_argument("--head-chunk", type=int, default=0, help="rows per chunk of the fused lm_head + cross-entropy (0 = default 2688: two chunks at the benchmark batch)")
     a = ap.parse_args()
+    import bench
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # start the ranks ourselves, as a child process, before any GPU call
+        raise SystemExit(bench.spawn_ranks(a.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
     import torch
     import torch.distributed as dist
-    import bench
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != a.gpus:
+        raise SystemExit(f"train_bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    gloo = os.environ.get("AKI_BENCH_BACKEND", "nccl") != "nccl"      # test hook: ranks may share one GPU
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if gloo else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1 or a.exchange_when_alone:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(os.environ.get("AKI_BENCH_BACKEND", "nccl"), rank=rank, world_size=world, device_id=dev)
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ranks_seen = 1
+    if dist.is_initialized():
+        one = torch.ones(1, device="cpu" if gloo else dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
     from aki_amd.factory import build_aki
     from aki_amd.trainer import AkiShardedTrainer, AkiTrainer
     from aki_amd.phi3 import make_phi3_config
@@ -96,7 +110,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if gloo else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # the whole exchange on its own: every bucket back to back, nothing else on the GPU
@@ -118,7 +132,7 @@ def main():
         ms = elapsed / a.steps * 1e3
         print(json.dumps({
             "metric": "training tokens/s, AKI-4B pre-training step (fwd+bwd+all-reduce+clip+AdamW)", "value": round(B * world * L * a.steps / elapsed, 1),
-            "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+            "unit": "tokens/s", "n_gpus": world, "rccl_ranks": ranks_seen, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "AKI-4B pre-training step, BASELINE configs[2]: 336px image + 512-token prompt per sample, batch 8 per GPU, "
                                    "bf16 compute / fp32 master weights; random-init weights", "global_batch": B * world, "seq_len": L,
