@@ -107,7 +107,7 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 // FP8: e4m3 operands through v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate).  A 128-byte
 // LDS row then holds BK = 128 k-values instead of 64, so staging, swizzle and the epilogues are byte-for-byte the same; the
 // per-row dequantisation scales (one per token, one per weight row) multiply the f32 accumulators before the epilogue.
-template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false, int NST = 2, bool PIPE = false>
+template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false, int NST = 2, int PIPE = 0>
 __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int BK = FP8 ? 128 : 64, ES = FP8 ? 1 : 2, NWAVES = WN * WM;
   constexpr int WROWS = NF * 16;      // features per wave
@@ -229,6 +229,8 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     }
   };
   constexpr bool EARLY_OPERANDS = !PIPE && !FP8 && NF * NT <= 16;
+  constexpr int RCH = BN / 8;                                  // 16-byte chunks per residual tile row (epilogue staging, below)
+  constexpr int CMASK = RCH >= 16 ? 15 : RCH - 1;
   if constexpr (EARLY_OPERANDS) fetch_epilogue_operands();
   auto compute = [&](const char* sb) {
     if constexpr (FP8) {   // one k128 step per BK: the lane's 32 bytes are chunks 2kg and 2kg+1 of its row
@@ -312,6 +314,24 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     // block and the scheduling directives can spread the reads and the DMA issue between the MFMAs instead of leaving
     // them in front: right after the barrier both waves of a SIMD would otherwise spend ~250 issue cycles on them with
     // the matrix core idle)
+    // PIPE == 2 (plain GEMM + residual, 16-byte path, host-checked): the residual tile - BM rows x BN*2 bytes = exactly the two
+    // stage buffers - is brought in by LDS-DMA under the LAST TWO K-steps instead of after the loop, where its round trip
+    // (every workgroup of a one-round launch at the same moment: 32 MB chip-wide) was fully exposed: +8 us on o_proj / down.
+    // Half h (token rows [BM/2*h, +BM/2)) goes into stage buffer h as soon as nobody reads that buffer any more: buffer
+    // (nk-2)&1 after the mid-step barrier of step nk-2 (no tile nk to fetch), the other one after the barrier of step nk-1.
+    // Image = the epilogue's: chunk c of token row t at chunk position c ^ (t & CMASK), swizzle on the SOURCE address.
+    auto issue_res_half = [&](int hb) {
+      static_assert(PIPE != 2 || (BM * RCH * 16 == 2 * STAGE_BYTES && NLD * NWAVES * 1024 == STAGE_BYTES), "residual tile = the two stage buffers");
+#pragma unroll
+      for (int j = 0; j < NLD; ++j) {
+        const int q = j * NWAVES + wave;                         // 1 KiB piece of the half = two token rows
+        const int tk = hb * (BM / 2) + 2 * q + (lane >> 5);
+        const int ch = (lane & (RCH - 1)) ^ (tk & CMASK);
+        const int f = min(n0 + 8 * ch, n_out - 8);
+        const bf16_t* src_ = p.residual + (size_t)min(m0 + tk, p.M - 1) * p.ldr + f;
+        __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src_), AKI_LDS_PTR(smem + hb * STAGE_BYTES + q * 1024), 16, 0, 0);
+      }
+    };
     auto step = [&](int kt, auto next1, auto next2) {
       constexpr bool NEXT1 = decltype(next1)::value, NEXT2 = decltype(next2)::value;
       const char* sb = smem + (kt & 1) * STAGE_BYTES;
@@ -319,13 +339,18 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
       mma(a0, b0);
       interleave_reads();
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my pieces of tile kt+1 landed; my reads of tile kt are done
+      if constexpr (NEXT1 || PIPE != 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my pieces of tile kt+1 landed; my reads of tile kt are done
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // last step: no tile is awaited, and the residual DMA of step nk-2 stays in flight
       __builtin_amdgcn_s_barrier();
       if constexpr (NEXT1) load_frags(smem + ((kt + 1) & 1) * STAGE_BYTES, 0, a0, b0);
       if constexpr (NEXT2) stage(kt & 1, kt + 2);
+      if constexpr (PIPE == 2 && !NEXT2) {
+        issue_res_half(kt & 1);
+        if constexpr (!NEXT1) { if (nk == 1) issue_res_half((kt & 1) ^ 1); }
+      }
       mma(a1, b1);
       if constexpr (NEXT1) interleave_reads();
-      if constexpr (NEXT2) interleave_dma();
+      if constexpr (NEXT2 || PIPE == 2) interleave_dma();
       __builtin_amdgcn_sched_barrier(0);
     };
     int kt = 0;
@@ -345,14 +370,14 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     // global -> LDS latency, which the 2-stage loop above pays every step.  NST - 1 tiles are in flight; the
     // counted vmcnt retires exactly tile kt (each stage() is NLD DMA instructions per thread), the raw barrier makes it a
     // workgroup-wide fact, and tile kt + NST - 1 then goes into the buffer tile kt - 1 was read from.
-    static_assert(NST == 4, "the counted waits below are written for four stages");
+    static_assert(NST == 3 || NST == 4, "the counted waits below are written for three or four stages");
 #pragma unroll
     for (int s_ = 0; s_ < NST - 1; ++s_)
       if (s_ < nk) stage(s_, s_);
     for (int kt = 0; kt < nk; ++kt) {
       const int rem = nk - 1 - kt;
-      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
-      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+      if (NST == 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+      else if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (kt + NST - 1 < nk) stage((kt + NST - 1) % NST, kt + NST - 1);
@@ -461,10 +486,11 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   // is NT*NOUT 8-byte loads (32 on the big tile, 128 KB per workgroup through the L1); staged it is 16-byte loads of whole
   // rows, two to sixteen per thread.  Chunk c of token row t sits at chunk c ^ (t & CMASK): the 16 token rows of a
   // ds_read_b64 land in 16 different bank groups without padding (a padded 256 x 256 tile would not fit).
-  constexpr int RCH = BN / 8;                                  // 16-byte chunks per residual tile row
-  constexpr int CMASK = RCH >= 16 ? 15 : RCH - 1;
   const bool res_lds = (EPI == EPI_PLAIN) && p.residual != nullptr && p.res_wide;   // workgroup-uniform
-  if (EPI == EPI_PLAIN && res_lds) {
+  if constexpr (PIPE == 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my pieces of the prefetched residual tile have landed ...
+    __syncthreads();                                           // ... and so have everybody else's
+  } else if (EPI == EPI_PLAIN && res_lds) {
     static_assert(EPI != EPI_PLAIN || BM * BN * 2 <= NST * STAGE_BYTES, "residual tile fits the K-loop buffers");
     __syncthreads();                                           // every wave is done reading the K-loop stages
     for (int c = tid; c < BM * RCH; c += NWAVES * 64) {
@@ -643,13 +669,13 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
 }
 
 #ifdef AKI_LAB_HOOKS
-int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;   // set by aki_lab_set_gemm_tile (lab build only)
+int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;   // set by aki_lab_set_gemm_tile (lab build only); g_pipe: 0 off, 1 on, 2 on without the residual prefetch
 long long* g_clock_probe = nullptr;                  // set by aki_lab_set_clock_probe
 #else
 static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;
 #endif
 
-template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, bool PIPE = false>
+template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, int PIPE = 0>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
   constexpr int SMEM = NST * (BN + BM) * 128;
@@ -743,7 +769,11 @@ static int launch_small(GemmParams& p, hipStream_t stream) {
 template <int EPI, int ACT, bool FP8>
 static int launch_big(GemmParams& p, hipStream_t stream) {
   if constexpr (!FP8) {
-    if (g_pipe && p.row_shift == nullptr) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, true>(p, stream);
+    if constexpr (EPI == EPI_PLAIN && ACT == 0) {   // residual tile prefetched under the last K-steps (o_proj, down_proj)
+      if (g_pipe == 1 && p.row_shift == nullptr && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && p.N % 8 == 0 && p.N >= 8)
+        return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 2>(p, stream);
+    }
+    if (g_pipe && p.row_shift == nullptr) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 1>(p, stream);
   }
   return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8>(p, stream);
 }

@@ -22,7 +22,7 @@ from .dp import FlatGradReducer
 class AkiTrainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                  max_grad_norm: float = 1.0, bucket_bytes: int = 512 << 20, group=None, shard_optimizer: bool = False,
-                 exchange_when_alone: bool = False):
+                 exchange_when_alone: bool = False, clip_every_microbatch: bool = False):
         """shard_optimizer: keep fp32 master weights and moments only for this rank's 1/world slice of every gradient
         bucket (reduce-scatter + all-gather instead of all-reduce) - the memory behaviour of the reference's FSDP launch
         configs (train/distributed.py:170-243, scripts/run_train.sh:23) for the optimizer state.
@@ -31,6 +31,9 @@ class AkiTrainer:
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
+        self.gacc = None                         # fp32 gradient accumulator (gradient accumulation windows only)
+        self._acc_open = False
+        self.clip_every_microbatch = bool(clip_every_microbatch)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         wd, nwd = model.group_params_by_weight_decay() if hasattr(model, "group_params_by_weight_decay") else (
             [p for p in model.parameters() if p.requires_grad], [])
@@ -103,6 +106,7 @@ class AkiTrainer:
 
     # ---- one step ---------------------------------------------------------------------------------------------------
     def zero_grad(self) -> None:
+        self._acc_open = False
         for p in self.params:
             p._aki_grad_live = False
             p.grad = None
@@ -110,9 +114,19 @@ class AkiTrainer:
     def backward(self, loss: torch.Tensor, last_microbatch: bool = True) -> None:
         """loss.backward() through the HIP kernels.  Gradient accumulation (train/train_utils.py:242-266 divides the loss
         by `gradient_accumulation_steps` and steps every k-th micro-batch): call zero_grad() once, then backward(loss / k,
-        last_microbatch=False) for the first k-1 micro-batches - gradients add up in the flat buffer, nothing is
-        exchanged - and backward(loss / k) for the last one, which also runs the (overlapped) gradient exchange."""
-        self.reducer.enabled = bool(last_microbatch)
+        last_microbatch=False) for the first k-1 micro-batches and backward(loss / k) for the last one.
+
+        Like the reference (fp32 parameter .grad under autocast; the sharded fp32 gradient of its FSDP wrap,
+        train/distributed.py:160-167) the micro-batch gradients are SUMMED IN FP32: every micro-batch writes its own bf16
+        gradients into the flat buffer (first writer overwrites), which is then added to an fp32 accumulator of the same
+        length (allocated on the first accumulation window; 15.6 GB for AKI-4B).  The last micro-batch rounds the fp32 sum to
+        bf16 ONCE, into the flat buffer, and exchanges that (after the backward pass - the exchange is linear, but overlapping
+        it with this backward would exchange the last micro-batch alone).  `clip_every_microbatch` additionally clips the
+        accumulated fp32 gradient to `max_grad_norm` after every micro-batch, which is where the reference's loop calls
+        clip_grad_norm_ (train/train_utils.py:254-258: after each backward, not once per optimizer step); the default
+        clips once, in the optimizer step.  With gradient_accumulation_steps = 1 nothing of this runs."""
+        accumulating = (not last_microbatch) or self._acc_open
+        self.reducer.enabled = bool(last_microbatch) and not accumulating
         loss.backward()
         for p in self.params:
             if p.grad is not None:               # a gradient autograd produced itself (no HIP writer took it): fold it in
@@ -123,10 +137,31 @@ class AkiTrainer:
                     p._aki_grad_live = True
                 p.grad = None
                 self.reducer.notify(p)
-            elif not p._aki_grad_live:           # unused so far in this window
-                if last_microbatch:
+            elif not p._aki_grad_live:           # unused in this backward pass
+                if last_microbatch or accumulating:
                     p._aki_grad.zero_()
                     self.reducer.notify(p)
+        if accumulating:
+            if self.gacc is None:
+                self.gacc = torch.empty(self.numel, dtype=torch.float32, device=self.g16.device)
+            if self._acc_open:
+                self.gacc.add_(self.g16)         # fp32 += bf16 (exact conversion, fp32 sum)
+            else:
+                self.gacc.copy_(self.g16)
+                self._acc_open = True
+            if self.clip_every_microbatch and self.max_grad_norm is not None and self.max_grad_norm > 0:
+                norm = self.gacc.norm()
+                self.gacc.mul_(torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0))     # torch.nn.utils.clip_grad_norm_
+            if last_microbatch:
+                self.g16.copy_(self.gacc)        # ONE rounding of the fp32 sum
+                self._acc_open = False
+                self.reducer.enabled = True
+                for p in self.params:
+                    p._aki_grad_live = True
+                    self.reducer.notify(p)
+            else:
+                for p in self.params:            # the next micro-batch's first writers overwrite their slices again
+                    p._aki_grad_live = False
         if last_microbatch:
             self.reducer.finish()
         self.reducer.enabled = True
@@ -247,6 +282,7 @@ class _Unit:
         self.delivered = set()
         self.inflight = None               # (work, tmp shard) of the reduce-scatter in flight
         self.fresh = True                  # g_shard holds nothing of this accumulation window yet
+        self.g_acc32 = None                # fp32 running sum of the window (second micro-batch onwards)
         self.release()
         self.release_grads()
 
@@ -310,8 +346,14 @@ class _Unit:
         if self.fresh:
             self.g_shard.copy_(tmp)
             self.fresh = False
+            self.g_acc32 = None
         else:
-            self.g_shard += tmp
+            # later micro-batch of an accumulation window: the running sum is kept in fp32 (the reference's FSDP wrap keeps its
+            # sharded gradient in fp32, train/distributed.py:160-167) and g_shard is its bf16 image, rounded once from the sum
+            if self.g_acc32 is None:
+                self.g_acc32 = self.g_shard.float()
+            self.g_acc32 += tmp
+            self.g_shard.copy_(self.g_acc32)
         self.inflight = None
         self.release_grads()
         self.release()

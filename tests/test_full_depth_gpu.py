@@ -88,3 +88,109 @@ def test_aki4b_full_depth_bf16_logits_vs_fp32_oracle():
     if "padded rows" in stats:                     # rows of padding tokens: finite, same convention (uniform softmax rows exist only beyond seq_len)
         pr = stats["padded rows"]
         assert pr["hip_mean"] <= 1.5 * pr["eager_bf16_mean"] + 1e-3 * mx, stats
+
+
+@pytest.mark.timeout(3000)
+def test_aki4b_full_depth_fp8_logits_vs_fp32_oracle_and_bf16():
+    """BASELINE configs[4] at the workload's width and depth: AKI-4B, 32 decoder layers with `enable_fp8()`
+    (e4m3 projections, per-token / per-weight-row scales; attention, residual stream and the vision side stay bf16), batch 2,
+    336 px + 512 tokens.  No reference behaviour exists for fp8 (parity unpinned): the yardsticks are the fp32 oracle on the same
+    bf16-rounded weights and this library's own bf16 path.  Three configurations: every projection + the head in e4m3 (the
+    benchmark's `--dtype fp8`), head in bf16, head + the residual-stream writers (o_proj, down_proj) in bf16.
+    What the numbers say (gpurun_out/parity_full_depth_fp8.json -> profiles/): an e4m3 GEMM output carries a few percent of
+    rounding noise, 128 such outputs feed the residual stream and the head puts its own straight on the logits; with RANDOM-INIT
+    weights the logits are nearly flat (top-1 / top-2 margins of a few 1e-2), so the arg-max agreement with fp32 collapses
+    (0.39 against bf16's 0.93) although the relative L2 error is the expected ~0.3.  Asserted: finite logits, the error inside the
+    random-walk model of the e4m3 noise, and that it shrinks as projections are moved back to bf16 - the arg-max figures are
+    recorded, not asserted (a trained checkpoint, which this build cannot load offline, is what they would be meaningful on)."""
+    import aki_torch as OT
+    from aki_amd.factory import build_aki
+    B = 2
+    m = build_aki(dtype=torch.bfloat16, device=DEV, seed=7).eval()
+    vx, ids, am = _prompts(B, m.media_token_id, 11)
+    vx16 = vx.to(torch.bfloat16)
+    run = lambda: m(vx16.to(DEV), ids.to(DEV), attention_mask=am.to(DEV)).logits.float().cpu()
+    got = {}
+    with torch.no_grad():
+        got["bf16"] = run()
+        m.lang_model.enable_fp8()
+        got["fp8"] = run()
+        m.lang_model.enable_fp8(True, head=False)
+        got["fp8_head_bf16"] = run()
+        m.lang_model.enable_fp8(True, head=False, residual_writers=False)
+        got["fp8_qkv_gateup_only"] = run()
+        m.lang_model.enable_fp8(False)
+    assert all(bool(torch.isfinite(g).all()) for g in got.values())
+    p16 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    del m
+    torch.cuda.empty_cache()
+    cfg = dict(vis_layers=27, vis_heads=16, lm_layers=32, lm_heads=32, max_original_id=32010, media_token_id=32011,
+               pad_token_id=32000, num_vision_tokens=NV)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    with torch.no_grad():
+        want = OT.aki_forward({k: v.float() for k, v in p16.items()}, cfg, vx16.float(), ids, am)
+    ref = want["logits"]
+    valid = torch.from_numpy(np.asarray(want["prep"]["mask_1d"]).astype(bool))
+    mx = max(1.0, float(ref.abs().max()))
+    top = ref.argmax(-1)
+    top2 = ref.topk(2, dim=-1).values
+    stats = dict(batch=B, L=N_TXT - 1 + NV, max_abs_ref=mx, ref_logit_std=float(ref[valid].std()),
+                 ref_median_top1_top2_margin=float((top2[..., 0] - top2[..., 1])[valid].median()))
+    for k, g in got.items():
+        e = (g - ref).abs()[valid]
+        stats[k] = dict(max=float(e.max()), mean=float(e.mean()), rel_l2=float((g - ref)[valid].norm() / ref[valid].norm()),
+                        argmax_agreement=float((g.argmax(-1) == top)[valid].float().mean()))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_full_depth_fp8.json"), "w") as f:
+        json.dump(stats, f, indent=1)
+    print(json.dumps(stats))
+    record_parity("AKI-4B 32+27 layers logits, fp8 projections + head, valid rows", torch.bfloat16, stats["fp8"]["max"], stats["fp8"]["mean"], mx,
+                  "rel L2 <= 0.5 (random walk of e4m3 noise over 129 GEMMs); no reference for fp8")
+    assert stats["fp8"]["rel_l2"] <= 0.5, stats
+    assert stats["fp8_qkv_gateup_only"]["rel_l2"] < stats["fp8_head_bf16"]["rel_l2"] <= stats["fp8"]["rel_l2"] * 1.02, stats
+    assert stats["fp8_qkv_gateup_only"]["argmax_agreement"] >= stats["fp8"]["argmax_agreement"], stats
+
+
+@pytest.mark.timeout(3000)
+def test_aki4b_full_size_training_step_properties():
+    """BASELINE configs[2]'s per-GPU workload in the suite the driver runs: AKI-4B, all 32 + 27 layers, batch 8 x
+    (336 px image + 512-token prompt), forward + backward + clip 1.0 + AdamW on the HIP kernels.  There is no oracle at this size
+    that finishes in seconds, so the checks are properties: the loss is finite and near ln(vocab) for random-init weights, it
+    DEcreases over three optimizer steps on the same batch, the global gradient norm is finite and positive, and a second run
+    from the same initial weights reproduces losses and gradients bit for bit (every kernel on the path is deterministic)."""
+    import bench
+    from aki_amd.factory import build_aki
+    from aki_amd.trainer import AkiTrainer
+
+    def run():
+        m = build_aki(dtype=torch.bfloat16, device=DEV, seed=3)
+        m.train()
+        m.set_trainable()
+        tr = AkiTrainer(m, lr=2e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=1.0)
+        vx, ids, am = bench.synth_batch(8, torch.device(DEV), torch.bfloat16, m.media_token_id, seed=5)
+        labels = ids.clone()
+        labels[labels == m.media_token_id] = -100
+        losses, norms = [], []
+        g_first = None
+        for i in range(3):
+            tr.zero_grad()
+            out = m(vx, ids, attention_mask=am, labels=labels)
+            tr.backward(out.loss)
+            if i == 0:
+                g_first = tr.g16.clone()
+            tr.optimizer_step()
+            losses.append(float(out.loss.detach()))
+            norms.append(float(tr.grad_norm()))
+        w_end = tr.w16.clone()
+        del tr, m
+        torch.cuda.empty_cache()
+        return losses, norms, g_first, w_end
+
+    l1, n1, g1, w1 = run()
+    assert all(np.isfinite(l1)) and all(np.isfinite(n1)) and min(n1) > 0.0, (l1, n1)
+    assert abs(l1[0] - np.log(32013.0)) < 1.0, l1                 # random init: about ln(vocab)
+    assert l1[2] < l1[1] < l1[0], f"loss does not decrease over three steps: {l1}"
+    l2, n2, g2, w2 = run()
+    assert l1 == l2 and n1 == n2, (l1, l2, n1, n2)
+    assert torch.equal(g1, g2), f"{int((g1 != g2).sum())} gradient elements differ between two runs"
+    assert torch.equal(w1, w2), "weights after three steps differ between two runs"
