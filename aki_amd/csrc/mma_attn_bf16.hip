@@ -36,8 +36,14 @@
 
 namespace aki {
 
-template <int NW>
+// SWP (lab library only) = software-pipelined tile loop (see "Software-pipelined loop" in the kernel body): P V of tile j-1 is
+// issued in front of K Q^T of tile j, so a wave's matrix work comes in one burst of 24 MFMAs per tile that covers its own LDS
+// fragment reads, and its softmax VALU sits alone between two bursts.  Same results bit for bit; measured 6-9 % SLOWER than the
+// plain loop on one box (B8 L655: 68.3 vs 64.3 us; B4 L4096: 670 vs 617 us; tools/attn_ab.py) - kept as a recorded experiment.
+template <int NW, int MODE>      // MODE 0: plain tile loop (product); 1: software-pipelined; 2: software-pipelined + 8-wave ping-pong (NW = 8); 3: plain, DMA issued behind the score MFMAs
 __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnParams p) {
+  constexpr bool SWP = MODE == 1 || MODE == 2;
+  static_assert(MODE != 2 || NW == 8, "the ping-pong loop is written for two groups of four waves");
   constexpr int BQ = NW * 32;
   constexpr int NT = NW * 64;
   constexpr int NCH = (64 * 12 + NT - 1) / NT;  // 16-B chunks per thread per tile (K and V each)
@@ -76,6 +82,30 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   // contiguous 12 KiB tile of the head-major layout; the K swizzle is applied on the per-lane SOURCE address.
   int tid_o = tid;   // re-made opaque once per rank: keeps hipcc from hoisting the per-chunk address arithmetic out of
                      // the rank loop (with it hoisted the tile loop spilled: 256 VGPRs + 31 in scratch)
+  auto issue_k = [&](int j, int stage) {
+    const int c0 = j * 64;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (NW == 8 && i == 1 && wave >= 4) break;  // 768 chunks on 512 threads: the half round of K belongs to waves 0-3 ...
+      const int ch = i * NT + tid_o;              // 16-B chunk index inside the tile image
+      const int kr = ch / 12, pos = ch - kr * 12;
+      const size_t rowoff = (size_t)min(c0 + kr, L - 1) * 192;
+      const int srcchunk = pos ^ ((kr >> 2) & 3);
+      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(kb + rowoff + srcchunk * 16), AKI_LDS_PTR(sK + stage * KTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  auto issue_v = [&](int j, int stage) {
+    const int c0 = j * 64;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (NW == 8 && i == 1 && wave < 4) break;   // ... the half round of V to waves 4-7: three pieces per wave and tile either way
+      const int sh = (NW == 8 && i == 1) ? 256 : 0;
+      const int ch = i * NT + tid_o - sh;
+      const int kr = ch / 12, pos = ch - kr * 12;
+      const size_t rowoff = (size_t)min(c0 + kr, L - 1) * 192;
+      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(vb_ + rowoff + pos * 16), AKI_LDS_PTR(sV + stage * VTILE + (i * NT + wave * 64 - sh) * 16), 16, 0, 0);
+    }
+  };
   auto issue_tile = [&](int j, int stage) {
     const int c0 = j * 64;
 #pragma unroll
@@ -162,15 +192,21 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   int lane_o = lane;
   asm volatile("" : "+v"(tid_o), "+v"(lane_o));
   // ---- per rank: the first two K/V tiles and the Q fragments are put in flight together ----------------------
-  issue_tile(0, 0);
-  if (L > 64) issue_tile(1, 1);
+  if constexpr (SWP) {
+    issue_k(0, 0);
+    issue_v(0, 0);
+    if (L > 64) issue_k(1, 1);
+  } else {
+    issue_tile(0, 0);
+    if (L > 64) issue_tile(1, 1);
+  }
   int wq0, hi_col;
   if (sched) {
     hi_col = 0;
     wq0 = L;                                      // rank past nblk (last rank of the sample): the wave idles
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      const unsigned long long m = __ballot(rank_s == 4 * g + w);
+      const unsigned long long m = __ballot(rank_s == NW * g + w);
       if (m != 0ull) {
         const int l = __builtin_ctzll(m);
         hi_col = max(hi_col, __builtin_amdgcn_readlane(ext_s, l));
@@ -235,13 +271,215 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   };
   unsigned long long vb_next = 0ull;
 
+  if constexpr (SWP) {
+  // ---- Software-pipelined loop (lab).  A tile is processed in two phases:
+  //   M(j): P V of tile j-1 (V^T fragment reads, 12 MFMAs) followed by K Q^T of tile j (K fragment reads issued behind the P V
+  //         MFMAs, mask bias, 12 MFMAs): one burst of 24 MFMAs that covers its own LDS reads;
+  //   V(j): the softmax of tile j - VALU only - leaving P as packed bf16 (16 registers) for the next M phase.
+  // V lags K by one tile in the ring: at iteration j the DMA of K tile j+2 replaces K tile j-1 and V tile j+1 replaces
+  // V tile j-2 (V tile j-1 is still being read).
+  // MODE 1 (4 waves): barrier, M(j), V(j) per iteration.  MODE 2 (8 waves = two groups of four on the same four SIMDs): two
+  // barriers per iteration and the groups half an iteration apart - group A runs M(j) then V(j), group B runs V(j-1) then M(j) -
+  // so that on every SIMD one wave is in its matrix phase while its partner is in its VALU phase (MI355X guide, "Two waves per
+  // SIMD"); waves 4-7, the younger half, get static priority 1.
+  bf16x8 pp[4];
+  f32x16 s0, s1;
+  const bool grp_b = (MODE == 2) && wave >= NW / 2;           // wave-uniform
+  if (MODE == 2 && grp_b) __builtin_amdgcn_s_setprio(1);
+  auto tile_active = [&](int j) -> bool {       // wave-uniform: does this wave's block see anything of tile j?
+    if (j >= jend) return false;
+    const int c0 = j * 64;
+    const unsigned long long vb = valid_word(j);
+    const bool causal_none = (c0 > wq0 + 31);
+    const bool rect_touch = (c0 < touch_hi && c0 + 64 > touch_lo);
+    return has_uniform || !(!wave_alive || vb == 0ull || (causal_none && !rect_touch));
+  };
+  auto pv = [&](int j) {           // O^T += V^T P of tile j-1 (P in pp): the V^T fragment reads, then 12 MFMAs
+    {
+      u32x2 vlo[4][3], vhi[4][3];
+      const unsigned vaddr = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)sV) + ((j + NSTAGE - 1) % NSTAGE) * VTILE + voff;
+      static_for<4>([&](auto ks4) {
+        static_for<3>([&](auto dt) {
+          constexpr int off = ks4 * 16 * VROW + dt * 64;
+          vlo[ks4][dt] = ds_read_tr<off>(vaddr);
+          vhi[ks4][dt] = ds_read_tr<off + 8 * VROW>(vaddr);
+        });
+      });
+      // every transposed read has to be back before its registers are touched
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]), "+v"(vlo[0][2]), "+v"(vhi[0][2]),
+                     "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]), "+v"(vlo[1][2]), "+v"(vhi[1][2]),
+                     "+v"(vlo[2][0]), "+v"(vhi[2][0]), "+v"(vlo[2][1]), "+v"(vhi[2][1]), "+v"(vlo[2][2]), "+v"(vhi[2][2]),
+                     "+v"(vlo[3][0]), "+v"(vhi[3][0]), "+v"(vlo[3][1]), "+v"(vhi[3][1]), "+v"(vlo[3][2]), "+v"(vhi[3][2]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks4 = 0; ks4 < 4; ++ks4) {
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+          const u32x4 vv = {vlo[ks4][dt][0], vlo[ks4][dt][1], vhi[ks4][dt][0], vhi[ks4][dt][1]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pp[ks4], o[dt], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto qk = [&](int j) {           // S^T = bias + K Q^T of tile j -> s0, s1.  Issued behind the P V MFMAs: the K fragment reads land while those execute
+    const int c0 = j * 64;
+    const unsigned long long vb = valid_word(j);
+    const bool causal_full = (c0 + 63 <= wq0);
+    const bool causal_none = (c0 > wq0 + 31);
+    const bool rect_full = (c0 >= full_lo && c0 + 64 <= full_hi);
+    {
+      bf16x8 ka[6], kc[6];
+      const char* Kb = sK + (j % NSTAGE) * KTILE;
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        const int coff = ((2 * ks + h) ^ kswz) << 4;
+        ka[ks] = *(const bf16x8*)(Kb + krow + coff);
+        kc[ks] = *(const bf16x8*)(Kb + krow + 32 * KROW + coff);
+      }
+      // the mask bias = the initial value of the score accumulators (see the plain loop)
+      const bool full = (vb == ~0ull) && (causal_full || rect_full) && !wave_has_dead;
+      const bool lane_covers = rc0 <= c0 && c0 + 64 <= rc1;
+      const bool lane_cut = !lane_covers && rc0 < c0 + 64 && rc1 > c0;
+      const bool rowwise = !full && causal_none && vb == ~0ull && !wave_has_dead && !__any(lane_cut);
+      if (full) {
+        // no bias: the first MFMA of each chain takes the constant 0 as its C operand (below)
+      } else if (rowwise) {
+        const float lane_bias = lane_covers ? 0.f : -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = lane_bias; s1[r] = lane_bias; }
+      } else {
+        const int base = c0 + 4 * h;
+        unsigned valid;                                                       // valid columns, register order
+        if ((vb & (vb + 1ull)) == 0ull) {                                     // wave-uniform: the bits form a prefix
+          valid = low_bits(count_le(c0 + (int)__builtin_popcountll(vb) - 1 - base));
+        } else {                                                              // holes in the 1-D mask (rare)
+          const unsigned long long vbh = vb >> (4 * h);
+          valid = 0u;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) valid |= ((unsigned)(vbh >> (8 * k)) & 0xFu) << (4 * k);
+        }
+        const unsigned alive = (low_bits(count_le(row - base)) | (low_bits(count_le(rc1 - 1 - base)) & ~low_bits(count_le(rc0 - 1 - base)))) & valid;
+        const unsigned uniform = low_bits(count_le(L - 1 - base));            // every column < L
+        const unsigned vis = row_uniform ? uniform : (row_alive ? alive : 0u);
+        const int hid = (int)~vis;
+        const int ninf = 0xFF800000;
+        static_for<16>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          s0[r] = mask_bias<r>(hid, ninf);
+          s1[r] = mask_bias<r + 16>(hid, ninf);
+        });
+        asm volatile("s_nop 1" : "+v"(s0), "+v"(s1));   // VALU write inside inline asm -> MFMA C operand (see the plain loop)
+      }
+      if (full) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0], f32x16{}, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[0], qf[0], f32x16{}, 0, 0, 0);
+      } else {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0], qf[0], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[0], qf[0], s1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 1; ks < 6; ++ks) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[ks], s1, 0, 0, 0);
+      }
+    }
+  };
+  auto softmax_tile = [&]() {      // softmax of the score tile in s0, s1 -> P (packed bf16) in pp, running max / sum, O brought to the new maximum
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_results_settle(s0, s1);   // the max3 chain below is inline asm
+    float mx = max3(s0[0], s0[1], s1[0]);
+    mx = max3(mx, s1[1], s0[2]);
+#pragma unroll
+    for (int r = 3; r < 16; r += 1) mx = max3(mx, s0[r], s1[r - 1]);
+    mx = fmaxf(mx, s1[15]);
+    mx = halves_max(mx) * p.scale_log2;
+    const float m_new = fmaxf(m_run, mx);
+    const bool moved = m_new != m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2, -m_new));
+      s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2, -m_new));
+      ps += s0[r] + s1[r];
+    }
+    l_part = l_part * alpha + ps;
+    if (__any(moved)) {   // O holds every tile before this one (their P V has been issued): bring it to the new maximum
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+#pragma unroll
+    for (int ks4 = 0; ks4 < 4; ++ks4)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pp[ks4][e] = (__bf16)((ks4 < 2) ? s0[8 * (ks4 & 1) + e] : s1[8 * (ks4 & 1) + e]);
+  };
+  auto top_of_iteration = [&](int j) {
+    // needed now: K tile j and V tile j-1, i.e. everything issued before iteration j-1; iteration j-1 issued K(j+1) and then V(j).
+    // Pieces per wave and tile: NCH of each with 4 waves; with 8 waves K 2 + V 1 for waves 0-3, K 1 + V 2 for waves 4-7.
+    if constexpr (MODE == 2) {
+      if (j + 1 < jend) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (j < jend) { if (wave < 4) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (j + 1 < jend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
+      else if (j < jend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (j + 2 < jend) issue_k(j + 2, (j + 2) % NSTAGE);
+    if (j + 1 < jend) issue_v(j + 1, (j + 1) % NSTAGE);
+  };
+  // The branches below put the second barrier of an iteration INSIDE both arms so that the score tile (group A) / the packed P
+  // (group B) is provably dead on the arm that does not use it - with the condition tested twice hipcc kept both live across
+  // the whole loop and spilled 94 registers.
+  if (!grp_b) {                    // MODE 1, and group A of MODE 2: [P V (j-1), K Q^T (j)] | softmax (j)
+    bool have_p = false;
+    for (int j = 0; j <= jend; ++j) {
+      top_of_iteration(j);
+      if (have_p) pv(j);
+      if (tile_active(j)) {
+        qk(j);
+        if constexpr (MODE == 2) __builtin_amdgcn_s_barrier();
+        softmax_tile();
+        have_p = true;
+      } else {
+        if constexpr (MODE == 2) __builtin_amdgcn_s_barrier();
+        have_p = false;
+      }
+    }
+  } else {                         // group B of MODE 2, half an iteration behind: softmax (j-1) | [P V (j-1), K Q^T (j)]
+    bool pend = false;
+    for (int j = 0; j <= jend; ++j) {
+      top_of_iteration(j);
+      if (pend) {
+        softmax_tile();
+        __builtin_amdgcn_s_barrier();
+        pv(j);
+      } else {
+        __builtin_amdgcn_s_barrier();
+      }
+      pend = tile_active(j);
+      if (pend) qk(j);
+    }
+  }
+  if (MODE == 2 && grp_b) __builtin_amdgcn_s_setprio(0);
+  } else {
   int stage = 0;
   for (int j = 0; j < jend; ++j) {
     // tile j's pieces are older than tile j+1's 2*NCH: wait for them, then make it a workgroup-wide fact
     if (j + 1 < jend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (j + 2 < jend) issue_tile(j + 2, stage >= 1 ? stage - 1 : NSTAGE - 1);   // the stage read in iteration j-1
+    // DMA of tile j+2 into the stage read in iteration j-1.  MODE 3 (lab): issued BEHIND the score MFMAs instead of here - a piece
+    // costs the issuing wave 60-185 cycles (MI355X guide, cycle constants), six of them in front of the K fragment reads are a
+    // good part of the ~730 cycles between the barrier and the first MFMA (profiles/r01i_attn_phase_cycles.txt)
+    constexpr bool DMA_LATE = (MODE == 3);
+    const int dma_stage = stage >= 1 ? stage - 1 : NSTAGE - 1;
+    if (!DMA_LATE && j + 2 < jend) issue_tile(j + 2, dma_stage);
     const int c0 = j * 64;
     // valid-column word of the tile (wave-uniform, SGPRs): word 0 is read here, behind the barrier that publishes the
     // prologue's LDS writes; every later word is fetched at the end of the previous tile, under its PV MFMAs
@@ -320,6 +558,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[ks], s1, 0, 0, 0);
       }
+      if (DMA_LATE && j + 2 < jend) issue_tile(j + 2, dma_stage);
       // The V^T fragments do not depend on the softmax: issue their transposed reads now, they land under the VALU work.
       u32x2 vlo[4][3], vhi[4][3];
       {
@@ -377,11 +616,14 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
         }
       }
+    } else if (DMA_LATE && j + 2 < jend) {
+      issue_tile(j + 2, dma_stage);
     }
     vb_next = valid_word(j + 1);
     if (++stage == NSTAGE) stage = 0;
   }
 
+  }
   // ---- epilogue: O = O^T / l.  A row that is inside seq_len but saw no visible column at all (e.g. left padding)
   // is rare: under AKI_DEAD_ROWS_UNIFORM its lanes average V themselves; otherwise it is written as zeros.
   // The lane-local layout (one query row per lane, 4 features per register quad) would store 8-byte pieces at a
@@ -434,7 +676,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
 // an A/B in one process (tools/attn_ab.py).  It is not part of the product library: as compiled by hipcc it is 1.7x SLOWER
 // than this kernel ("64-row attention core").
 int attn_core64_bf16(const aki_mma_attn_core_args* a, hipStream_t stream);
-int g_attn_variant = 0;   // 0 / 1 = this kernel, 2 = the 64-row kernel
+int g_attn_variant = 0;   // 0 / 1 = this kernel, 2 = the 64-row kernel, 3 = this kernel with the software-pipelined tile loop (lab: 6-9 % slower), 4 = 8-wave ping-pong on the software-pipelined loop
 #endif
 
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -478,7 +720,30 @@ int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, h
   p.scale_log2 = a->scale * 1.44269504088896340736f;
   p.dead_uniform = a->dead_rows == AKI_DEAD_ROWS_UNIFORM;
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL((mma_attn_bf16_kernel<NW>), dim3(a->B * a->H * p.splits), dim3(NW * 64), 0, stream, p);
+#ifdef AKI_LAB_HOOKS
+  if (g_attn_variant == 3) hipLaunchKernelGGL((mma_attn_bf16_kernel<NW, 1>), dim3(a->B * a->H * p.splits), dim3(NW * 64), 0, stream, p);
+  else if (g_attn_variant == 5) hipLaunchKernelGGL((mma_attn_bf16_kernel<NW, 3>), dim3(a->B * a->H * p.splits), dim3(NW * 64), 0, stream, p);
+  else if (g_attn_variant == 4) {
+    // 8-wave ping-pong (lab): one 512-thread workgroup per CU, ranks of eight 32-row blocks
+    constexpr int NW8 = 8;
+    static int cus8 = 0;
+    if (cus8 == 0) {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      cus8 = n;
+    }
+    const int nbh = a->B * a->H;
+    p.nqt = (a->L + NW8 * 32 - 1) / (NW8 * 32);
+    int splits = (cus8 + nbh - 1) / nbh;
+    const int s_l2 = a->L / (2 * AKI_ATTN_L2_ROWS);
+    if (splits < s_l2) splits = s_l2;
+    p.splits = splits < 1 ? 1 : (splits > p.nqt ? p.nqt : splits);
+    int grp = ((cus8 + p.splits - 1) / p.splits + 7) & ~7;
+    p.group_bh = grp > nbh ? nbh : grp;
+    hipLaunchKernelGGL((mma_attn_bf16_kernel<NW8, 2>), dim3(a->B * a->H * p.splits), dim3(NW8 * 64), 0, stream, p);
+  } else
+#endif
+  hipLaunchKernelGGL((mma_attn_bf16_kernel<NW, 0>), dim3(a->B * a->H * p.splits), dim3(NW * 64), 0, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }

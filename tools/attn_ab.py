@@ -1,10 +1,12 @@
-"""A/B of the two attention cores in one process (lab library: aki_lab_set_attn_variant 1 = 32-row kernel, two waves per
-SIMD; 2 = 64-row kernel, one wave per SIMD) at the benchmark shape and the long-context shape; interleaved rounds, random
-data, plus the largest output difference between the two."""
+"""A/B of attention-core variants in one process (lab library: aki_lab_set_attn_variant 1 = the product kernel - 32-row blocks,
+two waves per SIMD; 3 = the same kernel with the software-pipelined tile loop; 2 = 64-row kernel, one
+wave per SIMD) at the benchmark shape and the long-context shapes; interleaved rounds, random data, plus the largest output
+difference between the two.    python tools/attn_ab.py [variant_a variant_b]   (default 1 3)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from aki_amd import ops, _lib
+VA, VB = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1, 3)
 lab = _lib.load_lab()
 _lib._lib = lab
 dev = "cuda"
@@ -27,9 +29,9 @@ def run(q, k, v, table, n):
 for (B, H, L, rects) in CASES:
     q, k, v = (torch.randn(B, H, L, 96, device=dev, generator=g).to(torch.bfloat16) for _ in range(3))
     table = ops.MaskTable.from_host(rects, np.ones((B, L)), None, dev)
-    best, outs = {1: 1e9, 2: 1e9}, {}
+    best, outs = {VA: 1e9, VB: 1e9}, {}
     for r in range(5):
-        for var in (1, 2):
+        for var in (VA, VB):
             lab.aki_lab_set_attn_variant(var)
             t, o = run(q, k, v, table, 20)
             best[var] = min(best[var], t)
@@ -41,6 +43,6 @@ for (B, H, L, rects) in CASES:
         for r in range(r0, r1):
             pairs += max(0, c1 - max(c0, r + 1))
     fl = 4.0 * 96 * pairs * B * H
-    d = (outs[1].float() - outs[2].float()).abs().max().item()
-    print(f"B{B} H{H} L{L}: 32-row {best[1]:7.1f} us ({fl/best[1]/1e6:5.0f} TF/s)   64-row {best[2]:7.1f} us ({fl/best[2]/1e6:5.0f} TF/s)   "
-          f"speed-up {best[1]/best[2]:.2f}x   max |difference| {d:.4f}", flush=True)
+    d = (outs[VA].float() - outs[VB].float()).abs().max().item()
+    print(f"B{B} H{H} L{L}: variant {VA} {best[VA]:7.1f} us ({fl/best[VA]/1e6:5.0f} TF/s)   variant {VB} {best[VB]:7.1f} us ({fl/best[VB]/1e6:5.0f} TF/s)   "
+          f"{VB}/{VA} time ratio {best[VB]/best[VA]:.3f}   max |difference| {d:.4f}", flush=True)
