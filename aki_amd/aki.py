@@ -87,6 +87,8 @@ class AKI(VLMWithLanguageStream):
         The prompt's cache rows are expanded to K beams and re-ordered in place every step (AkiKVCache.select_rows)."""
         dev = logits.device
         B = logits.shape[0]
+        if max_new_tokens <= 0:                        # nothing to generate: the greedy path returns an empty tensor too
+            return torch.zeros((B, 0), dtype=torch.long, device=dev)
         cache.select_rows(torch.arange(B, device=dev).repeat_interleave(K))
         logp = torch.log_softmax(logits.float(), dim=-1).repeat_interleave(K, dim=0)             # [B*K, V]
         V = logp.shape[-1]

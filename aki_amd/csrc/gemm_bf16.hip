@@ -231,6 +231,12 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   constexpr bool EARLY_OPERANDS = !PIPE && !FP8 && NF * NT <= 16;
   constexpr int RCH = BN / 8;                                  // 16-byte chunks per residual tile row (epilogue staging, below)
   constexpr int CMASK = RCH >= 16 ? 15 : RCH - 1;
+  // residual prefetch of the two-stage loop (small tiles): possible when the residual tile fits ONE stage buffer in whole 1-KiB pieces
+  constexpr int RES_PIECES = (BM * RCH * 16) / (NWAVES * 1024);
+  constexpr bool RES_PF_OK = EPI == EPI_PLAIN && ACT == 0 && !FP8 && !PIPE && NST == 2 && RCH <= 64 && (64 % RCH == 0) && BM * RCH * 16 <= STAGE_BYTES &&
+                             (BM * RCH * 16) % (NWAVES * 1024) == 0;
+  const bool res_pf = RES_PF_OK && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && n_out >= 8;   // workgroup-uniform
+  int res_off = 0;                 // where the residual tile image sits in smem
   if constexpr (EARLY_OPERANDS) fetch_epilogue_operands();
   auto compute = [&](const char* sb) {
     if constexpr (FP8) {   // one k128 step per BK: the lane's 32 bytes are chunks 2kg and 2kg+1 of its row
@@ -362,6 +368,20 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();  // (vmcnt(0) + barrier): tile kt landed, the other buffer is no longer being read
       if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      else if (RES_PF_OK && res_pf) {
+        // last K-step: the other stage buffer is free - the residual tile goes there by LDS-DMA, under this step's MFMAs,
+        // instead of being fetched after the loop (same image as the epilogue's staging: chunk c of token row t at c ^ (t & CMASK))
+        res_off = ((kt + 1) & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < RES_PIECES; ++j) {
+          const int q = j * NWAVES + wave;                       // 1 KiB piece = 1024 / (RCH * 16) token rows
+          const int tk = q * (64 / RCH) + lane / RCH;
+          const int ch = (lane & (RCH - 1)) ^ (tk & CMASK);
+          const int f = min(n0 + 8 * ch, n_out - 8);
+          const bf16_t* src_ = p.residual + (size_t)min(m0 + tk, p.M - 1) * p.ldr + f;
+          __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src_), AKI_LDS_PTR(smem + res_off + q * 1024), 16, 0, 0);
+        }
+      }
       compute(smem + (kt & 1) * STAGE_BYTES);
     }
   } else {
@@ -490,6 +510,9 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   if constexpr (PIPE == 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my pieces of the prefetched residual tile have landed ...
     __syncthreads();                                           // ... and so have everybody else's
+  } else if (RES_PF_OK && res_pf) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   } else if (EPI == EPI_PLAIN && res_lds) {
     static_assert(EPI != EPI_PLAIN || BM * BN * 2 <= NST * STAGE_BYTES, "residual tile fits the K-loop buffers");
     __syncthreads();                                           // every wave is done reading the K-loop stages
@@ -546,7 +569,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
         u32x2 rr;
         if (res_lds) {
           const int tk = wm * WTOK + m * 16 + l15, ch = (wn * WROWS + n * 16) / 8 + (kg >> 1);
-          rr = *(const u32x2*)(smem + (tk * RCH + (ch ^ (tk & CMASK))) * 16 + (kg & 1) * 8);
+          rr = *(const u32x2*)(smem + res_off + (tk * RCH + (ch ^ (tk & CMASK))) * 16 + (kg & 1) * 8);
         } else {
           rr = *(const u32x2*)(rrow + f);
         }

@@ -106,6 +106,10 @@ class Prepared:
                 self._c[name] = (key, fn())
         return self._c[name][1]
 
+    def clear(self) -> None:
+        """Drop every cached transform (model.train(): the folded copies are only read by inference forwards)."""
+        self._c.clear()
+
 
 def fold_gain(w: torch.Tensor, gain: torch.Tensor) -> torch.Tensor:
     """W' = W * diag(gain), rounded once to W's dtype: x_normed(gain) @ W^T == (x * rstd) @ W'^T up to that rounding."""

@@ -247,8 +247,15 @@ class Phi3DecoderLayer(nn.Module):
         self._prep = ops.Prepared()
 
     def folds(self, h) -> bool:
-        """Inference in bf16: both RMSNorms are folded into the GEMMs around them (forward_folded)."""
-        return h.dtype == torch.bfloat16 and self._fp8 is None and not _ag(h, *self.parameters())
+        """Inference in bf16: both RMSNorms are folded into the GEMMs around them (forward_folded).  Not under parameter
+        sharding (train_ops.CACHE_WT is False there): the gain-folded weight copies are full-size and would stay resident on every
+        rank, which is what FULL_SHARD exists to avoid - an evaluation forward then takes the unfolded path."""
+        return h.dtype == torch.bfloat16 and self._fp8 is None and T.CACHE_WT and not _ag(h, *self.parameters())
+
+    def train(self, mode: bool = True):
+        if mode:
+            self._prep.clear()              # the gain-folded weight copies serve inference only (~5 GB for Phi-3.5-mini)
+        return super().train(mode)
 
     def forward_folded(self, h, st, cos, sin, table, position_ids=None, cache=None):
         """The inference layer without norm launches: h is the raw residual stream and `st` its per-token 1/rms, produced by the
@@ -407,6 +414,11 @@ class Phi3ForCausalLM(nn.Module):
         self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
         self.generation_config = None     # set from the checkpoint's generation_config.json by the loaders (eos ids for generate)
         self._prep = ops.Prepared()
+
+    def train(self, mode: bool = True):
+        if mode:
+            self._prep.clear()              # the gain-folded head copy serves inference only
+        return super().train(mode)
 
     # --- the accessors src/vlm.py:48,80-99 relies on -----------------------------------------------------
     def get_input_embeddings(self):

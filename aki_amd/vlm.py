@@ -214,7 +214,7 @@ class VLMWithLanguageStream(VLM):
 
     def get_fsdp_lambda_fn(self):
         """Predicate `module -> bool` naming the sharding units of the model - every decoder block and the vision tokenizer
-        (the granularity of train/distributed.py:170-222).  `aki_amd.trainer.AkiTrainer(shard_params=True)` cuts its gather /
+        (the granularity of train/distributed.py:170-222).  `aki_amd.trainer.AkiShardedTrainer` cuts its gather /
         reduce-scatter buckets at exactly these module boundaries."""
         blocks = getattr_recursive(self.lang_model, self.decoder_layers_attr_name)
         block_ids = {id(b) for b in blocks}
