@@ -21,7 +21,13 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target)
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    // bounded: nothing guarantees that every workgroup of a plain launch is resident at once (a shared or CU-masked GPU would
+    // otherwise spin here for ever and wedge the device) - after ~50 ms of wall clock the barrier gives up and traps
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > 5000000ull) __builtin_trap();      // 100 MHz ticks
+    }
   }
   __syncthreads();
 }
