@@ -230,3 +230,57 @@ def test_bench_gpus_2_starts_its_own_ranks():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
                            capture_output=True, text=True, env=env, timeout=300, cwd=root)
         assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], (r.returncode, r.stdout[-500:])
+
+
+def _accum_worker(rank, world, port, shard, ret):
+    """Each rank owns two samples and runs them as TWO micro-batches of one sample (gradient accumulation, fp32 sum), then one
+    exchange + optimizer step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from aki_amd.trainer import AkiTrainer
+    m, vx, lx, am, lab = _setup()
+    tr = AkiTrainer(m, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1, bucket_bytes=1 << 20, shard_optimizer=shard)
+    launched = []
+    orig = tr.reducer._launch
+    tr.reducer._launch = lambda b: (launched.append(1), orig(b))[1]
+    tr.zero_grad()
+    for i in range(2):
+        j = 2 * rank + i
+        loss = m(vx[j:j + 1], lx[j:j + 1], attention_mask=am[j:j + 1], labels=lab[j:j + 1]).loss / 2
+        n_before = len(launched)
+        tr.backward(loss, last_microbatch=(i == 1))
+        if i == 0:
+            assert len(launched) == n_before, "a non-final micro-batch must not exchange anything"
+    assert len(launched) >= 3
+    tr.optimizer_step()
+    ret[rank] = (_weights_in_param_order(tr), float(tr.grad_norm()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("shard", [False, True], ids=["allreduce", "sharded"])
+def test_two_rank_gradient_accumulation_matches_single_process(shard):
+    """Gradient accumulation under data parallelism: 2 ranks x 2 micro-batches of one sample (fp32 accumulation, the exchange only
+    after the last micro-batch) against one process accumulating the same four samples - the loss weighting is the same on both
+    sides (every micro-batch is one sample, loss / 2 per rank and 1 / world in the optimizer vs loss / 4), so the weights after the
+    step agree to bf16 rounding of the exchanged sums."""
+    from aki_amd.trainer import AkiTrainer
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_accum_worker, args=(world, _free_port(), shard, ret), nprocs=world, join=True)
+    (w0, g0), (w1, g1) = ret[0], ret[1]
+    assert torch.equal(w0, w1), "replicas diverged"
+    m, vx, lx, am, lab = _setup()
+    tr = AkiTrainer(m, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1)
+    tr.zero_grad()
+    for j in range(4):
+        tr.backward(m(vx[j:j + 1], lx[j:j + 1], attention_mask=am[j:j + 1], labels=lab[j:j + 1]).loss / 4, last_microbatch=(j == 3))
+    tr.optimizer_step()
+    wref = _weights_in_param_order(tr)
+    assert abs(g0 - float(tr.grad_norm())) < 0.03 * float(tr.grad_norm()) + 1e-3, (g0, float(tr.grad_norm()))
+    diff = (w0 - wref).abs()
+    assert float(diff.mean()) < 2e-4 and float(diff.max()) <= 2 * 2 ** -7, (float(diff.mean()), float(diff.max()))
