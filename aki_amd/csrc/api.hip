@@ -100,12 +100,12 @@ void aki_lab_set_gemm_tile(int mode) {
   aki::g_deep_ring = (mode & 256) ? 0 : 1;
   aki::g_pipe = (mode & 512) ? 0 : ((mode & 1024) ? 2 : 1);     // +1024: pipeline without the residual prefetch
   mode &= 255;
-  aki::g_force_tile = (mode >= 1 && mode <= 3) ? mode : 0;
+  aki::g_force_tile = (mode >= 1 && mode <= 4) ? mode : 0;
 }
 // 0 = product choice, 1 = 32-row attention core (two waves per SIMD), 2 = 64-row core (one wave per SIMD)
 void aki_lab_set_attn_variant(int v) { aki::g_attn_variant = v; }
 // device pointer to two int64: every bf16 GEMM launch then leaves {shader cycles, 100 MHz wall ticks} of its workgroup 0 there
-void aki_lab_set_clock_probe(void* two_int64) { aki::g_clock_probe = (long long*)two_int64; }
+void aki_lab_set_clock_probe(void* int64x32) { aki::g_clock_probe = (long long*)int64x32; }   // 32 int64 (layout: GemmParams::clock_probe)
 #endif
 
 // ---- attention core --------------------------------------------------------------------------------

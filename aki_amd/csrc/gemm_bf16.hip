@@ -33,6 +33,21 @@ namespace aki {
 
 enum { EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_QKV_ROPE8 = 3 };
 
+// compile-time loops (the hand-placed K-loop below needs immediates for the fragment index and the ds_read offset)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_impl(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_impl<I + 1, N>(f);
+  }
+}
+// chunk swizzle of a 64-byte-row LDS image read with ds_read_b128 by MFMA 16x16x32 fragment lanes (row = lane & 15, chunk = lane >> 4):
+// the instruction's four lane groups are {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS), so the
+// four lanes of a group that share row & 3 are rows q = 0, 3 of one chunk and q = 1, 2 of the next (q = row >> 2); 0, 3, 2, 1 keeps them apart
+__device__ __forceinline__ int swz4(int q) { return (q & 3) ^ ((q & 1) << 1); }
+template <class F> __device__ __forceinline__ void static_for16(F&& f) { static_for_impl<0, 16>(f); }
+template <class F> __device__ __forceinline__ void static_for64(F&& f) { static_for_impl<0, 64>(f); }
+
 // EPI_QKV_ROPE8: QKV + RoPE on the generic 256x256 / 128x128 tiles.  RoPE only needs d and d + 48 of a head in the same lane
 // and register slot, not a whole head per wave, so the 3*H*96 output features are re-ordered into 32-feature UNITS - for q
 // and k: (head slot hs, j) = d in [16j, 16j+16) plus its rotate-half partner block [48+16j, ...); for v: 32 consecutive d -
@@ -86,7 +101,7 @@ struct GemmParams {
   float* st_part;      // [slots][2][M] partial sums (sum of squares, sum), slot = tile column * WN + wave column
   unsigned* st_cnt;    // [tiles_m] arrival counters, zero between launches
 #ifdef AKI_LAB_HOOKS
-  long long* clock_probe;   // lab: {shader cycles, 100 MHz ticks} of workgroup 0
+  long long* clock_probe;   // lab: 32 int64: {shader cycles, 100 MHz ticks} of workgroup 0, [2..17] phase sums of the PIPE 3 loop, [18] prologue, [19] epilogue cycles
 #endif
   float st_eps;
 };
@@ -108,7 +123,7 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 // LDS row then holds BK = 128 k-values instead of 64, so staging, swizzle and the epilogues are byte-for-byte the same; the
 // per-row dequantisation scales (one per token, one per weight row) multiply the f32 accumulators before the epilogue.
 template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false, int NST = 2, int PIPE = 0>
-__global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int BK = FP8 ? 128 : 64, ES = FP8 ? 1 : 2, NWAVES = WN * WM;
   constexpr int WROWS = NF * 16;      // features per wave
   constexpr int BN = WN * WROWS;      // features per block tile
@@ -162,10 +177,13 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   const char* src[NLD];
 #pragma unroll
   for (int j = 0; j < NLD; ++j) {
+    // PIPE == 3 keeps the two k32 halves of a tile in separate 32 KiB regions (64-byte rows; a 1-KiB piece = 16 rows of one half,
+    // 16-byte chunk c of row r at position c ^ swz4(r >> 2)): a half is re-filled as soon as ITS fragments have been read
     const int rowgroup = j * NWAVES + wave;
-    const int row = rowgroup * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    if (rowgroup * 8 < BN) {
+    const int row = PIPE == 3 ? rowgroup * 16 + (lane >> 2) : rowgroup * 8 + (lane >> 3);
+    const int chunk = PIPE == 3 ? (lane & 3) ^ swz4(row >> 2) : (lane & 7) ^ ((row >> 1) & 7);
+    if (PIPE == 3 && j >= NLD / 2) { src[j] = nullptr; continue; }
+    if (row < BN) {
       const int wr = weight_row(row);
       const char* wp = (const char*)p.w + (size_t)wr * p.ldw * ES;
       if (EPI == EPI_PLAIN && !FP8) {
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   const int fwave = n0 + wn * (EPI == EPI_SWIGLU ? WROWS / 2 : WROWS);
   // folded LayerNorm (consumer), kernel-uniform.  Not on the PIPELINED 256^2 tile: its epilogue has no registers left for the
   // column sums (they spilled); the host sends row_shift launches that want the big tile to its unpipelined twin.
-  const bool shifted = !PIPE && (EPI == EPI_PLAIN) && p.row_shift != nullptr;
+  const bool shifted = PIPE <= 1 && (EPI == EPI_PLAIN) && p.row_shift != nullptr;
   u32x2 biasp[NOUT];
   f32x4 colc4[NOUT];
   float rsv[NT], muv[NT];
@@ -273,7 +291,127 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
       }
     }
   };
-  if constexpr (PIPE) {
+#ifdef AKI_LAB_HOOKS
+  long long probe_l0 = 0, probe_l1 = 0;                  // K-loop begin / end of workgroup 0 -> clock_probe[18] = prologue, [19] = epilogue cycles
+  if (blockIdx.x == 0 && tid == 0 && p.clock_probe) probe_l0 = clock64();
+#endif
+  if constexpr (PIPE == 3) {
+    // One wave per SIMD with a hand-placed stream (lab).  Four waves, wave tile 128 features x 128 tokens: 256 accumulator registers
+    // in the AGPR half of the file, the fragments of both k32 halves (128 VGPRs) in the other - a third fewer LDS fragment bytes
+    // per FLOP than the 8-wave tile, and 95 instead of 134 other instructions per 128 MFMAs and SIMD.  This is the structure of the
+    // vendor library's kernel for these shapes (MT256x256x64, 256 threads; profiles/r03_hipblaslt_kernel_name.csv).  Left to hipcc's
+    // register allocation the same tile moved fragments through AGPRs (132 v_accvgpr_* per K-step) and ran 16-20 % slower; here every
+    // MFMA is an asm statement with the accumulator constrained to an AGPR and the fragment reads are asm too, in program order:
+    // one ds_read_b128 behind every 4th MFMA of the first half-step (the k32-half-1 fragments of tile kt), one read or one LDS-DMA
+    // piece behind every 2nd MFMA of the second (half-0 fragments of tile kt+1, the 16 pieces of tile kt+2); waits are explicit.
+    static_assert(PIPE != 3 || (NF == 8 && NT == 8 && WN == 2 && WM == 2 && NST == 2 && !FP8 && NLD == 16), "256 x 256 tile on four waves");
+    const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
+    // stage buffer = [k32 half][512 rows: 256 features, 256 tokens][64 B]; stage 1 = address ^ STAGE_BYTES (64 KiB buffers, 64 KiB aligned)
+    constexpr int HALF_BYTES = STAGE_BYTES / 2;
+    const unsigned cpos = (unsigned)((kg ^ swz4(l15 >> 2)) << 4);
+    unsigned adrA0 = lds0 + (wn * WROWS + l15) * 64 + cpos, adrB0 = lds0 + (BN + wm * WTOK + l15) * 64 + cpos;
+    unsigned adrA1 = adrA0 + HALF_BYTES, adrB1 = adrB0 + HALF_BYTES;
+    bf16x8 a0[8], b0[8], a1[8], b1[8];
+#define AKI_DSR(dst, adr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(adr), "n"(OFF))
+#define AKI_MFMA(n_, m_, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[n_][m_]) : "v"(A_[n_]), "v"(B_[m_]))
+    auto read_frag = [&](auto idx, bf16x8 (&fa)[8], bf16x8 (&fb)[8], unsigned adra, unsigned adrb) {   // fragment 0..7 = features, 8..15 = tokens
+      constexpr int I = decltype(idx)::value;
+      if constexpr (I < 8) AKI_DSR(fa[I], adra, I * 1024); else AKI_DSR(fb[I - 8], adrb, (I - 8) * 1024);
+    };
+    constexpr int NH = NLD / 2;                                  // DMA pieces per wave and half tile
+    auto dma_piece = [&](auto jj, int s, int h, int kt_) {
+      constexpr int J = decltype(jj)::value;
+      char* dst = smem + s * STAGE_BYTES + h * HALF_BYTES + (J * NWAVES + wave) * 1024;
+      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[J] + (size_t)kt_ * 128 + h * 64), AKI_LDS_PTR(dst), 16, 0, 0);
+    };
+    // DMA order: (tile 0, half 0), (0, 1), (1, 0), (1, 1), then one half per half-step: (kt+2, h) during half-step (kt, h), into the region
+    // whose fragments every wave has finished reading at the barrier in front of that half-step.  A half then has a step and a half to land:
+    // it is awaited - counted, the two younger halves stay in flight - at the barrier in front of the half-step that READS it.
+    static_for_impl<0, NH>([&](auto j) { dma_piece(j, 0, 0, 0); });
+    static_for_impl<0, NH>([&](auto j) { dma_piece(j, 0, 1, 0); });
+    if (nk > 1) {
+      static_for_impl<0, NH>([&](auto j) { dma_piece(j, 1, 0, 1); });
+      static_for_impl<0, NH>([&](auto j) { dma_piece(j, 1, 1, 1); });
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NH) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    static_for16([&](auto i) { read_frag(i, a0, b0, adrA0, adrB0); });
+#ifdef AKI_LAB_HOOKS
+    // phase stamps (lab): shader cycles per wave of workgroup 0 spent in {top wait + barrier, first half-step, mid wait + barrier,
+    // second half-step}, summed over the K loop -> clock_probe[2 + 4 * wave ..].  s_memtime returns through lgkmcnt: a stamp is only
+    // read behind one of the loop's own lgkmcnt(0) waits (SETTLE pins that for the compiler), so the stamps add no wait of their own.
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, ph_a = 0, ph_b = 0, ph_c = 0, ph_d = 0;
+#define AKI_STAMP(t) asm volatile("s_memtime %0" : "=s"(t))
+#define AKI_SETTLE() asm volatile("" : "+s"(t0), "+s"(t1), "+s"(t2), "+s"(t3), "+s"(t4))
+#else
+#define AKI_STAMP(t)
+#define AKI_SETTLE()
+#endif
+    // one K-step; NEXT1 / NEXT2 (compile time): tiles kt+1 / kt+2 exist.  The 16 fragment reads of a half-step go out behind its FIRST
+    // 16 MFMAs (they are then 48 MFMAs = ~770 cycles old at the wait that needs them), the 8 DMA pieces behind every 4th MFMA after those
+    auto step3 = [&](int kt, auto n1, auto n2) {
+      constexpr bool NEXT1 = decltype(n1)::value, NEXT2 = decltype(n2)::value;
+      // half-0 fragments of tile kt are in a0 / b0; my pieces of (kt, half 1) have landed
+      AKI_STAMP(t0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEXT1 ? 2 * NH : 0) : "memory");
+      __builtin_amdgcn_s_barrier();                              // ... everybody's have, and nobody reads (kt, half 0) from LDS any more
+#ifdef AKI_LAB_HOOKS
+      AKI_SETTLE();
+      ph_c += t3 - t2; ph_d += t4 - t3;                          // the previous step's second half
+#endif
+      AKI_STAMP(t1);
+      static_for64([&](auto ii) {                                // first half-step: MFMAs on a0 / b0, half-1 fragments of tile kt -> a1 / b1
+        constexpr int I = decltype(ii)::value, N_ = I >> 3, M_ = I & 7;
+        AKI_MFMA(N_, M_, a0, b0);
+        if constexpr (I < 16) read_frag(std::integral_constant<int, I>{}, a1, b1, adrA1, adrB1);
+        if constexpr (NEXT2 && I >= 17 && I < 65 && (I - 17) % 6 == 0) dma_piece(std::integral_constant<int, ((I - 17) / 6)>{}, kt & 1, 0, kt + 2);
+      });
+      AKI_STAMP(t2);
+      if constexpr (NEXT1) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEXT2 ? 2 * NH : NH) : "memory");   // (kt+1, half 0) has landed; my reads of (kt, half 1) are done
+        __builtin_amdgcn_s_barrier();
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+#ifdef AKI_LAB_HOOKS
+      AKI_SETTLE();
+      ph_a += t1 - t0; ph_b += t2 - t1;
+#endif
+      AKI_STAMP(t3);
+      adrA0 ^= STAGE_BYTES; adrA1 ^= STAGE_BYTES; adrB0 ^= STAGE_BYTES; adrB1 ^= STAGE_BYTES;       // tile kt+1's buffer
+      static_for64([&](auto ii) {                                // second half-step: MFMAs on a1 / b1; tile kt+1's half-0 fragments
+        constexpr int I = decltype(ii)::value, N_ = I >> 3, M_ = I & 7;
+        AKI_MFMA(N_, M_, a1, b1);
+        if constexpr (NEXT1 && I < 16) read_frag(std::integral_constant<int, I>{}, a0, b0, adrA0, adrB0);
+        if constexpr (NEXT2 && I >= 17 && I < 65 && (I - 17) % 6 == 0) dma_piece(std::integral_constant<int, ((I - 17) / 6)>{}, kt & 1, 1, kt + 2);
+      });
+      AKI_STAMP(t4);
+    };
+    {
+      int kt = 0;
+      for (; kt + 2 < nk; ++kt) step3(kt, std::true_type{}, std::true_type{});
+      if (kt + 1 < nk) { step3(kt, std::true_type{}, std::false_type{}); ++kt; }
+      step3(kt, std::false_type{}, std::false_type{});
+    }
+#ifdef AKI_LAB_HOOKS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    AKI_SETTLE();
+    ph_c += t3 - t2; ph_d += t4 - t3;
+    if (blockIdx.x == 0 && lane == 0 && p.clock_probe) {
+      p.clock_probe[2 + 4 * wave + 0] = (long long)ph_a; p.clock_probe[2 + 4 * wave + 1] = (long long)ph_b;
+      p.clock_probe[2 + 4 * wave + 2] = (long long)ph_c; p.clock_probe[2 + 4 * wave + 3] = (long long)ph_d;
+    }
+#endif
+#undef AKI_STAMP
+#undef AKI_SETTLE
+    // hipcc does not see the asm MFMAs as matrix instructions: it pads no XDL-write -> VALU-read hazard in front of the epilogue's
+    // accumulator reads - the last MFMA (8 passes) has to have retired
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#undef AKI_DSR
+#undef AKI_MFMA
+  } else if constexpr (PIPE) {
     // Mid-step barrier pipeline (bf16, 2 stages).  In the loop below every LDS fragment read of a K-step sits between
     // the barrier and the MFMAs that need it, and all eight waves do theirs at the same time: the LDS array (24
     // ds_read_b128 per wave and step, ~770 array cycles per CU) and then the matrix cores (2048 cycles per SIMD) take
@@ -405,6 +543,9 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     }
   }
 
+#ifdef AKI_LAB_HOOKS
+  if (blockIdx.x == 0 && tid == 0 && p.clock_probe) probe_l1 = clock64();
+#endif
   if constexpr (FP8) {   // dequantise: acc[feature][token] *= sw[weight row] * sx[token]
     float sxm[NT];
 #pragma unroll
@@ -458,6 +599,10 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
       }
       __syncthreads();
     }
+#ifdef AKI_LAB_HOOKS
+    long long probe_s = 0;
+    if (blockIdx.x == 0 && tid == 0 && p.clock_probe) probe_s = clock64();
+#endif
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
       const int mrow = m0 + wm * WTOK + m * 16 + l15;
@@ -498,6 +643,15 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
         if (ok) *(u32x4*)(dst + dw) = o;
       }
     }
+#ifdef AKI_LAB_HOOKS
+    if (blockIdx.x == 0 && tid == 0 && p.clock_probe) {
+      p.clock_probe[0] = clock64() - probe_c0;
+      p.clock_probe[1] = wall_clock64() - probe_w0;
+      p.clock_probe[18] = probe_l0 - probe_c0;
+      p.clock_probe[19] = clock64() - probe_l1;
+      p.clock_probe[20] = probe_s - probe_l1;            // cos / sin staging
+    }
+#endif
     return;
   }
 
@@ -528,94 +682,155 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     __syncthreads();
   }
   const bool stats = (EPI == EPI_PLAIN) && p.st_part != nullptr;         // kernel-uniform
+  // The rows of the tile.  Each of the switches (tile inside the output, bias, residual, statistics, row scale, row shift) is
+  // 0 = no, 1 = yes or 2 = decided at run time.  With all of them decided at run time - the general path - the per-lane predicates put an
+  // exec-mask branch around every bias add, residual read and store (~20 basic blocks per token block), the residual pointer is LDS-or-
+  // global and so a FLAT load with a vmcnt(0) + lgkmcnt(0) wait behind each of the 32 reads (draining the stores in front), and the
+  // statistics arithmetic is speculated into launches that do not ask for it: 9-14 k cycles per tile, uncontended (tools/
+  // gemm_epilogue_probe.py).  The combinations the model launches on interior tiles are compiled as straight-line variants instead.
+  auto write_rows = [&](auto full_, auto hb_, auto hr_, auto hs_, auto hsc_, auto hsh_) {
+    constexpr int FULLK = decltype(full_)::value, HB = decltype(hb_)::value, HR = decltype(hr_)::value, HS = decltype(hs_)::value,
+                  HSC = decltype(hsc_)::value, HSH = decltype(hsh_)::value;
+    constexpr bool FULL = FULLK == 1;
+    const bool has_bias = EPI == EPI_PLAIN && (HB == 2 ? p.bias != nullptr : HB == 1);
+    const bool has_res = HR == 2 ? p.residual != nullptr : HR == 1;
+    const bool in_lds = HR == 2 ? res_lds : true;               // HR == 1: the dispatch below only takes staged residual tiles
+    const bool has_stats = EPI == EPI_PLAIN && (HS == 2 ? stats : HS == 1);
+    const bool has_shift = EPI == EPI_PLAIN && (HSH == 2 ? shifted : HSH == 1);
+    const bool wide = FULL || (NOUT % 2 == 0 && p.wide);
+    const __attribute__((address_space(3))) char* const lres = (const __attribute__((address_space(3))) char*)AKI_LDS_PTR(smem) + res_off;
 #pragma unroll
-  for (int m = 0; m < NT; ++m) {
-    const int mrow = m0 + wm * WTOK + m * 16 + l15;
-    const bool ok = mrow < p.M;
-    const int mr = min(mrow, p.M - 1);
-    bf16_t* yrow = p.y + (size_t)mr * p.ldy;
-    const bf16_t* rrow = nullptr;
-    if (p.residual) rrow = p.residual + (size_t)(p.res_row_mod > 0 ? (mr + p.m_offset) % p.res_row_mod : mr) * p.ldr;
-    const float rs = rsv[m], mu = muv[m];
-    float v[NOUT][4];
+    for (int m = 0; m < NT; ++m) {
+      const int tk = wm * WTOK + m * 16 + l15;
+      const int mrow = m0 + tk;
+      const bool ok = FULL || mrow < p.M;
+      const int mr = FULL ? mrow : min(mrow, p.M - 1);
+      bf16_t* yrow = p.y + (size_t)mr * p.ldy;
+      const bf16_t* rrow = nullptr;
+      if (HR == 2 && has_res) rrow = p.residual + (size_t)(p.res_row_mod > 0 ? (mr + p.m_offset) % p.res_row_mod : mr) * p.ldr;
+      const float rs = rsv[m], mu = muv[m];
+      float v[NOUT][4];
+      u32x2 rr[NOUT];
+      if (HR == 1) {                                             // all of the token block's residual reads first: one wait for the lot
 #pragma unroll
-    for (int n = 0; n < NOUT; ++n) {
-      const int f = fwave + n * 16 + 4 * kg;       // this lane's 4 features of block n
-      const bool fin = f < n_out;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (EPI == EPI_SWIGLU) {
-          const float g = acc[n][m][r] * rs, u = acc[n + NF / 2][m][r] * rs;
-          v[n][r] = u * silu_fast(g);
-        } else if (EPI == EPI_PLAIN && shifted) {
-          v[n][r] = (acc[n][m][r] - mu * colc4[n][r]) * rs;
-        } else {
-          v[n][r] = acc[n][m][r] * rs;
+        for (int n = 0; n < NOUT; ++n) {
+          const int ch = (wn * WROWS + n * 16) / 8 + (kg >> 1);
+          rr[n] = *(const __attribute__((address_space(3))) u32x2*)(lres + (tk * RCH + (ch ^ (tk & CMASK))) * 16 + (kg & 1) * 8);
         }
       }
-      if (EPI == EPI_PLAIN) {
-        if (p.bias && fin) {
-          v[n][0] += bf16_lo(biasp[n][0]); v[n][1] += bf16_hi(biasp[n][0]); v[n][2] += bf16_lo(biasp[n][1]); v[n][3] += bf16_hi(biasp[n][1]);
-        }
-        if (ACT == AKI_ACT_GELU_ERF) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[n][r] = gelu_erf_fast(v[n][r]);
-        } else if (ACT == AKI_ACT_GELU_TANH) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[n][r] = gelu_tanh_fast(v[n][r]);
-        }
-      }
-      if (rrow && fin) {
-        u32x2 rr;
-        if (res_lds) {
-          const int tk = wm * WTOK + m * 16 + l15, ch = (wn * WROWS + n * 16) / 8 + (kg >> 1);
-          rr = *(const u32x2*)(smem + res_off + (tk * RCH + (ch ^ (tk & CMASK))) * 16 + (kg & 1) * 8);
-        } else {
-          rr = *(const u32x2*)(rrow + f);
-        }
-        v[n][0] += bf16_lo(rr[0]); v[n][1] += bf16_hi(rr[0]); v[n][2] += bf16_lo(rr[1]); v[n][3] += bf16_hi(rr[1]);
-      }
-    }
-    if (EPI == EPI_PLAIN && stats) {
-      // producer: this wave's share of the token's sum / sum of squares over the tile's features, of the values AS STORED
-      // (bf16); the four lanes that hold a token (kg = 0..3) fold theirs, lane kg == 0 writes through (sc1) for the reducer
-      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int n = 0; n < NOUT; ++n) {
-        const bool fin = fwave + n * 16 + 4 * kg < n_out;
+        const int f = fwave + n * 16 + 4 * kg;       // this lane's 4 features of block n
+        const bool fin = FULL || f < n_out;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float vb = fin ? round_bf16(v[n][r]) : 0.f;
-          s1 += vb;
-          s2 += vb * vb;
+          if (EPI == EPI_SWIGLU) {
+            const float g = HSC == 0 ? acc[n][m][r] : acc[n][m][r] * rs, u = HSC == 0 ? acc[n + NF / 2][m][r] : acc[n + NF / 2][m][r] * rs;
+            v[n][r] = u * silu_fast(g);
+          } else if (has_shift) {
+            v[n][r] = (acc[n][m][r] - mu * colc4[n][r]) * rs;
+          } else {
+            v[n][r] = HSC == 0 ? acc[n][m][r] : acc[n][m][r] * rs;
+          }
+        }
+        if (EPI == EPI_PLAIN) {
+          if (has_bias && fin) {
+            v[n][0] += bf16_lo(biasp[n][0]); v[n][1] += bf16_hi(biasp[n][0]); v[n][2] += bf16_lo(biasp[n][1]); v[n][3] += bf16_hi(biasp[n][1]);
+          }
+          if (ACT == AKI_ACT_GELU_ERF) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[n][r] = gelu_erf_fast(v[n][r]);
+          } else if (ACT == AKI_ACT_GELU_TANH) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[n][r] = gelu_tanh_fast(v[n][r]);
+          }
+        }
+        if (HR == 2 && has_res && fin) {
+          if (in_lds) {
+            const int ch = (wn * WROWS + n * 16) / 8 + (kg >> 1);
+            rr[n] = *(const __attribute__((address_space(3))) u32x2*)(lres + (tk * RCH + (ch ^ (tk & CMASK))) * 16 + (kg & 1) * 8);
+          } else {
+            rr[n] = *(const u32x2*)(rrow + f);
+          }
+        }
+        if (has_res && fin) {
+          v[n][0] += bf16_lo(rr[n][0]); v[n][1] += bf16_hi(rr[n][0]); v[n][2] += bf16_lo(rr[n][1]); v[n][3] += bf16_hi(rr[n][1]);
         }
       }
-      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-      if (kg == 0 && ok) {   // one 8-byte write-through store: {sum of squares, sum}
-        unsigned long long* pp = (unsigned long long*)p.st_part + (size_t)(tn * WN + wn) * p.M + mrow;
-        const unsigned long long both = (unsigned long long)__float_as_uint(s2) | ((unsigned long long)__float_as_uint(s1) << 32);
-        __hip_atomic_store(pp, both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    if (NOUT % 2 == 0 && p.wide) {   // 16-byte stores pair two feature blocks
+      unsigned pk[NOUT][2];                                      // the values AS STORED
 #pragma unroll
-      for (int n = 0; n + 1 < NOUT; n += 2) {
-        const u32x4 o = pair_to_wide(pack_bf16x2(v[n][0], v[n][1]), pack_bf16x2(v[n][2], v[n][3]),
-                                     pack_bf16x2(v[n + 1][0], v[n + 1][1]), pack_bf16x2(v[n + 1][2], v[n + 1][3]));
-        const int f = fwave + (n + (kg & 1)) * 16 + 8 * (kg >> 1);
-        if (ok && f < n_out) *(u32x4*)(yrow + f) = o;
-      }
-    } else {
+      for (int n = 0; n < NOUT; ++n) { pk[n][0] = pack_bf16x2(v[n][0], v[n][1]); pk[n][1] = pack_bf16x2(v[n][2], v[n][3]); }
+      if (has_stats) {
+        // producer: this wave's share of the token's sum / sum of squares over the tile's features, of the values AS STORED
+        // (bf16); the four lanes that hold a token (kg = 0..3) fold theirs, lane kg == 0 writes through (sc1) for the reducer
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int n = 0; n < NOUT; ++n) {
-        const int f = fwave + n * 16 + 4 * kg;
-        if (ok && f < n_out) {
-          u32x2 o = {pack_bf16x2(v[n][0], v[n][1]), pack_bf16x2(v[n][2], v[n][3])};
-          *(u32x2*)(yrow + f) = o;
+        for (int n = 0; n < NOUT; ++n) {
+          const bool fin = FULL || fwave + n * 16 + 4 * kg < n_out;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned w_ = pk[n][r >> 1];
+            const float vb = fin ? ((r & 1) ? bf16_hi(w_) : bf16_lo(w_)) : 0.f;
+            s1 += vb;
+            s2 += vb * vb;
+          }
+        }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (kg == 0 && ok) {   // one 8-byte write-through store: {sum of squares, sum}
+          unsigned long long* pp = (unsigned long long*)p.st_part + (size_t)(tn * WN + wn) * p.M + mrow;
+          const unsigned long long both = (unsigned long long)__float_as_uint(s2) | ((unsigned long long)__float_as_uint(s1) << 32);
+          __hip_atomic_store(pp, both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // (A 16-byte store out of the fragment layout covers 16 rows x 64 bytes; alone on the chip such stores leave a CU at 74 cycles apiece
+      // against 20 for 4 rows x 256 bytes - tools/store_tail_probe.hip - but turning the wave's rows through an LDS patch to get that shape
+      // bought nothing at the model's shapes: the tail of a full round is bound by the write-back of 32 MB, and in a multi-round launch it
+      // drains under the next workgroup's K loop; profiles/r03_store_tail_probe.txt.)
+      if (wide) {   // 16-byte stores pair two feature blocks
+#pragma unroll
+        for (int n = 0; n + 1 < NOUT; n += 2) {
+          const u32x4 o = pair_to_wide(pk[n][0], pk[n][1], pk[n + 1][0], pk[n + 1][1]);
+          const int f = fwave + (n + (kg & 1)) * 16 + 8 * (kg >> 1);
+          if (ok && (FULL || f < n_out)) *(u32x4*)(yrow + f) = o;
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+          const int f = fwave + n * 16 + 4 * kg;
+          if (ok && f < n_out) {
+            u32x2 o = {pk[n][0], pk[n][1]};
+            *(u32x2*)(yrow + f) = o;
+          }
         }
       }
     }
+  };
+  {
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+    const bool inside = m0 + BM <= p.M && n0 + (EPI == EPI_SWIGLU ? BN / 2 : BN) <= n_out;
+    const bool fast = inside && NOUT % 2 == 0 && p.wide && (p.residual == nullptr || (EPI == EPI_PLAIN && res_lds));   // workgroup-uniform
+    const int key = (EPI == EPI_PLAIN && p.bias ? 1 : 0) | (p.residual ? 2 : 0) | (stats ? 4 : 0) | (p.row_scale ? 8 : 0) | (shifted ? 16 : 0);
+    bool done = false;
+    if (fast) {
+      done = true;
+      if (key == 0) write_rows(c1{}, c0{}, c0{}, c0{}, c0{}, c0{});                    // plain
+      else if (key == 8) write_rows(c1{}, c0{}, c0{}, c0{}, c1{}, c0{});               // folded RMSNorm (gate_up, lm_head)
+      else if constexpr (EPI == EPI_PLAIN) {
+        if (key == 1) write_rows(c1{}, c1{}, c0{}, c0{}, c0{}, c0{});                  // bias
+        else if (key == 2) write_rows(c1{}, c0{}, c1{}, c0{}, c0{}, c0{});             // residual
+        else if (key == 3) write_rows(c1{}, c1{}, c1{}, c0{}, c0{}, c0{});             // bias + residual
+        else if (key == 6) write_rows(c1{}, c0{}, c1{}, c1{}, c0{}, c0{});             // residual + statistics (o_proj, down)
+        else if (key == 7) write_rows(c1{}, c1{}, c1{}, c1{}, c0{}, c0{});             // + bias (SigLIP out / fc2)
+        else if constexpr (PIPE <= 1) {
+          if (key == 25) write_rows(c1{}, c1{}, c0{}, c0{}, c1{}, c1{});               // folded LayerNorm + bias (SigLIP qkv / fc1)
+          else done = false;
+        } else done = false;
+      } else done = false;
+    }
+    if (!done) write_rows(c0{}, c2{}, c2{}, c2{}, c2{}, c2{});
   }
   if (EPI == EPI_PLAIN && stats) {
     // Row statistics: the LAST tile of a row panel to get here folds the panel's partial sums in a fixed order (the result
@@ -623,6 +838,8 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
     // cdna_hip_programming.md Guideline 16 (R1 / ticket form): write-through partials, every storing wave drains them,
     // barrier, one lane draws a ticket; the reducer reads the partials with agent-scope loads.  It puts the counter back
     // to zero - the counters are zero again when the launch ends.
+    // (Drawing the ticket AHEAD of the tile's output stores, so that its round trip runs under their issue-bound tail, was measured and is
+    // slower: the write-through partials then drain alone, 21.8 k against 16.9 k epilogue cycles; profiles/r03_gemm_epilogue_probe.txt.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned* const flag = (unsigned*)smem;
@@ -687,6 +904,8 @@ __global__ __launch_bounds__(WN* WM * 64, 2) void gemm_bf16_kernel(const GemmPar
   if (blockIdx.x == 0 && tid == 0 && p.clock_probe) {
     p.clock_probe[0] = clock64() - probe_c0;
     p.clock_probe[1] = wall_clock64() - probe_w0;
+    p.clock_probe[18] = probe_l0 - probe_c0;
+    p.clock_probe[19] = clock64() - probe_l1;
   }
 #endif
 }
@@ -792,11 +1011,15 @@ static int launch_small(GemmParams& p, hipStream_t stream) {
 template <int EPI, int ACT, bool FP8>
 static int launch_big(GemmParams& p, hipStream_t stream) {
   if constexpr (!FP8) {
+#ifdef AKI_LAB_HOOKS
+    // lab: the same 256 x 256 tile on FOUR waves, one per SIMD (wave tile 128 features x 128 tokens, 256 accumulator registers)
+    if (g_force_tile == 4 && p.row_shift == nullptr) return launch_gemm<8, 8, 2, 2, EPI, ACT, FP8, 2, 3>(p, stream);
+#endif
     if constexpr (EPI == EPI_PLAIN && ACT == 0) {   // residual tile prefetched under the last K-steps (o_proj, down_proj)
       if (g_pipe == 1 && p.row_shift == nullptr && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && p.N % 8 == 0 && p.N >= 8)
         return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 2>(p, stream);
     }
-    if (g_pipe && p.row_shift == nullptr) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 1>(p, stream);
+    if (g_pipe) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 1>(p, stream);
   }
   return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8>(p, stream);
 }

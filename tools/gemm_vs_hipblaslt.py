@@ -46,10 +46,16 @@ def main():
         shapes = [sh for sh in shapes if sh[0] in a.shapes.split(",")]
     from aki_amd import _lib as L
 
-    def lab_arm(mode, fn):
+    lab_lib = L.load_lab() if a.lab_modes else None
+    prod_lib = L.load()
+
+    def lab_arm(mode, fn):          # the lab twin is bound ONCE; an arm only switches the library handle and the tile mode
         def run():
-            with L.use_lab(mode):
-                fn()
+            L._lib = lab_lib
+            lab_lib.aki_lab_set_gemm_tile(mode)
+            fn()
+            lab_lib.aki_lab_set_gemm_tile(0)
+            L._lib = prod_lib
         return run
     out = []
     for name, N, K in shapes:
