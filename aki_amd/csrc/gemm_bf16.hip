@@ -255,6 +255,8 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
                              (BM * RCH * 16) % (NWAVES * 1024) == 0;
   const bool res_pf = RES_PF_OK && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && n_out >= 8;   // workgroup-uniform
   int res_off = 0;                 // where the residual tile image sits in smem
+  // QKV + RoPE on the pipelined 256 x 256 tile: cos / sin rows prefetched under the last half K-step (issue_cos_sin below); workgroup-uniform
+  const bool cs_pf = EPI == EPI_QKV_ROPE8 && PIPE == 1 && BM == 256 && n0 / 32 < 6 * p.H && p.position_ids == nullptr && p.L >= BM;
   if constexpr (EARLY_OPERANDS) fetch_epilogue_operands();
   auto compute = [&](const char* sb) {
     if constexpr (FP8) {   // one k128 step per BK: the lane's 32 bytes are chunks 2kg and 2kg+1 of its row
@@ -476,6 +478,27 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
         __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src_), AKI_LDS_PTR(smem + hb * STAGE_BYTES + q * 1024), 16, 0, 0);
       }
     };
+    // QKV + RoPE: the cos / sin rows of the tile's tokens (the epilogue's LDS image: token row r at r * 400, 12 chunks of cos[0:48], 12 of
+    // sin[0:48], one pad chunk) come in by LDS-DMA under the LAST half K-step - behind its barrier nobody reads the stage buffers any more -
+    // instead of after the loop, where the round trip plus 12 ds_write_b128 per thread cost every tile ~6 k cycles (tools/
+    // gemm_epilogue_probe.py).  100 pieces of 1 KiB, lane i of piece q = chunk (64 q + i) % 25 of row (64 q + i) / 25.  Positions implied
+    // (token index mod L, L >= the tile's rows so that a tile wraps at most once); explicit position_ids keep the staging after the loop.
+    auto issue_cos_sin = [&]() {
+      if constexpr (EPI == EPI_QKV_ROPE8 && BM == 256) {
+        const int t0 = (m0 + p.m_offset) % p.L, last = min(BM, p.M - m0) - 1;
+#pragma unroll
+        for (int j = 0; j < (100 + NWAVES - 1) / NWAVES; ++j) {
+          const int q = j * NWAVES + wave;
+          if (q < 100) {
+            const int idx = q * 64 + lane, row = idx / 25, c = idx - row * 25;
+            int pos = t0 + min(row, last);
+            pos -= pos >= p.L ? p.L : 0;
+            const float* src_ = (c < 12 ? p.cos + 4 * c : p.sin + 4 * (c == 24 ? 0 : c - 12)) + (size_t)pos * 96;
+            __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src_), AKI_LDS_PTR(smem + q * 1024), 16, 0, 0);
+          }
+        }
+      }
+    };
     auto step = [&](int kt, auto next1, auto next2) {
       constexpr bool NEXT1 = decltype(next1)::value, NEXT2 = decltype(next2)::value;
       const char* sb = smem + (kt & 1) * STAGE_BYTES;
@@ -492,6 +515,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
         issue_res_half(kt & 1);
         if constexpr (!NEXT1) { if (nk == 1) issue_res_half((kt & 1) ^ 1); }
       }
+      if constexpr (EPI == EPI_QKV_ROPE8 && PIPE == 1 && !NEXT1) { if (cs_pf) issue_cos_sin(); }
       mma(a1, b1);
       if constexpr (NEXT1) interleave_reads();
       if constexpr (NEXT2 || PIPE == 2) interleave_dma();
@@ -582,7 +606,10 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
     constexpr int CSROW = 400;
     static_assert(EPI != EPI_QKV_ROPE8 || BM * CSROW <= NST * STAGE_BYTES, "cos/sin staging fits the K-loop buffers");
     const bool tile_has_rope = n0 / 32 < nqk;                 // workgroup-uniform
-    if (tile_has_rope) {
+    if (cs_pf) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my pieces of the prefetched cos / sin image have landed ...
+      __syncthreads();                                        // ... and so have everybody else's
+    } else if (tile_has_rope) {
       __syncthreads();                                        // every wave is done reading the K-loop stages
       for (int tk = tid >> 1; tk < BM; tk += (NWAVES * 64) >> 1) {
         const int mr = min(m0 + tk, p.M - 1) + p.m_offset;
@@ -603,46 +630,76 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
     long long probe_s = 0;
     if (blockIdx.x == 0 && tid == 0 && p.clock_probe) probe_s = clock64();
 #endif
+    // Units outside, token blocks inside: what a unit is (q / k with RoPE or v, its head, its plane of the output) is wave-uniform and
+    // decided once, and the NT token blocks under it are one basic block - their cos / sin reads, the rotation and the stores overlap.
+    // (Token blocks outside, every (block, unit) pair was a basic block of its own behind two uniform branches: read, wait, rotate, store,
+    // 16 times over - 13.8 k of the epilogue's cycles; tools/gemm_epilogue_probe.py.)
+    // Per token row: where it lives in a q plane (L rows per batch and head) and in a k / v plane (kvcap rows), as element offsets - the
+    // stores below then add a wave-uniform plane base and nothing else.
+    size_t offq[NT], dkv[NT];
+    int csoff[NT];
+    float rsq[NT];
+    bool okq[NT];
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
       const int mrow = m0 + wm * WTOK + m * 16 + l15;
-      const bool ok = mrow < p.M;
+      okq[m] = mrow < p.M;
       const int mr = min(mrow, p.M - 1) + p.m_offset;   // global token index
       const int b = mr / p.L, tt = mr - b * p.L;
-      const char* cs = smem + (wm * WTOK + m * 16 + l15) * CSROW + 16 * kg;
-      const float rs = p.row_scale ? p.row_scale[min(mrow, p.M - 1)] : 1.0f;   // folded RMSNorm: 1 / rms of the token's hidden state
+      offq[m] = ((size_t)b * ((size_t)p.H * p.L) + tt) * 96;
+      dkv[m] = (size_t)b * ((size_t)p.H * (p.kvcap - p.L)) * 96;   // k / v plane offset = offq + dkv
+      csoff[m] = (wm * WTOK + m * 16 + l15) * CSROW + 16 * kg;
+      rsq[m] = p.row_scale ? p.row_scale[min(mrow, p.M - 1)] : 1.0f;   // folded RMSNorm: 1 / rms of the token's hidden state
+    }
+    const __attribute__((address_space(3))) char* const lcs = (const __attribute__((address_space(3))) char*)AKI_LDS_PTR(smem);
+    // FULLM: every token row of the tile exists - no exec-mask branch around the stores, a unit's token blocks are one basic block
+    auto rope_rows = [&](auto fullm_) {
+      constexpr bool FULLM = decltype(fullm_)::value;
 #pragma unroll
       for (int q = 0; q < UW; ++q) {
-        const int u = u0 + q;                           // wave-uniform
+        const int u = u0 + q;                             // wave-uniform
         if (u >= 9 * p.H) continue;
-        float v1[4], v2[4];
-        bf16_t* dst;
-        int d1, d2;
-        if (u < nqk) {
-          const int hs = u / 3, j = u - 3 * hs, which = hs / p.H, head = hs - which * p.H;
-          const f32x4 c4 = *(const f32x4*)(cs + 64 * j), s4 = *(const f32x4*)(cs + 192 + 64 * j);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float x1 = acc[q][m][r] * rs, x2 = acc[q + UW][m][r] * rs;
-            v1[r] = x1 * c4[r] - x2 * s4[r];
-            v2[r] = x2 * c4[r] + x1 * s4[r];
-          }
-          dst = (which == 0 ? p.q_out : p.k_out) + ((size_t)(b * p.H + head) * (which == 0 ? p.L : p.kvcap) + tt) * 96;
-          d1 = 16 * j + 4 * kg; d2 = d1 + 48;
-        } else {
-          const int u2 = u - nqk, vh = u2 / 3, j2 = u2 - 3 * vh;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { v1[r] = acc[q][m][r] * rs; v2[r] = acc[q + UW][m][r] * rs; }
-          dst = p.v_out + ((size_t)(b * p.H + vh) * p.kvcap + tt) * 96;
-          d1 = 32 * j2 + 4 * kg; d2 = d1 + 16;
-        }
         // the lane's two 8-byte runs (block d1 and its partner block d2) become one 16-byte run of either block:
         // lane row kg ends up with features 8*(kg>>1) .. +7 of block (kg & 1 ? d2 : d1) - half the store instructions
-        const u32x4 o = pair_to_wide(pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3]), pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]));
-        const int dw = ((kg & 1) ? d2 : d1) - 4 * kg + 8 * (kg >> 1);
-        if (ok) *(u32x4*)(dst + dw) = o;
+        if (u < nqk) {
+          const int hs = u / 3, j = u - 3 * hs, which = hs / p.H, head = hs - which * p.H;
+          bf16_t* const plane = which == 0 ? p.q_out + (size_t)head * p.L * 96 : p.k_out + (size_t)head * p.kvcap * 96;
+          const int d1 = 16 * j + 4 * kg, d2 = d1 + 48;
+          const int dw = ((kg & 1) ? d2 : d1) - 4 * kg + 8 * (kg >> 1);
+#pragma unroll
+          for (int m = 0; m < NT; ++m) {
+            const f32x4 c4 = *(const __attribute__((address_space(3))) f32x4*)(lcs + csoff[m] + 64 * j);
+            const f32x4 s4 = *(const __attribute__((address_space(3))) f32x4*)(lcs + csoff[m] + 192 + 64 * j);
+            float v1[4], v2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float x1 = acc[q][m][r] * rsq[m], x2 = acc[q + UW][m][r] * rsq[m];
+              v1[r] = x1 * c4[r] - x2 * s4[r];
+              v2[r] = x2 * c4[r] + x1 * s4[r];
+            }
+            const u32x4 o = pair_to_wide(pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3]), pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]));
+            bf16_t* dst = plane + offq[m] + (which == 0 ? (size_t)0 : dkv[m]) + dw;
+            if (FULLM || okq[m]) *(u32x4*)dst = o;
+          }
+        } else {
+          const int u2 = u - nqk, vh = u2 / 3, j2 = u2 - 3 * vh;
+          bf16_t* const plane = p.v_out + (size_t)vh * p.kvcap * 96;
+          const int d1 = 32 * j2 + 4 * kg, d2 = d1 + 16;
+          const int dw = ((kg & 1) ? d2 : d1) - 4 * kg + 8 * (kg >> 1);
+#pragma unroll
+          for (int m = 0; m < NT; ++m) {
+            float v1[4], v2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v1[r] = acc[q][m][r] * rsq[m]; v2[r] = acc[q + UW][m][r] * rsq[m]; }
+            const u32x4 o = pair_to_wide(pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3]), pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]));
+            bf16_t* dst = plane + offq[m] + dkv[m] + dw;
+            if (FULLM || okq[m]) *(u32x4*)dst = o;
+          }
+        }
       }
-    }
+    };
+    if (m0 + BM <= p.M) rope_rows(std::true_type{});
+    else rope_rows(std::false_type{});
 #ifdef AKI_LAB_HOOKS
     if (blockIdx.x == 0 && tid == 0 && p.clock_probe) {
       p.clock_probe[0] = clock64() - probe_c0;

@@ -68,8 +68,31 @@ def main():
             mhz = v[0] / max(v[1], 1) * 100
             print(f"   {name:26s} tile mode {mode}: lifetime {v[0]:7d}  prologue {v[18]:5d}  K loop / step {(v[0] - v[18] - v[19]) / (d // 64):6.0f}  epilogue {v[19]:6d} cycles"
                   f"  ({mhz:.0f} MHz: epilogue {v[19] / mhz:.2f} us), of which cos/sin staging {v[20]}")
+    # the same GEMM inside the fused op, with and without the attention core behind it
+    table = ops.mask_to_table(torch.tril(torch.ones(Lq, Lq, device=dev, dtype=torch.int64)).expand(B, 1, Lq, Lq).contiguous())
     lib.aki_lab_set_gemm_tile(0)
+    for _ in range(20):
+        ops.mma_attn(x3, wq, cos, sin, table, H, row_scale=rs3)
+    torch.cuda.synchronize()
+    v = probe.tolist()
+    mhz = v[0] / max(v[1], 1) * 100
+    print(f"   {'fused op, row scale':26s} tile mode 0: lifetime {v[0]:7d}  prologue {v[18]:5d}  K loop / step {(v[0] - v[18] - v[19]) / (d // 64):6.0f}  epilogue {v[19]:6d} cycles"
+          f"  ({mhz:.0f} MHz: epilogue {v[19] / mhz:.2f} us), of which cos/sin staging {v[20]}")
+
+    def loop_us(fn, iters=20):
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn(); torch.cuda.synchronize()
+        a_.record()
+        for _ in range(iters):
+            fn()
+        b_.record()
+        torch.cuda.synchronize()
+        return a_.elapsed_time(b_) / iters * 1e3
     lib.aki_lab_set_clock_probe(None)
+    t_sep = sorted(loop_us(lambda: ops.qkv_rope(x3, wq, cos, sin, H, row_scale=rs3)) for _ in range(5))[2]
+    t_fused = sorted(loop_us(lambda: ops.mma_attn(x3, wq, cos, sin, table, H, row_scale=rs3)) for _ in range(5))[2]
+    print(f"   qkv_rope launch (natural order) {t_sep:7.1f} us; fused op (the same GEMM + attention core) {t_fused:7.1f} us")
+    lib.aki_lab_set_gemm_tile(0)
 
 
 if __name__ == "__main__":
