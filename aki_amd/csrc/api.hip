@@ -100,7 +100,7 @@ void aki_lab_set_gemm_tile(int mode) {
   aki::g_deep_ring = (mode & 256) ? 0 : 1;
   aki::g_pipe = (mode & 512) ? 0 : ((mode & 1024) ? 2 : 1);     // +1024: pipeline without the residual prefetch
   mode &= 255;
-  aki::g_force_tile = (mode >= 1 && mode <= 4) ? mode : 0;
+  aki::g_force_tile = (mode >= 1 && mode <= 5) ? mode : 0;
 }
 // 0 = product choice, 1 = 32-row attention core (two waves per SIMD), 2 = 64-row core (one wave per SIMD)
 void aki_lab_set_attn_variant(int v) { aki::g_attn_variant = v; }

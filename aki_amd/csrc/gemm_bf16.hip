@@ -999,7 +999,7 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   return AKI_OK;
 }
 
-// g_force_tile: 0 = heuristic, 1 = 256^2, 2 = 128^2, 3 = 128 features x 96 tokens (plain bf16 only)
+// g_force_tile: 0 = heuristic, 1 = 256^2, 2 = 128^2, 3 = 128 features x 96 tokens, 5 = 64 x 64 on a four-stage ring (plain bf16 only), 4 = lab loop
 
 // Cost model in units of one 256x256 tile's run time.  256^2 tiles: one workgroup per CU.  128-token tiles do a
 // quarter of the work; up to 256 of them run one per CU at ~75 % of the big tile's efficiency, beyond that two share a CU
@@ -1026,7 +1026,7 @@ static double cost_small(long tiles, double work) {
 // the 128^2 tiling would leave that round partly empty - SigLIP out-proj / fc2 (N = 1152: 324 -> 432 tiles, 21.7 -> 17.9 us
 // and 61.6 -> 50.5 us), Perceiver kv (360 -> 480 tiles, 20.4 -> 17.2 us).  Same K order per output element: bit-identical.
 static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_work = 0.25, bool mid_ok = false, int ksteps = 0) {
-  if (g_force_tile) return g_force_tile == 2 ? 1 : (g_force_tile == 3 ? (mid_ok ? 3 : 1) : 0);
+  if (g_force_tile) return g_force_tile == 2 ? 1 : (g_force_tile == 3 ? (mid_ok ? 3 : 1) : (g_force_tile == 5 ? (mid_ok ? 4 : 1) : 0));
   const long nb = (n_out + bn_big - 1) / bn_big, ns = (n_out + bn_small - 1) / bn_small;
   const double all_big = cost_big((long)((M + 255) / 256) * nb, ksteps);
   const double all_small = cost_small((long)((M + 127) / 128) * ns, small_work);
@@ -1035,6 +1035,9 @@ static int plan_tiles(int M, int n_out, int bn_big, int bn_small, double small_w
   if (m_main > 0 && tail > 0) split = cost_big((long)(m_main / 256) * nb) + cost_small((long)((tail + 127) / 128) * ns, small_work);
   if (mid_ok) {
     const long nm = (long)((M + 95) / 96) * ns;
+    // plan 4: a few rows against a long K (Perceiver ff2: 1152 x 1152 x 4608 = 108 tiles of 128 x 96 on 256 CUs, 72 K-steps each) - 64 x 64 tiles on a
+    // four-stage ring put 324 workgroups on the chip, two per CU: 43.2 -> 28.4 us (tools/perceiver_gemm_ab.py); same K order per output element: bit-identical.
+    if (M > 128 && nm <= 128 && ksteps >= 32 && (long)((M + 63) / 64) * ((n_out + 63) / 64) <= 512) return 4;   // (M <= 128: the weight-streaming tiles of launch_small)
     if (nm <= 512) {
       const double all_mid = cost_small(nm, 0.75 * small_work);
       if (all_mid < all_small && all_mid < all_big && all_mid < split) return 3;
@@ -1089,6 +1092,7 @@ static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
   if (plan == 0) return launch_big<EPI, ACT, FP8>(p, stream);
   if constexpr (EPI == EPI_PLAIN && !FP8) {
     if (plan == 3) return launch_gemm<4, 3, 2, 2, EPI, ACT, FP8>(p, stream);   // 128 features x 96 tokens
+    if (plan == 4) return launch_gemm<2, 2, 2, 2, EPI, ACT, FP8, 4>(p, stream);   // 64 features x 64 tokens, four-stage ring
   }
   const int m_main = p.M / 256 * 256;
   GemmParams a = p, b = p;

@@ -68,7 +68,7 @@ DTYPES = [torch.bfloat16, torch.float32]
 # ------------------------------------------------------------------------------------------------
 # linear
 # ------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[0, 1, 2, 3], ids=["tile-auto", "tile-256", "tile-128", "tile-128x96"])
+@pytest.fixture(params=[0, 1, 2, 3, 5], ids=["tile-auto", "tile-256", "tile-128", "tile-128x96", "tile-64x64-ring"])
 def gemm_tile(request):
     """Run the bf16 GEMM tests under the heuristic (product library) and with each tile configuration forced - the forcing
     switch exists only in the lab twin of the library (libaki_mi355x_lab.so: same sources + aki_lab_set_gemm_tile)."""
