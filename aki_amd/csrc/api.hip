@@ -98,7 +98,7 @@ int aki_abi_version(void) { return AKI_ABI_VERSION; }
 // not thread safe - which is why the product library does not carry it.
 void aki_lab_set_gemm_tile(int mode) {
   aki::g_deep_ring = (mode & 256) ? 0 : 1;
-  aki::g_pipe = (mode & 512) ? 0 : ((mode & 1024) ? 2 : 1);     // +1024: pipeline without the residual prefetch
+  aki::g_pipe = (mode & 512) ? 0 : ((mode & 1024) ? 2 : ((mode & 2048) ? 3 : 1));     // +1024: pipeline without the residual prefetch, +2048: with the two-deep weight ring
   mode &= 255;
   aki::g_force_tile = (mode >= 1 && mode <= 5) ? mode : 0;
 }

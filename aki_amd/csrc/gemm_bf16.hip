@@ -225,7 +225,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   const int fwave = n0 + wn * (EPI == EPI_SWIGLU ? WROWS / 2 : WROWS);
   // folded LayerNorm (consumer), kernel-uniform.  Not on the PIPELINED 256^2 tile: its epilogue has no registers left for the
   // column sums (they spilled); the host sends row_shift launches that want the big tile to its unpipelined twin.
-  const bool shifted = PIPE <= 1 && (EPI == EPI_PLAIN) && p.row_shift != nullptr;
+  const bool shifted = (PIPE <= 1 || PIPE == 4) && (EPI == EPI_PLAIN) && p.row_shift != nullptr;
   u32x2 biasp[NOUT];
   f32x4 colc4[NOUT];
   float rsv[NT], muv[NT];
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   const bool res_pf = RES_PF_OK && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && n_out >= 8;   // workgroup-uniform
   int res_off = 0;                 // where the residual tile image sits in smem
   // QKV + RoPE on the pipelined 256 x 256 tile: cos / sin rows prefetched under the last half K-step (issue_cos_sin below); workgroup-uniform
-  const bool cs_pf = EPI == EPI_QKV_ROPE8 && PIPE == 1 && BM == 256 && n0 / 32 < 6 * p.H && p.position_ids == nullptr && p.L >= BM;
+  const bool cs_pf = EPI == EPI_QKV_ROPE8 && (PIPE == 1 || PIPE == 4) && BM == 256 && n0 / 32 < 6 * p.H && p.position_ids == nullptr && p.L >= BM;
   if constexpr (EARLY_OPERANDS) fetch_epilogue_operands();
   auto compute = [&](const char* sb) {
     if constexpr (FP8) {   // one k128 step per BK: the lane's 32 bytes are chunks 2kg and 2kg+1 of its row
@@ -449,7 +449,96 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
     };
+    // QKV + RoPE: the cos / sin rows of the tile's tokens (the epilogue's LDS image: token row r at r * 400, 12 chunks of cos[0:48], 12 of
+    // sin[0:48], one pad chunk) come in by LDS-DMA under the LAST half K-step - behind its barrier nobody reads the stage buffers any more -
+    // instead of after the loop, where the round trip plus 12 ds_write_b128 per thread cost every tile ~6 k cycles (tools/
+    // gemm_epilogue_probe.py).  100 pieces of 1 KiB, lane i of piece q = chunk (64 q + i) % 25 of row (64 q + i) / 25.  Positions implied
+    // (token index mod L, L >= the tile's rows so that a tile wraps at most once); explicit position_ids keep the staging after the loop.
+    auto issue_cos_sin = [&]() {
+      if constexpr (EPI == EPI_QKV_ROPE8 && BM == 256) {
+        const int t0 = (m0 + p.m_offset) % p.L, last = min(BM, p.M - m0) - 1;
+#pragma unroll
+        for (int j = 0; j < (100 + NWAVES - 1) / NWAVES; ++j) {
+          const int q = j * NWAVES + wave;
+          if (q < 100) {
+            const int idx = q * 64 + lane, row = idx / 25, c = idx - row * 25;
+            int pos = t0 + min(row, last);
+            pos -= pos >= p.L ? p.L : 0;
+            const float* src_ = (c < 12 ? p.cos + 4 * c : p.sin + 4 * (c == 24 ? 0 : c - 12)) + (size_t)pos * 96;
+            __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src_), AKI_LDS_PTR(smem + q * 1024), 16, 0, 0);
+          }
+        }
+      }
+    };
     bf16x8 a0[NF], b0[NT], a1[NF], b1[NT];
+    if constexpr (PIPE == 4) {
+      // PIPE == 4: the same loop with the WEIGHT tiles on a three-deep ring (3 x 32 KiB) beside the two token-panel buffers (2 x 32 KiB; 160 KiB, all of
+      // the LDS): a weight tile is asked for TWO steps ahead instead of one.  Weights come out of HBM in every launch of the forward, and with the
+      // eight tiles that share a weight panel in lock-step every one of them waits for that first touch: workgroup 0's K-step is 2436 cycles with the
+      // weight on-die and 3032 with it in HBM (tools/gemm_cold_stamps.py), and the lab loop that asks 1.5 steps ahead loses a third of that.
+      // Issue order per step: token tile kt+2, then weight tile kt+3 - so the counted wait at the barrier leaves exactly the youngest weight tile in flight.
+      static_assert(PIPE != 4 || (BN == BM && (BN / 8) % NWAVES == 0 && NLD % 2 == 0), "weight / token pieces split evenly");
+      constexpr int WB = BN * 128, XB = BM * 128, NLH = NLD / 2;
+      char* const sX = smem + 3 * WB;
+      auto stage_w = [&](int slot, int kt_) {
+#pragma unroll
+        for (int j = 0; j < NLH; ++j)
+          __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[j] + (size_t)kt_ * 128), AKI_LDS_PTR(smem + slot * WB + (j * NWAVES + wave) * 1024), 16, 0, 0);
+      };
+      auto stage_x = [&](int slot, int kt_) {
+#pragma unroll
+        for (int j = NLH; j < NLD; ++j)
+          __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[j] + (size_t)kt_ * 128), AKI_LDS_PTR(sX + slot * XB + ((j - NLH) * NWAVES + wave) * 1024), 16, 0, 0);
+      };
+      const int xb0 = (wm * WTOK + l15) * 128;
+      auto load_frags2 = [&](const char* sw, const char* sx, int ks, bf16x8 (&a)[NF], bf16x8 (&b)[NT]) {
+        const int coff = ((4 * ks + kg) ^ swz) << 4;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) a[n] = *(const bf16x8*)(sw + wbase + n * 2048 + coff);
+#pragma unroll
+        for (int m = 0; m < NT; ++m) b[m] = *(const bf16x8*)(sx + xb0 + m * 2048 + coff);
+      };
+      auto interleave_pieces = [&](int n_) {
+        for (int i = 0; i < n_; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      };
+      stage_w(0, 0); stage_x(0, 0);
+      if (nk > 1) { stage_w(1, 1); stage_x(1, 1); }
+      if (nk > 2) stage_w(2, 2);
+      if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NLH) : "memory");      // tile 0 landed; tile 1 and weight tile 2 may be in flight
+      else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      load_frags2(smem, sX, 0, a0, b0);
+      int ws = 0;                                      // ring slot of weight tile kt
+      auto step4 = [&](int kt, auto next1, auto next2, auto next3) {
+        constexpr bool NEXT1 = decltype(next1)::value, NEXT2 = decltype(next2)::value, NEXT3 = decltype(next3)::value;
+        const int ws1 = ws == 2 ? 0 : ws + 1;
+        load_frags2(smem + ws * WB, sX + (kt & 1) * XB, 1, a1, b1);
+        mma(a0, b0);
+        interleave_reads();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NEXT2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLH) : "memory");   // tile kt+1 landed (weight tile kt+2 stays in flight); my reads of tile kt are done
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (NEXT1) load_frags2(smem + ws1 * WB, sX + ((kt + 1) & 1) * XB, 0, a0, b0);
+        if constexpr (NEXT2) stage_x(kt & 1, kt + 2);
+        if constexpr (NEXT3) stage_w(ws, kt + 3);
+        if constexpr (EPI == EPI_QKV_ROPE8 && !NEXT1) { if (cs_pf) issue_cos_sin(); }
+        mma(a1, b1);
+        if constexpr (NEXT1) interleave_reads();
+        if constexpr (NEXT2 || NEXT3) interleave_pieces((NEXT2 ? NLH : 0) + (NEXT3 ? NLH : 0));
+        __builtin_amdgcn_sched_barrier(0);
+        ws = ws1;
+      };
+      int kt = 0;
+      for (; kt + 3 < nk; ++kt) step4(kt, std::true_type{}, std::true_type{}, std::true_type{});
+      if (kt + 2 < nk) { step4(kt, std::true_type{}, std::true_type{}, std::false_type{}); ++kt; }
+      if (kt + 1 < nk) { step4(kt, std::true_type{}, std::false_type{}, std::false_type{}); ++kt; }
+      step4(kt, std::false_type{}, std::false_type{}, std::false_type{});
+    } else {
     stage(0, 0);
     if (nk > 1) stage(1, 1);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // tile 0 landed (tile 1 may be in flight)
@@ -478,27 +567,6 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
         __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src_), AKI_LDS_PTR(smem + hb * STAGE_BYTES + q * 1024), 16, 0, 0);
       }
     };
-    // QKV + RoPE: the cos / sin rows of the tile's tokens (the epilogue's LDS image: token row r at r * 400, 12 chunks of cos[0:48], 12 of
-    // sin[0:48], one pad chunk) come in by LDS-DMA under the LAST half K-step - behind its barrier nobody reads the stage buffers any more -
-    // instead of after the loop, where the round trip plus 12 ds_write_b128 per thread cost every tile ~6 k cycles (tools/
-    // gemm_epilogue_probe.py).  100 pieces of 1 KiB, lane i of piece q = chunk (64 q + i) % 25 of row (64 q + i) / 25.  Positions implied
-    // (token index mod L, L >= the tile's rows so that a tile wraps at most once); explicit position_ids keep the staging after the loop.
-    auto issue_cos_sin = [&]() {
-      if constexpr (EPI == EPI_QKV_ROPE8 && BM == 256) {
-        const int t0 = (m0 + p.m_offset) % p.L, last = min(BM, p.M - m0) - 1;
-#pragma unroll
-        for (int j = 0; j < (100 + NWAVES - 1) / NWAVES; ++j) {
-          const int q = j * NWAVES + wave;
-          if (q < 100) {
-            const int idx = q * 64 + lane, row = idx / 25, c = idx - row * 25;
-            int pos = t0 + min(row, last);
-            pos -= pos >= p.L ? p.L : 0;
-            const float* src_ = (c < 12 ? p.cos + 4 * c : p.sin + 4 * (c == 24 ? 0 : c - 12)) + (size_t)pos * 96;
-            __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src_), AKI_LDS_PTR(smem + q * 1024), 16, 0, 0);
-          }
-        }
-      }
-    };
     auto step = [&](int kt, auto next1, auto next2) {
       constexpr bool NEXT1 = decltype(next1)::value, NEXT2 = decltype(next2)::value;
       const char* sb = smem + (kt & 1) * STAGE_BYTES;
@@ -525,6 +593,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
     for (; kt + 2 < nk; ++kt) step(kt, std::true_type{}, std::true_type{});
     if (kt + 1 < nk) { step(kt, std::true_type{}, std::false_type{}); ++kt; }
     step(kt, std::false_type{}, std::false_type{});
+    }
   } else if constexpr (NST == 2) {
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -883,7 +952,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
         else if (key == 3) write_rows(c1{}, c1{}, c1{}, c0{}, c0{}, c0{});             // bias + residual
         else if (key == 6) write_rows(c1{}, c0{}, c1{}, c1{}, c0{}, c0{});             // residual + statistics (o_proj, down)
         else if (key == 7) write_rows(c1{}, c1{}, c1{}, c1{}, c0{}, c0{});             // + bias (SigLIP out / fc2)
-        else if constexpr (PIPE <= 1) {
+        else if constexpr (PIPE <= 1 || PIPE == 4) {
           if (key == 25) write_rows(c1{}, c1{}, c0{}, c0{}, c1{}, c1{});               // folded LayerNorm + bias (SigLIP qkv / fc1)
           else done = false;
         } else done = false;
@@ -979,7 +1048,8 @@ static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;
 template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, int PIPE = 0>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
-  constexpr int SMEM = NST * (BN + BM) * 128;
+  constexpr int SMEM = PIPE == 4 ? (3 * BN + 2 * BM) * 128 : NST * (BN + BM) * 128;   // PIPE 4: three weight tiles + two token tiles
+  static_assert(SMEM <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
@@ -1081,7 +1151,8 @@ static int launch_big(GemmParams& p, hipStream_t stream) {
       if (g_pipe == 1 && p.row_shift == nullptr && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && p.N % 8 == 0 && p.N >= 8)
         return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 2>(p, stream);
     }
-    if (g_pipe) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 1>(p, stream);
+    if (g_pipe == 3) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 1>(p, stream);   // lab: two-deep weight ring
+    if (g_pipe) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 4>(p, stream);
   }
   return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8>(p, stream);
 }
