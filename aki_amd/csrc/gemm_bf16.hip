@@ -471,13 +471,18 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       }
     };
     bf16x8 a0[NF], b0[NT], a1[NF], b1[NT];
-    if constexpr (PIPE == 4) {
+    if constexpr (PIPE == 4 || PIPE == 5) {
       // PIPE == 4: the same loop with the WEIGHT tiles on a three-deep ring (3 x 32 KiB) beside the two token-panel buffers (2 x 32 KiB; 160 KiB, all of
       // the LDS): a weight tile is asked for TWO steps ahead instead of one.  Weights come out of HBM in every launch of the forward, and with the
       // eight tiles that share a weight panel in lock-step every one of them waits for that first touch: workgroup 0's K-step is 2436 cycles with the
       // weight on-die and 3032 with it in HBM (tools/gemm_cold_stamps.py), and the lab loop that asks 1.5 steps ahead loses a third of that.
       // Issue order per step: token tile kt+2, then weight tile kt+3 - so the counted wait at the barrier leaves exactly the youngest weight tile in flight.
-      static_assert(PIPE != 4 || (BN == BM && (BN / 8) % NWAVES == 0 && NLD % 2 == 0), "weight / token pieces split evenly");
+      // PIPE == 5 = PIPE 4 + the residual tile prefetched under the last 1.5 K-steps (what PIPE 2 does on the two-stage layout): the tile's four
+      // blocks of 64 token rows (32 KiB each - the rows of one wave row wm) go wherever a 32 KiB slot has been read for the last time: block 0 into the
+      // slot of weight tile nk-3 after the barrier of step nk-3, blocks 1 and 2 into the slots of weight tile nk-2 and token tile nk-2 after the barrier
+      // of step nk-2, block 3 into the slot of weight tile nk-1 after the last barrier.  The epilogue finds a wave's block through res_off (set per wave below).
+      static_assert((PIPE != 4 && PIPE != 5) || (BN == BM && (BN / 8) % NWAVES == 0 && NLD % 2 == 0), "weight / token pieces split evenly");
+      static_assert(PIPE != 5 || (WTOK == 64 && RCH == 32 && BM == 256 && NWAVES == 8), "one 32 KiB residual block per wave row");
       constexpr int WB = BN * 128, XB = BM * 128, NLH = NLD / 2;
       char* const sX = smem + 3 * WB;
       auto stage_w = [&](int slot, int kt_) {
@@ -504,6 +509,21 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
           __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
       };
+      int blkoff[4] = {0, 0, 0, 0};                     // PIPE 5: LDS byte offset of residual block b
+      auto issue_res_block = [&](int b_, int dst_off) {
+        if constexpr (PIPE == 5) {
+          blkoff[b_] = dst_off;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int q = j * NWAVES + wave;                       // 1 KiB piece of the block = two token rows
+            const int tk = b_ * 64 + 2 * q + (lane >> 5);
+            const int ch = (lane & (RCH - 1)) ^ (tk & CMASK);
+            const int f = min(n0 + 8 * ch, n_out - 8);
+            const bf16_t* src_ = p.residual + (size_t)min(m0 + tk, p.M - 1) * p.ldr + f;
+            __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src_), AKI_LDS_PTR(smem + dst_off + q * 1024), 16, 0, 0);
+          }
+        }
+      };
       stage_w(0, 0); stage_x(0, 0);
       if (nk > 1) { stage_w(1, 1); stage_x(1, 1); }
       if (nk > 2) stage_w(2, 2);
@@ -521,15 +541,27 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
         interleave_reads();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NEXT2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLH) : "memory");   // tile kt+1 landed (weight tile kt+2 stays in flight); my reads of tile kt are done
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if constexpr (NEXT1 || PIPE != 5) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // PIPE 5, last step: no tile is awaited, the residual blocks of step nk-2 stay in flight
         __builtin_amdgcn_s_barrier();
         if constexpr (NEXT1) load_frags2(smem + ws1 * WB, sX + ((kt + 1) & 1) * XB, 0, a0, b0);
         if constexpr (NEXT2) stage_x(kt & 1, kt + 2);
         if constexpr (NEXT3) stage_w(ws, kt + 3);
+        if constexpr (PIPE == 5 && NEXT2 && !NEXT3) issue_res_block(0, ws * WB);   // step nk-3: no weight tile nk will ask for this slot
+        if constexpr (PIPE == 5 && NEXT1 && !NEXT2) {             // step nk-2: two more slots have been read for the last time
+          if (nk == 2) issue_res_block(0, 2 * WB);                //   (no step nk-3: the third weight slot was never used)
+          issue_res_block(1, ws * WB);
+          issue_res_block(2, 3 * WB + (kt & 1) * XB);
+        }
+        if constexpr (PIPE == 5 && !NEXT1) {                     // last step
+          if (nk == 1) { issue_res_block(0, 1 * WB); issue_res_block(1, 2 * WB); issue_res_block(2, 3 * WB + XB); }
+          issue_res_block(3, ws * WB);
+        }
         if constexpr (EPI == EPI_QKV_ROPE8 && !NEXT1) { if (cs_pf) issue_cos_sin(); }
         mma(a1, b1);
         if constexpr (NEXT1) interleave_reads();
         if constexpr (NEXT2 || NEXT3) interleave_pieces((NEXT2 ? NLH : 0) + (NEXT3 ? NLH : 0));
+        if constexpr (PIPE == 5 && !NEXT3) interleave_pieces(NEXT2 ? 4 : (NEXT1 ? 8 : 4));
         __builtin_amdgcn_sched_barrier(0);
         ws = ws1;
       };
@@ -538,6 +570,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       if (kt + 2 < nk) { step4(kt, std::true_type{}, std::true_type{}, std::false_type{}); ++kt; }
       if (kt + 1 < nk) { step4(kt, std::true_type{}, std::false_type{}, std::false_type{}); ++kt; }
       step4(kt, std::false_type{}, std::false_type{}, std::false_type{});
+      if constexpr (PIPE == 5) res_off = (wm == 0 ? blkoff[0] : wm == 1 ? blkoff[1] : wm == 2 ? blkoff[2] : blkoff[3]) - wm * (64 * RCH * 16);
     } else {
     stage(0, 0);
     if (nk > 1) stage(1, 1);
@@ -789,7 +822,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   // rows, two to sixteen per thread.  Chunk c of token row t sits at chunk c ^ (t & CMASK): the 16 token rows of a
   // ds_read_b64 land in 16 different bank groups without padding (a padded 256 x 256 tile would not fit).
   const bool res_lds = (EPI == EPI_PLAIN) && p.residual != nullptr && p.res_wide;   // workgroup-uniform
-  if constexpr (PIPE == 2) {
+  if constexpr (PIPE == 2 || PIPE == 5) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my pieces of the prefetched residual tile have landed ...
     __syncthreads();                                           // ... and so have everybody else's
   } else if (RES_PF_OK && res_pf) {
@@ -1048,7 +1081,7 @@ static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;
 template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, int PIPE = 0>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
-  constexpr int SMEM = PIPE == 4 ? (3 * BN + 2 * BM) * 128 : NST * (BN + BM) * 128;   // PIPE 4: three weight tiles + two token tiles
+  constexpr int SMEM = (PIPE == 4 || PIPE == 5) ? (3 * BN + 2 * BM) * 128 : NST * (BN + BM) * 128;   // PIPE 4 / 5: three weight tiles + two token tiles
   static_assert(SMEM <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
@@ -1148,8 +1181,8 @@ static int launch_big(GemmParams& p, hipStream_t stream) {
     if (g_force_tile == 4 && p.row_shift == nullptr) return launch_gemm<8, 8, 2, 2, EPI, ACT, FP8, 2, 3>(p, stream);
 #endif
     if constexpr (EPI == EPI_PLAIN && ACT == 0) {   // residual tile prefetched under the last K-steps (o_proj, down_proj)
-      if (g_pipe == 1 && p.row_shift == nullptr && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && p.N % 8 == 0 && p.N >= 8)
-        return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 2>(p, stream);
+      if ((g_pipe == 1 || g_pipe == 3) && p.row_shift == nullptr && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && p.N % 8 == 0 && p.N >= 8)
+        return g_pipe == 3 ? launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 2>(p, stream) : launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 5>(p, stream);
     }
     if (g_pipe == 3) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 1>(p, stream);   // lab: two-deep weight ring
     if (g_pipe) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 4>(p, stream);
