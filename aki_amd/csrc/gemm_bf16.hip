@@ -225,7 +225,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   const int fwave = n0 + wn * (EPI == EPI_SWIGLU ? WROWS / 2 : WROWS);
   // folded LayerNorm (consumer), kernel-uniform.  Not on the PIPELINED 256^2 tile: its epilogue has no registers left for the
   // column sums (they spilled); the host sends row_shift launches that want the big tile to its unpipelined twin.
-  const bool shifted = (PIPE <= 1 || PIPE == 4) && (EPI == EPI_PLAIN) && p.row_shift != nullptr;
+  const bool shifted = (PIPE <= 1 || PIPE == 4 || PIPE == 7) && (EPI == EPI_PLAIN) && p.row_shift != nullptr;
   u32x2 biasp[NOUT];
   f32x4 colc4[NOUT];
   float rsv[NT], muv[NT];
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   const bool res_pf = RES_PF_OK && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && n_out >= 8;   // workgroup-uniform
   int res_off = 0;                 // where the residual tile image sits in smem
   // QKV + RoPE on the pipelined 256 x 256 tile: cos / sin rows prefetched under the last half K-step (issue_cos_sin below); workgroup-uniform
-  const bool cs_pf = EPI == EPI_QKV_ROPE8 && (PIPE == 1 || PIPE == 4) && BM == 256 && n0 / 32 < 6 * p.H && p.position_ids == nullptr && p.L >= BM;
+  const bool cs_pf = EPI == EPI_QKV_ROPE8 && (PIPE == 1 || PIPE == 4 || PIPE == 7) && BM == 256 && n0 / 32 < 6 * p.H && p.position_ids == nullptr && p.L >= BM;
   if constexpr (EARLY_OPERANDS) fetch_epilogue_operands();
   auto compute = [&](const char* sb) {
     if constexpr (FP8) {   // one k128 step per BK: the lane's 32 bytes are chunks 2kg and 2kg+1 of its row
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       }
     };
     bf16x8 a0[NF], b0[NT], a1[NF], b1[NT];
-    if constexpr (PIPE == 4 || PIPE == 5) {
+    if constexpr (PIPE >= 4 && PIPE <= 7) {
       // PIPE == 4: the same loop with the WEIGHT tiles on a three-deep ring (3 x 32 KiB) beside the two token-panel buffers (2 x 32 KiB; 160 KiB, all of
       // the LDS): a weight tile is asked for TWO steps ahead instead of one.  Weights come out of HBM in every launch of the forward, and with the
       // eight tiles that share a weight panel in lock-step every one of them waits for that first touch: workgroup 0's K-step is 2436 cycles with the
@@ -481,22 +481,29 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       // blocks of 64 token rows (32 KiB each - the rows of one wave row wm) go wherever a 32 KiB slot has been read for the last time: block 0 into the
       // slot of weight tile nk-3 after the barrier of step nk-3, blocks 1 and 2 into the slots of weight tile nk-2 and token tile nk-2 after the barrier
       // of step nk-2, block 3 into the slot of weight tile nk-1 after the last barrier.  The epilogue finds a wave's block through res_off (set per wave below).
-      static_assert((PIPE != 4 && PIPE != 5) || (BN == BM && (BN / 8) % NWAVES == 0 && NLD % 2 == 0), "weight / token pieces split evenly");
-      static_assert(PIPE != 5 || (WTOK == 64 && RCH == 32 && BM == 256 && NWAVES == 8), "one 32 KiB residual block per wave row");
+      // PIPE == 7 / 6 = PIPE 4 / 5 with the roles swapped: the TOKEN tiles on the three-deep ring, the weight tiles on two buffers - for launches whose
+      // activation is the larger cold operand (down_proj: 86 MB of activations against 50 MB of weights).
+      constexpr bool DX = PIPE == 6 || PIPE == 7, RESPF = PIPE == 5 || PIPE == 6;
+      static_assert(PIPE < 4 || PIPE > 7 || (BN == BM && (BN / 8) % NWAVES == 0 && NLD % 2 == 0), "weight / token pieces split evenly");
+      static_assert(!RESPF || (WTOK == 64 && RCH == 32 && BM == 256 && NWAVES == 8), "one 32 KiB residual block per wave row");
       constexpr int WB = BN * 128, XB = BM * 128, NLH = NLD / 2;
-      char* const sX = smem + 3 * WB;
-      auto stage_w = [&](int slot, int kt_) {
+      static_assert(WB == XB, "equal slots");
+      char* const sS = smem + 3 * WB;                   // the two-deep ring behind the three-deep one
+      constexpr int JD = DX ? NLH : 0, JS = DX ? 0 : NLH;   // src[] indices of the deep / shallow operand's pieces (weights are src[0 .. NLH))
+      auto stage_w = [&](int slot, int kt_) {            // the DEEP operand's tile kt_ (weights unless DX)
 #pragma unroll
         for (int j = 0; j < NLH; ++j)
-          __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[j] + (size_t)kt_ * 128), AKI_LDS_PTR(smem + slot * WB + (j * NWAVES + wave) * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[JD + j] + (size_t)kt_ * 128), AKI_LDS_PTR(smem + slot * WB + (j * NWAVES + wave) * 1024), 16, 0, 0);
       };
-      auto stage_x = [&](int slot, int kt_) {
+      auto stage_x = [&](int slot, int kt_) {            // the SHALLOW operand's tile kt_
 #pragma unroll
-        for (int j = NLH; j < NLD; ++j)
-          __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[j] + (size_t)kt_ * 128), AKI_LDS_PTR(sX + slot * XB + ((j - NLH) * NWAVES + wave) * 1024), 16, 0, 0);
+        for (int j = 0; j < NLH; ++j)
+          __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[JS + j] + (size_t)kt_ * 128), AKI_LDS_PTR(sS + slot * XB + (j * NWAVES + wave) * 1024), 16, 0, 0);
       };
       const int xb0 = (wm * WTOK + l15) * 128;
-      auto load_frags2 = [&](const char* sw, const char* sx, int ks, bf16x8 (&a)[NF], bf16x8 (&b)[NT]) {
+      auto load_frags2 = [&](const char* sdeep, const char* sshal, int ks, bf16x8 (&a)[NF], bf16x8 (&b)[NT]) {
+        const char* const sw = DX ? sshal : sdeep;
+        const char* const sx = DX ? sdeep : sshal;
         const int coff = ((4 * ks + kg) ^ swz) << 4;
 #pragma unroll
         for (int n = 0; n < NF; ++n) a[n] = *(const bf16x8*)(sw + wbase + n * 2048 + coff);
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       };
       int blkoff[4] = {0, 0, 0, 0};                     // PIPE 5: LDS byte offset of residual block b
       auto issue_res_block = [&](int b_, int dst_off) {
-        if constexpr (PIPE == 5) {
+        if constexpr (RESPF) {
           blkoff[b_] = dst_off;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -531,29 +538,29 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      load_frags2(smem, sX, 0, a0, b0);
+      load_frags2(smem, sS, 0, a0, b0);
       int ws = 0;                                      // ring slot of weight tile kt
       auto step4 = [&](int kt, auto next1, auto next2, auto next3) {
         constexpr bool NEXT1 = decltype(next1)::value, NEXT2 = decltype(next2)::value, NEXT3 = decltype(next3)::value;
         const int ws1 = ws == 2 ? 0 : ws + 1;
-        load_frags2(smem + ws * WB, sX + (kt & 1) * XB, 1, a1, b1);
+        load_frags2(smem + ws * WB, sS + (kt & 1) * XB, 1, a1, b1);
         mma(a0, b0);
         interleave_reads();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NEXT2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLH) : "memory");   // tile kt+1 landed (weight tile kt+2 stays in flight); my reads of tile kt are done
-        else if constexpr (NEXT1 || PIPE != 5) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if constexpr (NEXT1 || !RESPF) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // PIPE 5, last step: no tile is awaited, the residual blocks of step nk-2 stay in flight
         __builtin_amdgcn_s_barrier();
-        if constexpr (NEXT1) load_frags2(smem + ws1 * WB, sX + ((kt + 1) & 1) * XB, 0, a0, b0);
+        if constexpr (NEXT1) load_frags2(smem + ws1 * WB, sS + ((kt + 1) & 1) * XB, 0, a0, b0);
         if constexpr (NEXT2) stage_x(kt & 1, kt + 2);
         if constexpr (NEXT3) stage_w(ws, kt + 3);
-        if constexpr (PIPE == 5 && NEXT2 && !NEXT3) issue_res_block(0, ws * WB);   // step nk-3: no weight tile nk will ask for this slot
-        if constexpr (PIPE == 5 && NEXT1 && !NEXT2) {             // step nk-2: two more slots have been read for the last time
+        if constexpr (RESPF && NEXT2 && !NEXT3) issue_res_block(0, ws * WB);   // step nk-3: no weight tile nk will ask for this slot
+        if constexpr (RESPF && NEXT1 && !NEXT2) {             // step nk-2: two more slots have been read for the last time
           if (nk == 2) issue_res_block(0, 2 * WB);                //   (no step nk-3: the third weight slot was never used)
           issue_res_block(1, ws * WB);
           issue_res_block(2, 3 * WB + (kt & 1) * XB);
         }
-        if constexpr (PIPE == 5 && !NEXT1) {                     // last step
+        if constexpr (RESPF && !NEXT1) {                     // last step
           if (nk == 1) { issue_res_block(0, 1 * WB); issue_res_block(1, 2 * WB); issue_res_block(2, 3 * WB + XB); }
           issue_res_block(3, ws * WB);
         }
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
         mma(a1, b1);
         if constexpr (NEXT1) interleave_reads();
         if constexpr (NEXT2 || NEXT3) interleave_pieces((NEXT2 ? NLH : 0) + (NEXT3 ? NLH : 0));
-        if constexpr (PIPE == 5 && !NEXT3) interleave_pieces(NEXT2 ? 4 : (NEXT1 ? 8 : 4));
+        if constexpr (RESPF && !NEXT3) interleave_pieces(NEXT2 ? 4 : (NEXT1 ? 8 : 4));
         __builtin_amdgcn_sched_barrier(0);
         ws = ws1;
       };
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       if (kt + 2 < nk) { step4(kt, std::true_type{}, std::true_type{}, std::false_type{}); ++kt; }
       if (kt + 1 < nk) { step4(kt, std::true_type{}, std::false_type{}, std::false_type{}); ++kt; }
       step4(kt, std::false_type{}, std::false_type{}, std::false_type{});
-      if constexpr (PIPE == 5) res_off = (wm == 0 ? blkoff[0] : wm == 1 ? blkoff[1] : wm == 2 ? blkoff[2] : blkoff[3]) - wm * (64 * RCH * 16);
+      if constexpr (RESPF) res_off = (wm == 0 ? blkoff[0] : wm == 1 ? blkoff[1] : wm == 2 ? blkoff[2] : blkoff[3]) - wm * (64 * RCH * 16);
     } else {
     stage(0, 0);
     if (nk > 1) stage(1, 1);
@@ -822,7 +829,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   // rows, two to sixteen per thread.  Chunk c of token row t sits at chunk c ^ (t & CMASK): the 16 token rows of a
   // ds_read_b64 land in 16 different bank groups without padding (a padded 256 x 256 tile would not fit).
   const bool res_lds = (EPI == EPI_PLAIN) && p.residual != nullptr && p.res_wide;   // workgroup-uniform
-  if constexpr (PIPE == 2 || PIPE == 5) {
+  if constexpr (PIPE == 2 || PIPE == 5 || PIPE == 6) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my pieces of the prefetched residual tile have landed ...
     __syncthreads();                                           // ... and so have everybody else's
   } else if (RES_PF_OK && res_pf) {
@@ -985,7 +992,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
         else if (key == 3) write_rows(c1{}, c1{}, c1{}, c0{}, c0{}, c0{});             // bias + residual
         else if (key == 6) write_rows(c1{}, c0{}, c1{}, c1{}, c0{}, c0{});             // residual + statistics (o_proj, down)
         else if (key == 7) write_rows(c1{}, c1{}, c1{}, c1{}, c0{}, c0{});             // + bias (SigLIP out / fc2)
-        else if constexpr (PIPE <= 1 || PIPE == 4) {
+        else if constexpr (PIPE <= 1 || PIPE == 4 || PIPE == 7) {
           if (key == 25) write_rows(c1{}, c1{}, c0{}, c0{}, c1{}, c1{});               // folded LayerNorm + bias (SigLIP qkv / fc1)
           else done = false;
         } else done = false;
@@ -1072,16 +1079,16 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
 }
 
 #ifdef AKI_LAB_HOOKS
-int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;   // set by aki_lab_set_gemm_tile (lab build only); g_pipe: 0 off, 1 on, 2 on without the residual prefetch
+int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0;   // set by aki_lab_set_gemm_tile (lab build only); g_pipe: 0 off, 1 on, 2 on without the residual prefetch
 long long* g_clock_probe = nullptr;                  // set by aki_lab_set_clock_probe
 #else
-static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1;
+static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0;
 #endif
 
 template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, int PIPE = 0>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
-  constexpr int SMEM = (PIPE == 4 || PIPE == 5) ? (3 * BN + 2 * BM) * 128 : NST * (BN + BM) * 128;   // PIPE 4 / 5: three weight tiles + two token tiles
+  constexpr int SMEM = (PIPE >= 4 && PIPE <= 7) ? (BN > BM ? 3 * BN + 2 * BM : 3 * BM + 2 * BN) * 128 : NST * (BN + BM) * 128;   // PIPE 4-7: three + two tiles
   static_assert(SMEM <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
@@ -1173,6 +1180,9 @@ static int launch_small(GemmParams& p, hipStream_t stream) {
 
 // g_pipe (lab bit 9 clears it): mid-step barrier pipeline on the 256 x 256 tile
 
+// Which operand of a residual GEMM gets the three-deep ring: the tokens when the activation panel is the larger cold operand (lab bit 12 forces it, bit 13 forbids it)
+static bool deep_tokens(const GemmParams& p) { return g_deepx == 1 || (g_deepx == 0 && (long)p.M > 3L * p.N / 2 && p.K >= 4096); }
+
 template <int EPI, int ACT, bool FP8>
 static int launch_big(GemmParams& p, hipStream_t stream) {
   if constexpr (!FP8) {
@@ -1182,7 +1192,8 @@ static int launch_big(GemmParams& p, hipStream_t stream) {
 #endif
     if constexpr (EPI == EPI_PLAIN && ACT == 0) {   // residual tile prefetched under the last K-steps (o_proj, down_proj)
       if ((g_pipe == 1 || g_pipe == 3) && p.row_shift == nullptr && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && p.N % 8 == 0 && p.N >= 8)
-        return g_pipe == 3 ? launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 2>(p, stream) : launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 5>(p, stream);
+        return g_pipe == 3 ? launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 2>(p, stream)
+               : (deep_tokens(p) ? launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 6>(p, stream) : launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 5>(p, stream));
     }
     if (g_pipe == 3) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 1>(p, stream);   // lab: two-deep weight ring
     if (g_pipe) return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8, 2, 4>(p, stream);
