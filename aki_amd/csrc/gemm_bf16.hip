@@ -225,7 +225,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   const int fwave = n0 + wn * (EPI == EPI_SWIGLU ? WROWS / 2 : WROWS);
   // folded LayerNorm (consumer), kernel-uniform.  Not on the PIPELINED 256^2 tile: its epilogue has no registers left for the
   // column sums (they spilled); the host sends row_shift launches that want the big tile to its unpipelined twin.
-  const bool shifted = (PIPE <= 1 || PIPE == 4 || PIPE == 7) && (EPI == EPI_PLAIN) && p.row_shift != nullptr;
+  const bool shifted = (PIPE <= 1 || PIPE == 4 || PIPE == 7 || PIPE == 8) && (EPI == EPI_PLAIN) && p.row_shift != nullptr;
   u32x2 biasp[NOUT];
   f32x4 colc4[NOUT];
   float rsv[NT], muv[NT];
@@ -246,12 +246,13 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       muv[m] = (EPI == EPI_PLAIN && shifted) ? p.row_shift[mr] : 0.0f;
     }
   };
-  constexpr bool EARLY_OPERANDS = !PIPE && !FP8 && NF * NT <= 16;
+  constexpr bool EARLY_OPERANDS = (!PIPE || PIPE == 8) && !FP8 && NF * NT <= 16;
   constexpr int RCH = BN / 8;                                  // 16-byte chunks per residual tile row (epilogue staging, below)
   constexpr int CMASK = RCH >= 16 ? 15 : RCH - 1;
   // residual prefetch of the two-stage loop (small tiles): possible when the residual tile fits ONE stage buffer in whole 1-KiB pieces
   constexpr int RES_PIECES = (BM * RCH * 16) / (NWAVES * 1024);
-  constexpr bool RES_PF_OK = EPI == EPI_PLAIN && ACT == 0 && !FP8 && !PIPE && NST == 2 && RCH <= 64 && (64 % RCH == 0) && BM * RCH * 16 <= STAGE_BYTES &&
+  constexpr bool RES_PF_OK = EPI == EPI_PLAIN && ACT == 0 && !FP8 && (!PIPE || PIPE == 8) && NST == 2 && RCH <= 64 && (64 % RCH == 0) && BM * RCH * 16 <= STAGE_BYTES &&
+                             (PIPE != 8 || BM * RCH * 16 <= 2 * BM * 128) &&
                              (BM * RCH * 16) % (NWAVES * 1024) == 0;
   const bool res_pf = RES_PF_OK && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && n_out >= 8;   // workgroup-uniform
   int res_off = 0;                 // where the residual tile image sits in smem
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 #undef AKI_DSR
 #undef AKI_MFMA
-  } else if constexpr (PIPE) {
+  } else if constexpr (PIPE && PIPE != 8) {
     // Mid-step barrier pipeline (bf16, 2 stages).  In the loop below every LDS fragment read of a K-step sits between
     // the barrier and the MFMAs that need it, and all eight waves do theirs at the same time: the LDS array (24
     // ds_read_b128 per wave and step, ~770 array cycles per CU) and then the matrix cores (2048 cycles per SIMD) take
@@ -633,6 +634,67 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
     for (; kt + 2 < nk; ++kt) step(kt, std::true_type{}, std::true_type{});
     if (kt + 1 < nk) { step(kt, std::true_type{}, std::false_type{}); ++kt; }
     step(kt, std::false_type{}, std::false_type{});
+    }
+  } else if constexpr (PIPE == 8) {
+    // Small tiles (two workgroups per CU), token tiles on a THREE-deep ring beside two weight buffers: a token tile is asked for two steps ahead.
+    // For launches whose activation comes out of HBM - SigLIP fc2 reads the 40 MB fc1 has just written: 53.8 us with it on-die, 65.1 from HBM
+    // (tools/siglip_cold_probe.py).  LDS: 2 weight slots, 3 token slots and one spare token-sized slot (for the residual tile of the last step).
+    static_assert(PIPE != 8 || (!FP8 && NST == 2 && (BN / 8) % NWAVES == 0 && (BM / 8) % NWAVES == 0), "whole pieces per operand and wave");
+    constexpr int WB = BN * 128, XB = BM * 128, NLW = BN / 8 / NWAVES, NLX = BM / 8 / NWAVES;
+    char* const sXr = smem + 2 * WB;
+    auto stage_w8 = [&](int slot, int kt_) {
+#pragma unroll
+      for (int j = 0; j < NLW; ++j)
+        __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[j] + (size_t)kt_ * 128), AKI_LDS_PTR(smem + slot * WB + (j * NWAVES + wave) * 1024), 16, 0, 0);
+    };
+    auto stage_x8 = [&](int slot, int kt_) {
+#pragma unroll
+      for (int j = 0; j < NLX; ++j)
+        __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[NLW + j] + (size_t)kt_ * 128), AKI_LDS_PTR(sXr + slot * XB + (j * NWAVES + wave) * 1024), 16, 0, 0);
+    };
+    const int xb8 = (wm * WTOK + l15) * 128;
+    auto compute8 = [&](const char* sw, const char* sx) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {  // two k32 steps per BK
+        const int coff = ((4 * ks + kg) ^ swz) << 4;
+        bf16x8 a[NF], b[NT];
+#pragma unroll
+        for (int n = 0; n < NF; ++n) a[n] = *(const bf16x8*)(sw + wbase + n * 2048 + coff);
+#pragma unroll
+        for (int m = 0; m < NT; ++m) b[m] = *(const bf16x8*)(sx + xb8 + m * 2048 + coff);
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+          for (int m = 0; m < NT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], b[m], acc[n][m], 0, 0, 0);
+      }
+    };
+    stage_w8(0, 0); stage_x8(0, 0);
+    if (nk > 1) stage_x8(1, 1);
+    int xs = 0;                                         // ring slot of token tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+      // weight tile kt and token tile kt have landed: the only younger transfer is token tile kt+1 (issue order per step: weights kt+1, tokens kt+2)
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLX) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                     // ... for every wave; nobody reads the slots of tile kt-1 any more
+      const int xs1 = xs == 2 ? 0 : xs + 1, xs2 = xs1 == 2 ? 0 : xs1 + 1;
+      if (kt + 1 < nk) stage_w8((kt + 1) & 1, kt + 1);
+      if (kt + 2 < nk) stage_x8(xs2, kt + 2);
+      if (kt + 1 == nk && RES_PF_OK && res_pf) {
+        // last K-step: two adjacent token-sized slots are free (slots 0-1 when this tile sits in slot 2, else slot 2 and the spare) - the residual tile
+        // goes there by LDS-DMA under this step's MFMAs (image as in the epilogue's staging: chunk c of token row t at c ^ (t & CMASK))
+        res_off = 2 * WB + (xs == 2 ? 0 : 2 * XB);
+#pragma unroll
+        for (int j = 0; j < RES_PIECES; ++j) {
+          const int q = j * NWAVES + wave;
+          const int tk = q * (64 / RCH) + lane / RCH;
+          const int ch = (lane & (RCH - 1)) ^ (tk & CMASK);
+          const int f = min(n0 + 8 * ch, n_out - 8);
+          const bf16_t* src_ = p.residual + (size_t)min(m0 + tk, p.M - 1) * p.ldr + f;
+          __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src_), AKI_LDS_PTR(smem + res_off + q * 1024), 16, 0, 0);
+        }
+      }
+      compute8(smem + (kt & 1) * WB, sXr + xs * XB);
+      xs = xs1;
     }
   } else if constexpr (NST == 2) {
     stage(0, 0);
@@ -992,7 +1054,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
         else if (key == 3) write_rows(c1{}, c1{}, c1{}, c0{}, c0{}, c0{});             // bias + residual
         else if (key == 6) write_rows(c1{}, c0{}, c1{}, c1{}, c0{}, c0{});             // residual + statistics (o_proj, down)
         else if (key == 7) write_rows(c1{}, c1{}, c1{}, c1{}, c0{}, c0{});             // + bias (SigLIP out / fc2)
-        else if constexpr (PIPE <= 1 || PIPE == 4 || PIPE == 7) {
+        else if constexpr (PIPE <= 1 || PIPE == 4 || PIPE == 7 || PIPE == 8) {
           if (key == 25) write_rows(c1{}, c1{}, c0{}, c0{}, c1{}, c1{});               // folded LayerNorm + bias (SigLIP qkv / fc1)
           else done = false;
         } else done = false;
@@ -1088,7 +1150,8 @@ static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0;
 template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, int PIPE = 0>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
-  constexpr int SMEM = (PIPE >= 4 && PIPE <= 7) ? (BN > BM ? 3 * BN + 2 * BM : 3 * BM + 2 * BN) * 128 : NST * (BN + BM) * 128;   // PIPE 4-7: three + two tiles
+  constexpr int SMEM = (PIPE >= 4 && PIPE <= 7) ? (BN > BM ? 3 * BN + 2 * BM : 3 * BM + 2 * BN) * 128   // PIPE 4-7: three + two tiles
+                       : (PIPE == 8 ? (2 * BN + 4 * BM) * 128 : NST * (BN + BM) * 128);                      // PIPE 8: two weight, three token slots + a spare
   static_assert(SMEM <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
@@ -1206,7 +1269,7 @@ static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
   if (plan == 1) return launch_small<EPI, ACT, FP8>(p, stream);
   if (plan == 0) return launch_big<EPI, ACT, FP8>(p, stream);
   if constexpr (EPI == EPI_PLAIN && !FP8) {
-    if (plan == 3) return launch_gemm<4, 3, 2, 2, EPI, ACT, FP8>(p, stream);   // 128 features x 96 tokens
+    if (plan == 3) return g_pipe == 3 ? launch_gemm<4, 3, 2, 2, EPI, ACT, FP8>(p, stream) : launch_gemm<4, 3, 2, 2, EPI, ACT, FP8, 2, 8>(p, stream);   // 128 features x 96 tokens (token tiles three deep)
     if (plan == 4) return launch_gemm<2, 2, 2, 2, EPI, ACT, FP8, 4>(p, stream);   // 64 features x 64 tokens, four-stage ring
   }
   const int m_main = p.M / 256 * 256;
