@@ -169,6 +169,8 @@ def load_lab() -> C.CDLL:
     lib.aki_lab_set_gemm_tile.argtypes = [C.c_int]
     lib.aki_lab_set_attn_variant.restype = None
     lib.aki_lab_set_attn_variant.argtypes = [C.c_int]
+    lib.aki_lab_set_probe_block.restype = None
+    lib.aki_lab_set_probe_block.argtypes = [C.c_int]
     lib.aki_lab_set_clock_probe.restype = None
     lib.aki_lab_set_clock_probe.argtypes = [C.c_void_p]
     return lib

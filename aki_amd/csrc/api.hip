@@ -47,6 +47,7 @@ extern int g_pipe;
 extern int g_deepx;
 extern int g_attn_variant;
 extern long long* g_clock_probe;
+extern int g_probe_block;
 #endif
 size_t attn_bwd_ws_bytes(int B, int H, int Lq);
 int attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq, void* dk,
@@ -107,6 +108,7 @@ void aki_lab_set_gemm_tile(int mode) {
 // 0 = product choice, 1 = 32-row attention core (two waves per SIMD), 2 = 64-row core (one wave per SIMD)
 void aki_lab_set_attn_variant(int v) { aki::g_attn_variant = v; }
 // device pointer to two int64: every bf16 GEMM launch then leaves {shader cycles, 100 MHz wall ticks} of its workgroup 0 there
+void aki_lab_set_probe_block(int b) { aki::g_probe_block = b; }   // which workgroup of a GEMM launch stamps
 void aki_lab_set_clock_probe(void* int64x32) { aki::g_clock_probe = (long long*)int64x32; }   // 32 int64 (layout: GemmParams::clock_probe)
 #endif
 

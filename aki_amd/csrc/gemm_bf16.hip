@@ -101,6 +101,7 @@ struct GemmParams {
   float* st_part;      // [slots][2][M] partial sums (sum of squares, sum), slot = tile column * WN + wave column
   unsigned* st_cnt;    // [tiles_m] arrival counters, zero between launches
 #ifdef AKI_LAB_HOOKS
+  int probe_block;          // lab: which workgroup stamps (default 0)
   long long* clock_probe;   // lab: 32 int64: {shader cycles, 100 MHz ticks} of workgroup 0, [2..17] phase sums of the PIPE 3 loop, [18] prologue, [19] epilogue cycles
 #endif
   float st_eps;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   // clock probe (lab build): shader cycles and the 100 MHz wall clock over workgroup 0's lifetime -> the engine clock the
   // kernel actually ran at (tools/gemm_clock.py)
   long long probe_c0 = 0, probe_w0 = 0;
-  if (blockIdx.x == 0 && tid == 0 && p.clock_probe) { probe_c0 = clock64(); probe_w0 = wall_clock64(); }
+  if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) { probe_c0 = clock64(); probe_w0 = wall_clock64(); }
 #endif
 
   // ---- tile id: XCD-contiguous chunks, grouped so concurrently running tiles of an XCD share operand panels ----
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   const int n_out = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
 
   // ---- per-thread staging sources ----------------------------------------------------------------------------
-  auto weight_row = [&](int row) {    // tile row (0 .. BN-1, wave-local feature blocks) -> row of the weight matrix
+  auto weight_row_n = [&](int n0, int row) {    // tile row (0 .. BN-1, wave-local feature blocks) of the tile at feature n0 -> row of the weight matrix
     if (EPI == EPI_SWIGLU) {  // wave-local blocks [0,NF/2) = gate rows, [NF/2,NF) = up rows of the same features
       const int w_ = row / WROWS, within = row % WROWS, nb = within >> 4, i = within & 15;
       const int f = min(n0 + w_ * (WROWS / 2) + (nb % (NF / 2)) * 16 + i, n_out - 1);
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       return min(n0 + row, p.N - 1);
     }
   };
+  auto weight_row = [&](int row) { return weight_row_n(n0, row); };
   const char* src[NLD];
 #pragma unroll
   for (int j = 0; j < NLD; ++j) {
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   };
 #ifdef AKI_LAB_HOOKS
   long long probe_l0 = 0, probe_l1 = 0;                  // K-loop begin / end of workgroup 0 -> clock_probe[18] = prologue, [19] = epilogue cycles
-  if (blockIdx.x == 0 && tid == 0 && p.clock_probe) probe_l0 = clock64();
+  if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) probe_l0 = clock64();
 #endif
   if constexpr (PIPE == 3) {
     // One wave per SIMD with a hand-placed stream (lab).  Four waves, wave tile 128 features x 128 tokens: 256 accumulator registers
@@ -539,6 +541,9 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+#ifdef AKI_LAB_HOOKS
+      if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) p.clock_probe[21] = clock64() - probe_l0;   // first tile landed
+#endif
       load_frags2(smem, sS, 0, a0, b0);
       int ws = 0;                                      // ring slot of weight tile kt
       auto step4 = [&](int kt, auto next1, auto next2, auto next3) {
@@ -741,7 +746,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   }
 
 #ifdef AKI_LAB_HOOKS
-  if (blockIdx.x == 0 && tid == 0 && p.clock_probe) probe_l1 = clock64();
+  if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) probe_l1 = clock64();
 #endif
   if constexpr (FP8) {   // dequantise: acc[feature][token] *= sw[weight row] * sx[token]
     float sxm[NT];
@@ -801,7 +806,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
     }
 #ifdef AKI_LAB_HOOKS
     long long probe_s = 0;
-    if (blockIdx.x == 0 && tid == 0 && p.clock_probe) probe_s = clock64();
+    if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) probe_s = clock64();
 #endif
     // Units outside, token blocks inside: what a unit is (q / k with RoPE or v, its head, its plane of the output) is wave-uniform and
     // decided once, and the NT token blocks under it are one basic block - their cos / sin reads, the rotation and the stores overlap.
@@ -874,7 +879,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
     if (m0 + BM <= p.M) rope_rows(std::true_type{});
     else rope_rows(std::false_type{});
 #ifdef AKI_LAB_HOOKS
-    if (blockIdx.x == 0 && tid == 0 && p.clock_probe) {
+    if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) {
       p.clock_probe[0] = clock64() - probe_c0;
       p.clock_probe[1] = wall_clock64() - probe_w0;
       p.clock_probe[18] = probe_l0 - probe_c0;
@@ -1131,7 +1136,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
     }
   }
 #ifdef AKI_LAB_HOOKS
-  if (blockIdx.x == 0 && tid == 0 && p.clock_probe) {
+  if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) {
     p.clock_probe[0] = clock64() - probe_c0;
     p.clock_probe[1] = wall_clock64() - probe_w0;
     p.clock_probe[18] = probe_l0 - probe_c0;
@@ -1143,6 +1148,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
 #ifdef AKI_LAB_HOOKS
 int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0;   // set by aki_lab_set_gemm_tile (lab build only); g_pipe: 0 off, 1 on, 2 on without the residual prefetch
 long long* g_clock_probe = nullptr;                  // set by aki_lab_set_clock_probe
+int g_probe_block = 0;                               // set by aki_lab_set_probe_block
 #else
 static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0;
 #endif
@@ -1166,6 +1172,7 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   AKI_CLEAR_ERR();
 #ifdef AKI_LAB_HOOKS
   p.clock_probe = g_clock_probe;
+  p.probe_block = g_probe_block;
 #endif
   hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
   AKI_LAUNCH_CHECK();
