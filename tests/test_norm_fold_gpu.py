@@ -40,7 +40,8 @@ def test_row_stats(rows, cols, ln):
         assert st.mean is None
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (37, 1152, 640), (1380, 3072, 256), (700, 1152, 4352), (17, 192, 64), (513, 72, 192), (3, 256, 128), (1, 3072, 3072)])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (37, 1152, 640), (1380, 3072, 256), (700, 1152, 4352), (17, 192, 64), (513, 72, 192), (3, 256, 128), (1, 3072, 3072),
+                                   (2100, 512, 4160)])   # the last one: tokens on the three-deep ring when the 256 x 256 tile is forced (M > 1.5 N, K >= 4096)
 @pytest.mark.parametrize("ln", [False, True])
 def test_linear_producer_statistics(M, N, K, ln, gemm_tile):
     """`stats_out`: the output is bit-identical to the plain launch, and the statistics are those of the bf16 values stored -
