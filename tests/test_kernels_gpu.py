@@ -82,7 +82,8 @@ def gemm_tile(request):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (256, 256, 64), (1, 768, 128), (700, 1152, 640), (513, 36, 192), (120, 4096, 512), (97, 40000, 256)])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (256, 256, 64), (1, 768, 128), (700, 1152, 640), (513, 36, 192), (120, 4096, 512), (97, 40000, 256),
+                                   (300, 512, 128), (300, 512, 192)])   # K = 128 / 192: two / three K-steps through the three-deep rings and the residual blocks
 def test_linear_plain_bias_act_residual(dtype, M, N, K, gemm_tile):
     ops = _ops()
     if dtype == torch.float32 and gemm_tile:
