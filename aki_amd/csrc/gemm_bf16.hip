@@ -25,6 +25,16 @@
 // the 16x16 fragment read groups.  One vmcnt(0)+barrier per K-step; tile k+1 streams in under tile k's MFMAs.
 // (tools/gemm_lab.hip: a deeper BK=32 x 4-stage counted-vmcnt ring, interleaved LDS-DMA issue, fragment
 // double-buffering, setprio and wave staggering were all measured and bought nothing on this structure.)
+//
+// K-loop variants (template parameter PIPE; which one a launch gets is decided in launch_big / run_planned):
+//   0  two stages, one vmcnt(0) + barrier per K-step (small tiles, fp8); NST 3-4: a ring for one-row weight-streaming launches
+//   1  256 x 256: the barrier in the MIDDLE of the step, fragment reads and DMA issue spread between the MFMAs (lab: the form before the three-deep rings)
+//   2  = 1 + the residual tile prefetched under the last two K-steps into the two stage buffers (lab, as above)
+//   3  lab: four waves, one per SIMD, hand-placed stream (asm MFMAs on AGPR accumulators), per-phase stamps
+//   4  = 1 with the WEIGHT tiles on a three-deep ring (160 KiB of LDS): a weight tile is asked for two K-steps ahead - operands come out of HBM
+//   5  = 4 + the residual tile's four 32 KiB blocks prefetched into ring slots as they fall free (o_proj)
+//   6  = 5 with the TOKEN tiles three deep instead (down_proj: the activation is the larger cold operand);  7 = 4 likewise (not dispatched)
+//   8  128 x 96 tile, unpipelined loop, token tiles three deep (SigLIP fc2 reads a 40 MB activation out of HBM)
 #include <type_traits>
 
 #include "aki_device.h"
