@@ -45,7 +45,6 @@ extern int g_force_tile;
 extern int g_deep_ring;
 extern int g_pipe;
 extern int g_deepx;
-extern int g_pipe8;
 extern int g_attn_variant;
 extern long long* g_clock_probe;
 extern int g_probe_block;
@@ -101,8 +100,7 @@ int aki_abi_version(void) { return AKI_ABI_VERSION; }
 // not thread safe - which is why the product library does not carry it.
 void aki_lab_set_gemm_tile(int mode) {
   aki::g_deep_ring = (mode & 256) ? 0 : 1;
-  aki::g_deepx = (mode & 4096) ? 1 : ((mode & 8192) ? 2 : 0);
-  aki::g_pipe8 = (mode & 16384) ? 1 : 0;                          // +16384: token tiles three deep on the 128 x 96 tile (lab only)   // residual GEMMs: three-deep ring on the tokens (forced / forbidden)
+  aki::g_deepx = (mode & 4096) ? 1 : ((mode & 8192) ? 2 : 0);   // residual GEMMs: three-deep ring on the tokens (forced / forbidden)
   aki::g_pipe = (mode & 512) ? 0 : ((mode & 1024) ? 2 : ((mode & 2048) ? 3 : 1));     // +1024: pipeline without the residual prefetch, +2048: with the two-deep weight ring
   mode &= 255;
   aki::g_force_tile = (mode >= 1 && mode <= 5) ? mode : 0;

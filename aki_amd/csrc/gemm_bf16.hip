@@ -34,7 +34,7 @@
 //   4  = 1 with the WEIGHT tiles on a three-deep ring (160 KiB of LDS): a weight tile is asked for two K-steps ahead - operands come out of HBM
 //   5  = 4 + the residual tile's four 32 KiB blocks prefetched into ring slots as they fall free (o_proj)
 //   6  = 5 with the TOKEN tiles three deep instead (down_proj: the activation is the larger cold operand);  7 = 4 likewise (not dispatched)
-//   8  lab only: 128 x 96 tile, unpipelined loop, token tiles three deep (statistics hand-off behind it unreliable: see run_planned)
+//   8  128 x 96 tile, unpipelined loop, token tiles three deep (SigLIP fc2 reads a 40 MB activation out of HBM)
 #include <type_traits>
 
 #include "aki_device.h"
@@ -1124,7 +1124,11 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
         __syncthreads();
         if (tid < BM) {
           for (int sl = 0; sl < total / BM; ++sl) {
-            const unsigned long long both = park[sl * BM + tid];
+            unsigned long long both = park[sl * BM + tid];
+            // Explicit wait: with hipcc's own lgkmcnt for this read (merged into ds_read2st64_b64 on the 96- and 64-row tiles) the SUM half of one slot was
+            // consumed before it had arrived - lanes 48..63, the last quarter the LDS returns - in 0.5 % of LayerNorm-statistics launches at long K
+            // (tools/stats_stress_modes.py; outputs and the partials in memory were right every time).  The fold runs once per row panel: the wait is free.
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(both));
             s2 += __uint_as_float((unsigned)both);
             s1 += __uint_as_float((unsigned)(both >> 32));
           }
@@ -1156,11 +1160,11 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
 }
 
 #ifdef AKI_LAB_HOOKS
-int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0, g_pipe8 = 0;   // set by aki_lab_set_gemm_tile (lab build only); g_pipe: 0 off, 1 on, 2 on without the residual prefetch
+int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0;   // set by aki_lab_set_gemm_tile (lab build only); g_pipe: 0 off, 1 on, 2 on without the residual prefetch
 long long* g_clock_probe = nullptr;                  // set by aki_lab_set_clock_probe
 int g_probe_block = 0;                               // set by aki_lab_set_probe_block
 #else
-static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0, g_pipe8 = 0;
+static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0;
 #endif
 
 template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, int PIPE = 0>
@@ -1286,9 +1290,7 @@ static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
   if (plan == 1) return launch_small<EPI, ACT, FP8>(p, stream);
   if (plan == 0) return launch_big<EPI, ACT, FP8>(p, stream);
   if constexpr (EPI == EPI_PLAIN && !FP8) {
-    // (PIPE 8 - token tiles three deep on this tile - is dispatched by the lab library only, bit 14: with it the statistics hand-off of SigLIP fc2 lost one
-    // slot's partial for 16 rows in 0.7 % of launches (tools/stats_stress.py); y was bit-exact every time.  Not understood yet, so not in the product.)
-    if (plan == 3) return g_pipe8 ? launch_gemm<4, 3, 2, 2, EPI, ACT, FP8, 2, 8>(p, stream) : launch_gemm<4, 3, 2, 2, EPI, ACT, FP8>(p, stream);   // 128 features x 96 tokens
+    if (plan == 3) return g_pipe == 3 ? launch_gemm<4, 3, 2, 2, EPI, ACT, FP8>(p, stream) : launch_gemm<4, 3, 2, 2, EPI, ACT, FP8, 2, 8>(p, stream);   // 128 features x 96 tokens (token tiles three deep)
     if (plan == 4) return launch_gemm<2, 2, 2, 2, EPI, ACT, FP8, 4>(p, stream);   // 64 features x 64 tokens, four-stage ring
   }
   const int m_main = p.M / 256 * 256;
