@@ -28,9 +28,13 @@ def make_siglip_config(**kw):
 _Prepared = ops.Prepared
 
 
-def _epoch() -> int:
+def _epoch(params) -> int:
     """The trainers write weights through raw pointers without bumping tensor versions and announce it through the weight epoch
-    (train_ops.bump_weight_epoch): every cached transform of a weight is keyed on it, the same rule as in phi3.py."""
+    (train_ops.bump_weight_epoch): every cached transform of a TRAINABLE weight is keyed on it, the same rule as in phi3.py.  A trainer only
+    ever writes parameters with requires_grad - the frozen tower of the reference's recipes keeps its folded copies across optimizer steps
+    (keyed on the epoch they were rebuilt in every training step: 27 x 3 transforms, ≈6 ms of small torch kernels and as much idle GPU)."""
+    if not any(p.requires_grad for p in params):
+        return 0
     from . import train_ops as T
     return T._EPOCH
 
@@ -103,7 +107,7 @@ class SiglipAttention(nn.Module):
         ps = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.q_proj.bias, self.k_proj.bias, self.v_proj.bias,
               ln.weight, ln.bias]
         wqkv, bqkv, cqkv = self._prep.get("qkv_ln", ps, lambda: fold_layernorm(torch.cat([p.detach() for p in ps[:3]], 0),
-                                                                                torch.cat([p.detach() for p in ps[3:6]], 0), ln), _epoch())
+                                                                                torch.cat([p.detach() for p in ps[3:6]], 0), ln), _epoch(ps))
         qkv = ops.linear(h, wqkv, bias=bqkv, row_scale=st.rstd, row_shift=st.mean, col_shift=cqkv)
         qkv = qkv.view(N, L, 3, self.num_heads, self.head_dim)
         a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], self.scale)
@@ -113,7 +117,7 @@ class SiglipAttention(nn.Module):
         N, L, E = x.shape
         ps = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]
         wqkv, bqkv = self._prep.get("qkv", ps, lambda: (torch.cat([p.detach() for p in ps[:3]], 0).contiguous(),
-                                                        torch.cat([p.detach() for p in ps[3:]], 0).contiguous()), _epoch())
+                                                        torch.cat([p.detach() for p in ps[3:]], 0).contiguous()), _epoch(ps))
         qkv = ops.linear(x, wqkv, bias=bqkv).view(N, L, 3, self.num_heads, self.head_dim)
         a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], self.scale)   # strided views, no copies
         return ops.linear(a, self.out_proj.weight, bias=self.out_proj.bias, residual=residual)
@@ -135,7 +139,7 @@ class SiglipMLP(nn.Module):
         SiglipAttention.forward_folded); `stats_out` receives the statistics of the result."""
         inter = self.fc1.weight.shape[0]
         Kp = (inter + 63) // 64 * 64
-        w2 = self._prep.get("w2", [self.fc2.weight], lambda: ops.pad_k(self.fc2.weight.detach()), _epoch())
+        w2 = self._prep.get("w2", [self.fc2.weight], lambda: ops.pad_k(self.fc2.weight.detach()), _epoch([self.fc2.weight]))
         lead = x.shape[:-1]
         # fc1 writes into a K-padded buffer; the pad columns must be finite zeros for fc2 (zero weights there).  The buffer
         # is kept per shape: fc1 overwrites columns [:inter] every call and nothing ever writes the pad columns, so they are
@@ -150,7 +154,8 @@ class SiglipMLP(nn.Module):
             ops.linear(x, self.fc1.weight, bias=self.fc1.bias, act=self.act, out=hbuf[..., :inter])
         else:
             w1, b1, c1 = self._prep.get("fc1_ln", [self.fc1.weight, self.fc1.bias, ln.weight, ln.bias],
-                                        lambda: fold_layernorm(self.fc1.weight.detach(), self.fc1.bias.detach(), ln), _epoch())
+                                        lambda: fold_layernorm(self.fc1.weight.detach(), self.fc1.bias.detach(), ln),
+                                        _epoch([self.fc1.weight, self.fc1.bias, ln.weight, ln.bias]))
             ops.linear(x, w1, bias=b1, act=self.act, out=hbuf[..., :inter], row_scale=st.rstd, row_shift=st.mean, col_shift=c1)
         return ops.linear(hbuf, w2, bias=self.fc2.bias, residual=residual, stats_out=stats_out, stats_eps=stats_eps)
 

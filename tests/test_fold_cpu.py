@@ -71,3 +71,27 @@ def test_prepared_cache_follows_parameter_versions_and_epochs():
     assert len(calls) == 3
     cache.get("k", [p], make, epoch=1)
     assert len(calls) == 3
+
+
+def test_siglip_fold_epoch_only_for_trainable_parameters():
+    """aki_amd/siglip.py::_epoch: cached transforms of FROZEN weights (the vision tower of the reference's recipes, src/vlm.py:184-207 runs it under
+    no_grad) are not keyed on the trainer's weight epoch - a trainer writes only parameters with requires_grad; trainable ones follow the epoch."""
+    from aki_amd import siglip, train_ops as T
+    frozen = torch.nn.Parameter(torch.ones(4), requires_grad=False)
+    live = torch.nn.Parameter(torch.ones(4))
+    e0 = T._EPOCH
+    try:
+        T.bump_weight_epoch()
+        assert siglip._epoch([frozen]) == 0
+        assert siglip._epoch([frozen, live]) == T._EPOCH == e0 + 1
+        cache, calls = ops.Prepared(), []
+        make = lambda: calls.append(1) or frozen.detach() * 2
+        cache.get("k", [frozen], make, siglip._epoch([frozen]))
+        T.bump_weight_epoch()
+        cache.get("k", [frozen], make, siglip._epoch([frozen]))
+        assert len(calls) == 1                                            # an optimizer step does not rebuild a frozen weight's transform
+        frozen.requires_grad_(True)                                       # un-freezing it does
+        cache.get("k", [frozen], make, siglip._epoch([frozen]))
+        assert len(calls) == 2
+    finally:
+        T._EPOCH = e0
