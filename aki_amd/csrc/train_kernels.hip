@@ -87,15 +87,16 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* x, const bf
     wv[i] = c < nchunk ? *(const u32x4*)(w + c * 8) : u32x4{0u, 0u, 0u, 0u};
   }
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-    u32x4 xv[MAXC], gv[MAXC];
+    u32x4 xv[MAXC], gv[MAXC], rv[MAXC];   // the residual-branch gradient is asked for with the row, not behind the two reductions (a third DRAM round trip per row)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = tid + i * 256;
-      xv[i] = u32x4{0u, 0u, 0u, 0u}; gv[i] = xv[i];
+      xv[i] = u32x4{0u, 0u, 0u, 0u}; gv[i] = xv[i]; rv[i] = xv[i];
       if (c < nchunk) {
         xv[i] = *(const u32x4*)(x + (size_t)row * ldx + c * 8);
         gv[i] = *(const u32x4*)(dy + (size_t)row * lddy + c * 8);
+        if (dres) rv[i] = *(const u32x4*)(dres + (size_t)row * lddr + c * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float a = bf16_lo(xv[i][e]), b = bf16_hi(xv[i][e]);
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* x, const bf
     for (int i = 0; i < MAXC; ++i) {
       const int c = tid + i * 256;
       if (c < nchunk) {
-        u32x4 o, rr = {0u, 0u, 0u, 0u};
-        if (dres) rr = *(const u32x4*)(dres + (size_t)row * lddr + c * 8);     // gradient of the residual branch, summed in here
+        u32x4 o;
+        const u32x4 rr = rv[i];     // gradient of the residual branch, summed in here
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           o[e] = pack_bf16x2(rstd * (dxh[i][2 * e] - c2 - xh[i][2 * e] * c1) + bf16_lo(rr[e]),
