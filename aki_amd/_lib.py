@@ -16,7 +16,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 11
+AKI_ABI_VERSION = 12
 
 
 class AkiError(RuntimeError):
@@ -117,6 +117,7 @@ SIGNATURES = {
     "aki_attn_bwd_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
     "aki_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_transpose": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),
+    "aki_gemm_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 3 + [C.c_int64] * 3 + [C.c_int32, C.c_void_p]),
     "aki_norm_bwd_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "aki_norm_bwd": (C.c_int, [C.c_int32] + [C.c_void_p] * 7 + [C.c_int32] * 6 + [C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                                                                   C.c_void_p]),

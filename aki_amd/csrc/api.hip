@@ -54,6 +54,7 @@ int attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, co
                   void* dv, const aki_mma_rect* rects, int max_rects, const uint64_t* vbits, const int* seq_lens, int masked, int B,
                   int H, int Lq, int Lk, int Dh, float scale, void* ws, size_t ws_bytes, hipStream_t s);
 int transpose_bf16_launch(const void* x, void* y, int R, int C, int ldx, int ldy, int Rpad, hipStream_t s);
+int gemm_tn_launch(const void* a, const void* b, void* c, int Kc, int I, int J, long lda, long ldb, long ldc, hipStream_t stream);
 size_t norm_bwd_ws_bytes(int cols);
 int norm_bwd_launch(bool rms, const void* x, const void* w, const void* dy, const void* dres, void* dx, void* dw, void* db, int rows,
                     int cols, int ldx, int lddy, int lddx, int lddr, float eps, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
@@ -409,6 +410,14 @@ int aki_transpose(const void* x, void* y, int32_t R, int32_t C, int32_t ldx, int
   AKI_CHECK_ARG(x && y && R > 0 && C > 0 && ldx >= C && Rpad >= R && ldy >= Rpad);
   AKI_BF16_ONLY(dtype);
   return transpose_bf16_launch(x, y, R, C, ldx, ldy, Rpad, (hipStream_t)stream);
+}
+
+int aki_gemm_tn(const void* a, const void* b, void* c, int32_t Kc, int32_t I, int32_t J, int64_t lda, int64_t ldb, int64_t ldc, int32_t dtype,
+                void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(a && b && c && Kc > 0 && I > 0 && J > 0 && lda >= I && ldb >= J && ldc >= J);
+  AKI_BF16_ONLY(dtype);
+  return gemm_tn_launch(a, b, c, Kc, I, J, (long)lda, (long)ldb, (long)ldc, (hipStream_t)stream);
 }
 
 size_t aki_norm_bwd_workspace_bytes(int32_t cols) { return cols > 0 ? norm_bwd_ws_bytes(cols) : 0; }

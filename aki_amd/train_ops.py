@@ -47,6 +47,31 @@ def transpose(x: torch.Tensor, pad_to: int = 64, out: Optional[torch.Tensor] = N
     return out
 
 
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """c [I, J] = a[Kc, I]^T @ b[Kc, J]  (bf16, f32 accumulate): a weight gradient dW = dY^T X on the operands as they lie - both tiles are staged
+    row-major and read transposed from LDS (aki_gemm_tn), no transpose pass.  I, J and the row strides multiples of 8."""
+    _need_bf16(a, b)
+    dev = _dev(a, b, out)
+    Kc, I = a.shape
+    J = b.shape[1]
+    if b.shape[0] != Kc or a.stride(1) != 1 or b.stride(1) != 1:
+        raise AkiError("gemm_tn: operands must be [Kc, I] and [Kc, J] with unit column stride")
+    if out is None:
+        out = torch.empty((I, J), dtype=a.dtype, device=dev)
+    if out.shape != (I, J) or out.stride(1) != 1:
+        raise AkiError("gemm_tn: bad output buffer")
+    L.check(L.load().aki_gemm_tn(_ptr(a), _ptr(b), _ptr(out), Kc, I, J, a.stride(0), b.stride(0), out.stride(0), _BF16, _stream()), "aki_gemm_tn")
+    return out
+
+
+USE_GEMM_TN = True    # tools/train_step_ab_tn.py flips it to time the transposes + forward-GEMM form on the same box
+
+
+def _tn_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return USE_GEMM_TN and (a.shape[1] % 8 == 0 and b.shape[1] % 8 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
 def norm_bwd(rms: bool, x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps: float, need_db: bool = False,
              dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None, dres: Optional[torch.Tensor] = None):
     """dx, dw, db of RMSNorm / LayerNorm.  dw_out / db_out: write the weight gradients there (e.g. a view of the trainer's
@@ -243,6 +268,19 @@ def _deliver(param: torch.Tensor, grad_writer):
     return grad_writer(None)
 
 
+def _wgrad(param, dy2: torch.Tensor, x2: torch.Tensor):
+    """dW = dY^T X delivered to the parameter's owner: on the operands as they lie (aki_gemm_tn) when their layout allows, else through two
+    transposes and the forward GEMM."""
+    if _tn_ok(dy2, x2):
+        def write(out):
+            if out is None or (out.stride(0) % 4 == 0 and out.data_ptr() % 8 == 0):
+                return gemm_tn(dy2, x2, out=out)
+            return out.copy_(gemm_tn(dy2, x2))
+        return _deliver(param, write)
+    dyT, xT = transpose(dy2), transpose(x2)       # [N, Mp], [K, Mp]
+    return _deliver(param, lambda out: ops.linear(dyT, xT, out=out))
+
+
 # ---- autograd Functions ---------------------------------------------------------------------------------------------
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b [+ residual]   (HIP MFMA GEMM both ways: dX = dY W, dW = dY^T X, db = colsum dY)."""
@@ -277,8 +315,7 @@ class LinearFn(torch.autograd.Function):
             dx = ops.linear(dy2p, _weight_t(w)).view(x.shape)
         if ctx.needs_input_grad[1]:
             x2 = _rows2d(x)
-            dyT, xT = transpose(dy2), transpose(x2)       # [N, Mp], [K, Mp]
-            dw = _deliver(ctx.w_ref, lambda out: ops.linear(dyT, xT, out=out))
+            dw = _wgrad(ctx.w_ref, dy2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _deliver(ctx.bias_ref, lambda out: colsum(dy2) if out is None else out.copy_(colsum(dy2)))
         return dx, dw, db, (dy if ctx.has_res else None)
@@ -386,8 +423,7 @@ class QkvRopeFn(torch.autograd.Function):
         dx = ops.linear(d2, _weight_t(w)).view(x.shape) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dT, xT = transpose(d2), transpose(_rows2d(x))
-            dw = _deliver(ctx.w_ref, lambda out: ops.linear(dT, xT, out=out))
+            dw = _wgrad(ctx.w_ref, d2, _rows2d(x))
         return dx, dw, None, None, None, None
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 11
+#define AKI_ABI_VERSION 12
 
 typedef enum {
   AKI_OK = 0,
@@ -356,12 +356,15 @@ int aki_decode_linear_fwd(const aki_linear_args* args, const void* rms_weight, f
  * eager forward under bf16 autocast, followed by clip_grad_norm_(1.0) and AdamW (train/train_utils.py:242-266,
  * train/train.py:330-337, train/losses.py:83-116).  These entry points are the kernels an autograd wrapper of the
  * forward ops needs; all of them are bf16 (dtype must be AKI_DT_BF16), caller-owned buffers, stream-ordered.
- * GEMM-shaped gradients (dX = dY W, dW = dY^T X) run through aki_linear_fwd on operands produced by aki_transpose.
+ * GEMM-shaped gradients: dX = dY W runs through aki_linear_fwd on W^T (aki_transpose, once per optimizer step), dW = dY^T X through aki_gemm_tn.
  *
  * aki_attn_bwd      backward of aki_mma_attn_core_fwd (masked = 1; needs Lq == Lk) or of aki_attn_fwd (masked = 0):
  *                   q,k,v [B,H,L,Dh] (k rotated) as the forward saw them, o and d_o [B,Lq,H*Dh], lse [B,H,Lq] from the
  *                   forward -> dq,dk,dv [B,H,L,Dh].  Dh 96 or 64.  Rows >= seq_lens[b] get zero gradient.
  * aki_transpose     y[C][ldy] = x[R][C]^T with columns R..Rpad-1 of y zero-filled (Rpad <= ldy).
+ * aki_gemm_tn       c[I][ldc] = sum over the Kc rows of a[Kc][lda]^T b[Kc][ldb]: the weight gradient dW = dY^T X on dY [M,N] and X [M,K] AS THEY LIE
+ *                   (contraction over the row index of both; the operands are staged row-major and read transposed from LDS - no
+ *                   aki_transpose pass).  I, J, lda, ldb multiples of 8, ldc of 4; a, b 16-byte aligned, c 8-byte aligned.
  * aki_norm_bwd      RMSNorm (rms=1) / LayerNorm backward: dx [rows,cols] (+ dres when given: the gradient arriving through
  *                   the residual branch of a pre-norm block, so the two are summed without a separate pass); dw (and db
  *                   for LayerNorm) [cols], written or accumulated (accumulate=1).  cols % 8 == 0, cols <= 4096.
@@ -398,6 +401,8 @@ typedef struct {
 size_t aki_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Lq);
 int aki_attn_bwd(const aki_attn_bwd_args* args, void* workspace, size_t workspace_bytes, void* stream);
 int aki_transpose(const void* x, void* y, int32_t R, int32_t C, int32_t ldx, int32_t ldy, int32_t Rpad, int32_t dtype, void* stream);
+int aki_gemm_tn(const void* a, const void* b, void* c, int32_t Kc, int32_t I, int32_t J, int64_t lda, int64_t ldb, int64_t ldc, int32_t dtype,
+                void* stream);
 size_t aki_norm_bwd_workspace_bytes(int32_t cols);
 int aki_norm_bwd(int32_t rms, const void* x, const void* w, const void* dy, const void* dres, void* dx, void* dw, void* db,
                  int32_t rows, int32_t cols, int32_t ldx, int32_t lddy, int32_t lddr, int32_t lddx, float eps, int32_t accumulate,

@@ -52,6 +52,40 @@ def test_transpose_pads_with_zeros():
     assert bool((out[0] == 7).all()) and bool((out[257] == 7).all())
 
 
+@pytest.mark.parametrize("Kc,I,J", [(5240, 3072, 3072), (655, 9216, 3072), (300, 264, 136), (64, 256, 256), (63, 8, 8), (1, 16, 24), (129, 520, 1032), (1310, 1152, 4608)])
+def test_gemm_tn_weight_gradient_on_operands_as_they_lie(Kc, I, J):
+    """aki_gemm_tn: dW = dY^T X with both operands row-major over the contraction index (staged as they lie, read transposed from LDS) against the fp32
+    product and, bit for bit, against the path it replaces (two aki_transpose passes + aki_linear_fwd: same K order per output element).
+    Tails: Kc not a multiple of 64 (zero line), I / J not multiples of 256 (clamped loads, dropped stores), strided operand and output views."""
+    from aki_amd import ops, train_ops as T
+    dy, x = rt(Kc, I, seed=Kc + I), rt(Kc, J, seed=Kc + J + 1)
+    got = T.gemm_tn(dy, x)
+    close(got, dy.float().t() @ x.float(), what=f"gemm_tn {Kc}x{I}x{J}")
+    old = ops.linear(T.transpose(dy), T.transpose(x))
+    assert torch.equal(got, old)
+    # operands that are column slices of wider tensors, output into a slice of a wider (poisoned) buffer: nothing outside [I, J] is written
+    wide_a, wide_b = rt(Kc, I + 64, seed=1), rt(Kc, J + 24, seed=2)
+    a, b = wide_a[:, 8:8 + I], wide_b[:, 16:16 + J]
+    buf = torch.full((I + 2, J + 8), 7.0, dtype=BF, device=DEV)
+    out = buf[1:1 + I, 4:4 + J]
+    T.gemm_tn(a, b, out=out)
+    close(out, a.float().t() @ b.float(), what="gemm_tn strided")
+    guard = buf.clone(); guard[1:1 + I, 4:4 + J] = 7.0
+    assert (guard == 7.0).all()
+    # launch-to-launch determinism
+    assert torch.equal(T.gemm_tn(dy, x), got)
+
+
+def test_gemm_tn_rejects_what_it_cannot_address():
+    from aki_amd import train_ops as T, AkiError
+    with pytest.raises(AkiError):
+        T.gemm_tn(rt(64, 12), rt(64, 16))                 # I not a multiple of 8
+    with pytest.raises(AkiError):
+        T.gemm_tn(rt(64, 16), rt(32, 16))                 # different contraction lengths
+    with pytest.raises(AkiError):
+        T.gemm_tn(rt(64, 16).float(), rt(64, 16).float())  # bf16 only
+
+
 @pytest.mark.parametrize("rms", [True, False])
 @pytest.mark.parametrize("rows,cols", [(700, 3072), (37, 1152), (5, 192)])
 def test_norm_backward(rms, rows, cols):
