@@ -7,12 +7,12 @@
 //
 //   tile          256 (i) x 256 (j), 64 contraction rows per step; 8 waves as 2 (i) x 4 (j), wave tile 128 x 64 = 8 x 4 accumulators of
 //                 v_mfma_f32_16x16x32_bf16 (the j fragment is the first operand: a lane then holds 4 consecutive j of one i - 8-byte stores)
-//   LDS           A tiles (64 rows x 512 B) on a three-deep ring, B tiles on a two-deep one = 160 KB, filled by global_load_lds (16 B per lane, 1 KB per wave
+//   LDS           A tiles (64 rows x 512 B) on a three-deep ring, B tiles on a two-deep one = 160 KB, filled by buffer_load ... lds (16 B per lane, 1 KB per wave
 //                 instruction = two tile rows).  The 32-byte piece q of row r sits at piece q ^ g(r), g(r) = (r & 3) | ((r >> 3) & 1) << 2 (applied on
 //                 the SOURCE side - the DMA image is lane-linear): the 8 rows a 32-lane half of a transposed read touches (r, r+1, r+2, r+3 of two
 //                 8-row groups) then cover all 64 banks once.
 //   K loop        counted wait for the step's tiles, one barrier, issue B one step and A two steps ahead, then 16 fragment steps (see the loop).
-//   tails         rows c >= Kc of the last step come from a zero line; columns beyond I / J are clamped on the load and dropped on the store.
+//   tails         rows c >= Kc of the last step lie beyond the buffer descriptor (zeros); columns beyond I / J are clamped on the load, dropped on the store.
 //
 // HBM: reads (I + J) * Kc * 2 B per tile row / column panel, writes I * J * 2 B.  MFMA-bound like aki_linear_fwd: 2 * I * J * Kc FLOP.
 #include "aki_device.h"
@@ -28,8 +28,6 @@ struct GemmTnParams {
   long lda, ldb, ldc;
   int tiles_i, tiles_j;
 };
-
-__device__ __attribute__((aligned(16))) char g_zero_line[16] = {0};
 
 constexpr int TN_BI = 256, TN_BJ = 256, TN_BK = 64;
 constexpr int TN_OP_BYTES = TN_BK * 512;            // one operand tile: 64 rows x 256 bf16
@@ -51,8 +49,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
 
   // ---- staging sources: wave instruction n (0..7) of a stage fills 1 KB = tile rows 2 blk, 2 blk + 1 of operand (n >> 2), blk = (n & 3) * 8 + wave
   unsigned voff[8];                                              // byte offset of the lane's chunk from the operand's base (step 0)
-  int srow[8];
-  const char* zero = g_zero_line;
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
     const int blk = (n & 3) * 8 + wave;
@@ -60,32 +56,30 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
     const int ch = lane & 31;                                    // 16-byte chunk of the LDS row
     const int g = (row & 3) | (((row >> 3) & 1) << 2);
     const int col = (((ch >> 1) ^ g) * 2 + (ch & 1)) * 8;        // first column (of the tile) this chunk holds
-    srow[n] = row;
     if (n < 4) voff[n] = (unsigned)(((size_t)row * p.lda + min(i0 + col, p.I - 8)) * 2);
     else voff[n] = (unsigned)(((size_t)row * p.ldb + min(j0 + col, p.J - 8)) * 2);
   }
   const size_t step_a = (size_t)TN_BK * p.lda * 2, step_b = (size_t)TN_BK * p.ldb * 2;
   // The A tiles sit on a three-deep ring (asked for two K-steps ahead: both operands are activations that come out of HBM, and a panel of A is shared by
   // fewer concurrently running tiles than a panel of B), the B tiles on a two-deep one: 3 x 32 KB + 2 x 32 KB = the CU's 160 KB.
-  // TAIL = the step a piece belongs to may reach beyond row Kc (only the last step can): rows >= Kc then come from the zero line.  Everywhere else the
-  // address is the lane's fixed pointer plus a wave-uniform offset - no per-lane arithmetic inside the loop.
-  auto piece_a = [&](auto tailc, int n, int slot, int kt) {       // n = 0..3: one 1 KB piece (two tile rows) of this wave
-    const char* from = ((const char*)p.a + (size_t)kt * step_a) + voff[n];
-    if constexpr (decltype(tailc)::value) { if (kt * TN_BK + srow[n] >= p.Kc) from = zero; }
-    __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(from), AKI_LDS_PTR(smem + slot * TN_OP_BYTES + (n * 8 + wave) * 1024), 16, 0, 0);
+  // Buffer loads: the address of a piece is (descriptor base) + the lane's fixed 32-bit offset + a wave-uniform SGPR offset - no vector arithmetic per piece
+  // (≈55 VALU instructions of 64-bit address selects per K-step beside the MFMAs cost 8 %), and rows >= Kc of the last step lie beyond the descriptor's
+  // size and come back as zeros.
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, (short)0, (int)(((size_t)(p.Kc - 1) * p.lda + p.I) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, (short)0, (int)(((size_t)(p.Kc - 1) * p.ldb + p.J) * 2), 0x00020000);
+  auto piece_a = [&](int n, int slot, int kt) {       // n = 0..3: one 1 KB piece (two tile rows) of this wave
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, AKI_LDS_PTR(smem + slot * TN_OP_BYTES + (n * 8 + wave) * 1024), 16, (int)voff[n], (int)((unsigned)kt * (unsigned)step_a), 0, 0);
   };
-  auto piece_b = [&](auto tailc, int n, int slot, int kt) {
-    const char* from = ((const char*)p.b + (size_t)kt * step_b) + voff[4 + n];
-    if constexpr (decltype(tailc)::value) { if (kt * TN_BK + srow[4 + n] >= p.Kc) from = zero; }
-    __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(from), AKI_LDS_PTR(smem + (3 + slot) * TN_OP_BYTES + (n * 8 + wave) * 1024), 16, 0, 0);
+  auto piece_b = [&](int n, int slot, int kt) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, AKI_LDS_PTR(smem + (3 + slot) * TN_OP_BYTES + (n * 8 + wave) * 1024), 16, (int)voff[4 + n], (int)((unsigned)kt * (unsigned)step_b), 0, 0);
   };
   auto stage_a = [&](int slot, int kt) {
 #pragma unroll
-    for (int n = 0; n < 4; ++n) piece_a(std::true_type{}, n, slot, kt);
+    for (int n = 0; n < 4; ++n) piece_a(n, slot, kt);
   };
   auto stage_b = [&](int slot, int kt) {
 #pragma unroll
-    for (int n = 0; n < 4; ++n) piece_b(std::true_type{}, n, slot, kt);
+    for (int n = 0; n < 4; ++n) piece_b(n, slot, kt);
   };
 
   // ---- transposed-read addresses: fragment cb (16 columns = the 32-byte piece cb of a row) for contraction rows 8 kg + {0..3} (+4: second read)
@@ -110,7 +104,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
   stage_a(0, 0);
   if (nk > 1) stage_a(1, 1);
   int aslot = 0;                                                 // kt % 3
-  auto kstep = [&](auto tailc, int kt) {
+  for (int kt = 0; kt < nk; ++kt) {
     // tiles A(kt), B(kt) have to be there; A(kt+1), the newest four pieces of this wave, may stay in flight (loads complete in issue order)
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -161,14 +155,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
         const u32x4 bv = {bl[H][m][0], bl[H][m][1], bh[H][m][0], bh[H][m][1]};
         acc[N][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), acc[N][m], 0, 0, 0);
       }
-      if constexpr (S < 4) { if (more_b) piece_b(tailc, S, (kt + 1) & 1, kt + 1); }
-      else if constexpr (S < 8) { if (more_a) piece_a(tailc, S - 4, a_next, kt + 2); }
+      if constexpr (S < 4) { if (more_b) piece_b(S, (kt + 1) & 1, kt + 1); }
+      else if constexpr (S < 8) { if (more_a) piece_a(S - 4, a_next, kt + 2); }
       __builtin_amdgcn_sched_barrier(0);
     });
-  };
-  int kt = 0;
-  for (; kt + 3 < nk; ++kt) kstep(std::false_type{}, kt);        // its pieces belong to steps kt+1, kt+2 < nk-1: whole tiles
-  for (; kt < nk; ++kt) kstep(std::true_type{}, kt);
+  }
 
   // ---- epilogue: lane holds C[i = i0 + 128 wi + 16 n + (lane & 15)][j = j0 + 64 wj + 16 m + 4 kg + {0..3}]
 #pragma unroll
@@ -190,6 +181,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
 int gemm_tn_launch(const void* a, const void* b, void* c, int Kc, int I, int J, long lda, long ldb, long ldc, hipStream_t stream) {
   if (Kc <= 0 || I < 8 || J < 8 || I % 8 || J % 8 || lda % 8 || ldb % 8 || ldc % 4 || lda < I || ldb < J || ldc < J) return AKI_ERR_UNSUPPORTED;
   if (((size_t)a | (size_t)b) % 16 || (size_t)c % 8) return AKI_ERR_UNSUPPORTED;
+  if ((((size_t)(Kc - 1) * lda + I) * 2) >> 32 || (((size_t)(Kc - 1) * ldb + J) * 2) >> 32) return AKI_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   GemmTnParams p;
   p.a = (const bf16_t*)a; p.b = (const bf16_t*)b; p.c = (bf16_t*)c;
   p.Kc = Kc; p.I = I; p.J = J; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
