@@ -27,6 +27,7 @@ struct GemmTnParams {
   int Kc, I, J;
   long lda, ldb, ldc;
   int tiles_i, tiles_j;
+  int wide;          // c and ldc allow 16-byte stores
 };
 
 constexpr int TN_BI = 256, TN_BJ = 256, TN_BK = 64;
@@ -161,11 +162,23 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
     });
   }
 
-  // ---- epilogue: lane holds C[i = i0 + 128 wi + 16 n + (lane & 15)][j = j0 + 64 wj + 16 m + 4 kg + {0..3}]
+  // ---- epilogue: lane holds C[i = i0 + 128 wi + 16 n + (lane & 15)][j = j0 + 64 wj + 16 m + 4 kg + {0..3}]: 8 bytes per fragment.  Two neighbouring j fragments
+  // trade halves across the 16-lane rows (v_permlane16_swap: the odd rows of the first operand against the even rows of the second), after which a lane holds
+  // 8 consecutive j of fragment m + (kg & 1) - one 16-byte store instead of two 8-byte ones, 64 contiguous bytes per output row and store instruction.
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
     const int i = i0 + wi * 128 + n * 16 + li;
-    if (i < p.I) {
+    if (p.wide) {
+#pragma unroll
+      for (int m = 0; m < 4; m += 2) {
+        unsigned a0 = pack_bf16x2(acc[n][m][0], acc[n][m][1]), a1 = pack_bf16x2(acc[n][m][2], acc[n][m][3]);
+        unsigned b0 = pack_bf16x2(acc[n][m + 1][0], acc[n][m + 1][1]), b1 = pack_bf16x2(acc[n][m + 1][2], acc[n][m + 1][3]);
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
+        const int j = j0 + wj * 64 + (m + (kg & 1)) * 16 + (kg >> 1) * 8;
+        if (i < p.I && j < p.J) *(u32x4*)(p.c + (size_t)i * p.ldc + j) = u32x4{a0, a1, b0, b1};
+      }
+    } else if (i < p.I) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int j = j0 + wj * 64 + m * 16 + kg * 4;
@@ -187,6 +200,7 @@ int gemm_tn_launch(const void* a, const void* b, void* c, int Kc, int I, int J, 
   p.Kc = Kc; p.I = I; p.J = J; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.tiles_i = (I + TN_BI - 1) / TN_BI;
   p.tiles_j = (J + TN_BJ - 1) / TN_BJ;
+  p.wide = (ldc % 8 == 0 && (size_t)c % 16 == 0) ? 1 : 0;
   constexpr int SMEM = 5 * TN_OP_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
