@@ -105,15 +105,16 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
   stage_a(0, 0);
   if (nk > 1) stage_a(1, 1);
   int aslot = 0;                                                 // kt % 3
-  for (int kt = 0; kt < nk; ++kt) {
+  auto kstep = [&](auto fullc, int kt) {                         // fullc: steps kt+1 and kt+2 exist (no wave-uniform branches around the DMA pieces)
+    constexpr bool FULL = decltype(fullc)::value;
     // tiles A(kt), B(kt) have to be there; A(kt+1), the newest four pieces of this wave, may stay in flight (loads complete in issue order)
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (FULL || kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                // everyone's pieces have landed, and everyone is done reading step kt-1's slots
     // The step's eight DMA pieces are issued one at a time BEHIND the MFMAs of fragment steps 0-7 (B's four first: the wait above must not cover the A tile
     // asked for two steps ahead): issued in one block behind the barrier, the 64 pieces of the eight waves queue up in the CU's address path and every wave
     // sits in its VMEM issue while the matrix cores idle (gate_up 1080 -> 1158 TF/s).
-    const bool more_b = kt + 1 < nk, more_a = kt + 2 < nk;
+    const bool more_b = FULL || kt + 1 < nk, more_a = FULL || kt + 2 < nk;
     const int a_next = aslot == 0 ? 2 : aslot - 1;
     const unsigned sa = (unsigned)(aslot * TN_OP_BYTES), sb = (unsigned)((kt & 1) * TN_OP_BYTES);
     aslot = aslot == 2 ? 0 : aslot + 1;
@@ -160,7 +161,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
       else if constexpr (S < 8) { if (more_a) piece_a(S - 4, a_next, kt + 2); }
       __builtin_amdgcn_sched_barrier(0);
     });
-  }
+  };
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) kstep(std::true_type{}, kt);
+  for (; kt < nk; ++kt) kstep(std::false_type{}, kt);
 
   // ---- epilogue: lane holds C[i = i0 + 128 wi + 16 n + (lane & 15)][j = j0 + 64 wj + 16 m + 4 kg + {0..3}]: 8 bytes per fragment.  Two neighbouring j fragments
   // trade halves across the 16-lane rows (v_permlane16_swap: the odd rows of the first operand against the even rows of the second), after which a lane holds
