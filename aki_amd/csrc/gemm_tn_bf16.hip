@@ -118,10 +118,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
     const int a_next = aslot == 0 ? 2 : aslot - 1;
     const unsigned sa = (unsigned)(aslot * TN_OP_BYTES), sb = (unsigned)((kt & 1) * TN_OP_BYTES);
     aslot = aslot == 2 ? 0 : aslot + 1;
-    // One K-step = 16 fragment steps (k-half h = step >> 3, i fragment n = step & 7): step s consumes A fragment s (ring of four) and the four B fragments
-    // of its half.  The transposed reads run three fragment steps ahead of the MFMAs and the second half's B fragments are asked for during step 1, so the
-    // LDS time of all eight waves (768 of a K-step's 2048 matrix cycles) sits under MFMAs instead of in a lock-step phase behind the barrier.  DS reads return
-    // in order: `lgkmcnt(N)` with N = the reads issued behind fragment s is the exact wait for it.
+    // One K-step = 8 pairs of fragment steps (step s: k-half h = s >> 3, i fragment n = s & 7; it consumes A fragment s - ring of four - and the four B
+    // fragments of its half).  The transposed reads of a pair are issued one pair ahead of its eight MFMAs and the second half's B fragments during pair 0,
+    // so the LDS time of all eight waves (768 of a K-step's 2048 matrix cycles) sits under MFMAs instead of in a lock-step phase behind the barrier.  DS reads
+    // return in order: `lgkmcnt(N)` with N = the reads issued behind a pair is the exact wait for it.  One DMA piece follows each pair's MFMAs.
     u32x2 bl[2][4], bh[2][4], al[4], ah[4];
     auto issue_b = [&](auto hc) {
       constexpr int H = decltype(hc)::value, KO = H * 32 * 512;
@@ -136,29 +136,30 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
     issue_b(std::integral_constant<int, 0>{});
     issue_a(std::integral_constant<int, 0>{});
     issue_a(std::integral_constant<int, 1>{});
-    issue_a(std::integral_constant<int, 2>{});
-    static_for<16>([&](auto sc) {
-      constexpr int S = decltype(sc)::value, H = S >> 3, N = S & 7, R = S & 3;
-      if constexpr (S == 1) issue_b(std::integral_constant<int, 1>{});
-      if constexpr (S + 3 < 16) issue_a(std::integral_constant<int, (S + 3 < 16 ? S + 3 : 0)>{});
-      // reads issued behind fragment S: fragments S+1..S+3 (two each, while they exist) and, for S = 1..3, the eight of the second half's B set
-      constexpr int BEHIND = 2 * ((S + 3 < 16 ? S + 3 : 15) - S) + ((S >= 1 && S <= 3) ? 8 : 0);
-      if constexpr (S == 0)
-        asm volatile("s_waitcnt lgkmcnt(%16)" : "+v"(al[R]), "+v"(ah[R]), "+v"(bl[0][0]), "+v"(bh[0][0]), "+v"(bl[0][1]), "+v"(bh[0][1]), "+v"(bl[0][2]), "+v"(bh[0][2]),
-                     "+v"(bl[0][3]), "+v"(bh[0][3]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]) : "n"(BEHIND));
-      else if constexpr (S == 8)
-        asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(al[R]), "+v"(ah[R]), "+v"(bl[1][0]), "+v"(bh[1][0]), "+v"(bl[1][1]), "+v"(bh[1][1]), "+v"(bl[1][2]), "+v"(bh[1][2]),
-                     "+v"(bl[1][3]), "+v"(bh[1][3]) : "n"(BEHIND));
-      else
-        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(al[R]), "+v"(ah[R]) : "n"(BEHIND));
-      const u32x4 av = {al[R][0], al[R][1], ah[R][0], ah[R][1]};
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const u32x4 bv = {bl[H][m][0], bl[H][m][1], bh[H][m][0], bh[H][m][1]};
-        acc[N][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), acc[N][m], 0, 0, 0);
+    static_for<8>([&](auto pc) {
+      constexpr int P = decltype(pc)::value, S0 = 2 * P, S1 = 2 * P + 1, H = S0 >> 3, R0 = S0 & 3, R1 = S1 & 3;
+      if constexpr (P == 0) issue_b(std::integral_constant<int, 1>{});
+      if constexpr (P < 7) {
+        issue_a(std::integral_constant<int, (P < 7 ? S0 + 2 : 0)>{});
+        issue_a(std::integral_constant<int, (P < 7 ? S1 + 2 : 0)>{});
       }
-      if constexpr (S < 4) { if (more_b) piece_b(S, (kt + 1) & 1, kt + 1); }
-      else if constexpr (S < 8) { if (more_a) piece_a(S - 4, a_next, kt + 2); }
+      constexpr int BEHIND = (P == 0 ? 8 : 0) + (P < 7 ? 4 : 0);
+      if constexpr (P == 0 || P == 4)
+        asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(al[R0]), "+v"(ah[R0]), "+v"(al[R1]), "+v"(ah[R1]), "+v"(bl[H][0]), "+v"(bh[H][0]), "+v"(bl[H][1]), "+v"(bh[H][1]),
+                     "+v"(bl[H][2]), "+v"(bh[H][2]), "+v"(bl[H][3]), "+v"(bh[H][3]) : "n"(BEHIND));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(al[R0]), "+v"(ah[R0]), "+v"(al[R1]), "+v"(ah[R1]) : "n"(BEHIND));
+      static_for<2>([&](auto ec) {
+        constexpr int S = S0 + decltype(ec)::value, N = S & 7, R = S & 3;
+        const u32x4 av = {al[R][0], al[R][1], ah[R][0], ah[R][1]};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const u32x4 bv = {bl[H][m][0], bl[H][m][1], bh[H][m][0], bh[H][m][1]};
+          acc[N][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), acc[N][m], 0, 0, 0);
+        }
+      });
+      if constexpr (P < 4) { if (more_b) piece_b(P, (kt + 1) & 1, kt + 1); }
+      else { if (more_a) piece_a(P - 4, a_next, kt + 2); }
       __builtin_amdgcn_sched_barrier(0);
     });
   };
