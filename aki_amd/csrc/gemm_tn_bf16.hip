@@ -91,6 +91,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
   unsigned fa[8], fb[4];                                         // byte address in stage 0, k32 = 0, first read
 #pragma unroll
   for (int n = 0; n < 8; ++n) fa[n] = lds0 + rowoff + (unsigned)(((wi * 8 + n) ^ gl) << 5);
+  unsigned fa2[8];                                               // the same in A slot 2 (64 KB further: beyond a DS instruction's 16-bit offset)
+#pragma unroll
+  for (int n = 0; n < 8; ++n) fa2[n] = fa[n] + 2 * TN_OP_BYTES;
 #pragma unroll
   for (int m = 0; m < 4; ++m) fb[m] = lds0 + 3 * TN_OP_BYTES + rowoff + (unsigned)(((wj * 4 + m) ^ gl) << 5);
 
@@ -105,8 +108,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
   stage_a(0, 0);
   if (nk > 1) stage_a(1, 1);
   int aslot = 0;                                                 // kt % 3
-  auto kstep = [&](auto fullc, int kt) {                         // fullc: steps kt+1 and kt+2 exist (no wave-uniform branches around the DMA pieces)
+  // fullc: steps kt+1 and kt+2 exist (no wave-uniform branches around the DMA pieces).  phc: kt % 6 as a compile-time constant (the hot loop is unrolled six
+  // times: every ring slot is then an immediate - DS offsets, M0 values - and the loop carries no slot arithmetic), or -1: slots computed at run time (tail).
+  auto kstep = [&](auto fullc, auto phc, int kt) {
     constexpr bool FULL = decltype(fullc)::value;
+    constexpr int PH = decltype(phc)::value;
     // tiles A(kt), B(kt) have to be there; A(kt+1), the newest four pieces of this wave, may stay in flight (loads complete in issue order)
     if (FULL || kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -115,9 +121,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
     // asked for two steps ahead): issued in one block behind the barrier, the 64 pieces of the eight waves queue up in the CU's address path and every wave
     // sits in its VMEM issue while the matrix cores idle (gate_up 1080 -> 1158 TF/s).
     const bool more_b = FULL || kt + 1 < nk, more_a = FULL || kt + 2 < nk;
-    const int a_next = aslot == 0 ? 2 : aslot - 1;
-    const unsigned sa = (unsigned)(aslot * TN_OP_BYTES), sb = (unsigned)((kt & 1) * TN_OP_BYTES);
-    aslot = aslot == 2 ? 0 : aslot + 1;
+    constexpr int AS_C = PH >= 0 ? PH % 3 : 0, BS_C = PH >= 0 ? (PH & 1) : 0;
+    const int a_next = PH >= 0 ? (PH + 2) % 3 : (aslot == 0 ? 2 : aslot - 1), b_next = PH >= 0 ? ((PH + 1) & 1) : ((kt + 1) & 1);
+    const unsigned sa = PH >= 0 ? 0u : (unsigned)(aslot * TN_OP_BYTES), sb = PH >= 0 ? 0u : (unsigned)((kt & 1) * TN_OP_BYTES);
+    if constexpr (PH < 0) aslot = aslot == 2 ? 0 : aslot + 1;
+    constexpr int AOFF = AS_C == 1 ? TN_OP_BYTES : 0, BOFF = BS_C * TN_OP_BYTES;   // immediates (slot 2 of A goes through fa2)
     // One K-step = 8 pairs of fragment steps (step s: k-half h = s >> 3, i fragment n = s & 7; it consumes A fragment s - ring of four - and the four B
     // fragments of its half).  The transposed reads of a pair are issued one pair ahead of its eight MFMAs and the second half's B fragments during pair 0,
     // so the LDS time of all eight waves (768 of a K-step's 2048 matrix cycles) sits under MFMAs instead of in a lock-step phase behind the barrier.  DS reads
@@ -126,12 +134,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
     auto issue_b = [&](auto hc) {
       constexpr int H = decltype(hc)::value, KO = H * 32 * 512;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) { bl[H][m] = ds_read_tr<KO>(fb[m] + sb); bh[H][m] = ds_read_tr<KO + 4 * 512>(fb[m] + sb); }
+      for (int m = 0; m < 4; ++m) { bl[H][m] = ds_read_tr<KO + BOFF>(fb[m] + sb); bh[H][m] = ds_read_tr<KO + BOFF + 4 * 512>(fb[m] + sb); }
     };
     auto issue_a = [&](auto sc) {
       constexpr int S = decltype(sc)::value, KO = (S >> 3) * 32 * 512, N = S & 7;
-      al[S & 3] = ds_read_tr<KO>(fa[N] + sa);
-      ah[S & 3] = ds_read_tr<KO + 4 * 512>(fa[N] + sa);
+      const unsigned base = (AS_C == 2 ? fa2[N] : fa[N]) + sa;
+      al[S & 3] = ds_read_tr<KO + AOFF>(base);
+      ah[S & 3] = ds_read_tr<KO + AOFF + 4 * 512>(base);
     };
     issue_b(std::integral_constant<int, 0>{});
     issue_a(std::integral_constant<int, 0>{});
@@ -158,14 +167,16 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16_kernel(const GemmTnParams
           acc[N][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), acc[N][m], 0, 0, 0);
         }
       });
-      if constexpr (P < 4) { if (more_b) piece_b(P, (kt + 1) & 1, kt + 1); }
+      if constexpr (P < 4) { if (more_b) piece_b(P, b_next, kt + 1); }
       else { if (more_a) piece_a(P - 4, a_next, kt + 2); }
       __builtin_amdgcn_sched_barrier(0);
     });
   };
   int kt = 0;
-  for (; kt + 2 < nk; ++kt) kstep(std::true_type{}, kt);
-  for (; kt < nk; ++kt) kstep(std::false_type{}, kt);
+  for (; kt + 7 < nk; kt += 6)
+    static_for<6>([&](auto ph) { kstep(std::true_type{}, ph, kt + decltype(ph)::value); });
+  for (; kt + 2 < nk; ++kt) kstep(std::true_type{}, std::integral_constant<int, -1>{}, kt);      // kt is a multiple of 6 here: aslot = 0 = kt % 3
+  for (; kt < nk; ++kt) kstep(std::false_type{}, std::integral_constant<int, -1>{}, kt);
 
   // ---- epilogue: lane holds C[i = i0 + 128 wi + 16 n + (lane & 15)][j = j0 + 64 wj + 16 m + 4 kg + {0..3}]: 8 bytes per fragment.  Two neighbouring j fragments
   // trade halves across the 16-lane rows (v_permlane16_swap: the odd rows of the first operand against the even rows of the second), after which a lane holds
