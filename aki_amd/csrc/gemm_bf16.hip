@@ -1312,11 +1312,15 @@ static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
 }
 
 // Arrival counters: one per row panel (>= 64 rows), at the front of the statistics workspace; the partial sums follow.  The
-// area grows with M in 4 KB steps (4 KB serves M <= 65536, every size the models launch today) - a caller that re-uses one
-// workspace for a LARGER M than before zero-fills the (then larger) counter area again (include/aki_mi355x.h).
+// counter area has ONE size whatever M is (1 MiB = 262 144 panels: M <= 16 777 216 rows; more is refused), so the layout of a
+// workspace never depends on the launches it served before: zero-filled once really means once.  (Until ABI 12 the area grew
+// with M and a shrink-then-grow sequence on one buffer - M = 70 000, 3 000, 70 000 - left partial sums of the middle launch
+// where the third one's counters were: ADVICE r3.)
+constexpr size_t kStatsCntBytes = size_t(1) << 20;
+constexpr int kStatsMaxRows = int(kStatsCntBytes / sizeof(unsigned)) * 64;
 size_t linear_stats_cnt_bytes(int M) {
-  const size_t panels = ((size_t)(M > 0 ? M : 1) + 63) / 64;
-  return (panels * sizeof(unsigned) + 4095) / 4096 * 4096;
+  (void)M;
+  return kStatsCntBytes;
 }
 size_t linear_stats_ws_bytes(int M, int n_out) {
   return linear_stats_cnt_bytes(M) + (size_t)(2 * ((n_out + 63) / 64) + 2) * 2 * (size_t)M * sizeof(float);   // <= 2 waves x N/64 tile columns
@@ -1344,7 +1348,7 @@ int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
   p.row_scale = a->row_scale; p.row_shift = a->row_shift; p.col_c = a->col_shift;
   if (a->row_shift && (!a->col_shift || !a->row_scale || (((uintptr_t)a->col_shift) & 15) || a->act == AKI_ACT_SWIGLU)) return AKI_ERR_INVALID_ARG;
   if (a->stats_rstd) {
-    if (a->act == AKI_ACT_SWIGLU) return AKI_ERR_UNSUPPORTED;
+    if (a->act == AKI_ACT_SWIGLU || a->M > kStatsMaxRows) return AKI_ERR_UNSUPPORTED;
     if (!a->stats_workspace || a->stats_workspace_bytes < linear_stats_ws_bytes(a->M, n_out) || (((uintptr_t)a->stats_workspace) & 15)) return AKI_ERR_WORKSPACE;
     p.st_rstd = a->stats_rstd; p.st_mean = a->stats_mean; p.st_eps = a->stats_eps;
     p.st_cnt = (unsigned*)a->stats_workspace;

@@ -129,20 +129,14 @@ _STATS_WS = {}
 
 
 def _stats_ws(M: int, n_out: int, dev) -> torch.Tensor:
-    """Workspace of the producer side (arrival counters + partial sums): zero-filled once per (device, stream, size class).
-    The counter area at its front grows with M (include/aki_mi355x.h): when a launch needs a larger one than this buffer has
-    served so far, the new area is zero-filled again - partial sums of earlier, smaller launches lie there."""
-    lib = L.load()
-    need = int(lib.aki_linear_stats_workspace_bytes(M, n_out))
-    cnt = int(lib.aki_linear_stats_counter_bytes(M))
+    """Workspace of the producer side (arrival counters + partial sums): zero-filled once per (device, stream).  The counter
+    area at its front has one size for every M (include/aki_mi355x.h), so a buffer serves launches of any size in any order."""
+    need = int(L.load().aki_linear_stats_workspace_bytes(M, n_out))
     key = (torch.device(dev).index, torch.cuda.current_stream().cuda_stream)
     hit = _STATS_WS.get(key)
-    if hit is None or hit[0].numel() < need:
-        hit = _STATS_WS[key] = [torch.zeros(max(need, 8 << 20), dtype=torch.uint8, device=dev), cnt]
-    elif cnt > hit[1]:
-        hit[0][:cnt].zero_()          # stream-ordered behind the launches that used the smaller layout
-        hit[1] = cnt
-    return hit[0]
+    if hit is None or hit.numel() < need:
+        hit = _STATS_WS[key] = torch.zeros(max(need, 8 << 20), dtype=torch.uint8, device=dev)
+    return hit
 
 
 def new_stats(M: int, dev, ln: bool = False) -> RowStats:

@@ -68,8 +68,13 @@ USE_GEMM_TN = True    # tools/train_step_ab_tn.py flips it to time the transpose
 
 
 def _tn_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
-    return USE_GEMM_TN and (a.shape[1] % 8 == 0 and b.shape[1] % 8 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
-            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+    """Every condition of gemm_tn_launch (gemm_tn_bf16.hip), so that an operand it would refuse takes the transposes +
+    forward-GEMM form instead of raising inside backward - including its 32-bit buffer offsets: ((Kc-1)*ld + cols)*2 < 4 GiB
+    (e.g. > 131k token rows against the 16384-wide gate_up output)."""
+    span = lambda t: ((t.shape[0] - 1) * t.stride(0) + t.shape[1]) * 2
+    return USE_GEMM_TN and (a.shape[1] % 8 == 0 and b.shape[1] % 8 == 0 and a.shape[1] >= 8 and b.shape[1] >= 8 and a.stride(1) == 1 and b.stride(1) == 1
+            and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+            and span(a) < (1 << 32) and span(b) < (1 << 32))
 
 
 def norm_bwd(rms: bool, x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps: float, need_db: bool = False,

@@ -215,21 +215,19 @@ def cpu_baseline_c2_est(threads=None):
 def spawn_ranks(n, argv, script=None):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
     CHILD process (nothing in this process has touched the GPU) and return its exit code.  Refuses when fewer than N GPUs are
-    visible (torch.cuda.device_count() does not initialise the device) - unless the gloo test hook lets ranks share one."""
-    import socket
+    visible - unless the gloo test hook lets ranks share one.  (torch.cuda.device_count() counts through amdsmi where the build
+    has it and through hipGetDeviceCount otherwise; either way the ranks are fresh child processes, never an exec of this one.)
+    The launcher picks its own free rendezvous port (`--standalone`): no bind-close-reuse window for a concurrent run to take."""
     import subprocess
     import torch
     ndev = torch.cuda.device_count()
     if os.environ.get("AKI_BENCH_BACKEND", "nccl") == "nccl" and ndev < n:
         print(f"bench.py: --gpus {n} but only {ndev} GPUs are visible; not falling back to fewer ranks", file=sys.stderr)
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--standalone", "--local-addr", "127.0.0.1",
+           script or os.path.abspath(__file__)] + list(argv)
     return subprocess.run(cmd, env=env).returncode
 
 

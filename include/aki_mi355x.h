@@ -223,8 +223,12 @@ typedef struct {
    *   producer   stats_rstd != NULL: while writing y, the GEMM also computes the row statistics of y AS STORED (bf16):
    *              stats_rstd[m] = 1/sqrt(mean(y_m^2) + eps)                      (stats_mean == NULL: RMSNorm of the next block)
    *              stats_mean[m] = mean(y_m), stats_rstd[m] = 1/sqrt(var(y_m) + eps)   (stats_mean != NULL: LayerNorm)
-   *              stats_workspace: aki_linear_stats_workspace_bytes(M, N_out) bytes, 16-byte aligned, ZERO-FILLED ONCE (arrival
-   *              counters the kernel puts back to zero; launches sharing it must be stream-ordered).  act must not be SWIGLU.
+   *              stats_workspace: aki_linear_stats_workspace_bytes(M, N_out) bytes, 16-byte aligned, ZERO-FILLED ONCE by the
+   *              caller before its first use (arrival counters at its front, which every launch puts back to zero; launches
+   *              sharing a workspace must be stream-ordered).  The counter area has a fixed size -
+   *              aki_linear_stats_counter_bytes(M) is the same 1 MiB for every M - so one buffer sized for the largest
+   *              (M, N_out) serves any sequence of smaller and larger launches without being zero-filled again.
+   *              M <= 16 777 216 rows; act must not be SWIGLU.
    * All NULL: plain GEMM. */
   const float* row_scale;
   const float* row_shift;

@@ -46,6 +46,46 @@ def linear(x, w, b=None):
     return F.linear(x, w, b)
 
 
+# ---- BASELINE configs[4]: e4m3 fake quantisation at the build's quantisation points -----------------------------------
+# No reference behaviour exists for fp8 (the reference has no fp8 path): this block is a BUILD-DEFINED oracle.  It restates what
+# the product computes - aki_amd/csrc/fp8_quant.hip (one dynamic scale per row: per token for activations, per output feature
+# for nn.Linear weights, s = max(amax, 1e-12) / 448, q = RNE_e4m3(clamp(y / s))) and the fp8 GEMM (f32 accumulation of the
+# e4m3 products, accumulator times s_x[token] * s_w[feature]) - with torch's own float8_e4m3fn cast, so that the HIP fp8 path
+# has something to be compared with at bf16-level bars instead of "within the format's noise of the fp32 model".
+FP8_MAX = 448.0
+
+
+def quant_rows_e4m3(y):
+    """-> (q: e4m3 VALUES as f32 [rows.., cols], s: f32 [rows.., 1]) with y ~= q * s."""
+    yf = y.float()
+    s = yf.abs().amax(-1, keepdim=True).clamp(min=1e-12) * (1.0 / FP8_MAX)
+    q = (yf * (1.0 / s)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).float()
+    return q, s
+
+
+def linear_e4m3(x, w, b=None):
+    """F.linear with both operands fake-quantised per row to e4m3; products and sums in f32, one rounding to x.dtype at the end
+    (the GEMM epilogue's)."""
+    wq, ws = quant_rows_e4m3(w.detach())
+    xq, xs = quant_rows_e4m3(x)
+    y = F.linear(xq, wq) * xs * ws.reshape(-1)
+    if b is not None:
+        y = y + b.float()
+    return y.to(x.dtype)
+
+
+def _lin(fp8, which):
+    """The linear used for projection `which` under the fp8 configuration dict (None = everything in the model dtype).
+    Keys mirror Phi3ForCausalLM.enable_fp8(head=..., residual_writers=...)."""
+    if not fp8:
+        return linear
+    if which in ("o", "down") and not fp8.get("residual_writers", True):
+        return linear
+    if which == "head" and not fp8.get("head", True):
+        return linear
+    return linear_e4m3
+
+
 # ---- a5 / a12 -------------------------------------------------------------------------------------
 def decoupled_embedding(ids, weight, additional_weight, max_original_id):
     """src/helpers.py:445-484."""
@@ -57,11 +97,11 @@ def decoupled_embedding(ids, weight, additional_weight, max_original_id):
     return torch.where(hi[..., None], add, low)
 
 
-def decoupled_linear(x, weight, bias, add_weight, add_bias, max_original_id):
+def decoupled_linear(x, weight, bias, add_weight, add_bias, max_original_id, lin=linear):
     """src/helpers.py:594-603."""
-    out = F.linear(x, weight, bias)[..., : max_original_id + 1]
+    out = lin(x, weight, bias)[..., : max_original_id + 1]
     if add_weight is not None:
-        out = torch.cat((out, F.linear(x, add_weight, add_bias)), -1)
+        out = torch.cat((out, lin(x, add_weight, add_bias)), -1)
     return out
 
 
@@ -157,11 +197,11 @@ def rotate_half(x):
     return torch.cat((-x[..., h:], x[..., :h]), -1)
 
 
-def phi3_attention(x, w_qkv, w_o, cos, sin, add_mask, n_heads):
-    """HF:phi3/modeling_phi3.py:145-167,170-197,218-263."""
+def phi3_attention(x, w_qkv, w_o, cos, sin, add_mask, n_heads, fp8=None):
+    """HF:phi3/modeling_phi3.py:145-167,170-197,218-263.  fp8: see _lin (build-defined; the attention core itself stays in x.dtype)."""
     B, L, d = x.shape
     Dh = d // n_heads
-    qkv = F.linear(x, w_qkv)
+    qkv = _lin(fp8, "qkv")(x, w_qkv)
     q, k, v = (t.reshape(B, L, n_heads, Dh).transpose(1, 2) for t in (qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]))
     cu, su = cos[:, None].to(x.dtype), sin[:, None].to(x.dtype)
     q = q * cu + rotate_half(q) * su
@@ -169,32 +209,43 @@ def phi3_attention(x, w_qkv, w_o, cos, sin, add_mask, n_heads):
     s = (q @ k.transpose(-1, -2)) * Dh ** -0.5 + add_mask
     p = s.float().softmax(-1).to(x.dtype)
     o = (p @ v).transpose(1, 2).reshape(B, L, d)
-    return F.linear(o, w_o)
+    return _lin(fp8, "o")(o, w_o)
 
 
-def phi3_mlp(x, w_gate_up, w_down):
-    up = F.linear(x, w_gate_up)
-    gate, u = up.chunk(2, -1)
-    return F.linear(u * F.silu(gate), w_down)
+def phi3_mlp(x, w_gate_up, w_down, fp8=None):
+    if fp8 and x.dtype != torch.float32:
+        # the product's gate_up epilogue applies SwiGLU to the f32 accumulators and rounds once; staying in f32 up to that
+        # rounding keeps the low-precision yardstick run from adding a rounding the kernel does not have
+        up = linear_e4m3(x.float(), w_gate_up)
+        gate, u = up.chunk(2, -1)
+        a = (u * F.silu(gate)).to(x.dtype)
+    else:
+        up = _lin(fp8, "gate_up")(x, w_gate_up)
+        gate, u = up.chunk(2, -1)
+        a = u * F.silu(gate)
+    return _lin(fp8, "down")(a, w_down)
 
 
-def phi3_decoder_layer(h, p, cos, sin, add_mask, n_heads, eps=1e-5):
+def phi3_decoder_layer(h, p, cos, sin, add_mask, n_heads, eps=1e-5, fp8=None):
     x = rms_norm(h, p["input_layernorm.weight"], eps)
-    h = h + phi3_attention(x, p["self_attn.qkv_proj.weight"], p["self_attn.o_proj.weight"], cos, sin, add_mask, n_heads)
+    h = h + phi3_attention(x, p["self_attn.qkv_proj.weight"], p["self_attn.o_proj.weight"], cos, sin, add_mask, n_heads, fp8)
     x = rms_norm(h, p["post_attention_layernorm.weight"], eps)
-    return h + phi3_mlp(x, p["mlp.gate_up_proj.weight"], p["mlp.down_proj.weight"])
+    return h + phi3_mlp(x, p["mlp.gate_up_proj.weight"], p["mlp.down_proj.weight"], fp8)
 
 
-def phi3_lm_forward(inputs_embeds, mask01_4d, p, n_layers, n_heads, max_original_id, theta=10000.0, eps=1e-5):
+def phi3_lm_forward(inputs_embeds, mask01_4d, p, n_layers, n_heads, max_original_id, theta=10000.0, eps=1e-5, fp8=None):
+    """fp8 (None or {"head": bool, "residual_writers": bool}): BASELINE configs[4], build-defined - the decoder's projections
+    (and optionally the head) on e4m3 fake-quantised operands at exactly the product's quantisation points: after each fused
+    RMSNorm (qkv, gate_up, head), on the attention output (o_proj) and on the SwiGLU output (down_proj)."""
     B, L, d = inputs_embeds.shape
     cos, sin = rope_cos_sin(np.arange(L)[None], d // n_heads, theta)
     add = invert_mask_441(mask01_4d, inputs_embeds.dtype)
     h = inputs_embeds
     for l in range(n_layers):
-        h = phi3_decoder_layer(h, _sub(p, f"model.layers.{l}."), cos, sin, add, n_heads, eps)
+        h = phi3_decoder_layer(h, _sub(p, f"model.layers.{l}."), cos, sin, add, n_heads, eps, fp8)
     h = rms_norm(h, p["model.norm.weight"], eps)
     return decoupled_linear(h, p["lm_head.weight"], p.get("lm_head.bias"), p.get("lm_head.additional_fc.weight"),
-                            p.get("lm_head.additional_fc.bias"), max_original_id)
+                            p.get("lm_head.additional_fc.bias"), max_original_id, _lin(fp8, "head"))
 
 
 def causal_lm_loss(logits, labels, ignore_index=-100):
@@ -261,6 +312,6 @@ def aki_forward(p: Dict[str, torch.Tensor], cfg: Dict, vision_x, lang_x, attenti
     prep = prepare_inputs_for_forward(vt, lang_x, attention_mask, labels, emb, cfg["media_token_id"], cfg["pad_token_id"],
                                       cfg["num_vision_tokens"], "right")
     logits = phi3_lm_forward(prep["inputs_embeds"], prep["attention_mask"], lm, cfg["lm_layers"], cfg["lm_heads"],
-                             cfg["max_original_id"], cfg.get("rope_theta", 10000.0), cfg.get("rms_eps", 1e-5))
+                             cfg["max_original_id"], cfg.get("rope_theta", 10000.0), cfg.get("rms_eps", 1e-5), cfg.get("fp8"))
     loss = causal_lm_loss(logits, prep["labels"]) if labels is not None else None
     return {"logits": logits, "loss": loss, "prep": prep, "vision_tokens": vt}

@@ -38,7 +38,9 @@ def test_quantiser_matches_torch_e4m3_cast(rows, cols, rms):
     assert (deq(q, s) - y).abs().max().item() <= 0.0625 * y.abs().amax().item() + 1e-6   # e4m3: 3 mantissa bits
 
 
-@pytest.mark.parametrize("M,N,K,act", [(5240, 3072, 3072, "none"), (700, 1024, 512, "swiglu"), (333, 32016, 3072, "bias"), (64, 3072, 8192, "res")])
+@pytest.mark.parametrize("M,N,K,act", [(5240, 3072, 3072, "none"), (700, 1024, 512, "swiglu"), (333, 32016, 3072, "bias"), (64, 3072, 8192, "res"),
+                                       # BASELINE configs[4]'s own shapes: batch 16 x 655 = 10 480 token rows (gate_up + SwiGLU, down + residual)
+                                       (10480, 16384, 3072, "swiglu"), (10480, 3072, 8192, "res"), (10480, 9216, 3072, "none")])
 def test_fp8_gemm_exact_on_quantised_operands(M, N, K, act):
     from aki_amd import ops
     x, w = rt(M, K, seed=2), rt(N, K, seed=3, scale=0.05)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, record_parity
+from conftest import ROOT, randomize_norms_and_biases, record_parity
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -39,12 +39,23 @@ def test_aki4b_full_depth_bf16_logits_vs_fp32_oracle():
     B = 2
     m = build_aki(dtype=torch.bfloat16, device=DEV, seed=7).eval()           # AKI-4B: 32 + 27 layers, real widths
     assert len(m.lang_model.model.layers) == 32 and len(m.vision_encoder.encoder.layers) == 27
+    # non-unit gains and non-zero biases in every norm / biased linear of the 32 + 27 + 6 layers: with the factory's
+    # gains = 1, biases = 0 the folded-norm arithmetic (phi3.py forward_folded, siglip.py fold_layernorm) is the identity at depth
+    n_touched = randomize_norms_and_biases(m, seed=13)
+    assert n_touched >= 2 * 32 + 1 + 27 * 10
     vx, ids, am = _prompts(B, m.media_token_id, 11)
     vx16 = vx.to(torch.bfloat16)
     with torch.no_grad():
         got = m(vx16.to(DEV), ids.to(DEV), attention_mask=am.to(DEV)).logits.float().cpu()
+        # the same forward with every norm as its own kernel (fold_norms=False), recorded side by side
+        m.lang_model.model.fold_norms = False
+        m.vision_encoder.encoder.fold_norms = False
+        got_unfolded = m(vx16.to(DEV), ids.to(DEV), attention_mask=am.to(DEV)).logits.float().cpu()
+        m.lang_model.model.fold_norms = True
+        m.vision_encoder.encoder.fold_norms = True
     L = N_TXT - 1 + NV
-    assert got.shape == (B, L, 32011 + 2) and bool(torch.isfinite(got).all())
+    assert got.shape == (B, L, 32011 + 2) and bool(torch.isfinite(got).all()) and bool(torch.isfinite(got_unfolded).all())
+    assert not torch.equal(got, got_unfolded), "fold_norms=False did not change the path"
     p16 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     del m
     torch.cuda.empty_cache()
@@ -65,12 +76,13 @@ def test_aki4b_full_depth_bf16_logits_vs_fp32_oracle():
     # rows of real tokens (the splice keeps padded positions as rows; they are compared too, separately)
     valid = torch.from_numpy(np.asarray(want["prep"]["mask_1d"]).astype(bool))            # [B, L]
     mx = max(1.0, float(ref.abs().max()))
-    e_hip, e_ref = (got - ref).abs(), (ref16 - ref).abs()
-    stats = {}
+    e_hip, e_unf, e_ref = (got - ref).abs(), (got_unfolded - ref).abs(), (ref16 - ref).abs()
+    stats = {"norm_gains": "1 + 0.2 N(0,1)", "norm_and_linear_biases": "0.1 N(0,1)"}
     for name, rows in (("valid rows", valid), ("padded rows", ~valid)):
         if not bool(rows.any()):
             continue
         stats[name] = dict(hip_max=float(e_hip[rows].max()), hip_mean=float(e_hip[rows].mean()),
+                           hip_unfolded_max=float(e_unf[rows].max()), hip_unfolded_mean=float(e_unf[rows].mean()),
                            eager_bf16_max=float(e_ref[rows].max()), eager_bf16_mean=float(e_ref[rows].mean()))
     top_ref = ref.argmax(-1)
     stats["argmax_agreement_hip"] = float((got.argmax(-1) == top_ref)[valid].float().mean())
@@ -83,72 +95,173 @@ def test_aki4b_full_depth_bf16_logits_vs_fp32_oracle():
     v = stats["valid rows"]
     record_parity("AKI-4B 32+27 layers logits, valid rows", torch.bfloat16, v["hip_max"], v["hip_mean"], mx,
                   "<= 1.5x mean / 2x max of the oracle's own bf16-eager error + 1e-3*max|ref|")
+    record_parity("AKI-4B 32+27 layers logits, valid rows, fold_norms=False", torch.bfloat16, v["hip_unfolded_max"], v["hip_unfolded_mean"], mx,
+                  "<= 1.5x mean / 2x max of the oracle's own bf16-eager error + 1e-3*max|ref|")
     assert v["hip_mean"] <= 1.5 * v["eager_bf16_mean"] + 1e-3 * mx, stats
     assert v["hip_max"] <= 2.0 * v["eager_bf16_max"] + 1e-2 * mx, stats
+    assert v["hip_unfolded_mean"] <= 1.5 * v["eager_bf16_mean"] + 1e-3 * mx, stats
+    assert v["hip_mean"] <= 1.25 * v["hip_unfolded_mean"] + 1e-3 * mx, stats       # folding must not cost accuracy
     if "padded rows" in stats:                     # rows of padding tokens: finite, same convention (uniform softmax rows exist only beyond seq_len)
         pr = stats["padded rows"]
         assert pr["hip_mean"] <= 1.5 * pr["eager_bf16_mean"] + 1e-3 * mx, stats
 
 
+def _layer_taps(lm):
+    """Forward hooks on every decoder layer: (input residual stream, output residual stream) of the last forward, on the host."""
+    taps, handles = [], []
+
+    def hook(_mod, args, out):
+        o = out[0] if isinstance(out, tuple) else out
+        taps.append((args[0].detach().float().cpu(), o.detach().float().cpu()))
+    for layer in lm.model.layers:
+        handles.append(layer.register_forward_hook(hook))
+    return taps, handles
+
+
 @pytest.mark.timeout(3000)
-def test_aki4b_full_depth_fp8_logits_vs_fp32_oracle_and_bf16():
-    """BASELINE configs[4] at the workload's width and depth: AKI-4B, 32 decoder layers with `enable_fp8()`
-    (e4m3 projections, per-token / per-weight-row scales; attention, residual stream and the vision side stay bf16), batch 2,
-    336 px + 512 tokens.  No reference behaviour exists for fp8 (parity unpinned): the yardsticks are the fp32 oracle on the same
-    bf16-rounded weights and this library's own bf16 path.  Three configurations: every projection + the head in e4m3 (the
-    benchmark's `--dtype fp8`), head in bf16, head + the residual-stream writers (o_proj, down_proj) in bf16.
-    What the numbers say (gpurun_out/parity_full_depth_fp8.json -> profiles/): an e4m3 GEMM output carries a few percent of
-    rounding noise, 128 such outputs feed the residual stream and the head puts its own straight on the logits; with RANDOM-INIT
-    weights the logits are nearly flat (top-1 / top-2 margins of a few 1e-2), so the arg-max agreement with fp32 collapses
-    (0.39 against bf16's 0.93) although the relative L2 error is the expected ~0.3.  Asserted: finite logits, the error inside the
-    random-walk model of the e4m3 noise, and that it shrinks as projections are moved back to bf16 - the arg-max figures are
-    recorded, not asserted (a trained checkpoint, which this build cannot load offline, is what they would be meaningful on)."""
+def test_aki4b_full_depth_fp8_vs_fake_quant_oracle():
+    """BASELINE configs[4] at the workload's width and depth: AKI-4B, 32 decoder layers with `enable_fp8()` (e4m3 projections,
+    per-token / per-weight-row scales; attention, residual stream and the vision side stay bf16), batch 2, 336 px + 512 tokens.
+    The reference has no fp8 path, so the oracle here is BUILD-DEFINED (stated in oracle/aki_torch.py): the reference's eager
+    graph with e4m3 fake quantisation (torch.float8_e4m3fn) at exactly the product's quantisation points, multiplied in f32.
+
+    Two comparisons, both with a bar that fails on a real fault (`rel_l2 <= 0.5` against the fp32 model could not):
+      * LAYER BY LAYER, teacher-forced: every decoder layer of the HIP run is re-computed by the fake-quant oracle from the HIP
+        layer's own input, so nothing accumulates across layers.  Error and yardstick are relative to the layer's update
+        (h_out - h_in); the yardstick is the same fake-quant layer in eager bf16 arithmetic against its f32 self - the exact analogue
+        of the bf16 test's "oracle's own bf16-eager error".  A scale on the wrong axis, a swapped gate/up half or a missing scale in
+        any ONE of the 128 GEMMs moves that layer's figure to O(1); measured figures are at the percent level.
+      * END TO END against the fake-quant oracle run from the same inputs.  A network of quantisers is chaotic - a bf16-level
+        difference ahead of a quantiser flips roundings and comes out sqrt(delta * step) large (measured on the CPU: the eager-bf16
+        run of the fake-quant graph is 7x further from its f32 self than the plain bf16 graph is from plain f32) - so the yardstick
+        is again the fake-quant graph's own eager-bf16 error, not the plain one.
+    The figures against the PLAIN fp32 oracle (what e4m3 costs the model: rel L2 ~0.3 on random-init weights) stay recorded."""
     import aki_torch as OT
     from aki_amd.factory import build_aki
     B = 2
     m = build_aki(dtype=torch.bfloat16, device=DEV, seed=7).eval()
+    randomize_norms_and_biases(m, seed=13)
     vx, ids, am = _prompts(B, m.media_token_id, 11)
     vx16 = vx.to(torch.bfloat16)
     run = lambda: m(vx16.to(DEV), ids.to(DEV), attention_mask=am.to(DEV)).logits.float().cpu()
-    got = {}
+    confs = {"fp8": dict(head=True, residual_writers=True), "fp8_head_bf16": dict(head=False, residual_writers=True),
+             "fp8_qkv_gateup_only": dict(head=False, residual_writers=False)}
+    got, taps = {}, {}
     with torch.no_grad():
         got["bf16"] = run()
-        m.lang_model.enable_fp8()
-        got["fp8"] = run()
-        m.lang_model.enable_fp8(True, head=False)
-        got["fp8_head_bf16"] = run()
-        m.lang_model.enable_fp8(True, head=False, residual_writers=False)
-        got["fp8_qkv_gateup_only"] = run()
+        for name, kw in confs.items():
+            m.lang_model.enable_fp8(True, **kw)
+            t, handles = _layer_taps(m.lang_model) if name == "fp8" else ([], [])
+            got[name] = run()
+            for h_ in handles:
+                h_.remove()
+            if name == "fp8":
+                taps = t
         m.lang_model.enable_fp8(False)
-    assert all(bool(torch.isfinite(g).all()) for g in got.values())
+    assert all(bool(torch.isfinite(g).all()) for g in got.values()) and len(taps) == 32
     p16 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     del m
     torch.cuda.empty_cache()
     cfg = dict(vis_layers=27, vis_heads=16, lm_layers=32, lm_heads=32, max_original_id=32010, media_token_id=32011,
                pad_token_id=32000, num_vision_tokens=NV)
     torch.set_num_threads(min(32, os.cpu_count() or 8))
+    p32 = {k: v.float() for k, v in p16.items()}
     with torch.no_grad():
-        want = OT.aki_forward({k: v.float() for k, v in p16.items()}, cfg, vx16.float(), ids, am)
-    ref = want["logits"]
-    valid = torch.from_numpy(np.asarray(want["prep"]["mask_1d"]).astype(bool))
+        want = OT.aki_forward(p32, cfg, vx16.float(), ids, am)
+        ref = want["logits"]
+        valid = torch.from_numpy(np.asarray(want["prep"]["mask_1d"]).astype(bool))
+        refq = {k: OT.aki_forward(p32, dict(cfg, fp8=kw), vx16.float(), ids, am)["logits"] for k, kw in confs.items()}
+        refq16 = OT.aki_forward(p16, dict(cfg, fp8=confs["fp8"]), vx16, ids, am)["logits"].float()      # yardstick: eager bf16 on the same graph
     mx = max(1.0, float(ref.abs().max()))
     top = ref.argmax(-1)
     top2 = ref.topk(2, dim=-1).values
     stats = dict(batch=B, L=N_TXT - 1 + NV, max_abs_ref=mx, ref_logit_std=float(ref[valid].std()),
-                 ref_median_top1_top2_margin=float((top2[..., 0] - top2[..., 1])[valid].median()))
+                 ref_median_top1_top2_margin=float((top2[..., 0] - top2[..., 1])[valid].median()),
+                 norm_gains="1 + 0.2 N(0,1)", oracle="fake-quant e4m3 (build-defined; the reference has no fp8)")
+    rl = lambda a, b_: float((a - b_)[valid].norm() / b_[valid].norm())
     for k, g in got.items():
         e = (g - ref).abs()[valid]
-        stats[k] = dict(max=float(e.max()), mean=float(e.mean()), rel_l2=float((g - ref)[valid].norm() / ref[valid].norm()),
-                        argmax_agreement=float((g.argmax(-1) == top)[valid].float().mean()))
+        stats[k] = dict(vs_plain_fp32=dict(max=float(e.max()), mean=float(e.mean()), rel_l2=rl(g, ref),
+                                           argmax_agreement=float((g.argmax(-1) == top)[valid].float().mean())))
+        if k in refq:
+            eq = (g - refq[k]).abs()[valid]
+            stats[k]["vs_fake_quant_fp32"] = dict(max=float(eq.max()), mean=float(eq.mean()), rel_l2=rl(g, refq[k]),
+                                                  argmax_agreement=float((g.argmax(-1) == refq[k].argmax(-1))[valid].float().mean()))
+    ey = (refq16 - refq["fp8"]).abs()[valid]
+    stats["yardstick_eager_bf16_fake_quant_vs_its_fp32_self"] = dict(
+        max=float(ey.max()), mean=float(ey.mean()), rel_l2=rl(refq16, refq["fp8"]),
+        argmax_agreement=float((refq16.argmax(-1) == refq["fp8"].argmax(-1))[valid].float().mean()))
+    stats["oracle_fake_quant_vs_plain_fp32_rel_l2"] = rl(refq["fp8"], ref)
+
+    # ---- layer by layer, teacher-forced -------------------------------------------------------------------------------------
+    lm32, lm16 = OT._sub(p32, "lang_model."), OT._sub(p16, "lang_model.")
+    L = N_TXT - 1 + NV
+    cos, sin = OT.rope_cos_sin(np.arange(L)[None], 96)
+    mask01 = want["prep"]["attention_mask"]
+    add32, add16 = OT.invert_mask_441(mask01, torch.float32), OT.invert_mask_441(mask01, torch.bfloat16)
+    vrow = valid[..., None]
+    per_layer = []
+    with torch.no_grad():
+        for l, (h_in, h_out) in enumerate(taps):
+            pl32, pl16 = OT._sub(lm32, f"model.layers.{l}."), OT._sub(lm16, f"model.layers.{l}.")
+            r32 = OT.phi3_decoder_layer(h_in, pl32, cos, sin, add32, 32, 1e-5, confs["fp8"])
+            r16 = OT.phi3_decoder_layer(h_in.to(torch.bfloat16), pl16, cos, sin, add16, 32, 1e-5, confs["fp8"]).float()
+            plain = OT.phi3_decoder_layer(h_in, pl32, cos, sin, add32, 32, 1e-5, None)
+            upd = ((r32 - h_in) * vrow).norm()
+            per_layer.append(dict(layer=l, hip=float(((h_out - r32) * vrow).norm() / upd), eager_bf16=float(((r16 - r32) * vrow).norm() / upd),
+                                  e4m3_cost=float(((r32 - plain) * vrow).norm() / ((plain - h_in) * vrow).norm())))
+        # the head, teacher-forced on the HIP stack's last residual stream
+        h_last = taps[-1][1]
+        hq = lambda h, pp, lin: OT.decoupled_linear(OT.rms_norm(h, pp["model.norm.weight"], 1e-5), pp["lm_head.weight"], pp.get("lm_head.bias"),
+                                                    pp.get("lm_head.additional_fc.weight"), pp.get("lm_head.additional_fc.bias"), 32010, lin)
+        head32 = hq(h_last, lm32, OT.linear_e4m3)
+        head16 = hq(h_last.to(torch.bfloat16), lm16, OT.linear_e4m3).float()
+    stats["head_teacher_forced"] = dict(hip=rl(got["fp8"], head32), eager_bf16=rl(head16, head32))
+    stats["per_layer_teacher_forced"] = per_layer
+    hip_l = np.array([r["hip"] for r in per_layer])
+    yard_l = np.array([r["eager_bf16"] for r in per_layer])
+    stats["per_layer_summary"] = dict(hip_mean=float(hip_l.mean()), hip_max=float(hip_l.max()), eager_bf16_mean=float(yard_l.mean()),
+                                      eager_bf16_max=float(yard_l.max()), e4m3_cost_mean=float(np.mean([r["e4m3_cost"] for r in per_layer])))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity_full_depth_fp8.json"), "w") as f:
         json.dump(stats, f, indent=1)
-    print(json.dumps(stats))
-    record_parity("AKI-4B 32+27 layers logits, fp8 projections + head, valid rows", torch.bfloat16, stats["fp8"]["max"], stats["fp8"]["mean"], mx,
-                  "rel L2 <= 0.5 (random walk of e4m3 noise over 129 GEMMs); no reference for fp8")
-    assert stats["fp8"]["rel_l2"] <= 0.5, stats
-    assert stats["fp8_qkv_gateup_only"]["rel_l2"] < stats["fp8_head_bf16"]["rel_l2"] <= stats["fp8"]["rel_l2"] * 1.02, stats
-    assert stats["fp8_qkv_gateup_only"]["argmax_agreement"] >= stats["fp8"]["argmax_agreement"], stats
+    print(json.dumps({k: v for k, v in stats.items() if k != "per_layer_teacher_forced"}))
+    q = stats["fp8"]["vs_fake_quant_fp32"]
+    yd = stats["yardstick_eager_bf16_fake_quant_vs_its_fp32_self"]
+    record_parity("AKI-4B fp8, each of 32 layers teacher-forced vs the fake-quant oracle (rel. to the layer update; worst layer)", torch.bfloat16,
+                  float(hip_l.max()), float(hip_l.mean()), 1.0, f"each <= 2x, mean <= 1.5x the eager-bf16 fake-quant layer ({yard_l.mean():.4g}) + 2e-3")
+    record_parity("AKI-4B 32+27 layers logits, fp8 projections + head vs the fake-quant oracle, valid rows", torch.bfloat16, q["max"], q["mean"], mx,
+                  f"mean <= 1.5x the fake-quant graph's own eager-bf16 error ({yd['mean']:.4g}) + 1e-3*max|ref|")
+    # layer level: no accumulation, so this is where a mis-scaled GEMM cannot hide
+    assert float(hip_l.mean()) <= 1.5 * float(yard_l.mean()) + 2e-3, stats["per_layer_summary"]
+    assert bool((hip_l <= 2.0 * yard_l + 5e-3).all()), [r for r in per_layer if r["hip"] > 2.0 * r["eager_bf16"] + 5e-3]
+    assert stats["head_teacher_forced"]["hip"] <= 1.5 * stats["head_teacher_forced"]["eager_bf16"] + 2e-3, stats["head_teacher_forced"]
+    # end to end: the fake-quant graph's own eager-bf16 run is the yardstick
+    assert q["mean"] <= 1.5 * yd["mean"] + 1e-3 * mx, (q, yd)
+    assert q["rel_l2"] <= 1.5 * yd["rel_l2"] + 1e-3, (q, yd)
+    for k in ("fp8_head_bf16", "fp8_qkv_gateup_only"):
+        assert stats[k]["vs_fake_quant_fp32"]["rel_l2"] <= 1.5 * yd["rel_l2"] + 1e-3, (k, stats[k], yd)
+    # what e4m3 costs the model (recorded; ordering asserted as before)
+    c = {k: stats[k]["vs_plain_fp32"]["rel_l2"] for k in confs}
+    assert c["fp8_qkv_gateup_only"] < c["fp8_head_bf16"] <= c["fp8"] * 1.02, c
+
+
+@pytest.mark.timeout(1200)
+def test_config5_fp8_batch16_full_depth_runs_and_is_reproducible():
+    """BASELINE configs[4]'s actual workload - batch 16 x (336 px + 512 tokens), M = 10 480 token rows, all 32 + 27 layers, e4m3
+    projections + head - in the driver's suite: the tile plans of M = 10 480 run, the logits are finite and a second forward
+    reproduces them bit for bit.  (Values are checked at batch 2 above and at GEMM level in test_fp8_gpu.py - same kernels.)"""
+    import bench
+    from aki_amd.factory import build_aki
+    m = build_aki(dtype=torch.bfloat16, device=DEV, seed=7).eval()
+    m.lang_model.enable_fp8()
+    vx, ids, am = bench.synth_batch(16, torch.device(DEV), torch.bfloat16, m.media_token_id, seed=5)
+    with torch.no_grad():
+        a = m(vx, ids, attention_mask=am).logits
+        b = m(vx, ids, attention_mask=am).logits
+    assert a.shape == (16, N_TXT - 1 + NV, 32011 + 2)
+    assert bool(torch.isfinite(a.float()).all())
+    assert torch.equal(a, b)
 
 
 @pytest.mark.timeout(3000)

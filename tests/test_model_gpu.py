@@ -210,6 +210,8 @@ def test_full_width_decoder_vs_transformers_eager_under_441_mask(dtype):
                      num_key_value_heads=32, max_position_embeddings=4096, original_max_position_embeddings=4096,
                      pad_token_id=32000, attn_implementation="eager")
     hf = HFPhi3(cfg).eval()
+    from conftest import randomize_norms_and_biases, record_parity
+    assert randomize_norms_and_biases(hf, seed=21) == 5         # RMSNorm gains 1 + 0.2 N: the gain fold is not the identity
     B, L = 2, 300
     x = torch.randn(B, L, 3072, generator=torch.Generator().manual_seed(1)) * 0.5
     am = np.ones((B, L), dtype=bool)
@@ -229,7 +231,6 @@ def test_full_width_decoder_vs_transformers_eager_under_441_mask(dtype):
         got = lm(inputs_embeds=x.to(DEV).to(dtype), attention_mask=table).logits.float().cpu()
         if dtype == torch.float32:
             err = ((got - want).abs() * valid).max().item()
-            from conftest import record_parity
             record_parity("full-width decoder, fp32 logits vs transformers eager", torch.float32, err, ((got - want).abs() * valid).mean().item(),
                           want.abs().max().item(), "1e-5*max(1,max|ref|)")
             assert err <= 1e-5 * max(1.0, want.abs().max().item()), err
@@ -237,12 +238,23 @@ def test_full_width_decoder_vs_transformers_eager_under_441_mask(dtype):
             errp = ((got - want).abs() * (~valid)).max().item()
             assert errp <= 1e-3 * max(1.0, want.abs().max().item()), errp
         else:
+            lm.model.fold_norms = False                      # every RMSNorm as its own kernel: recorded beside the folded path
+            got_unf = lm(inputs_embeds=x.to(DEV).to(dtype), attention_mask=table).logits.float().cpu()
+            assert not torch.equal(got, got_unf)
             hf16 = hf.to(torch.bfloat16)
             m16 = add_mask.to(torch.bfloat16).masked_fill(inv.bool(), torch.finfo(torch.bfloat16).min)
             ref16 = hf16(inputs_embeds=x.to(torch.bfloat16), attention_mask=m16, position_ids=pos).logits.float()
             e_hip = ((got - want).abs() * valid).mean().item()
+            e_unf = ((got_unf - want).abs() * valid).mean().item()
             e_ref = ((ref16 - want).abs() * valid).mean().item()
-            assert e_hip <= 1.5 * e_ref + 1e-3, (e_hip, e_ref)
+            mxw = want.abs().max().item()
+            record_parity(f"full-width decoder, random norm gains, bf16 folded (HF bf16 eager: {e_ref:.4g})", dtype,
+                          ((got - want).abs() * valid).max().item(), e_hip, mxw, "mean <= 1.5x HF bf16-eager mean + 1e-3")
+            record_parity("full-width decoder, random norm gains, bf16 fold_norms=False", dtype,
+                          ((got_unf - want).abs() * valid).max().item(), e_unf, mxw, "mean <= 1.5x HF bf16-eager mean + 1e-3")
+            assert e_hip <= 1.5 * e_ref + 1e-3, (e_hip, e_unf, e_ref)
+            assert e_unf <= 1.5 * e_ref + 1e-3, (e_hip, e_unf, e_ref)
+            assert e_hip <= 1.25 * e_unf + 1e-3, (e_hip, e_unf, e_ref)
 
 
 @pytest.mark.parametrize("px", [384, 336])
@@ -257,6 +269,9 @@ def test_full_width_siglip_tower_vs_transformers(px):
     cfg = SiglipVisionConfig(hidden_size=1152, intermediate_size=4304, num_hidden_layers=2, num_attention_heads=16, image_size=384,
                              patch_size=14, attn_implementation="eager")
     hf = SiglipVisionModel(cfg).eval()
+    from conftest import randomize_norms_and_biases, record_parity
+    # LayerNorm gains 1 + 0.2 N, LayerNorm and linear biases 0.1 N: the folded `W diag(gamma)`, `W beta + b` and `mean * c` terms all live
+    assert randomize_norms_and_biases(hf, seed=22) >= 2 * 10 + 3
     x = torch.rand(2, 3, px, px, generator=torch.Generator().manual_seed(1)) * 2 - 1
     with torch.no_grad():
         want = hf(pixel_values=x, interpolate_pos_encoding=(px != 384)).last_hidden_state
@@ -267,11 +282,20 @@ def test_full_width_siglip_tower_vs_transformers(px):
         assert not missing.missing_keys
         got32 = vt.to(DEV).eval()(x.to(DEV), interpolate_pos_encoding=(px != 384)).last_hidden_state.cpu()
         err = (got32 - want).abs().max().item()
-        from conftest import record_parity
         record_parity(f"full-width SigLIP tower at {px} px, fp32 vs transformers", torch.float32, err, (got32 - want).abs().mean().item(),
                       want.abs().max().item(), "1e-5*max(1,max|ref|)")
         assert err <= 1e-5 * max(1.0, want.abs().max().item()), err
         got16 = vt.to(torch.bfloat16)(x.to(DEV).to(torch.bfloat16), interpolate_pos_encoding=(px != 384)).last_hidden_state.float().cpu()
         ref16 = hf.to(torch.bfloat16)(pixel_values=x.to(torch.bfloat16), interpolate_pos_encoding=(px != 384)).last_hidden_state.float()
-        e_hip, e_ref = (got16 - want).abs().mean().item(), (ref16 - want).abs().mean().item()
-        assert e_hip <= 1.5 * e_ref + 1e-3, (e_hip, e_ref)
+        vt.encoder.fold_norms = False
+        got16u = vt(x.to(DEV).to(torch.bfloat16), interpolate_pos_encoding=(px != 384)).last_hidden_state.float().cpu()
+        assert not torch.equal(got16, got16u)
+        e_hip, e_unf, e_ref = (got16 - want).abs().mean().item(), (got16u - want).abs().mean().item(), (ref16 - want).abs().mean().item()
+        mxw = want.abs().max().item()
+        record_parity(f"full-width SigLIP tower at {px} px, random LN gains/biases, bf16 folded (HF bf16 eager: {e_ref:.4g})", torch.bfloat16,
+                      (got16 - want).abs().max().item(), e_hip, mxw, "mean <= 1.5x HF bf16-eager mean + 1e-3")
+        record_parity(f"full-width SigLIP tower at {px} px, random LN gains/biases, bf16 fold_norms=False", torch.bfloat16,
+                      (got16u - want).abs().max().item(), e_unf, mxw, "mean <= 1.5x HF bf16-eager mean + 1e-3")
+        assert e_hip <= 1.5 * e_ref + 1e-3, (e_hip, e_unf, e_ref)
+        assert e_unf <= 1.5 * e_ref + 1e-3, (e_hip, e_unf, e_ref)
+        assert e_hip <= 1.25 * e_unf + 1e-3, (e_hip, e_unf, e_ref)

@@ -190,15 +190,16 @@ def test_folded_arguments_are_validated():
         ops.linear(x.float(), w.float(), row_scale=st.rstd)
 
 
-def test_stats_producer_beyond_65536_rows_and_growing_counter_area():
-    """the statistics-producing GEMM refused M > 65536 (a fixed 4 KB counter area).  The area now grows with
-    M; a workspace that served a smaller M first (its partial sums lie where the larger counter area will be) is re-zeroed by
-    the host wrapper.  Statistics of a 70 000-row launch are checked against torch on the stored bf16 output."""
+def test_stats_producer_beyond_65536_rows_any_order_on_one_workspace():
+    """the statistics-producing GEMM refused M > 65536 (a fixed 4 KB counter area).  ADVICE r3 (medium): the
+    area that then grew with M was re-zeroed only on growth beyond the largest size seen, so 70 000 -> 3 000 -> 70 000 rows on
+    one workspace left the middle launch's partial sums under the third launch's counters.  The counter area now has one size
+    for every M: any order of sizes on the same buffer, each checked against torch on the stored bf16 output."""
     from aki_amd import ops
     g = torch.Generator(device=DEV).manual_seed(5)
     K, N = 128, 256
     w = (torch.randn(N, K, device=DEV, generator=g) * 0.2).to(torch.bfloat16)
-    for M in (3000, 70000, 131073):          # ascending: every step enlarges the counter area of the SAME workspace
+    for M in (3000, 70000, 131073, 3000, 70000, 64, 131073, 70000):     # grow, shrink, grow again on the SAME workspace
         x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
         st = ops.new_stats(M, DEV)
         y = ops.linear(x, w, stats_out=st, stats_eps=1e-5)

@@ -264,3 +264,26 @@ def test_torch_oracle_greedy_continuation_matches_the_reference():
                 np.testing.assert_allclose(logits[cols].numpy(), gg["logits"][b, t], atol=2e-4, rtol=1e-3)
                 assert int(logits.argmax()) == int(gg["tokens"][b, t]), (b, t)
                 ids = torch.cat([ids, torch.tensor([[int(gg["tokens"][b, t])]])], dim=1)
+
+
+def test_fake_quant_e4m3_oracle_is_the_plain_oracle_plus_format_noise():
+    """BASELINE configs[4] (build-defined; the reference has no fp8): the fake-quant mode of the torch oracle.  (1) its quantiser
+    returns e4m3-representable values whose per-row scale maps the row's amax to 448; (2) with quantisation switched off (fp8=None)
+    it IS the pinned plain oracle; (3) on the tiny model it tracks the reference's logits within the e4m3 format's noise and
+    moves towards them as projections return to the model dtype - the property the full-depth GPU test leans on."""
+    import torch
+    OT, g, p, vision_x = _tiny_torch()
+    x = torch.randn(7, 96, generator=torch.Generator().manual_seed(0)) * 3
+    q, s = OT.quant_rows_e4m3(x)
+    assert torch.equal(q, q.to(torch.float8_e4m3fn).float()) and float(q.abs().max()) == 448.0
+    assert torch.allclose((q * s).abs().amax(-1), x.abs().amax(-1), rtol=1e-6)
+    assert float(((q * s) - x).abs().max()) <= 0.0625 * float(x.abs().max())
+    ids, am = torch.from_numpy(g["lang_x"]), torch.from_numpy(g["attention_mask"])
+    with torch.no_grad():
+        plain = OT.aki_forward(p, tiny_cfg(), vision_x, ids, am)["logits"]
+        same = OT.aki_forward(p, dict(tiny_cfg(), fp8=None), vision_x, ids, am)["logits"]
+        full = OT.aki_forward(p, dict(tiny_cfg(), fp8=dict(head=True, residual_writers=True)), vision_x, ids, am)["logits"]
+        part = OT.aki_forward(p, dict(tiny_cfg(), fp8=dict(head=False, residual_writers=False)), vision_x, ids, am)["logits"]
+    assert torch.equal(plain, same)
+    rel = lambda a: float((a - plain).norm() / plain.norm())
+    assert 0.0 < rel(part) < rel(full) < 0.25, (rel(part), rel(full))
