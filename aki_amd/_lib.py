@@ -16,7 +16,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 12
+AKI_ABI_VERSION = 13
 
 
 class AkiError(RuntimeError):
@@ -83,6 +83,20 @@ class SpliceArgs(C.Structure):
                 ("padding_side", C.c_int32), ("dtype", C.c_int32)]
 
 
+class DecodeChainLayer(C.Structure):
+    _fields_ = [("w_qkv", C.c_void_p), ("w_o", C.c_void_p), ("w_gate_up", C.c_void_p), ("w_down", C.c_void_p), ("norm1", C.c_void_p),
+                ("norm2", C.c_void_p), ("k_cache", C.c_void_p), ("v_cache", C.c_void_p), ("s_qkv", C.c_void_p), ("s_o", C.c_void_p),
+                ("s_gate_up", C.c_void_p), ("s_down", C.c_void_p)]
+
+
+class DecodeChainArgs(C.Structure):
+    _fields_ = [("layers", C.c_void_p), ("h_in", C.c_void_p), ("h_out", C.c_void_p), ("cos", C.c_void_p), ("sin", C.c_void_p),
+                ("cache_len", C.c_void_p), ("col_valid_bits", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("n_layers", C.c_int32), ("nwords", C.c_int32), ("d", C.c_int32), ("H", C.c_int32), ("Dh", C.c_int32), ("F", C.c_int32),
+                ("capacity", C.c_int32), ("max_keys", C.c_int32), ("scale", C.c_float), ("rms_eps", C.c_float), ("dtype", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 # name -> (restype, argtypes); also the list of symbols include/aki_mi355x.h declares
 SIGNATURES = {
     "aki_strerror": (C.c_char_p, [C.c_int]),
@@ -114,6 +128,9 @@ SIGNATURES = {
     "aki_decode_attn_fused_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 6 + [C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
                                             C.c_void_p]),
     "aki_decode_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p, C.c_float, C.c_void_p]),
+    "aki_decode_chain_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
+    "aki_decode_chain_error_offset": (C.c_size_t, [C.c_int32] * 2),
+    "aki_decode_chain_fwd": (C.c_int, [C.POINTER(DecodeChainArgs), C.c_void_p]),
     "aki_attn_bwd_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
     "aki_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_transpose": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),

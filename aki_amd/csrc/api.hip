@@ -25,6 +25,9 @@ int decode_attn_split_launch(const void* q_or_qkv, const float* cos, const float
                              void* ws, size_t ws_bytes, hipStream_t s);
 int rope_append_launch(const void* qkv, const float* cos, const float* sin, const int* pos, const int* cache_len, void* q_out,
                        void* k_cache, void* v_cache, int B, int H, int Dh, int cap, int dtype, hipStream_t s);
+size_t decode_chain_ws_bytes(int n_layers, int d, int H, int F, int cap);
+size_t decode_chain_err_offset(int n_layers, int H);
+int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream);
 int decode_attn_launch(const void* q, const void* kc, const void* vc, void* o, const int* n_keys, const uint64_t* vbits, int nwords,
                        int B, int H, int Dh, int cap, float scale, int dtype, hipStream_t s);
 int norm_launch(bool rms, const void* x, const void* w, const void* b, void* y, int rows, int cols, int ldx, int ldy,
@@ -388,6 +391,21 @@ int aki_decode_linear_fwd(const aki_linear_args* a, const void* rms_weight, floa
   const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
   AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));
   return gemv_bf16(a, rms_weight, rms_eps, (hipStream_t)stream);
+}
+
+size_t aki_decode_chain_workspace_bytes(int32_t n_layers, int32_t d, int32_t H, int32_t F, int32_t capacity) {
+  if (n_layers <= 0 || d <= 0 || H <= 0 || F <= 0 || capacity <= 0) return 0;
+  return decode_chain_ws_bytes(n_layers, d, H, F, capacity);
+}
+
+size_t aki_decode_chain_error_offset(int32_t n_layers, int32_t H) { return (n_layers > 0 && H > 0) ? decode_chain_err_offset(n_layers, H) : 0; }
+
+int aki_decode_chain_fwd(const aki_decode_chain_args* a, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(a && a->layers && a->h_in && a->h_out && a->cos && a->sin && a->cache_len && a->workspace);
+  AKI_CHECK_ARG(a->n_layers > 0 && a->d > 0 && a->H > 0 && a->Dh > 0 && a->F > 0 && a->capacity > 0 && a->scale > 0.f && a->rms_eps > 0.f);
+  AKI_CHECK_ARG(!a->col_valid_bits || a->nwords > 0);
+  return decode_chain_launch(a, (hipStream_t)stream);
 }
 
 // ---- training step ---------------------------------------------------------------------------------------

@@ -1,0 +1,588 @@
+// decode_chain.hip - the whole decoder stack of ONE decode step (batch 1) as ONE launch: a dataflow chain of
+// weight-streaming workgroups (what `lang_model.generate` runs per token after the MMA prefill,
+// src/aki.py:136-209 + src/aki_generation.py:36-86, HF:phi3/modeling_phi3.py:287-328 per layer).
+//
+// Why.  At batch 1 a decode step is 7.4 GB of weights read once; decode.hip runs it as 5 launches per layer, and every launch
+// of that chain is a latency chain of its own - launch, stage x, first weight round trip, reduce, store, drain - during which
+// HBM idles: the three K = 3072 GEMVs are ONE batch of loads per wave (10.7 us for 19-57 MB), 1.96 ms per token = 0.47 of the
+// HBM peak.  Weights do not depend on activations.  Here a workgroup issues its weight loads FIRST and only then
+// waits for its input vector, so the stream runs ahead of the dependency chain by everything the register files of the
+// resident workgroups hold (~40-50 MB chip-wide), across phase AND layer seams.
+//
+// How.  grid = n_layers x (qkv | attention | o_proj | gate_up | down) workgroups in DISPATCH ORDER = dependency order.  A
+// workgroup: (1) finds its (layer, phase, slice) from blockIdx, (2) issues every weight load of its slice (non-temporal,
+// 12-16 x 16 B per lane), (3) one lane polls the producer phase's arrival counter (relaxed agent-scope loads + s_sleep),
+// (4) stages its input vector from the hand-off buffer into LDS (RMSNorm fused where the layer has one), (5) dot products
+// out of registers, wave reduce, epilogue (SwiGLU / residual), (6) publishes: outputs stored write-through (sc1), every
+// storing wave drains vmcnt, barrier, one lane adds 1 to its phase's counter.  (cdna_hip_programming.md Guideline 16, R1 +
+// counter form; every handed-off byte is stored sc1 and loaded sc1, so no acquire fence is needed.)
+//
+// Progress.  A workgroup only ever waits for workgroups with SMALLER block indices.  The dispatcher hands out workgroups of
+// a grid in index order (per XCD queue), so every workgroup a resident one waits for is resident or finished: the lowest
+// unfinished index is always resident with all its producers finished.  Every spin is bounded all the same: a poller that
+// gives up writes its code to the error word, releases every counter of the launch (so the rest drains in microseconds)
+// and the host wrapper raises - a broken assumption is a loud error, never a hung GPU.
+//
+// Arithmetic = decode.hip's, row for row: one wave owns whole weight rows, lane l takes 16-byte chunks l, l+64, ... of a row
+// in ascending order, the same xor-shuffle reduction, the same epilogue formulas, the same split-KV attention (same tiles,
+// same merge order) - a chained step reproduces the five-launch step bit for bit (tests/test_decode_gpu.py).
+#include "aki_device.h"
+
+namespace aki {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 chain_bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 chain_bf16x2_t;
+
+__device__ __forceinline__ float cdot8(const u32x4 a, const u32x4 b, float acc) {
+  const chain_bf16x8_t a8 = __builtin_bit_cast(chain_bf16x8_t, a), b8 = __builtin_bit_cast(chain_bf16x8_t, b);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a8, a8, 0, 1), __builtin_shufflevector(b8, b8, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a8, a8, 2, 3), __builtin_shufflevector(b8, b8, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a8, a8, 4, 5), __builtin_shufflevector(b8, b8, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a8, a8, 6, 7), __builtin_shufflevector(b8, b8, 6, 7), acc, false);
+  return acc;
+}
+// weight-only fp8: same pairing as decode.hip's dot16_w8 (a 16-byte weight chunk = 16 k-values against two x chunks)
+__device__ __forceinline__ float cdot16_w8(const u32x4 w, const u32x4 x0, const u32x4 x1, float acc) {
+  const chain_bf16x8_t xa = __builtin_bit_cast(chain_bf16x8_t, x0), xb = __builtin_bit_cast(chain_bf16x8_t, x1);
+#define AKI_CW8_PAIR(word, hi, xv, i0)                                                                              \
+  {                                                                                                                 \
+    const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)(word), hi);                                                \
+    chain_bf16x2_t wb;                                                                                              \
+    wb[0] = (__bf16)f2[0];                                                                                          \
+    wb[1] = (__bf16)f2[1];                                                                                          \
+    acc = __builtin_amdgcn_fdot2_f32_bf16(wb, __builtin_shufflevector(xv, xv, i0, i0 + 1), acc, false);             \
+  }
+  AKI_CW8_PAIR(w[0], false, xa, 0) AKI_CW8_PAIR(w[0], true, xa, 2) AKI_CW8_PAIR(w[1], false, xa, 4) AKI_CW8_PAIR(w[1], true, xa, 6)
+  AKI_CW8_PAIR(w[2], false, xb, 0) AKI_CW8_PAIR(w[2], true, xb, 2) AKI_CW8_PAIR(w[3], false, xb, 4) AKI_CW8_PAIR(w[3], true, xb, 6)
+#undef AKI_CW8_PAIR
+  return acc;
+}
+
+#define AKI_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// pointers that arrive through the layer table are generic to the compiler: say "global" or every load is a flat_load
+typedef const __attribute__((address_space(1))) u32x4* gptr_u32x4;
+typedef const __attribute__((address_space(1))) unsigned* gptr_u32;
+typedef const __attribute__((address_space(1))) float* gptr_f32;
+#define AKI_G128(p) ((gptr_u32x4)(p))
+constexpr int CH_PSTRIDE = 104;          // decode.hip's DEC_PSTRIDE: m, l, 6 pad, acc[96]
+// Synchronisation block of one (layer, phase), every word in a 128-byte line of its own:
+//   [0..15] arrival shards (producer workgroup i adds to shard i % 16), [16] the top counter (a completed shard adds 1),
+//   [17..17+CH_FLAGS) READY flags, all written by the arriver that completes the top counter; consumer workgroup j polls flag j % CH_FLAGS.
+// Why not one counter: a phase has 400-2000 producers and ~1000 resident consumers.  One word takes ~90 atomics/us
+// (MI355X_MICROARCH.md, dequeue) - 2048 arrivals would cost 23 us - and a thousand lanes polling one word (agent-scope loads
+// are served memory-side, not by the per-XCD L2) saturate the channel that owns it, which every weight stream crosses: the
+// first version of this file, with one counter per phase, ran 3x SLOWER than five launches per layer.
+constexpr int CH_SHARDS = 16;
+constexpr int CH_FLAGS = 32;
+constexpr int CH_SYNC_WORDS = (CH_SHARDS + 1 + CH_FLAGS) * 32;   // 128-byte lines, in 4-byte words
+constexpr int CH_PHASES = 5;             // [0] qkv [1] attention (per-head mergers) [2] o_proj [3] gate_up [4] down
+constexpr int CH_XREP = 8;               // copies of every hand-off vector: consumer j reads copy j % 8 (1152 readers of one 128-byte line -> 144)
+constexpr unsigned CH_SPIN_LIMIT = 200000u;
+
+struct ChainParams {
+  const aki_decode_chain_layer* layers;
+  int n_layers;
+  const bf16_t* h_in; bf16_t* h_out;
+  const float* cos; const float* sin; const int* cache_len; const uint64_t* vbits; int nwords;
+  int d, H, F, cap, S, T; float scale, eps;
+  unsigned* sync;         // [n_layers][CH_PHASES][CH_SYNC_WORDS], then [n_layers][H] attention tickets: zeroed by the launch function
+  unsigned* attn_cnt;     // a ticket per (layer, head): nothing is re-armed inside the launch
+  unsigned* err;          // sticky error word (outside the zeroed block)
+  bf16_t* qkv; bf16_t* attn_o; bf16_t* h1; bf16_t* act; bf16_t* hbuf;   // hand-off vectors (copy 0); hbuf = 2 x d
+  int rep_stride;         // elements between the copies of a hand-off vector
+  float* part;            // [H][S][CH_PSTRIDE]
+  int n_qkv, n_attn, n_o, n_gu, n_down, wg_layer;
+};
+
+// ---- hand-off primitives ------------------------------------------------------------------------------------------------
+// Vector loads of handed-off bytes: buffer_load_dwordx4 ... sc1 (aux 16), 16-byte aligned offsets.
+__device__ __forceinline__ u32x4 ld_sc1_b128(const __amdgpu_buffer_rsrc_t rs, int byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, bytes, 0x00020000);
+}
+
+// One lane polls this workgroup's READY flag of the producer phase; bounded.  On give-up: error word, then every flag of the
+// launch is raised (so the rest drains in microseconds).
+__device__ __forceinline__ void chain_wait(const ChainParams& p, unsigned* sync, int wg, unsigned code) {
+  if (threadIdx.x == 0 && sync != nullptr) {
+    unsigned* flag = sync + (CH_SHARDS + 1 + (wg % CH_FLAGS)) * 32;
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, AKI_RLX_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > CH_SPIN_LIMIT) {
+        __hip_atomic_store(p.err, code, AKI_RLX_AGENT);
+        for (int i = 0; i < p.n_layers * CH_PHASES; ++i)
+          for (int f = 0; f < CH_FLAGS; ++f) __hip_atomic_store(p.sync + (size_t)i * CH_SYNC_WORDS + (CH_SHARDS + 1 + f) * 32, 2u, AKI_RLX_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Arrival of producer `idx` of `n` (wave 0, after the outputs are at the coherence point): its shard; the arriver that completes
+// a shard adds to the top counter; the one that completes the top counter raises every READY flag (32 lanes, one store each).
+__device__ __forceinline__ void chain_arrive(unsigned* sync, int idx, int n, int lane) {
+  unsigned done = 0;
+  if (lane == 0) {
+    const int shard = idx % CH_SHARDS;
+    const unsigned target = (unsigned)(n / CH_SHARDS + ((n % CH_SHARDS) > shard ? 1 : 0));
+    const unsigned prev = __hip_atomic_fetch_add(sync + shard * 32, 1u, AKI_RLX_AGENT);
+    if (prev + 1u == target) {
+      const unsigned nshards = (unsigned)min(n, CH_SHARDS);
+      done = (__hip_atomic_fetch_add(sync + CH_SHARDS * 32, 1u, AKI_RLX_AGENT) + 1u == nshards) ? 1u : 0u;
+    }
+  }
+  done = __shfl(done, 0);
+  if (done && lane < CH_FLAGS) __hip_atomic_store(sync + (CH_SHARDS + 1 + lane) * 32, 1u, AKI_RLX_AGENT);
+}
+
+// Every storing wave has drained (vmcnt(0)) before the barrier; wave 0 signals.
+__device__ __forceinline__ void chain_publish(unsigned* sync, int idx, int n) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x < 64) chain_arrive(sync, idx, n, threadIdx.x);
+}
+
+// ---- one GEMV phase ----------------------------------------------------------------------------------------------------
+// NR weight rows per wave, KC 16-byte chunks per lane and row (bf16: K = 512 KC; W8: K = 1024 KC).  SWIGLU: the wave's rows are
+// gate rows f.. and up rows n_out + f.. (NR/2 features).  NORM: x is RMS-normalised (weight norm_w) on its way into LDS.
+template <int NR, int KC, bool SWIGLU, bool NORM, bool W8>
+__device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_wg, const void* w, const float* w_scale, int K, int n_out,
+                                           const bf16_t* x, int x_rep, const bf16_t* norm_w, const bf16_t* residual, int res_rep, bf16_t* y,
+                                           int y_reps, unsigned* wait_sync, unsigned* done_sync, unsigned code, char* sx, float* s_red) {
+  constexpr int FPW = SWIGLU ? NR / 2 : NR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f0 = (wg * 4 + wave) * FPW;
+  const size_t row_bytes = W8 ? (size_t)K : (size_t)K * 2;
+  // (2) the weight loads of this wave's rows, all of them, before anything that depends on another workgroup
+  u32x4 wv[NR][KC];
+  float wsc[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int f = min(f0 + (r % FPW), n_out - 1);
+    const int row = (SWIGLU && r >= FPW) ? n_out + f : f;
+    const char* wr = (const char*)w + (size_t)row * row_bytes;
+    wsc[r] = W8 ? ((gptr_f32)w_scale)[row] : 1.f;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) wv[r][kc] = __builtin_nontemporal_load(AKI_G128(wr + (size_t)(lane + 64 * kc) * 16));
+  }
+  // (3) the producer phase has published
+  chain_wait(p, wait_sync, wg, code);
+  // (4) x -> LDS.  Handed-off bytes: sc1 loads only, from this workgroup's copy of the vector.
+  const int nchunk = K / 8;
+  x += (size_t)(x_rep ? (wg % CH_XREP) * p.rep_stride : 0);
+  if (residual != nullptr && res_rep) residual += (size_t)(wg % CH_XREP) * p.rep_stride;
+  const __amdgpu_buffer_rsrc_t rx = chain_rsrc(x, K * 2);
+  unsigned long long res_bits = 0;
+  if (residual != nullptr && lane == 0 && f0 < n_out) {            // in flight under the staging
+    if constexpr (FPW == 4) res_bits = __hip_atomic_load((const unsigned long long*)(residual + f0), AKI_RLX_AGENT);
+    else if constexpr (FPW == 2) res_bits = __hip_atomic_load((const unsigned*)(residual + f0), AKI_RLX_AGENT);
+    else res_bits = __hip_atomic_load((const unsigned short*)(residual + f0), AKI_RLX_AGENT);
+  }
+  if constexpr (NORM) {
+    // y = bf16(x * rsqrt(mean(x^2) + eps) * w): decode.hip's gemv_bf16_kernel staging, the row kept in registers between the passes
+    u32x4 xv[2];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      xv[i] = u32x4{0u, 0u, 0u, 0u};
+      if (c < nchunk) xv[i] = ld_sc1_b128(rx, c * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = bf16_lo(xv[i][e]), hi = bf16_hi(xv[i][e]);
+        ss = __builtin_fmaf(lo, lo, ss);
+        ss = __builtin_fmaf(hi, hi, ss);
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) s_red[wave] = ss;
+    __syncthreads();
+    const float rs = rsqrtf((s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)K + p.eps);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      if (c < nchunk) {
+        const u32x4 g = *AKI_G128(norm_w + c * 8);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack_bf16x2(round_bf16(bf16_lo(xv[i][e]) * rs) * bf16_lo(g[e]), round_bf16(bf16_hi(xv[i][e]) * rs) * bf16_hi(g[e]));
+        *(u32x4*)(sx + (size_t)c * 16) = o;
+      }
+    }
+  } else {
+    for (int c = tid; c < nchunk; c += 256) *(u32x4*)(sx + (size_t)c * 16) = ld_sc1_b128(rx, c * 16);
+  }
+  __syncthreads();
+  // (5) dot products out of the registers, chunk order ascending per lane and row
+  float acc[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const int c = lane + 64 * kc;
+    if constexpr (W8) {
+      const u32x4 x0 = *(const u32x4*)(sx + (size_t)(2 * c) * 16), x1 = *(const u32x4*)(sx + (size_t)(2 * c + 1) * 16);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r] = cdot16_w8(wv[r][kc], x0, x1, acc[r]);
+    } else {
+      const u32x4 xc = *(const u32x4*)(sx + (size_t)c * 16);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r] = cdot8(wv[r][kc], xc, acc[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    float v = acc[r];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    acc[r] = W8 ? v * wsc[r] : v;
+  }
+  // (6) epilogue + publish
+  if (lane == 0 && f0 < n_out) {
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < FPW; ++f) {
+      float v = SWIGLU ? acc[FPW + f] * silu_fast(acc[f]) : acc[f];
+      if (residual != nullptr) v += bf16_bits_to_f32((unsigned short)(res_bits >> (16 * f)));
+      out[f] = v;
+    }
+    // n_out is a multiple of FPW on every matrix of the stack: a wave's features are all in range or none is
+    for (int rep = 0; rep < y_reps; ++rep) {
+      bf16_t* yr = y + (size_t)rep * p.rep_stride + f0;
+      if constexpr (FPW == 4) {
+        const unsigned long long o = (unsigned long long)pack_bf16x2(out[0], out[1]) | ((unsigned long long)pack_bf16x2(out[2], out[3]) << 32);
+        __hip_atomic_store((unsigned long long*)yr, o, AKI_RLX_AGENT);
+      } else if constexpr (FPW == 2) {
+        __hip_atomic_store((unsigned*)yr, pack_bf16x2(out[0], out[1]), AKI_RLX_AGENT);
+      } else {
+        __hip_atomic_store((unsigned short*)yr, (unsigned short)(pack_bf16x2(out[0], 0.f) & 0xffffu), AKI_RLX_AGENT);
+      }
+    }
+  }
+  chain_publish(done_sync, wg, n_wg);
+}
+
+// ---- the attention phase: decode.hip's decode_attn_split_kernel<true>, one (head, split) item per WAVE ---------------------
+// qkv (un-rotated, handed off by phase 0) -> rotated q; the item whose key range holds the new position also rotates k, appends
+// k / v to the cache and uses them from LDS.  Partials (m, l, acc[96]) meet in the workspace; the item that arrives last at its
+// head's ticket merges, stores the head's 96 outputs write-through and adds 1 to the layer's attention counter.
+__device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decode_chain_layer& ly, int layer, int wg, unsigned* wait_sync,
+                                           unsigned* done_sync, unsigned code, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // per-wave LDS: s_q, s_k, s_v (96 bf16 each, 16-byte aligned) and the merge scratch s_mg[5][12][10] floats
+  bf16_t* s_q = (bf16_t*)(smem + wave * 3072);
+  bf16_t* s_k = s_q + 96;
+  bf16_t* s_v = s_k + 96;
+  float* s_mg = (float*)(smem + wave * 3072 + 576);
+  const int item = wg * 4 + wave;
+  const bool live = item < p.H * p.S;
+  const int h = live ? item / p.S : 0, split = live ? item - h * p.S : 0;
+  const int ln = p.cache_len[0];
+  const int n = ln + 1;
+  const int k_begin = split * p.T * 64;
+  const int k_end = live ? min(n, k_begin + p.T * 64) : 0;
+  bf16_t* kb = (bf16_t*)ly.k_cache + (size_t)h * p.cap * 96;
+  bf16_t* vb = (bf16_t*)ly.v_cache + (size_t)h * p.cap * 96;
+  float* part = p.part + ((size_t)h * p.S + split) * CH_PSTRIDE;
+  const int g = lane >> 4, i16 = lane & 15;
+  float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const bool work = k_begin < k_end;
+  const bool owner = work && ln >= k_begin;              // ln < k_end by construction
+  // Register budget: the whole launch runs at this phase's VGPR count, and the depth of the weight prefetch is what the
+  // resident workgroups' registers hold - so only the K tile (48 VGPRs) waits in registers across the dependency.  The V
+  // tile is TOUCHED ahead of it (one dword per 128-byte line: the tile's 64 rows are 12 KiB contiguous, the lines then sit in
+  // this XCD's L2) and loaded for real once the scores have released the K registers; q is re-read from LDS (a broadcast).
+  u32x4 kr[12], vr[16];
+  auto issue_k = [&](int base) {
+    const bf16_t* krow = kb + (size_t)min(base + lane, k_end - 1) * 96;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) kr[i] = *AKI_G128(krow + i * 8);
+  };
+  auto issue_v = [&](int base) {
+#pragma unroll
+    for (int t2 = 0; t2 < 16; ++t2) {
+      const int r = min(base + 4 * t2 + g, k_end - 1);
+      vr[t2] = *AKI_G128(vb + (size_t)r * 96 + min(i16, 11) * 8);
+    }
+  };
+  unsigned touch0 = 0, touch1 = 0;
+  if (work) {                                            // the cache does not depend on this token's qkv: in flight under the wait
+    issue_k(k_begin);
+    const int rows = min(64, k_end - k_begin);
+    const char* vt = (const char*)(vb + (size_t)k_begin * 96);
+    if (lane * 128 < rows * 192) touch0 = *(gptr_u32)(vt + lane * 128);
+    if ((lane + 64) * 128 < rows * 192) touch1 = *(gptr_u32)(vt + (lane + 64) * 128);
+  }
+  chain_wait(p, wait_sync, wg, code);
+  if (!live) return;                                     // no workgroup barrier below this line
+  if (work) {
+    if (lane < 48) {
+      const bf16_t* row = p.qkv + (size_t)(item % CH_XREP) * p.rep_stride + h * 96;
+      const float c0 = p.cos[(size_t)ln * 96 + lane], c1 = p.cos[(size_t)ln * 96 + lane + 48];
+      const float s0 = p.sin[(size_t)ln * 96 + lane], s1 = p.sin[(size_t)ln * 96 + lane + 48];
+      const float q0 = bf16_bits_to_f32(__hip_atomic_load(row + lane, AKI_RLX_AGENT));
+      const float q1 = bf16_bits_to_f32(__hip_atomic_load(row + lane + 48, AKI_RLX_AGENT));
+      ((__bf16*)s_q)[lane] = (__bf16)(q0 * c0 - q1 * s0);
+      ((__bf16*)s_q)[lane + 48] = (__bf16)(q1 * c1 + q0 * s1);
+      if (owner) {
+        const bf16_t* krw = row + p.H * 96;
+        const bf16_t* vrw = row + 2 * p.H * 96;
+        const float k0 = bf16_bits_to_f32(__hip_atomic_load(krw + lane, AKI_RLX_AGENT));
+        const float k1 = bf16_bits_to_f32(__hip_atomic_load(krw + lane + 48, AKI_RLX_AGENT));
+        const unsigned short v0 = __hip_atomic_load(vrw + lane, AKI_RLX_AGENT), v1 = __hip_atomic_load(vrw + lane + 48, AKI_RLX_AGENT);
+        const __bf16 kn0 = (__bf16)(k0 * c0 - k1 * s0), kn1 = (__bf16)(k1 * c1 + k0 * s1);
+        ((__bf16*)s_k)[lane] = kn0;
+        ((__bf16*)s_k)[lane + 48] = kn1;
+        ((__bf16*)kb)[(size_t)ln * 96 + lane] = kn0;
+        ((__bf16*)kb)[(size_t)ln * 96 + lane + 48] = kn1;
+        s_v[lane] = v0;
+        s_v[lane + 48] = v1;
+        vb[(size_t)ln * 96 + lane] = v0;
+        vb[(size_t)ln * 96 + lane + 48] = v1;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: its LDS operations complete in order
+    __builtin_amdgcn_wave_barrier();
+    // the touches are consumed here (never true): the loads stay, their wait falls where the tile's lines are needed anyway
+    if (touch0 == 0x7fc0dead && touch1 == 0x7fc0beef && p.scale < 0.f) l = 1.f;
+    for (int t = 0; t < p.T; ++t) {
+      const int base = k_begin + t * 64;
+      if (base >= k_end) break;
+      const int j = base + lane;
+      if (t > 0) issue_k(base);
+      const bool fresh = owner && base <= ln && ln < base + 64;
+      // The new token's row lives in LDS: the tile loads were issued before it was stored, so every lane whose (clamped) row
+      // index is ln - the row itself and all rows past k_end - 1 = ln, which carry probability 0 - takes the row from LDS
+      // instead of stale cache contents (0 * NaN would poison the sum).
+      if (fresh && min(j, k_end - 1) == ln) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) kr[i] = *(const u32x4*)(s_k + i * 8);
+      }
+      bool ok = j < k_end;
+      if (p.vbits && (base >> 6) < p.nwords) ok = ok && ((p.vbits[base >> 6] >> lane) & 1ull);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s = cdot8(kr[i], *(const u32x4*)(s_q + i * 8), s);
+      asm volatile("" : "+v"(s));
+      __builtin_amdgcn_sched_barrier(0);
+      issue_v(base);                                     // the K registers are free now; the lines were touched before the wait
+      s = ok ? s * p.scale : -INFINITY;
+      const float mn = fmaxf(m, wave_max(s));
+      if (mn == -INFINITY) continue;
+      const float a = __expf(m - mn);
+      const float pr = ok ? __expf(s - mn) : 0.f;
+      l = l * a + wave_sum(pr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= a;
+      if (fresh) {
+#pragma unroll
+        for (int t2 = 0; t2 < 16; ++t2)
+          if (min(base + 4 * t2 + g, k_end - 1) == ln) vr[t2] = *(const u32x4*)(s_v + min(i16, 11) * 8);
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < 16; ++t2) {
+        const float w = __shfl(pr, 4 * t2 + g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[2 * e] = __builtin_fmaf(w, bf16_lo(vr[t2][e]), acc[2 * e]);
+          acc[2 * e + 1] = __builtin_fmaf(w, bf16_hi(vr[t2][e]), acc[2 * e + 1]);
+        }
+      }
+      m = mn;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      acc[e] += __shfl_xor(acc[e], 16);
+      acc[e] += __shfl_xor(acc[e], 32);
+    }
+  }
+  if (lane == 0) { __hip_atomic_store(part, m, AKI_RLX_AGENT); __hip_atomic_store(part + 1, l, AKI_RLX_AGENT); }
+  if (lane < 12) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) __hip_atomic_store(part + 8 + lane * 8 + e, acc[e], AKI_RLX_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned prev = 0;
+  if (lane == 0) prev = __hip_atomic_fetch_add(p.attn_cnt + layer * p.H + h, 1u, AKI_RLX_AGENT);
+  prev = __shfl(prev, 0);
+  if (prev != (unsigned)(p.S - 1)) return;
+  asm volatile("" ::: "memory");
+  // the last arriver of head h merges the S partials (decode.hip's order: five split slots per pass, the slots then meet in LDS)
+  const float* pp = p.part + (size_t)h * p.S * CH_PSTRIDE;
+  const int sl = lane / 12, ch = lane - sl * 12;
+  float gm = -INFINITY, lt = 0.f, o8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o8[e] = 0.f;
+  if (sl < 5) {
+    for (int s2 = sl; s2 < p.S; s2 += 5) {
+      const float* ps = pp + (size_t)s2 * CH_PSTRIDE;
+      const float ms = __hip_atomic_load(ps, AKI_RLX_AGENT), ls = __hip_atomic_load(ps + 1, AKI_RLX_AGENT);
+      float a[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = __hip_atomic_load(ps + 8 + ch * 8 + e, AKI_RLX_AGENT);
+      const float mn = fmaxf(gm, ms);
+      const float fa = gm == -INFINITY ? 0.f : __expf(gm - mn), fb = ms == -INFINITY ? 0.f : __expf(ms - mn);
+      lt = lt * fa + ls * fb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = o8[e] * fa + a[e] * fb;
+      gm = mn;
+    }
+    float* sm = s_mg + (sl * 12 + ch) * 10;
+    sm[0] = gm;
+    sm[1] = lt;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[2 + e] = o8[e];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 12) {
+    float M5 = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) M5 = fmaxf(M5, s_mg[(q * 12 + lane) * 10]);
+    lt = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const float* sm = s_mg + (q * 12 + lane) * 10;
+      const float mq = sm[0];
+      const float f = mq == -INFINITY ? 0.f : __expf(mq - M5);
+      lt += sm[1] * f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] += sm[2 + e] * f;
+    }
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    u32x4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = pack_bf16x2(o8[2 * e] * inv, o8[2 * e + 1] * inv);
+    for (int rep = 0; rep < CH_XREP; ++rep) {
+      const __amdgpu_buffer_rsrc_t ro = chain_rsrc(p.attn_o + (size_t)rep * p.rep_stride, p.H * 96 * 2);
+      __builtin_amdgcn_raw_buffer_store_b128(ov, ro, (h * 96 + lane * 8) * 2, 0, 16);     // sc1: write-through
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  chain_arrive(done_sync, h, p.H, lane);                 // one arrival per head
+}
+
+// KCD = d / 512, KCF = F / 512 (bf16) - the register arrays are static; W8 halves both.
+template <int KCD, int KCF, bool W8>
+__global__ __launch_bounds__(256) void decode_chain_kernel(const ChainParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_red = (float*)(smem + 16384);
+  char* sx = smem;
+  const int bid = blockIdx.x;
+  const int layer = bid / p.wg_layer;
+  int r = bid - layer * p.wg_layer;
+  const aki_decode_chain_layer& ly = p.layers[layer];
+  unsigned* sy = p.sync + (size_t)layer * CH_PHASES * CH_SYNC_WORDS;
+  unsigned* prev_down = layer > 0 ? sy - CH_SYNC_WORDS : nullptr;          // phase 4 of the layer before
+  const bf16_t* h0 = layer == 0 ? p.h_in : p.hbuf + ((layer - 1) & 1) * p.d;
+  const int h0_rep = layer == 0 ? 0 : 1;                                   // the embedding has one copy
+  const bool last = layer == p.n_layers - 1;
+  bf16_t* h2 = last ? p.h_out : p.hbuf + (layer & 1) * p.d;
+  const unsigned code = ((unsigned)layer << 8);
+  constexpr int NRD = W8 ? 4 : 2;          // rows per wave on the K = d matrices
+  constexpr int KD = W8 ? KCD / 2 : KCD;
+  constexpr int NRF = W8 ? 2 : 1;          // rows per wave on the K = F matrix
+  constexpr int KF = W8 ? KCF / 2 : KCF;
+  if (r < p.n_qkv) {
+    chain_gemv<NRD, KD, false, true, W8>(p, r, p.n_qkv, ly.w_qkv, ly.s_qkv, p.d, 3 * p.H * 96, h0, h0_rep, (const bf16_t*)ly.norm1, nullptr, 0, p.qkv,
+                                          CH_XREP, prev_down, sy + 0 * CH_SYNC_WORDS, code | 1u, sx, s_red);
+    return;
+  }
+  r -= p.n_qkv;
+  if (r < p.n_attn) {
+    chain_attn(p, ly, layer, r, sy + 0 * CH_SYNC_WORDS, sy + 1 * CH_SYNC_WORDS, code | 2u, smem);
+    return;
+  }
+  r -= p.n_attn;
+  if (r < p.n_o) {
+    chain_gemv<NRD, KD, false, false, W8>(p, r, p.n_o, ly.w_o, ly.s_o, p.H * 96, p.d, p.attn_o, 1, nullptr, h0, h0_rep, p.h1, CH_XREP,
+                                           sy + 1 * CH_SYNC_WORDS, sy + 2 * CH_SYNC_WORDS, code | 3u, sx, s_red);
+    return;
+  }
+  r -= p.n_o;
+  if (r < p.n_gu) {
+    chain_gemv<NRD, KD, true, true, W8>(p, r, p.n_gu, ly.w_gate_up, ly.s_gate_up, p.d, p.F, p.h1, 1, (const bf16_t*)ly.norm2, nullptr, 0, p.act,
+                                         CH_XREP, sy + 2 * CH_SYNC_WORDS, sy + 3 * CH_SYNC_WORDS, code | 4u, sx, s_red);
+    return;
+  }
+  r -= p.n_gu;
+  chain_gemv<NRF, KF, false, false, W8>(p, r, p.n_down, ly.w_down, ly.s_down, p.F, p.d, p.act, 1, nullptr, p.h1, 1, h2, last ? 1 : CH_XREP,
+                                         sy + 3 * CH_SYNC_WORDS, sy + 4 * CH_SYNC_WORDS, code | 5u, sx, s_red);
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+static inline size_t chain_cnt_bytes(int n_layers, int H) { return aki_align_up((size_t)n_layers * ((size_t)CH_PHASES * CH_SYNC_WORDS + H) * 4, 256); }
+static inline size_t chain_vec_elems(int d, int H, int F) { return aki_align_up((size_t)(3 * H * 96 + H * 96 + d + F + 2 * d) * 2 + 256, 256) / 2; }   // one copy
+
+static void chain_split(int H, int cap, int max_keys, int& S, int& T) {
+  if (max_keys <= 0 || max_keys > cap) max_keys = cap;
+  const int tiles = (max_keys + 63) / 64;
+  T = (int)(((size_t)H * tiles + 2047) / 2048);
+  if (T < 1) T = 1;
+  S = (tiles + T - 1) / T;
+}
+
+size_t decode_chain_err_offset(int n_layers, int H) { return chain_cnt_bytes(n_layers, H); }
+
+size_t decode_chain_ws_bytes(int n_layers, int d, int H, int F, int cap) {
+  const size_t tiles = ((size_t)cap + 63) / 64;
+  return chain_cnt_bytes(n_layers, H) + 256 /* error word */ + chain_vec_elems(d, H, F) * 2 * CH_XREP + (size_t)H * tiles * CH_PSTRIDE * 4;
+}
+
+int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
+  const int d = a->d, H = a->H, F = a->F;
+  if (a->Dh != 96 || d != H * 96 || d % 512 || F % 512) return AKI_ERR_UNSUPPORTED;
+  const bool w8 = a->dtype == AKI_DT_W8A16;
+  if (!w8 && a->dtype != AKI_DT_BF16) return AKI_ERR_UNSUPPORTED;
+  if (!(d == 3072 && F == 8192)) return AKI_ERR_UNSUPPORTED;     // the register arrays are sized at compile time: Phi-3.5-mini
+  if (a->workspace_bytes < decode_chain_ws_bytes(a->n_layers, d, H, F, a->capacity) || ((uintptr_t)a->workspace & 255)) return AKI_ERR_WORKSPACE;
+  ChainParams p;
+  p.layers = a->layers; p.n_layers = a->n_layers;
+  p.h_in = (const bf16_t*)a->h_in; p.h_out = (bf16_t*)a->h_out;
+  p.cos = a->cos; p.sin = a->sin; p.cache_len = a->cache_len; p.vbits = a->col_valid_bits; p.nwords = a->nwords;
+  p.d = d; p.H = H; p.F = F; p.cap = a->capacity; p.scale = a->scale; p.eps = a->rms_eps;
+  chain_split(H, a->capacity, a->max_keys, p.S, p.T);
+  char* ws = (char*)a->workspace;
+  const size_t cb = chain_cnt_bytes(a->n_layers, H);
+  p.sync = (unsigned*)ws;
+  p.attn_cnt = p.sync + (size_t)a->n_layers * CH_PHASES * CH_SYNC_WORDS;
+  p.err = (unsigned*)(ws + cb);
+  bf16_t* v = (bf16_t*)(ws + cb + 256);
+  p.rep_stride = (int)chain_vec_elems(d, H, F);
+  p.qkv = v; v += 3 * H * 96;
+  p.attn_o = v; v += H * 96;
+  p.h1 = v; v += d;
+  p.act = v; v += F;
+  p.hbuf = v;
+  p.part = (float*)(ws + cb + 256 + chain_vec_elems(d, H, F) * 2 * CH_XREP);
+  const int rd = w8 ? 4 : 2, rf = w8 ? 2 : 1;     // rows per wave (see the kernel)
+  p.n_qkv = (3 * H * 96 + 4 * rd - 1) / (4 * rd);
+  p.n_attn = (H * p.S + 3) / 4;
+  p.n_o = (d + 4 * rd - 1) / (4 * rd);
+  p.n_gu = (F + 4 * (rd / 2) - 1) / (4 * (rd / 2));
+  p.n_down = (d + 4 * rf - 1) / (4 * rf);
+  p.wg_layer = p.n_qkv + p.n_attn + p.n_o + p.n_gu + p.n_down;
+  AKI_CLEAR_ERR();
+  // every polled word is zeroed by the call itself (a memset node under graph capture: replayed before the kernel)
+  if (hipMemsetAsync(ws, 0, cb, stream) != hipSuccess) return AKI_ERR_LAUNCH;
+  constexpr int SMEM = 16384 + 64;       // x (<= 8192 bf16) + the norm's partial sums; the attention phase carves 4 x 3 KiB of it
+  const dim3 grid((unsigned)a->n_layers * (unsigned)p.wg_layer), block(256);
+  if (w8) hipLaunchKernelGGL((decode_chain_kernel<6, 16, true>), grid, block, SMEM, stream, p);
+  else hipLaunchKernelGGL((decode_chain_kernel<6, 16, false>), grid, block, SMEM, stream, p);
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
+}
+
+}  // namespace aki

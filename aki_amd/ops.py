@@ -448,6 +448,68 @@ def decode_attn_fused(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, c
     return o
 
 
+class DecodeChain:
+    """The whole decoder stack of a batch-1 decode step as ONE launch (aki_decode_chain_fwd, decode_chain.hip): a device-resident
+    table of per-layer pointers + the workspace with the hand-off vectors and arrival counters.  Built once per (model weights,
+    KV cache); `step(h_in)` -> the residual stream after the last layer (pre final norm), bit-identical to the per-layer
+    launches.  `check()` reads the sticky error word (a device sync): non-zero means a dependency wait gave up."""
+
+    SUPPORTED = dict(d=3072, F=8192, Dh=96)
+
+    def __init__(self, layers, k_caches, v_caches, H: int, Dh: int, d: int, F: int, capacity: int, scale: float, eps: float, device, w8: bool):
+        """layers: per layer (w_qkv, w_o, w_gate_up, w_down, norm1, norm2, s_qkv, s_o, s_gate_up, s_down) - scales None for bf16."""
+        lib = L.load()
+        self.n_layers = len(layers)
+        rows = []
+        for (wq, wo, wg, wd, n1, n2, sq, so, sg, sd), k, v in zip(layers, k_caches, v_caches):
+            for t_ in (wq, wo, wg, wd):
+                if not t_.is_contiguous():
+                    raise AkiError("decode chain: weights must be contiguous [N, K]")
+            rows.append([wq.data_ptr(), wo.data_ptr(), wg.data_ptr(), wd.data_ptr(), n1.data_ptr(), n2.data_ptr(), k.data_ptr(), v.data_ptr(),
+                         _ptr(sq) or 0, _ptr(so) or 0, _ptr(sg) or 0, _ptr(sd) or 0])
+        self.keep = (layers, k_caches, v_caches)                      # the table holds raw pointers: keep the tensors alive
+        self.key = tuple(r[0] for r in rows) + tuple(r[6] for r in rows)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+        assert C.sizeof(L.DecodeChainLayer) == 12 * 8
+        nbytes = int(lib.aki_decode_chain_workspace_bytes(self.n_layers, d, H, F, capacity))
+        if nbytes == 0:
+            raise AkiError("decode chain: bad dimensions")
+        self.ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
+        off = (-self.ws.data_ptr()) % 256
+        self.ws_ptr = self.ws.data_ptr() + off
+        self.ws_bytes = nbytes
+        self.err_index = (off + int(lib.aki_decode_chain_error_offset(self.n_layers, H))) // 4
+        self.h_out = torch.empty((1, d), dtype=torch.bfloat16, device=device)
+        self.dims = (H, Dh, d, F, capacity)
+        self.scale, self.eps, self.w8 = float(scale), float(eps), bool(w8)
+
+    def step(self, h_in: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, cache_len: torch.Tensor, col_valid_bits: Optional[torch.Tensor],
+             max_keys: int) -> torch.Tensor:
+        H, Dh, d, F, cap = self.dims
+        if h_in.dtype != torch.bfloat16 or h_in.numel() != d or not h_in.is_contiguous():
+            raise AkiError("decode chain: h_in must be one contiguous bf16 row")
+        if cos.shape[0] < cap or cos.shape[1] != Dh:
+            raise AkiError("decode chain: cos/sin tables must cover the cache capacity")
+        _dev(h_in, cos, sin, cache_len, col_valid_bits, self.table)
+        a = L.DecodeChainArgs(self.table.data_ptr(), _ptr(h_in), _ptr(self.h_out), _ptr(cos), _ptr(sin), _ptr(cache_len), _ptr(col_valid_bits),
+                              self.ws_ptr, self.ws_bytes, self.n_layers, 0 if col_valid_bits is None else col_valid_bits.shape[-1], d, H, Dh, F,
+                              cap, int(max_keys), self.scale, self.eps, L.AKI_DT_W8A16 if self.w8 else L.AKI_DT_BF16, 0)
+        end = _TAP.begin(("decode_chain", self.n_layers)) if (_TAP is not None and _TAP.want(("decode_chain",))) else None
+        L.check(L.load().aki_decode_chain_fwd(C.byref(a), _stream()), "aki_decode_chain_fwd")
+        if end is not None:
+            end.record()
+        return self.h_out
+
+    def error_code(self) -> int:
+        """The sticky error word (synchronises the device): 0, or (layer << 8 | phase) of a wait that gave up."""
+        return int(self.ws.view(torch.int32)[self.err_index].item())
+
+    def check(self) -> None:
+        code = self.error_code()
+        if code:
+            raise AkiError(f"decode chain: a dependency wait gave up (layer {code >> 8}, phase {code & 255}); the step's output is invalid")
+
+
 def decode_linear(x: torch.Tensor, w: torch.Tensor, rms_weight: torch.Tensor, eps: float, act: int = ACT_NONE,
                   bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = act(rmsnorm(x; rms_weight, eps) W^T + bias) [+ residual] for the few rows of a decode step: one weight-streaming

@@ -397,10 +397,51 @@ class Phi3Model(nn.Module):
                                                       cache.capacity, inputs_embeds.device)
         cache.grid_keys = cache.capacity if torch.cuda.is_current_stream_capturing() else min(cache.capacity, cache.host_len)
         h = inputs_embeds
-        for layer in self.layers:
-            h = layer.decode(h, cos, sin, cache)
+        chain = self._decode_chain(h, cache)
+        if chain is not None:                       # one sequence: the 32 layers as ONE launch (decode_chain.hip)
+            h = chain.step(h.reshape(1, -1), cos, sin, cache.cache_len, cache.valid_bits, cache.grid_keys)
+        else:
+            for layer in self.layers:
+                h = layer.decode(h, cos, sin, cache)
         cache.cache_len += 1
         return h                                    # PRE-norm: the head applies self.norm inside its GEMV
+
+    use_decode_chain = True                         # False: the five-launch-per-layer path (A/B and the bit-identity tests)
+
+    def _decode_chain(self, h, cache):
+        """The one-launch decode step when it applies: one sequence, bf16 stream, Phi-3.5-mini's dimensions, every layer either
+        bf16 or fully e4m3-quantised (the fp8 configuration's weight-only GEMVs).  Built once per (weights, KV cache)."""
+        if not self.use_decode_chain or h.shape[0] != 1 or h.dtype != torch.bfloat16 or not h.is_cuda:
+            return None
+        l0 = self.layers[0]
+        at, mlp = l0.self_attn, l0.mlp
+        sup = ops.DecodeChain.SUPPORTED
+        if (at.head_dim != sup["Dh"] or h.shape[-1] != sup["d"] or mlp.down_proj.weight.shape[1] != sup["F"]
+                or any(n.variance_epsilon != l0.input_layernorm.variance_epsilon for ly in self.layers
+                       for n in (ly.input_layernorm, ly.post_attention_layernorm))):
+            return None
+        w8 = l0._fp8 is not None and l0._fp8["o"] is not None
+        if any((ly._fp8 is not None and ly._fp8["o"] is not None) != w8 for ly in self.layers):
+            return None
+        if l0._fp8 is not None and not w8:
+            return None                             # qkv / gate_up only in e4m3: the mixed per-layer path
+        key = tuple((ly._fp8["qkv"][0] if w8 else ly.self_attn.qkv_proj.weight).data_ptr() for ly in self.layers) + tuple(k.data_ptr() for k in cache.k)
+        chain = getattr(cache, "chain", None)
+        if chain is None or chain.key != key:
+            rows = []
+            for ly in self.layers:
+                a_, m_ = ly.self_attn, ly.mlp
+                if w8:
+                    f = ly._fp8
+                    rows.append((f["qkv"][0], f["o"][0], f["gate_up"][0], f["down"][0], ly.input_layernorm.weight, ly.post_attention_layernorm.weight,
+                                 f["qkv"][1], f["o"][1], f["gate_up"][1], f["down"][1]))
+                else:
+                    rows.append((a_.qkv_proj.weight, a_.o_proj.weight, m_.gate_up_proj.weight, m_.down_proj.weight, ly.input_layernorm.weight,
+                                 ly.post_attention_layernorm.weight, None, None, None, None))
+            chain = cache.chain = ops.DecodeChain(rows, list(cache.k), list(cache.v), at.num_heads, at.head_dim, h.shape[-1],
+                                                  mlp.down_proj.weight.shape[1], cache.capacity, at.scaling, l0.input_layernorm.variance_epsilon,
+                                                  h.device, w8)
+        return chain
 
 
 class Phi3ForCausalLM(nn.Module):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 12
+#define AKI_ABI_VERSION 13
 
 typedef enum {
   AKI_OK = 0,
@@ -354,6 +354,65 @@ int aki_decode_attn_fused_fwd(const void* qkv, const float* cos, const float* si
                               int32_t Dh, int32_t capacity, int32_t max_keys, float scale, int32_t dtype, void* ws,
                               size_t ws_bytes, void* stream);
 int aki_decode_linear_fwd(const aki_linear_args* args, const void* rms_weight, float rms_eps, void* stream);
+
+/* aki_decode_chain_fwd - ALL decoder layers of one decode step for ONE sequence (batch 1) in one launch (bf16 weights, or
+ * AKI_DT_W8A16: e4m3 weights with one f32 scale per weight row).  Same arithmetic as the per-layer calls above
+ * (aki_decode_linear_fwd -> aki_decode_attn_fused_fwd -> aki_linear_fwd + residual -> aki_decode_linear_fwd SwiGLU -> aki_linear_fwd
+ * + residual), bit for bit; what changes is the schedule: every workgroup issues its weight loads before it waits for its
+ * input vector, so the weight stream runs ahead of the dependency chain across phase and layer seams (decode_chain.hip).
+ *   layers        DEVICE array of n_layers descriptors (weights as stored by nn.Linear, [N, K] row-major, K contiguous;
+ *                 k_cache / v_cache [1, H, capacity, 96] bf16; s_* = per-row scales for AKI_DT_W8A16, else NULL)
+ *   h_in / h_out  [d] bf16: the new token's embedding in, the residual stream after the last layer out (PRE final norm)
+ *   cache_len     device int32 [1]: tokens cached so far = the new token's position and append index (not advanced here)
+ *   max_keys      host upper bound of cache_len + 1 that sizes the attention split (0 = capacity)
+ *   workspace     aki_decode_chain_workspace_bytes(...) bytes, 256-byte aligned, ZERO-FILLED ONCE by the caller before its
+ *                 first use; the call re-zeroes its own arrival counters (a memset node under graph capture).  The 32-bit
+ *                 word at aki_decode_chain_error_offset(...) is sticky: 0 = every wait of every call so far was satisfied;
+ *                 otherwise (layer << 8 | phase) of a wait that gave up after its bounded spin (the launch then drains and
+ *                 h_out is garbage) - read it after synchronising.
+ * Supported: Dh = 96, d = H * 96 = 3072, F = 8192 (Phi-3.5-mini); AKI_ERR_UNSUPPORTED otherwise (use the per-layer calls). */
+typedef struct {
+  const void* w_qkv;
+  const void* w_o;
+  const void* w_gate_up;
+  const void* w_down;
+  const void* norm1;
+  const void* norm2;
+  void* k_cache;
+  void* v_cache;
+  const float* s_qkv;
+  const float* s_o;
+  const float* s_gate_up;
+  const float* s_down;
+} aki_decode_chain_layer;
+
+typedef struct {
+  const aki_decode_chain_layer* layers;
+  const void* h_in;
+  void* h_out;
+  const float* cos;
+  const float* sin;
+  const int32_t* cache_len;
+  const uint64_t* col_valid_bits;
+  void* workspace;
+  size_t workspace_bytes;
+  int32_t n_layers;
+  int32_t nwords;
+  int32_t d;
+  int32_t H;
+  int32_t Dh;
+  int32_t F;
+  int32_t capacity;
+  int32_t max_keys;
+  float scale;
+  float rms_eps;
+  int32_t dtype;
+  int32_t reserved;
+} aki_decode_chain_args;
+
+size_t aki_decode_chain_workspace_bytes(int32_t n_layers, int32_t d, int32_t H, int32_t F, int32_t capacity);
+size_t aki_decode_chain_error_offset(int32_t n_layers, int32_t H);
+int aki_decode_chain_fwd(const aki_decode_chain_args* args, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Training step (BASELINE configs[2]).  The reference's backward is torch autograd over its

@@ -396,3 +396,89 @@ def test_beam_search_stops_on_eos_and_pads():
         hits = [i for i, t_ in enumerate(row) if t_ in eos]
         if hits:                                              # everything behind the first EOS is padding
             assert all(t_ == 0 for t_ in row[hits[0] + 1:])
+
+
+# ---- the one-launch decode step (decode_chain.hip) -----------------------------------------------------------------------
+def _full_width_lm(n_layers, seed=0):
+    from aki_amd.phi3 import Phi3ForCausalLM, make_phi3_config
+    torch.manual_seed(seed)
+    cfg = make_phi3_config(num_hidden_layers=n_layers, vocab_size=4096, pad_token_id=0, eos_token_id=2)
+    lm = Phi3ForCausalLM(cfg)
+    g = torch.Generator().manual_seed(seed)
+    for n, p in lm.named_parameters():
+        if p.dim() == 1:
+            p.data.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))          # non-unit RMSNorm gains
+        else:
+            p.data.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    return lm.to(DEV).to(torch.bfloat16).eval(), cfg
+
+
+@pytest.mark.parametrize("prompt,steps,fp8", [(655, 6, False), (70, 70, False), (4200, 3, False), (655, 4, True)])
+def test_decode_chain_is_bit_identical_to_the_per_layer_launches(prompt, steps, fp8):
+    """decode_chain.hip runs every layer of a batch-1 decode step in ONE launch; its arithmetic is decode.hip's row for row, so the
+    logits of every step - and the K/V rows it appends - equal the five-launch-per-layer path's bit for bit, at Phi-3.5-mini's
+    width (3 layers), across a 64-key tile boundary of the cache (70 + 70 steps), at a long context where the attention splits
+    over 66+ workgroups per head, and with e4m3 weights (the fp8 configuration's weight-only GEMVs).  The chain's sticky error
+    word (a dependency wait that gave up) must stay 0."""
+    from aki_amd import ops
+    lm, cfg = _full_width_lm(3)
+    if fp8:
+        lm.enable_fp8()
+    x = (torch.randn(1, prompt, cfg.hidden_size, generator=torch.Generator().manual_seed(1)) * 0.5).to(torch.bfloat16).to(DEV)
+    am = np.ones((1, prompt), dtype=bool)
+    am[0, 3:9] = False                                        # a hole in the prompt: the valid-column bits are honoured
+    table = ops.MaskTable.from_host([[(4, 40, 40, prompt - 8)]], am, [prompt], DEV)
+    outs = {}
+    for chained in (False, True):
+        lm.model.use_decode_chain = chained
+        with torch.no_grad():
+            out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=prompt + steps + 3)
+            cache = out.past_key_values
+            ids = out.logits[:, -1].float().argmax(-1)
+            logits = []
+            for _ in range(steps):
+                lg = lm.decode_step(input_ids=ids, past_key_values=cache)
+                logits.append(lg.clone())
+                ids = lg.float().argmax(-1)
+        chain = getattr(cache, "chain", None)
+        assert (chain is not None) == chained
+        if chained:
+            assert chain.error_code() == 0
+        outs[chained] = (torch.stack(logits), [k[:, :, : prompt + steps].clone() for k in cache.k], [v[:, :, : prompt + steps].clone() for v in cache.v])
+    lm.model.use_decode_chain = True
+    a, b = outs[False], outs[True]
+    assert bool(torch.isfinite(a[0].float()).all())
+    assert torch.equal(a[0], b[0]), f"{int((a[0] != b[0]).sum())} logits differ over {steps} steps"
+    for ka, kb in zip(a[1] + a[2], b[1] + b[2]):
+        assert torch.equal(ka, kb)
+
+
+def test_decode_chain_graph_replay_and_poisoned_workspace():
+    """The chained step under hipGraph replay (its counter memset is a graph node) equals eager steps bit for bit, and a workspace
+    whose hand-off vectors are poisoned between steps changes nothing: every byte a phase reads was written in the same step."""
+    from aki_amd import ops
+    from aki_amd.phi3 import DecodeGraph
+    lm, cfg = _full_width_lm(2, seed=3)
+    prompt, steps = 200, 5
+    x = (torch.randn(1, prompt, cfg.hidden_size, generator=torch.Generator().manual_seed(2)) * 0.5).to(torch.bfloat16).to(DEV)
+    table = ops.MaskTable.from_host([[(4, 100, 100, 180)]], np.ones((1, prompt), dtype=bool), [prompt], DEV)
+    res = {}
+    for mode in ("eager", "graph"):
+        with torch.no_grad():
+            out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=prompt + steps + 8)
+            cache = out.past_key_values
+            ids = out.logits[:, -1].float().argmax(-1)
+            stepper = DecodeGraph(lm, cache) if mode == "graph" else None
+            logits = []
+            for i in range(steps):
+                lg = stepper.step(ids) if stepper else lm.decode_step(input_ids=ids, past_key_values=cache)
+                logits.append(lg.clone())
+                ids = lg.float().argmax(-1)
+                if mode == "eager":                              # poison everything behind the counters and the error word
+                    torch.cuda.synchronize()
+                    ch = cache.chain
+                    lo = ch.err_index * 4 + 256
+                    ch.ws[lo:].fill_(0xFF)
+        assert cache.chain.error_code() == 0
+        res[mode] = torch.stack(logits)
+    assert torch.equal(res["eager"], res["graph"])

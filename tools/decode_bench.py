@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--fp8", action="store_true", help="fp8 configuration: e4m3 prefill GEMMs, weight-only e4m3 GEMVs for batch 1")
+    ap.add_argument("--no-chain", action="store_true", help="batch 1: the five-launch-per-layer path instead of the one-launch chain")
     a = ap.parse_args()
     from aki_amd import ops
     from aki_amd.phi3 import Phi3ForCausalLM, make_phi3_config, DecodeGraph
@@ -27,6 +28,7 @@ def main():
     lm = lm.to(dev).to(torch.bfloat16).eval()
     if a.fp8:
         lm.enable_fp8()
+    lm.model.use_decode_chain = not a.no_chain
     wbytes = sum(p.numel() * 2 for n, p in lm.named_parameters() if "embed_tokens" not in n)
     B, L = a.batch, a.prompt
     x = torch.randn(B, L, cfg.hidden_size, device=dev, dtype=torch.bfloat16) * 0.5
@@ -34,7 +36,11 @@ def main():
     table = ops.MaskTable.from_host([[(4, 148, 4, 148)]] * B, am.numpy(), [L] * B, dev)
     if a.fp8 and B == 1:
         wbytes //= 2
-    res = {"batch": B, "prompt": L, "steps": a.steps, "weight_bytes": wbytes, "fp8": bool(a.fp8)}
+    # algorithmic HBM bytes of one step: every decoder + head weight once (B <= 16 rows ride on one pass), the K/V rows of the
+    # cache once per sequence (mid-run length), activations negligible.  Peak: 8 TB/s (MI355X_MICROARCH.md; ~6.3 TB/s achievable).
+    kv_bytes = B * a.layers * 2 * cfg.num_attention_heads * 96 * 2 * (L + 4 + a.steps // 2)
+    res = {"batch": B, "prompt": L, "steps": a.steps, "weight_bytes": wbytes, "kv_bytes": kv_bytes, "fp8": bool(a.fp8),
+           "chain": bool(B == 1 and not a.no_chain)}
     with torch.no_grad():
         for mode in ("eager", "graph"):
             out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=L + 2 * a.steps + 8)
@@ -51,6 +57,12 @@ def main():
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) * 1e3 / a.steps
             res[mode] = {"ms_per_token": round(ms, 4), "tokens_per_s": round(B * 1e3 / ms, 1), "weight_GBps": round(wbytes / ms / 1e6, 1)}
+            chain = getattr(cache, "chain", None)
+            if chain is not None:
+                chain.check()
+    gbps = (wbytes + kv_bytes) / res["graph"]["ms_per_token"] / 1e6
+    res["roofline"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4),
+                       "bytes_per_token": wbytes + kv_bytes, "timed": "hipGraph replay, host wall clock over the timed steps"}
     print(json.dumps(res))
 
 
