@@ -191,6 +191,10 @@ def load_lab() -> C.CDLL:
     lib.aki_lab_set_probe_block.argtypes = [C.c_int]
     lib.aki_lab_set_clock_probe.restype = None
     lib.aki_lab_set_clock_probe.argtypes = [C.c_void_p]
+    lib.aki_lab_set_chain.restype = None
+    lib.aki_lab_set_chain.argtypes = [C.c_int] * 4
+    lib.aki_lab_set_chain_nb.restype = None
+    lib.aki_lab_set_chain_nb.argtypes = [C.c_int]
     return lib
 
 

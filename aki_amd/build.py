@@ -22,7 +22,7 @@ LIB = os.path.join(LIBDIR, "libaki_mi355x.so")
 # Lab twin: the same sources with -DAKI_LAB_HOOKS (adds aki_lab_set_gemm_tile, a process-global tile-forcing switch that the
 # product library must not carry).  Used by the forced-tile GEMM tests and tools/siglip_gemm_bench.py only.
 LAB_LIB = os.path.join(LIBDIR, "libaki_mi355x_lab.so")
-LAB_SOURCES = ["api.hip", "gemm_bf16.hip", "gemm_tn_bf16.hip", "mma_attn_bf16.hip"]
+LAB_SOURCES = ["api.hip", "gemm_bf16.hip", "gemm_tn_bf16.hip", "mma_attn_bf16.hip", "decode_chain.hip"]
 LAB_ONLY_SOURCES = ["mma_attn64_bf16.hip"]     # experiments that exist in the lab library only
 SOURCES = ["api.hip", "gemm_bf16.hip", "gemm_tn_bf16.hip", "mma_attn_bf16.hip", "attn_nc_bf16.hip", "decode.hip", "decode_chain.hip", "train_kernels.hip", "attn_bwd_bf16.hip", "fp8_quant.hip", "simple_f32.hip", "aux_kernels.hip"]
 ARCH = "gfx950"

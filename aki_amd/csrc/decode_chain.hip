@@ -76,7 +76,11 @@ constexpr int CH_SHARDS = 16;
 constexpr int CH_FLAGS = 32;
 constexpr int CH_SYNC_WORDS = (CH_SHARDS + 1 + CH_FLAGS) * 32;   // 128-byte lines, in 4-byte words
 constexpr int CH_PHASES = 5;             // [0] qkv [1] attention (per-head mergers) [2] o_proj [3] gate_up [4] down
-constexpr int CH_XREP = 8;               // copies of every hand-off vector: consumer j reads copy j % 8 (1152 readers of one 128-byte line -> 144)
+// feature batches per workgroup (one staging of x each) of the qkv / o_proj / gate_up / down phases
+constexpr int CH_NBQ = 8, CH_NBO = 4, CH_NBG = 16, CH_NBD = 4;     // 144 / 96 / 128 / 192 workgroups per layer (tools/decode_chain_ab.py)
+constexpr int CH_XREP = 8;               // room for copies of every hand-off vector: consumer j reads copy j % xrep
+constexpr int CH_XREP_USED = 2;          // copies in use: with 100-200 consumers per phase two spread the readers enough, and every copy is
+                                         // one more write-through store per producing lane (8 copies: +35 us per token)
 constexpr unsigned CH_SPIN_LIMIT = 200000u;
 
 struct ChainParams {
@@ -92,6 +96,8 @@ struct ChainParams {
   int rep_stride;         // elements between the copies of a hand-off vector
   float* part;            // [H][S][CH_PSTRIDE]
   int n_qkv, n_attn, n_o, n_gu, n_down, wg_layer;
+  int sleep_n, xrep, nflags, nowait;   // product: 8, CH_XREP_USED, CH_FLAGS, 0; the lab library can change them (aki_lab_set_chain)
+  int nbq, nbo, nbg, nbd;              // batches of 4 x FPW features per workgroup of the qkv / o_proj / gate_up / down phases
 };
 
 // ---- hand-off primitives ------------------------------------------------------------------------------------------------
@@ -106,11 +112,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_rsrc(const void* p, int 
 // One lane polls this workgroup's READY flag of the producer phase; bounded.  On give-up: error word, then every flag of the
 // launch is raised (so the rest drains in microseconds).
 __device__ __forceinline__ void chain_wait(const ChainParams& p, unsigned* sync, int wg, unsigned code) {
-  if (threadIdx.x == 0 && sync != nullptr) {
-    unsigned* flag = sync + (CH_SHARDS + 1 + (wg % CH_FLAGS)) * 32;
+  if (threadIdx.x == 0 && sync != nullptr && !p.nowait) {
+    unsigned* flag = sync + (CH_SHARDS + 1 + (wg % p.nflags)) * 32;
     unsigned spins = 0;
     while (__hip_atomic_load(flag, AKI_RLX_AGENT) == 0u) {
-      __builtin_amdgcn_s_sleep(8);
+      for (int i = 0; i < p.sleep_n; ++i) __builtin_amdgcn_s_sleep(1);
       if (++spins > CH_SPIN_LIMIT) {
         __hip_atomic_store(p.err, code, AKI_RLX_AGENT);
         for (int i = 0; i < p.n_layers * CH_PHASES; ++i)
@@ -147,41 +153,43 @@ __device__ __forceinline__ void chain_publish(unsigned* sync, int idx, int n) {
 }
 
 // ---- one GEMV phase ----------------------------------------------------------------------------------------------------
-// NR weight rows per wave, KC 16-byte chunks per lane and row (bf16: K = 512 KC; W8: K = 1024 KC).  SWIGLU: the wave's rows are
-// gate rows f.. and up rows n_out + f.. (NR/2 features).  NORM: x is RMS-normalised (weight norm_w) on its way into LDS.
-template <int NR, int KC, bool SWIGLU, bool NORM, bool W8>
+// NR weight rows per wave and batch, KC 16-byte chunks per lane and row (bf16: K = 512 KC; W8: K = 1024 KC).  SWIGLU: the wave's
+// rows are gate rows f.. and up rows n_out + f.. (NR/2 features).  NORM: x is RMS-normalised (weight norm_w) on its way into LDS.
+// A workgroup takes `nb` batches of 4 x FPW consecutive features against ONE staging of x: every workgroup reads its whole input
+// vector through the fabric (sc1), and at one batch per workgroup those reads were 15 % of all bytes moved - the weight stream
+// ran at exactly 6.3 TB/s / 1.15 with the dependency waits switched off (tools/decode_chain_ab.py).  Batch 0 is loaded before the
+// wait; batch b+1 as soon as the dot products have released the registers of batch b, under its reduction and epilogue.
+template <int NR, int KC, bool SWIGLU, bool NORM, bool W8, int NB>
 __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_wg, const void* w, const float* w_scale, int K, int n_out,
                                            const bf16_t* x, int x_rep, const bf16_t* norm_w, const bf16_t* residual, int res_rep, bf16_t* y,
                                            int y_reps, unsigned* wait_sync, unsigned* done_sync, unsigned code, char* sx, float* s_red) {
   constexpr int FPW = SWIGLU ? NR / 2 : NR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int f0 = (wg * 4 + wave) * FPW;
+  constexpr int nb = NB;
+  const int fbase = wg * (4 * FPW * nb) + wave * FPW;
   const size_t row_bytes = W8 ? (size_t)K : (size_t)K * 2;
-  // (2) the weight loads of this wave's rows, all of them, before anything that depends on another workgroup
   u32x4 wv[NR][KC];
   float wsc[NR];
+  auto issue = [&](int f0) {
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const int f = min(f0 + (r % FPW), n_out - 1);
-    const int row = (SWIGLU && r >= FPW) ? n_out + f : f;
-    const char* wr = (const char*)w + (size_t)row * row_bytes;
-    wsc[r] = W8 ? ((gptr_f32)w_scale)[row] : 1.f;
+    for (int r = 0; r < NR; ++r) {
+      const int f = min(f0 + (r % FPW), n_out - 1);
+      const int row = (SWIGLU && r >= FPW) ? n_out + f : f;
+      const char* wr = (const char*)w + (size_t)row * row_bytes;
+      wsc[r] = W8 ? ((gptr_f32)w_scale)[row] : 1.f;
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) wv[r][kc] = __builtin_nontemporal_load(AKI_G128(wr + (size_t)(lane + 64 * kc) * 16));
-  }
+      for (int kc = 0; kc < KC; ++kc) wv[r][kc] = __builtin_nontemporal_load(AKI_G128(wr + (size_t)(lane + 64 * kc) * 16));
+    }
+  };
+  // (2) the weight loads of this wave's first batch, before anything that depends on another workgroup
+  issue(fbase);
   // (3) the producer phase has published
   chain_wait(p, wait_sync, wg, code);
   // (4) x -> LDS.  Handed-off bytes: sc1 loads only, from this workgroup's copy of the vector.
   const int nchunk = K / 8;
-  x += (size_t)(x_rep ? (wg % CH_XREP) * p.rep_stride : 0);
-  if (residual != nullptr && res_rep) residual += (size_t)(wg % CH_XREP) * p.rep_stride;
+  x += (size_t)(x_rep ? (wg % p.xrep) * p.rep_stride : 0);
+  if (residual != nullptr && res_rep) residual += (size_t)(wg % p.xrep) * p.rep_stride;
   const __amdgpu_buffer_rsrc_t rx = chain_rsrc(x, K * 2);
-  unsigned long long res_bits = 0;
-  if (residual != nullptr && lane == 0 && f0 < n_out) {            // in flight under the staging
-    if constexpr (FPW == 4) res_bits = __hip_atomic_load((const unsigned long long*)(residual + f0), AKI_RLX_AGENT);
-    else if constexpr (FPW == 2) res_bits = __hip_atomic_load((const unsigned*)(residual + f0), AKI_RLX_AGENT);
-    else res_bits = __hip_atomic_load((const unsigned short*)(residual + f0), AKI_RLX_AGENT);
-  }
   if constexpr (NORM) {
     // y = bf16(x * rsqrt(mean(x^2) + eps) * w): decode.hip's gemv_bf16_kernel staging, the row kept in registers between the passes
     u32x4 xv[2];
@@ -221,49 +229,64 @@ __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_w
     for (int c = tid; c < nchunk; c += 256) *(u32x4*)(sx + (size_t)c * 16) = ld_sc1_b128(rx, c * 16);
   }
   __syncthreads();
-  // (5) dot products out of the registers, chunk order ascending per lane and row
-  float acc[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) acc[r] = 0.f;
-#pragma unroll
-  for (int kc = 0; kc < KC; ++kc) {
-    const int c = lane + 64 * kc;
-    if constexpr (W8) {
-      const u32x4 x0 = *(const u32x4*)(sx + (size_t)(2 * c) * 16), x1 = *(const u32x4*)(sx + (size_t)(2 * c + 1) * 16);
-#pragma unroll
-      for (int r = 0; r < NR; ++r) acc[r] = cdot16_w8(wv[r][kc], x0, x1, acc[r]);
-    } else {
-      const u32x4 xc = *(const u32x4*)(sx + (size_t)c * 16);
-#pragma unroll
-      for (int r = 0; r < NR; ++r) acc[r] = cdot8(wv[r][kc], xc, acc[r]);
+  for (int b = 0; b < nb; ++b) {
+    const int f0 = fbase + b * 4 * FPW;
+    unsigned long long res_bits = 0;
+    if (residual != nullptr && lane == 0 && f0 < n_out) {            // in flight under the dot products
+      if constexpr (FPW == 4) res_bits = __hip_atomic_load((const unsigned long long*)(residual + f0), AKI_RLX_AGENT);
+      else if constexpr (FPW == 2) res_bits = __hip_atomic_load((const unsigned*)(residual + f0), AKI_RLX_AGENT);
+      else res_bits = __hip_atomic_load((const unsigned short*)(residual + f0), AKI_RLX_AGENT);
     }
-  }
+    // (5) dot products out of the registers, chunk order ascending per lane and row
+    float acc[NR];
+    float sc[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    float v = acc[r];
+    for (int r = 0; r < NR; ++r) { acc[r] = 0.f; sc[r] = wsc[r]; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    acc[r] = W8 ? v * wsc[r] : v;
-  }
-  // (6) epilogue + publish
-  if (lane == 0 && f0 < n_out) {
-    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < KC; ++kc) {
+      const int c = lane + 64 * kc;
+      if constexpr (W8) {
+        const u32x4 x0 = *(const u32x4*)(sx + (size_t)(2 * c) * 16), x1 = *(const u32x4*)(sx + (size_t)(2 * c + 1) * 16);
 #pragma unroll
-    for (int f = 0; f < FPW; ++f) {
-      float v = SWIGLU ? acc[FPW + f] * silu_fast(acc[f]) : acc[f];
-      if (residual != nullptr) v += bf16_bits_to_f32((unsigned short)(res_bits >> (16 * f)));
-      out[f] = v;
-    }
-    // n_out is a multiple of FPW on every matrix of the stack: a wave's features are all in range or none is
-    for (int rep = 0; rep < y_reps; ++rep) {
-      bf16_t* yr = y + (size_t)rep * p.rep_stride + f0;
-      if constexpr (FPW == 4) {
-        const unsigned long long o = (unsigned long long)pack_bf16x2(out[0], out[1]) | ((unsigned long long)pack_bf16x2(out[2], out[3]) << 32);
-        __hip_atomic_store((unsigned long long*)yr, o, AKI_RLX_AGENT);
-      } else if constexpr (FPW == 2) {
-        __hip_atomic_store((unsigned*)yr, pack_bf16x2(out[0], out[1]), AKI_RLX_AGENT);
+        for (int r = 0; r < NR; ++r) acc[r] = cdot16_w8(wv[r][kc], x0, x1, acc[r]);
       } else {
-        __hip_atomic_store((unsigned short*)yr, (unsigned short)(pack_bf16x2(out[0], 0.f) & 0xffffu), AKI_RLX_AGENT);
+        const u32x4 xc = *(const u32x4*)(sx + (size_t)c * 16);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] = cdot8(wv[r][kc], xc, acc[r]);
+      }
+    }
+    // the next batch's loads, as soon as the registers are free (the barrier keeps the scheduler from renaming them upwards)
+    asm volatile("" : "+v"(acc[0]));
+    __builtin_amdgcn_sched_barrier(0);
+    if (b + 1 < nb) issue(f0 + 4 * FPW);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      float v = acc[r];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      acc[r] = W8 ? v * sc[r] : v;
+    }
+    // (6) epilogue
+    if (lane == 0 && f0 < n_out) {
+      float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int f = 0; f < FPW; ++f) {
+        float v = SWIGLU ? acc[FPW + f] * silu_fast(acc[f]) : acc[f];
+        if (residual != nullptr) v += bf16_bits_to_f32((unsigned short)(res_bits >> (16 * f)));
+        out[f] = v;
+      }
+      // n_out is a multiple of FPW on every matrix of the stack: a wave's features are all in range or none is
+      for (int rep = 0; rep < min(y_reps, p.xrep); ++rep) {
+        bf16_t* yr = y + (size_t)rep * p.rep_stride + f0;
+        if constexpr (FPW == 4) {
+          const unsigned long long o = (unsigned long long)pack_bf16x2(out[0], out[1]) | ((unsigned long long)pack_bf16x2(out[2], out[3]) << 32);
+          __hip_atomic_store((unsigned long long*)yr, o, AKI_RLX_AGENT);
+        } else if constexpr (FPW == 2) {
+          __hip_atomic_store((unsigned*)yr, pack_bf16x2(out[0], out[1]), AKI_RLX_AGENT);
+        } else {
+          __hip_atomic_store((unsigned short*)yr, (unsigned short)(pack_bf16x2(out[0], 0.f) & 0xffffu), AKI_RLX_AGENT);
+        }
       }
     }
   }
@@ -327,7 +350,7 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
   if (!live) return;                                     // no workgroup barrier below this line
   if (work) {
     if (lane < 48) {
-      const bf16_t* row = p.qkv + (size_t)(item % CH_XREP) * p.rep_stride + h * 96;
+      const bf16_t* row = p.qkv + (size_t)(item % p.xrep) * p.rep_stride + h * 96;
       const float c0 = p.cos[(size_t)ln * 96 + lane], c1 = p.cos[(size_t)ln * 96 + lane + 48];
       const float s0 = p.sin[(size_t)ln * 96 + lane], s1 = p.sin[(size_t)ln * 96 + lane + 48];
       const float q0 = bf16_bits_to_f32(__hip_atomic_load(row + lane, AKI_RLX_AGENT));
@@ -465,7 +488,7 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
     u32x4 ov;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ov[e] = pack_bf16x2(o8[2 * e] * inv, o8[2 * e + 1] * inv);
-    for (int rep = 0; rep < CH_XREP; ++rep) {
+    for (int rep = 0; rep < p.xrep; ++rep) {
       const __amdgpu_buffer_rsrc_t ro = chain_rsrc(p.attn_o + (size_t)rep * p.rep_stride, p.H * 96 * 2);
       __builtin_amdgcn_raw_buffer_store_b128(ov, ro, (h * 96 + lane * 8) * 2, 0, 16);     // sc1: write-through
     }
@@ -475,7 +498,7 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
 }
 
 // KCD = d / 512, KCF = F / 512 (bf16) - the register arrays are static; W8 halves both.
-template <int KCD, int KCF, bool W8>
+template <int KCD, int KCF, bool W8, int NBQ, int NBO, int NBG, int NBD>
 __global__ __launch_bounds__(256) void decode_chain_kernel(const ChainParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_red = (float*)(smem + 16384);
@@ -496,7 +519,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(const ChainParams p) 
   constexpr int NRF = W8 ? 2 : 1;          // rows per wave on the K = F matrix
   constexpr int KF = W8 ? KCF / 2 : KCF;
   if (r < p.n_qkv) {
-    chain_gemv<NRD, KD, false, true, W8>(p, r, p.n_qkv, ly.w_qkv, ly.s_qkv, p.d, 3 * p.H * 96, h0, h0_rep, (const bf16_t*)ly.norm1, nullptr, 0, p.qkv,
+    chain_gemv<NRD, KD, false, true, W8, NBQ>(p, r, p.n_qkv, ly.w_qkv, ly.s_qkv, p.d, 3 * p.H * 96, h0, h0_rep, (const bf16_t*)ly.norm1, nullptr, 0, p.qkv,
                                           CH_XREP, prev_down, sy + 0 * CH_SYNC_WORDS, code | 1u, sx, s_red);
     return;
   }
@@ -507,24 +530,28 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(const ChainParams p) 
   }
   r -= p.n_attn;
   if (r < p.n_o) {
-    chain_gemv<NRD, KD, false, false, W8>(p, r, p.n_o, ly.w_o, ly.s_o, p.H * 96, p.d, p.attn_o, 1, nullptr, h0, h0_rep, p.h1, CH_XREP,
+    chain_gemv<NRD, KD, false, false, W8, NBO>(p, r, p.n_o, ly.w_o, ly.s_o, p.H * 96, p.d, p.attn_o, 1, nullptr, h0, h0_rep, p.h1, CH_XREP,
                                            sy + 1 * CH_SYNC_WORDS, sy + 2 * CH_SYNC_WORDS, code | 3u, sx, s_red);
     return;
   }
   r -= p.n_o;
   if (r < p.n_gu) {
-    chain_gemv<NRD, KD, true, true, W8>(p, r, p.n_gu, ly.w_gate_up, ly.s_gate_up, p.d, p.F, p.h1, 1, (const bf16_t*)ly.norm2, nullptr, 0, p.act,
+    chain_gemv<NRD, KD, true, true, W8, NBG>(p, r, p.n_gu, ly.w_gate_up, ly.s_gate_up, p.d, p.F, p.h1, 1, (const bf16_t*)ly.norm2, nullptr, 0, p.act,
                                          CH_XREP, sy + 2 * CH_SYNC_WORDS, sy + 3 * CH_SYNC_WORDS, code | 4u, sx, s_red);
     return;
   }
   r -= p.n_gu;
-  chain_gemv<NRF, KF, false, false, W8>(p, r, p.n_down, ly.w_down, ly.s_down, p.F, p.d, p.act, 1, nullptr, p.h1, 1, h2, last ? 1 : CH_XREP,
+  chain_gemv<NRF, KF, false, false, W8, NBD>(p, r, p.n_down, ly.w_down, ly.s_down, p.F, p.d, p.act, 1, nullptr, p.h1, 1, h2, last ? 1 : CH_XREP,
                                          sy + 3 * CH_SYNC_WORDS, sy + 4 * CH_SYNC_WORDS, code | 5u, sx, s_red);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 static inline size_t chain_cnt_bytes(int n_layers, int H) { return aki_align_up((size_t)n_layers * ((size_t)CH_PHASES * CH_SYNC_WORDS + H) * 4, 256); }
 static inline size_t chain_vec_elems(int d, int H, int F) { return aki_align_up((size_t)(3 * H * 96 + H * 96 + d + F + 2 * d) * 2 + 256, 256) / 2; }   // one copy
+
+#ifdef AKI_LAB_HOOKS
+static int g_chain_sleep = 8, g_chain_xrep = CH_XREP_USED, g_chain_nflags = CH_FLAGS, g_chain_nowait = 0, g_chain_nb = 0;
+#endif
 
 static void chain_split(int H, int cap, int max_keys, int& S, int& T) {
   if (max_keys <= 0 || max_keys > cap) max_keys = cap;
@@ -567,22 +594,57 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   p.act = v; v += F;
   p.hbuf = v;
   p.part = (float*)(ws + cb + 256 + chain_vec_elems(d, H, F) * 2 * CH_XREP);
-  const int rd = w8 ? 4 : 2, rf = w8 ? 2 : 1;     // rows per wave (see the kernel)
-  p.n_qkv = (3 * H * 96 + 4 * rd - 1) / (4 * rd);
+  const int rd = w8 ? 4 : 2, rf = w8 ? 2 : 1;     // rows per wave and batch (see the kernel)
+  p.nbq = CH_NBQ; p.nbo = CH_NBO; p.nbg = CH_NBG; p.nbd = CH_NBD;
+#ifdef AKI_LAB_HOOKS
+  static const int presets[][4] = {{CH_NBQ, CH_NBO, CH_NBG, CH_NBD}, {8, 8, 8, 8}, {4, 2, 8, 2}, {8, 2, 8, 4}, {4, 4, 4, 4}, {16, 4, 16, 4}, {8, 2, 16, 2}, {1, 1, 1, 1}};
+  const int* ps = presets[w8 ? 0 : g_chain_nb];
+  p.nbq = ps[0]; p.nbo = ps[1]; p.nbg = ps[2]; p.nbd = ps[3];
+#endif
+  auto wgs = [&](int n_out, int fpw, int nb) { return (n_out + 4 * fpw * nb - 1) / (4 * fpw * nb); };
+  p.n_qkv = wgs(3 * H * 96, rd, p.nbq);
   p.n_attn = (H * p.S + 3) / 4;
-  p.n_o = (d + 4 * rd - 1) / (4 * rd);
-  p.n_gu = (F + 4 * (rd / 2) - 1) / (4 * (rd / 2));
-  p.n_down = (d + 4 * rf - 1) / (4 * rf);
+  p.n_o = wgs(d, rd, p.nbo);
+  p.n_gu = wgs(F, rd / 2, p.nbg);
+  p.n_down = wgs(d, rf, p.nbd);
   p.wg_layer = p.n_qkv + p.n_attn + p.n_o + p.n_gu + p.n_down;
+  p.sleep_n = 8; p.xrep = CH_XREP_USED; p.nflags = CH_FLAGS; p.nowait = 0;
+#ifdef AKI_LAB_HOOKS
+  p.sleep_n = g_chain_sleep; p.xrep = g_chain_xrep; p.nflags = g_chain_nflags; p.nowait = g_chain_nowait;
+#endif
   AKI_CLEAR_ERR();
   // every polled word is zeroed by the call itself (a memset node under graph capture: replayed before the kernel)
   if (hipMemsetAsync(ws, 0, cb, stream) != hipSuccess) return AKI_ERR_LAUNCH;
   constexpr int SMEM = 16384 + 64;       // x (<= 8192 bf16) + the norm's partial sums; the attention phase carves 4 x 3 KiB of it
   const dim3 grid((unsigned)a->n_layers * (unsigned)p.wg_layer), block(256);
-  if (w8) hipLaunchKernelGGL((decode_chain_kernel<6, 16, true>), grid, block, SMEM, stream, p);
-  else hipLaunchKernelGGL((decode_chain_kernel<6, 16, false>), grid, block, SMEM, stream, p);
+#define AKI_CHAIN_LAUNCH(W8V, A, B, C, D) hipLaunchKernelGGL((decode_chain_kernel<6, 16, W8V, A, B, C, D>), grid, block, SMEM, stream, p)
+  if (w8) AKI_CHAIN_LAUNCH(true, CH_NBQ, CH_NBO, CH_NBG, CH_NBD);
+#ifdef AKI_LAB_HOOKS
+  else if (g_chain_nb == 1) AKI_CHAIN_LAUNCH(false, 8, 8, 8, 8);
+  else if (g_chain_nb == 2) AKI_CHAIN_LAUNCH(false, 4, 2, 8, 2);
+  else if (g_chain_nb == 3) AKI_CHAIN_LAUNCH(false, 8, 2, 8, 4);
+  else if (g_chain_nb == 4) AKI_CHAIN_LAUNCH(false, 4, 4, 4, 4);
+  else if (g_chain_nb == 5) AKI_CHAIN_LAUNCH(false, 16, 4, 16, 4);
+  else if (g_chain_nb == 6) AKI_CHAIN_LAUNCH(false, 8, 2, 16, 2);
+  else if (g_chain_nb == 7) AKI_CHAIN_LAUNCH(false, 1, 1, 1, 1);
+#endif
+  else AKI_CHAIN_LAUNCH(false, CH_NBQ, CH_NBO, CH_NBG, CH_NBD);
+#undef AKI_CHAIN_LAUNCH
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }
 
 }  // namespace aki
+
+#ifdef AKI_LAB_HOOKS
+// Lab build only: poll period (x 64 cycles), copies of the hand-off vectors (1..8), READY flags per phase (1..32), and
+// nowait = 1: no dependency waits at all (WRONG results - the time of the bare weight stream in this workgroup structure).
+// preset of batches per workgroup (qkv, o_proj, gate_up, down): 0 product {8,4,16,4}, 1 {8,8,8,8}, 2 {4,2,8,2}, 3 {8,2,8,4}, 4 {4,4,4,4}, 5 {16,4,16,4}, 6 {8,2,16,2}, 7 {1,1,1,1}
+extern "C" void aki_lab_set_chain_nb(int preset) { aki::g_chain_nb = (preset >= 0 && preset <= 7) ? preset : 0; }
+extern "C" void aki_lab_set_chain(int sleep_n, int xrep, int nflags, int nowait) {
+  aki::g_chain_sleep = sleep_n < 0 ? 0 : sleep_n;
+  aki::g_chain_xrep = xrep < 1 ? 1 : (xrep > aki::CH_XREP ? aki::CH_XREP : xrep);
+  aki::g_chain_nflags = nflags < 1 ? 1 : (nflags > aki::CH_FLAGS ? aki::CH_FLAGS : nflags);
+  aki::g_chain_nowait = nowait ? 1 : 0;
+}
+#endif

@@ -100,6 +100,7 @@ class AkiKVCache:
         self.attn_ws = None                                                     # split-KV attention workspace (zeroed once)
         self.grid_keys = capacity                                               # host bound of n_keys sizing the decode grid
         self.attn_ws_rows = B
+        self.chain, self.chain_sig = None, None                                 # ops.DecodeChain of the one-launch step (batch 1)
 
     def get_seq_length(self, layer_idx=0):
         return int(self.cache_len.max())
@@ -413,7 +414,17 @@ class Phi3Model(nn.Module):
         bf16 or fully e4m3-quantised (the fp8 configuration's weight-only GEMVs).  Built once per (weights, KV cache)."""
         if not self.use_decode_chain or h.shape[0] != 1 or h.dtype != torch.bfloat16 or not h.is_cuda:
             return None
-        l0 = self.layers[0]
+        l0, ll = self.layers[0], self.layers[-1]
+        chain = getattr(cache, "chain", None)
+        # a cheap signature per step (module attribute lookups cost ~1 us each; the full scan below runs only when it changes):
+        # re-allocated weights (model.to / a new quantisation) or KV tensors (beam re-ordering) move these pointers
+        sig = (l0.self_attn.qkv_proj.weight.data_ptr(), ll.mlp.down_proj.weight.data_ptr(), id(l0._fp8), id(ll._fp8), cache.k[0].data_ptr(),
+               cache.k[-1].data_ptr(), len(self.layers))
+        if chain is not None and chain.sig == sig:
+            return chain
+        if chain is None and getattr(cache, "chain_sig", None) == sig:
+            return None                             # this (model, cache) pair was found unsupported before
+        cache.chain_sig, cache.chain = sig, None
         at, mlp = l0.self_attn, l0.mlp
         sup = ops.DecodeChain.SUPPORTED
         if (at.head_dim != sup["Dh"] or h.shape[-1] != sup["d"] or mlp.down_proj.weight.shape[1] != sup["F"]
@@ -425,22 +436,20 @@ class Phi3Model(nn.Module):
             return None
         if l0._fp8 is not None and not w8:
             return None                             # qkv / gate_up only in e4m3: the mixed per-layer path
-        key = tuple((ly._fp8["qkv"][0] if w8 else ly.self_attn.qkv_proj.weight).data_ptr() for ly in self.layers) + tuple(k.data_ptr() for k in cache.k)
-        chain = getattr(cache, "chain", None)
-        if chain is None or chain.key != key:
-            rows = []
-            for ly in self.layers:
-                a_, m_ = ly.self_attn, ly.mlp
-                if w8:
-                    f = ly._fp8
-                    rows.append((f["qkv"][0], f["o"][0], f["gate_up"][0], f["down"][0], ly.input_layernorm.weight, ly.post_attention_layernorm.weight,
-                                 f["qkv"][1], f["o"][1], f["gate_up"][1], f["down"][1]))
-                else:
-                    rows.append((a_.qkv_proj.weight, a_.o_proj.weight, m_.gate_up_proj.weight, m_.down_proj.weight, ly.input_layernorm.weight,
-                                 ly.post_attention_layernorm.weight, None, None, None, None))
-            chain = cache.chain = ops.DecodeChain(rows, list(cache.k), list(cache.v), at.num_heads, at.head_dim, h.shape[-1],
-                                                  mlp.down_proj.weight.shape[1], cache.capacity, at.scaling, l0.input_layernorm.variance_epsilon,
-                                                  h.device, w8)
+        rows = []
+        for ly in self.layers:
+            a_, m_ = ly.self_attn, ly.mlp
+            if w8:
+                f = ly._fp8
+                rows.append((f["qkv"][0], f["o"][0], f["gate_up"][0], f["down"][0], ly.input_layernorm.weight, ly.post_attention_layernorm.weight,
+                             f["qkv"][1], f["o"][1], f["gate_up"][1], f["down"][1]))
+            else:
+                rows.append((a_.qkv_proj.weight, a_.o_proj.weight, m_.gate_up_proj.weight, m_.down_proj.weight, ly.input_layernorm.weight,
+                             ly.post_attention_layernorm.weight, None, None, None, None))
+        chain = cache.chain = ops.DecodeChain(rows, list(cache.k), list(cache.v), at.num_heads, at.head_dim, h.shape[-1],
+                                              mlp.down_proj.weight.shape[1], cache.capacity, at.scaling, l0.input_layernorm.variance_epsilon,
+                                              h.device, w8)
+        chain.sig = sig
         return chain
 
 
