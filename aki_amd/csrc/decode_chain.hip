@@ -77,7 +77,10 @@ constexpr int CH_FLAGS = 32;
 constexpr int CH_SYNC_WORDS = (CH_SHARDS + 1 + CH_FLAGS) * 32;   // 128-byte lines, in 4-byte words
 constexpr int CH_PHASES = 5;             // [0] qkv [1] attention (per-head mergers) [2] o_proj [3] gate_up [4] down
 // feature batches per workgroup (one staging of x each) of the qkv / o_proj / gate_up / down phases
-constexpr int CH_NBQ = 8, CH_NBO = 4, CH_NBG = 16, CH_NBD = 4;     // 144 / 96 / 128 / 192 workgroups per layer (tools/decode_chain_ab.py)
+// Two each: 576 / 192 / 1024 / 384 workgroups per layer.  More batches cut the x traffic (the bare stream runs 1.41 ms per token at two,
+// 1.20 ms at {8,4,16,4}) but every batch after the first is loaded AFTER the dependency wait, on the critical path of its phase:
+// with the waits in, {1,1,1,1} 1.90, {2,2,2,2} 1.80, {4,4,4,4} 2.40, {8,4,16,4} 3.04 ms per token (tools/decode_chain_regimes.py).
+constexpr int CH_NBQ = 2, CH_NBO = 2, CH_NBG = 2, CH_NBD = 2;
 constexpr int CH_XREP = 8;               // room for copies of every hand-off vector: consumer j reads copy j % xrep
 constexpr int CH_XREP_USED = 2;          // copies in use: with 100-200 consumers per phase two spread the readers enough, and every copy is
                                          // one more write-through store per producing lane (8 copies: +35 us per token)
@@ -133,12 +136,13 @@ __device__ __forceinline__ void chain_wait(const ChainParams& p, unsigned* sync,
 __device__ __forceinline__ void chain_arrive(unsigned* sync, int idx, int n, int lane) {
   unsigned done = 0;
   if (lane == 0) {
-    const int shard = idx % CH_SHARDS;
-    const unsigned target = (unsigned)(n / CH_SHARDS + ((n % CH_SHARDS) > shard ? 1 : 0));
-    const unsigned prev = __hip_atomic_fetch_add(sync + shard * 32, 1u, AKI_RLX_AGENT);
-    if (prev + 1u == target) {
-      const unsigned nshards = (unsigned)min(n, CH_SHARDS);
-      done = (__hip_atomic_fetch_add(sync + CH_SHARDS * 32, 1u, AKI_RLX_AGENT) + 1u == nshards) ? 1u : 0u;
+    if (n <= 64) {     // few producers (the 32 head mergers): straight to the top counter - one memory round trip less on the edge
+      done = (__hip_atomic_fetch_add(sync + CH_SHARDS * 32, 1u, AKI_RLX_AGENT) + 1u == (unsigned)n) ? 1u : 0u;
+    } else {
+      const int shard = idx % CH_SHARDS;
+      const unsigned target = (unsigned)(n / CH_SHARDS + ((n % CH_SHARDS) > shard ? 1 : 0));
+      const unsigned prev = __hip_atomic_fetch_add(sync + shard * 32, 1u, AKI_RLX_AGENT);
+      if (prev + 1u == target) done = (__hip_atomic_fetch_add(sync + CH_SHARDS * 32, 1u, AKI_RLX_AGENT) + 1u == (unsigned)CH_SHARDS) ? 1u : 0u;
     }
   }
   done = __shfl(done, 0);
@@ -447,18 +451,29 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
 #pragma unroll
   for (int e = 0; e < 8; ++e) o8[e] = 0.f;
   if (sl < 5) {
-    for (int s2 = sl; s2 < p.S; s2 += 5) {
-      const float* ps = pp + (size_t)s2 * CH_PSTRIDE;
-      const float ms = __hip_atomic_load(ps, AKI_RLX_AGENT), ls = __hip_atomic_load(ps + 1, AKI_RLX_AGENT);
-      float a[8];
+    // every partial of this slot is requested before the first is used (each load is a round trip to memory; S <= 15 is three of
+    // them in a row otherwise, on the critical path of the layer); the combination runs in decode.hip's order
+    for (int s0 = sl; s0 < p.S; s0 += 15) {
+      float ms[3], ls[3], a[3][8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = __hip_atomic_load(ps + 8 + ch * 8 + e, AKI_RLX_AGENT);
-      const float mn = fmaxf(gm, ms);
-      const float fa = gm == -INFINITY ? 0.f : __expf(gm - mn), fb = ms == -INFINITY ? 0.f : __expf(ms - mn);
-      lt = lt * fa + ls * fb;
+      for (int u = 0; u < 3; ++u) {
+        const int s2 = s0 + 5 * u;
+        const float* ps = pp + (size_t)min(s2, p.S - 1) * CH_PSTRIDE;
+        ms[u] = __hip_atomic_load(ps, AKI_RLX_AGENT);
+        ls[u] = __hip_atomic_load(ps + 1, AKI_RLX_AGENT);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o8[e] = o8[e] * fa + a[e] * fb;
-      gm = mn;
+        for (int e = 0; e < 8; ++e) a[u][e] = __hip_atomic_load(ps + 8 + ch * 8 + e, AKI_RLX_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (s0 + 5 * u >= p.S) break;
+        const float mn = fmaxf(gm, ms[u]);
+        const float fa = gm == -INFINITY ? 0.f : __expf(gm - mn), fb = ms[u] == -INFINITY ? 0.f : __expf(ms[u] - mn);
+        lt = lt * fa + ls[u] * fb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = o8[e] * fa + a[u][e] * fb;
+        gm = mn;
+      }
     }
     float* sm = s_mg + (sl * 12 + ch) * 10;
     sm[0] = gm;
@@ -495,6 +510,11 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   chain_arrive(done_sync, h, p.H, lane);                 // one arrival per head
+}
+
+__global__ __launch_bounds__(256) void chain_zero_kernel(u32x4* p, int n16) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) p[i] = u32x4{0u, 0u, 0u, 0u};
 }
 
 // KCD = d / 512, KCF = F / 512 (bf16) - the register arrays are static; W8 halves both.
@@ -597,7 +617,7 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   const int rd = w8 ? 4 : 2, rf = w8 ? 2 : 1;     // rows per wave and batch (see the kernel)
   p.nbq = CH_NBQ; p.nbo = CH_NBO; p.nbg = CH_NBG; p.nbd = CH_NBD;
 #ifdef AKI_LAB_HOOKS
-  static const int presets[][4] = {{CH_NBQ, CH_NBO, CH_NBG, CH_NBD}, {8, 8, 8, 8}, {4, 2, 8, 2}, {8, 2, 8, 4}, {4, 4, 4, 4}, {16, 4, 16, 4}, {8, 2, 16, 2}, {1, 1, 1, 1}};
+  static const int presets[][4] = {{CH_NBQ, CH_NBO, CH_NBG, CH_NBD}, {8, 8, 8, 8}, {4, 2, 8, 2}, {8, 2, 8, 4}, {4, 4, 4, 4}, {16, 4, 16, 4}, {8, 2, 16, 2}, {1, 1, 1, 1}, {8, 4, 16, 4}, {2, 1, 4, 1}, {4, 2, 4, 2}, {2, 2, 4, 2}};
   const int* ps = presets[w8 ? 0 : g_chain_nb];
   p.nbq = ps[0]; p.nbo = ps[1]; p.nbg = ps[2]; p.nbd = ps[3];
 #endif
@@ -613,8 +633,12 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   p.sleep_n = g_chain_sleep; p.xrep = g_chain_xrep; p.nflags = g_chain_nflags; p.nowait = g_chain_nowait;
 #endif
   AKI_CLEAR_ERR();
-  // every polled word is zeroed by the call itself (a memset node under graph capture: replayed before the kernel)
-  if (hipMemsetAsync(ws, 0, cb, stream) != hipSuccess) return AKI_ERR_LAUNCH;
+  // Every polled word is zeroed by the call itself, by a KERNEL of this library.  hipMemsetAsync was used first: eager calls
+  // were fine, but as a captured memset node (ROCm 7.2, 1 MB) it left a constant non-zero word pattern in the block in some
+  // processes - every READY flag then read "set", no workgroup ever waited, and the replayed step ran at the speed of the bare
+  // weight stream (1.28 ms) with wrong logits, while the 2-layer graph test of the time happened to pass.
+  // tests/test_decode_gpu.py now compares a FULL-DEPTH graph replay with the five-launch path, and every timing tool checks logits.
+  hipLaunchKernelGGL(chain_zero_kernel, dim3((unsigned)((cb / 16 + 255) / 256)), dim3(256), 0, stream, (u32x4*)ws, (int)(cb / 16));
   constexpr int SMEM = 16384 + 64;       // x (<= 8192 bf16) + the norm's partial sums; the attention phase carves 4 x 3 KiB of it
   const dim3 grid((unsigned)a->n_layers * (unsigned)p.wg_layer), block(256);
 #define AKI_CHAIN_LAUNCH(W8V, A, B, C, D) hipLaunchKernelGGL((decode_chain_kernel<6, 16, W8V, A, B, C, D>), grid, block, SMEM, stream, p)
@@ -627,6 +651,10 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   else if (g_chain_nb == 5) AKI_CHAIN_LAUNCH(false, 16, 4, 16, 4);
   else if (g_chain_nb == 6) AKI_CHAIN_LAUNCH(false, 8, 2, 16, 2);
   else if (g_chain_nb == 7) AKI_CHAIN_LAUNCH(false, 1, 1, 1, 1);
+  else if (g_chain_nb == 8) AKI_CHAIN_LAUNCH(false, 8, 4, 16, 4);
+  else if (g_chain_nb == 9) AKI_CHAIN_LAUNCH(false, 2, 1, 4, 1);
+  else if (g_chain_nb == 10) AKI_CHAIN_LAUNCH(false, 4, 2, 4, 2);
+  else if (g_chain_nb == 11) AKI_CHAIN_LAUNCH(false, 2, 2, 4, 2);
 #endif
   else AKI_CHAIN_LAUNCH(false, CH_NBQ, CH_NBO, CH_NBG, CH_NBD);
 #undef AKI_CHAIN_LAUNCH
@@ -639,8 +667,8 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
 #ifdef AKI_LAB_HOOKS
 // Lab build only: poll period (x 64 cycles), copies of the hand-off vectors (1..8), READY flags per phase (1..32), and
 // nowait = 1: no dependency waits at all (WRONG results - the time of the bare weight stream in this workgroup structure).
-// preset of batches per workgroup (qkv, o_proj, gate_up, down): 0 product {8,4,16,4}, 1 {8,8,8,8}, 2 {4,2,8,2}, 3 {8,2,8,4}, 4 {4,4,4,4}, 5 {16,4,16,4}, 6 {8,2,16,2}, 7 {1,1,1,1}
-extern "C" void aki_lab_set_chain_nb(int preset) { aki::g_chain_nb = (preset >= 0 && preset <= 7) ? preset : 0; }
+// preset of batches per workgroup (qkv, o_proj, gate_up, down): 0 product {2,2,2,2}, 1 {8,8,8,8}, 2 {4,2,8,2}, 3 {8,2,8,4}, 4 {4,4,4,4}, 5 {16,4,16,4}, 6 {8,2,16,2}, 7 {1,1,1,1}, 8 {8,4,16,4}, 9 {2,1,4,1}, 10 {4,2,4,2}, 11 {2,2,4,2}
+extern "C" void aki_lab_set_chain_nb(int preset) { aki::g_chain_nb = (preset >= 0 && preset <= 11) ? preset : 0; }
 extern "C" void aki_lab_set_chain(int sleep_n, int xrep, int nflags, int nowait) {
   aki::g_chain_sleep = sleep_n < 0 ? 0 : sleep_n;
   aki::g_chain_xrep = xrep < 1 ? 1 : (xrep > aki::CH_XREP ? aki::CH_XREP : xrep);

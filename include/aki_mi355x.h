@@ -366,7 +366,7 @@ int aki_decode_linear_fwd(const aki_linear_args* args, const void* rms_weight, f
  *   cache_len     device int32 [1]: tokens cached so far = the new token's position and append index (not advanced here)
  *   max_keys      host upper bound of cache_len + 1 that sizes the attention split (0 = capacity)
  *   workspace     aki_decode_chain_workspace_bytes(...) bytes, 256-byte aligned, ZERO-FILLED ONCE by the caller before its
- *                 first use; the call re-zeroes its own arrival counters (a memset node under graph capture).  The 32-bit
+ *                 first use; the call re-zeroes its own arrival counters (a small kernel launched ahead of the chain).  The 32-bit
  *                 word at aki_decode_chain_error_offset(...) is sticky: 0 = every wait of every call so far was satisfied;
  *                 otherwise (layer << 8 | phase) of a wait that gave up after its bounded spin (the launch then drains and
  *                 h_out is garbage) - read it after synchronising.
