@@ -28,6 +28,18 @@ SOURCES = ["api.hip", "gemm_bf16.hip", "gemm_tn_bf16.hip", "mma_attn_bf16.hip", 
 ARCH = "gfx950"
 
 
+def csrc_hash() -> str:
+    """sha256 over the kernel sources and headers (names + contents, sorted): profiles/*_pmc_summary.json carry the hash of the
+    tree their counters were collected on, and bench.py marks `roofline.traffic` stale when it differs from the running tree's."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.join(ROOT, "include", "aki_mi355x.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):

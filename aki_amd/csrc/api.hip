@@ -72,9 +72,9 @@ int ce_launch(const void* logits, const int64_t* labels, int* n_valid, float* lo
 int ce_rows_launch(const void* logits, const int64_t* targets, const int* n_valid, float* loss_rows, void* dlogits, int rows, int V,
                    int ldl, int lddl, float gscale, hipStream_t s);
 size_t grad_sqnorm_ws_bytes();
-int grad_sqnorm_launch(const void* g, size_t n, float* out, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int grad_sqnorm_launch(const void* g, size_t n, float* out, int accumulate, void* ws, size_t ws_bytes, bool g32, hipStream_t s);
 int adamw_launch(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
-                 float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s);
+                 float lr, float beta1, float beta2, float eps, float wd, int step, bool g32, hipStream_t s);
 }  // namespace aki
 
 using namespace aki;
@@ -519,15 +519,22 @@ size_t aki_grad_sqnorm_workspace_bytes(void) { return grad_sqnorm_ws_bytes(); }
 int aki_grad_sqnorm(const void* g, size_t n, float* out, int32_t accumulate, int32_t dtype, void* ws, size_t ws_bytes, void* stream) {
   AKI_CLEAR_ERR();
   AKI_CHECK_ARG(g && out && n > 0);
-  AKI_BF16_ONLY(dtype);
-  return grad_sqnorm_launch(g, n, out, accumulate, ws, ws_bytes, (hipStream_t)stream);
+  if (dtype != AKI_DT_BF16 && dtype != AKI_DT_F32) return AKI_ERR_UNSUPPORTED;
+  return grad_sqnorm_launch(g, n, out, accumulate, ws, ws_bytes, dtype == AKI_DT_F32, (hipStream_t)stream);
 }
 
 int aki_adamw_step(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream) {
   AKI_CLEAR_ERR();
   AKI_CHECK_ARG(p && m && v && g && w16 && n > 0 && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f);
-  return adamw_launch(p, m, v, g, w16, n, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+  return adamw_launch(p, m, v, g, w16, n, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step, false, (hipStream_t)stream);
+}
+
+int aki_adamw_step_g32(float* p, float* m, float* v, const float* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(p && m && v && g && w16 && n > 0 && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f);
+  return adamw_launch(p, m, v, g, w16, n, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step, true, (hipStream_t)stream);
 }
 
 // ---- splice / mask -------------------------------------------------------------------------------------

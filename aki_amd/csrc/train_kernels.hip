@@ -513,12 +513,19 @@ int ce_rows_launch(const void* logits, const int64_t* targets, const int* n_vali
 //   adamw:       g' = g * gscale * clip,  clip = min(1, max_norm / (sqrt(*sqnorm) * gscale + 1e-6))   (torch semantics)
 //                m, v, p updated in fp32 (decoupled weight decay, bias correction); w16 = bf16(p)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const bf16_t* g, size_t nchunks, float* part) {
+template <bool G32>
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const void* gp, size_t nchunks, float* part) {
   float s = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
-    const u32x4 v = *(const u32x4*)(g + i * 8);
+    if constexpr (G32) {
+      const f32x4 a = *(const f32x4*)((const float*)gp + i * 8), b = *(const f32x4*)((const float*)gp + i * 8 + 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const float a = bf16_lo(v[e]), b = bf16_hi(v[e]); s += a * a + b * b; }
+      for (int e = 0; e < 4; ++e) s += a[e] * a[e] + b[e] * b[e];
+    } else {
+      const u32x4 v = *(const u32x4*)((const bf16_t*)gp + i * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float a = bf16_lo(v[e]), b = bf16_hi(v[e]); s += a * a + b * b; }
+    }
   }
   __shared__ float red[16];
   float dummy = 0.f;
@@ -538,30 +545,40 @@ __global__ __launch_bounds__(256) void fold_scalar_kernel(const float* part, int
 constexpr int SQNORM_GROUPS = 1024;
 size_t grad_sqnorm_ws_bytes() { return SQNORM_GROUPS * 4; }
 
-int grad_sqnorm_launch(const void* g, size_t n, float* out, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+int grad_sqnorm_launch(const void* g, size_t n, float* out, int accumulate, void* ws, size_t ws_bytes, bool g32, hipStream_t s) {
   if (n % 8) return AKI_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < grad_sqnorm_ws_bytes()) return AKI_ERR_WORKSPACE;
   int G = (int)((n / 8 + 255) / 256);
   if (G > SQNORM_GROUPS) G = SQNORM_GROUPS;
   if (G < 1) G = 1;
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(G), dim3(256), 0, s, (const bf16_t*)g, n / 8, (float*)ws);
+  if (g32) hipLaunchKernelGGL(grad_sqnorm_kernel<true>, dim3(G), dim3(256), 0, s, g, n / 8, (float*)ws);
+  else hipLaunchKernelGGL(grad_sqnorm_kernel<false>, dim3(G), dim3(256), 0, s, g, n / 8, (float*)ws);
   hipLaunchKernelGGL(fold_scalar_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, G, out, accumulate);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }
 
 struct AdamwParams {
-  float* p; float* m; float* v; const bf16_t* g; bf16_t* w16; size_t nchunks;
+  float* p; float* m; float* v; const void* g; bf16_t* w16; size_t nchunks;
   const float* sqnorm; float max_norm, gscale, lr, beta1, beta2, eps, wd, bc1, bc2;
 };
 
+template <bool G32>
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamwParams a) {
   float clip = 1.f;
   if (a.sqnorm && a.max_norm > 0.f) clip = fminf(1.f, a.max_norm / (sqrtf(*a.sqnorm) * a.gscale + 1e-6f));
   const float gs = a.gscale * clip;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.nchunks; i += (size_t)gridDim.x * 256) {
-    const u32x4 gv = *(const u32x4*)(a.g + i * 8);
+    float gin[8];
+    if constexpr (G32) {
+      *(f32x4*)&gin[0] = *(const f32x4*)((const float*)a.g + i * 8);
+      *(f32x4*)&gin[4] = *(const f32x4*)((const float*)a.g + i * 8 + 4);
+    } else {
+      const u32x4 gv = *(const u32x4*)((const bf16_t*)a.g + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gin[j] = (j & 1) ? bf16_hi(gv[j >> 1]) : bf16_lo(gv[j >> 1]);
+    }
     float p[8], m[8], v[8];
     *(f32x4*)&p[0] = *(const f32x4*)(a.p + i * 8); *(f32x4*)&p[4] = *(const f32x4*)(a.p + i * 8 + 4);
     *(f32x4*)&m[0] = *(const f32x4*)(a.m + i * 8); *(f32x4*)&m[4] = *(const f32x4*)(a.m + i * 8 + 4);
@@ -569,7 +586,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamwParams a) {
     u32x4 wo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float g = ((j & 1) ? bf16_hi(gv[j >> 1]) : bf16_lo(gv[j >> 1])) * gs;
+      const float g = gin[j] * gs;
       p[j] *= 1.f - a.lr * a.wd;
       m[j] = a.beta1 * m[j] + (1.f - a.beta1) * g;
       v[j] = a.beta2 * v[j] + (1.f - a.beta2) * g * g;
@@ -585,12 +602,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamwParams a) {
 }
 
 int adamw_launch(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
-                 float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s) {
+                 float lr, float beta1, float beta2, float eps, float wd, int step, bool g32, hipStream_t s) {
   if (n % 8 || step < 1) return AKI_ERR_INVALID_ARG;
-  AdamwParams a = {p, m, v, (const bf16_t*)g, (bf16_t*)w16, n / 8, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, wd,
+  AdamwParams a = {p, m, v, g, (bf16_t*)w16, n / 8, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, wd,
                    1.f - powf(beta1, (float)step), 1.f - powf(beta2, (float)step)};
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, s, a);
+  if (g32) hipLaunchKernelGGL(adamw_kernel<true>, dim3(ew_grid(n / 8)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(adamw_kernel<false>, dim3(ew_grid(n / 8)), dim3(256), 0, s, a);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }

@@ -129,11 +129,15 @@ class FlatGradReducer:
     """
 
     def __init__(self, flat_grad: torch.Tensor, spans, bucket_bytes: int = 512 << 20, group=None, shard: bool = False,
-                 breaks=(), exchange_when_alone: bool = False):
+                 breaks=(), exchange_when_alone: bool = False, flat32: Optional[torch.Tensor] = None):
         """spans: list of (param, start, stop) element ranges inside flat_grad, in buffer order.
         exchange_when_alone: issue the collectives even in a world of one rank (they are identities there) - how the RCCL
         entry points and the compute-stream -> communicator-stream hand-off are exercised on a single GPU."""
         self.flat, self.group, self.shard = flat_grad, group, shard
+        # fp32 exchange (the reference's DDP path under amp_bf16 all-reduces fp32 .grad, train/train.py:311-312): a bucket's slice of
+        # `flat` is widened into `flat32` (same length) when the bucket is launched and the collective runs on the fp32 slice; the sum
+        # stays there for the optimizer.  copy_in = False: flat32 already holds the gradients (an fp32 accumulation window).
+        self.flat32, self.copy_in = flat32, True
         self.enabled = True           # False during the non-final micro-batches of a gradient-accumulation window
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -144,7 +148,7 @@ class FlatGradReducer:
         self._delivered = set()       # ids of parameters already counted in this accumulation window
         per = max(1, bucket_bytes // flat_grad.element_size())
         brk = sorted(set(int(b) for b in breaks) | {flat_grad.numel()})
-        self.buckets = []             # [start, stop, n_params, pending, work]
+        self.buckets = []             # [start, stop, n_params, pending, work, widened into flat32]
         self._owner = {}
         cur_start, cur_n = None, 0
         for i, (p, lo, hi) in enumerate(spans):
@@ -154,10 +158,10 @@ class FlatGradReducer:
             cur_n += 1
             nxt = spans[i + 1][1] if i + 1 < len(spans) else flat_grad.numel()   # bucket ends where the next param starts
             if nxt - cur_start >= per or nxt in brk:
-                self.buckets.append([cur_start, nxt, cur_n, cur_n, None])
+                self.buckets.append([cur_start, nxt, cur_n, cur_n, None, False])
                 cur_start, cur_n = None, 0
         if cur_start is not None:
-            self.buckets.append([cur_start, flat_grad.numel(), cur_n, cur_n, None])
+            self.buckets.append([cur_start, flat_grad.numel(), cur_n, cur_n, None, False])
         if shard:
             for b in self.buckets:
                 if (b[1] - b[0]) % (8 * self.world):
@@ -183,14 +187,20 @@ class FlatGradReducer:
             self._launch(b)
 
     def _launch(self, b) -> None:
-        if not self.active or b[4] is not None:
+        if b[4] is not None:
             return
-        buf = self.flat[b[0]: b[1]]
+        if self.flat32 is not None and self.copy_in and b[4] is None and not b[5]:
+            self.flat32[b[0]: b[1]].copy_(self.flat[b[0]: b[1]])        # stream-ordered ahead of the collective
+            b[5] = True
+        if not self.active:
+            return
+        src = self.flat if self.flat32 is None else self.flat32
+        buf = src[b[0]: b[1]]
         if not self.shard or self.no_scatter:
             b[4] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             return
         lo, hi = self.owned(b)
-        b[4] = dist.reduce_scatter_tensor(self.flat[lo:hi], buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b[4] = dist.reduce_scatter_tensor(src[lo:hi], buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:
         for b in self.buckets:
@@ -198,7 +208,7 @@ class FlatGradReducer:
         for b in self.buckets:
             if b[4] is not None:
                 b[4].wait()
-            b[3], b[4] = b[2], None
+            b[3], b[4], b[5] = b[2], None, False
         self._delivered.clear()
 
     def all_gather_weights(self, flat_w: torch.Tensor) -> None:

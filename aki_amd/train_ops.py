@@ -204,18 +204,21 @@ def attn_bwd(q, k, v, o, d_o, lse, table: Optional[ops.MaskTable], scale: float)
 
 
 def grad_sqnorm(g: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> None:
-    _need_bf16(g)
+    """*out (+)= sum g^2; g bf16, or f32 (the fp32 gradient exchange)."""
+    if g.dtype != torch.float32:
+        _need_bf16(g)
     lib = L.load()
     ws = _ws(lib.aki_grad_sqnorm_workspace_bytes(), _dev(g, out))
-    L.check(lib.aki_grad_sqnorm(_ptr(g), g.numel(), _ptr(out), 1 if accumulate else 0, _BF16, _ptr(ws), ws.numel(), _stream()),
-            "aki_grad_sqnorm")
+    L.check(lib.aki_grad_sqnorm(_ptr(g), g.numel(), _ptr(out), 1 if accumulate else 0, L.AKI_DT_F32 if g.dtype == torch.float32 else _BF16,
+                                _ptr(ws), ws.numel(), _stream()), "aki_grad_sqnorm")
 
 
-def adamw_step(p32, m, v, g16, w16, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, wd, step) -> None:
-    _dev(p32, m, v, g16, w16, sqnorm)
-    L.check(L.load().aki_adamw_step(_ptr(p32), _ptr(m), _ptr(v), _ptr(g16), _ptr(w16), p32.numel(), _ptr(sqnorm), float(max_norm),
-                                    float(gscale), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), _stream()),
-            "aki_adamw_step")
+def adamw_step(p32, m, v, g, w16, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, wd, step) -> None:
+    """g: bf16 gradients, or f32 (aki_adamw_step_g32)."""
+    _dev(p32, m, v, g, w16, sqnorm)
+    fn = L.load().aki_adamw_step_g32 if g.dtype == torch.float32 else L.load().aki_adamw_step
+    L.check(fn(_ptr(p32), _ptr(m), _ptr(v), _ptr(g), _ptr(w16), p32.numel(), _ptr(sqnorm), float(max_norm), float(gscale), float(lr),
+               float(beta1), float(beta2), float(eps), float(wd), int(step), _stream()), "aki_adamw_step")
 
 
 # ---- transposed-weight cache -------------------------------------------------------------------------------------

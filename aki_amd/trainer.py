@@ -21,13 +21,22 @@ from .dp import FlatGradReducer
 
 class AkiTrainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
-                 max_grad_norm: float = 1.0, bucket_bytes: int = 512 << 20, group=None, shard_optimizer: bool = False,
-                 exchange_when_alone: bool = False, clip_every_microbatch: bool = False):
+                 max_grad_norm: float = 1.0, bucket_bytes: int = 512 << 20, group=None, shard_optimizer: Optional[bool] = None,
+                 exchange_when_alone: bool = False, clip_every_microbatch: bool = False, reduce_dtype: Optional[torch.dtype] = None):
         """shard_optimizer: keep fp32 master weights and moments only for this rank's 1/world slice of every gradient
         bucket (reduce-scatter + all-gather instead of all-reduce) - the memory behaviour of the reference's FSDP launch
-        configs (train/distributed.py:170-243, scripts/run_train.sh:23) for the optimizer state.
+        configs (train/distributed.py:170-243, scripts/run_train.sh:23) for the optimizer state.  Default (None): ON whenever
+        there is more than one rank - the AdamW pass is HBM-bound (21 ms of a 150 ms step at world 1, 24 bytes per parameter) and
+        sharding is the only thing that shrinks it (projected 2.6 ms at 8 ranks) at the same exchanged bytes; False restores the
+        reference's plain DDP replica (every rank updates everything).
+        reduce_dtype: None / bfloat16 exchanges the bf16 gradients where the backward kernels left them (the reference's FSDP
+        default, train/distributed.py:160-167 `reduce_dtype=bf16`); float32 widens every bucket into an fp32 buffer, sums in fp32
+        across ranks and lets the optimizer consume the fp32 sum - the arithmetic of the reference's DDP path under
+        `--precision amp_bf16` (fp32 parameters and gradients: train/train.py:311-312, train/train_utils.py:56-65) at twice the
+        exchanged bytes and one more flat buffer (4 bytes per parameter).
         exchange_when_alone: run the collectives even when the process group has a single rank (identities) - a one-GPU
-        box then exercises the real RCCL reduce-scatter / all-gather / all-reduce entry points and stream hand-off."""
+        box then exercises the real RCCL reduce-scatter / all-gather / all-reduce entry points and stream hand-off.
+        clip_every_microbatch: single-rank parity only (see backward())."""
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
@@ -35,6 +44,11 @@ class AkiTrainer:
         self._acc_open = False
         self.clip_every_microbatch = bool(clip_every_microbatch)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if shard_optimizer is None:
+            shard_optimizer = self.world > 1
+        if reduce_dtype not in (None, torch.bfloat16, torch.float32):
+            raise ValueError("reduce_dtype must be None, torch.bfloat16 or torch.float32")
+        self.reduce_dtype = torch.float32 if reduce_dtype == torch.float32 else torch.bfloat16
         wd, nwd = model.group_params_by_weight_decay() if hasattr(model, "group_params_by_weight_decay") else (
             [p for p in model.parameters() if p.requires_grad], [])
         groups = [(list(wd), weight_decay), (list(nwd), 0.0)]
@@ -65,8 +79,11 @@ class AkiTrainer:
         self.w16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
         self.g16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
         self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        # fp32 exchange: g32 receives each bucket of g16 widened, is summed across ranks in fp32 and feeds the optimizer; it doubles
+        # as the fp32 accumulator of gradient-accumulation windows
+        self.g32 = torch.zeros(n, dtype=torch.float32, device=dev) if self.reduce_dtype == torch.float32 else None
         self.reducer = FlatGradReducer(self.g16, spans, bucket_bytes, group, shard=self.shard, breaks=breaks,
-                                       exchange_when_alone=alone)
+                                       exchange_when_alone=alone, flat32=self.g32)
         self.params = []
         self.span_of = {id(p): (lo, hi) for p, lo, hi in spans}
         for p, lo, hi in spans:
@@ -124,7 +141,10 @@ class AkiTrainer:
         it with this backward would exchange the last micro-batch alone).  `clip_every_microbatch` additionally clips the
         accumulated fp32 gradient to `max_grad_norm` after every micro-batch, which is where the reference's loop calls
         clip_grad_norm_ (train/train_utils.py:254-258: after each backward, not once per optimizer step); the default
-        clips once, in the optimizer step.  With gradient_accumulation_steps = 1 nothing of this runs."""
+        clips once, in the optimizer step.  SINGLE-RANK parity only: the reference clips gradients its DDP / FSDP wrap has
+        already reduced across ranks, this flag clips the rank-LOCAL accumulator before any exchange - with more than one rank
+        the norms and clip factors differ per rank and the clip precedes the average.  With gradient_accumulation_steps = 1
+        nothing of this runs."""
         accumulating = (not last_microbatch) or self._acc_open
         self.reducer.enabled = bool(last_microbatch) and not accumulating
         loss.backward()
@@ -142,7 +162,9 @@ class AkiTrainer:
                     p._aki_grad.zero_()
                     self.reducer.notify(p)
         if accumulating:
-            if self.gacc is None:
+            if self.g32 is not None:
+                self.gacc = self.g32             # fp32 exchange: the accumulator IS the exchanged buffer
+            elif self.gacc is None:
                 self.gacc = torch.empty(self.numel, dtype=torch.float32, device=self.g16.device)
             if self._acc_open:
                 self.gacc.add_(self.g16)         # fp32 += bf16 (exact conversion, fp32 sum)
@@ -153,9 +175,11 @@ class AkiTrainer:
                 norm = self.gacc.norm()
                 self.gacc.mul_(torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0))     # torch.nn.utils.clip_grad_norm_
             if last_microbatch:
-                self.g16.copy_(self.gacc)        # ONE rounding of the fp32 sum
+                if self.g32 is None:
+                    self.g16.copy_(self.gacc)    # ONE rounding of the fp32 sum
                 self._acc_open = False
                 self.reducer.enabled = True
+                self.reducer.copy_in = False     # (fp32 exchange) g32 already holds the window's sum
                 for p in self.params:
                     p._aki_grad_live = True
                     self.reducer.notify(p)
@@ -164,23 +188,27 @@ class AkiTrainer:
                     p._aki_grad_live = False
         if last_microbatch:
             self.reducer.finish()
+            self.reducer.copy_in = True
         self.reducer.enabled = True
 
     def optimizer_step(self) -> None:
         self.step_count += 1
         gscale = 1.0 / self.world
+        g = self.g16 if self.g32 is None else self.g32      # fp32 exchange: the optimizer consumes the fp32 sum
         first = True
         for lo, hi, _, _ in self.owned:
-            T.grad_sqnorm(self.g16[lo:hi], self.sqnorm, accumulate=not first)
+            T.grad_sqnorm(g[lo:hi], self.sqnorm, accumulate=not first)
             first = False
         if self.shard:                           # every rank holds the sum over its own slices: one scalar all-reduce
             dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
         for lo, hi, so, decay in self.owned:
             n = hi - lo
-            T.adamw_step(self.master[so:so + n], self.m[so:so + n], self.v[so:so + n], self.g16[lo:hi], self.w16[lo:hi],
+            T.adamw_step(self.master[so:so + n], self.m[so:so + n], self.v[so:so + n], g[lo:hi], self.w16[lo:hi],
                          self.sqnorm, self.max_grad_norm, gscale, self.lr, self.betas[0], self.betas[1], self.eps, decay,
                          self.step_count)
         self.reducer.all_gather_weights(self.w16)
+        if self.g32 is None:
+            self.gacc = None                     # the fp32 accumulator of a finished window (15.6 GB for AKI-4B) is not kept
         T.bump_weight_epoch()
 
     # ---- checkpoint / resume (train/train_utils.py:395-460 saves model + optimizer state; the I/O itself is out of scope) ----
@@ -493,6 +521,7 @@ class AkiShardedTrainer:
         for u in self.all_units:
             T.adamw_step(u.master, u.m, u.v, u.g_shard, u.w_shard, self.sqnorm, self.max_grad_norm, 1.0 / self.world, self.lr,
                          self.betas[0], self.betas[1], self.eps, u.decay, self.step_count)
+            u.g_acc32 = None                   # the fp32 sum of a finished accumulation window is not kept across steps
         T.bump_weight_epoch()
 
     def grad_norm(self) -> torch.Tensor:

@@ -212,6 +212,17 @@ def cpu_baseline_c2_est(threads=None):
             "seconds_per_forward_est": round(total, 3), "parts_s": {k: round(v, 4) for k, v in t.items()}}
 
 
+def rank_spread(elapsed, device):
+    """(max, min) over the ranks of this rank's elapsed seconds - two scalar all-reduces after the timed region."""
+    import torch
+    import torch.distributed as dist
+    hi = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    lo = hi.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return float(hi.item()), float(lo.item())
+
+
 def spawn_ranks(n, argv, script=None):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
     CHILD process (nothing in this process has touched the GPU) and return its exit code.  Refuses when fewer than N GPUs are
@@ -315,12 +326,11 @@ def main():
         out = step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_min = elapsed
     ops.set_event_tap(None)
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, elapsed_min = rank_spread(elapsed, dev if backend == "nccl" else "cpu")
     assert torch.isfinite(out.logits.float()).all()
     # the same loop once more WITHOUT the event probes (reported next to ms_per_step: what the probes cost)
     n_un = min(args.steps, 10)
@@ -379,23 +389,27 @@ def main():
         def pmc_traffic(*kernel_sigs):
             """HBM-side bytes per launch of one kernel (or the sum over the kernels of one op) from the committed rocprofv3
             --pmc passes of THIS command (profiles/*_pmc_summary.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE;
-            counters cannot be read from inside the process).  None when no profile of the same configuration is committed."""
+            counters cannot be read from inside the process).  -> (bytes, source file, stale): stale = the summary was taken on
+            another tree of aki_amd/csrc (or predates the hash stamp tools/summarize_prof.py writes).  (None, None, None) when no
+            profile of the same configuration is committed."""
             if fp8 or world != 1 or B != BATCH:
-                return None, None
+                return None, None, None
             import glob
+            from aki_amd.build import csrc_hash
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
                 try:
                     entries = json.load(open(f))
+                    meta = [e for e in entries if e.get("kernel") == "__meta__"]
                     tot = 0
                     for sig in kernel_sigs:
                         hit = [e for e in entries if sig in e["kernel"] and "hbm_read_bytes_corrected_x2" in e and "hbm_write_bytes" in e]
                         if not hit:
                             raise KeyError(sig)
                         tot += int(hit[0]["hbm_read_bytes_corrected_x2"] + hit[0]["hbm_write_bytes"])
-                    return tot, os.path.relpath(f, ROOT)
+                    return tot, os.path.relpath(f, ROOT), (not meta) or meta[0].get("csrc_tree_hash") != csrc_hash()
                 except Exception:
                     continue
-            return None, None
+            return None, None, None
         peak_of = lambda r: 5000.0 if r["tag"] == "linear_fp8" else PEAK_BF16_TFLOPS     # dense fp8 MFMA peak (guide): ~5 PF
         mk = lambda r: {"kernel": r["kernel"], "bound": "mfma", "achieved": round(r["tflops"], 1), "peak": peak_of(r),
                         "unit": "TFLOP/s", "frac": round(r["tflops"] / peak_of(r), 4), "traffic": None,
@@ -404,6 +418,8 @@ def main():
             "metric": "image+text tokens/sec forward, AKI-4B, 336px img + 512 txt",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_step_untapped": round(ms_untapped, 3), "rccl_ranks": ranks_seen,
+            # every rank's own clock around the same K steps: `ms_per_step` is the slowest rank's (what `value` uses); a straggler shows here
+            "ms_per_step_rank_min": round(elapsed_min / args.steps * 1e3, 3), "ms_per_step_rank_max": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8-e4m3 projections (f32 accumulate), bf16 attention/residual" if fp8 else "bf16", "data": "synthetic",
             "config": {"workload": "AKI-4B (Phi-3.5-mini + SigLIP-so400m/14 + Perceiver) forward, bf16, 1x336px image + "
@@ -413,9 +429,10 @@ def main():
             "roofline": mk(dom),
         }
         if dom["tag"] == "linear" and "+swiglu" in dom["kernel"]:
-            tr, src = pmc_traffic("gemm_bf16_kernel<8, 4, 2, 4, 1, 0")
+            tr, src, stale = pmc_traffic("gemm_bf16_kernel<8, 4, 2, 4, 1, 0")
             res["roofline"]["traffic"] = tr
             if src:
+                res["roofline"]["traffic_stale"] = bool(stale)
                 res["roofline"]["traffic_unit"] = "bytes per launch (L2<->fabric: FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache hits)"
                 res["roofline"]["traffic_source"] = src
                 res["roofline"]["algorithmic_bytes_per_launch"] = int(2 * (dom["flops"] / 2 / 16384 / 3072 * 3072 + 16384 * 3072 + dom["flops"] / 2 / 16384 / 3072 * 8192))
@@ -423,14 +440,14 @@ def main():
         TUNIT = "bytes per launch (L2<->fabric: FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache hits)"
         if mma:
             res["mma_kernel"] = mk(mma[0])
-            tr, src = pmc_traffic("gemm_bf16_kernel<8, 4, 2, 4, 3, 0", "mma_attn_bf16_kernel")
+            tr, src, stale = pmc_traffic("gemm_bf16_kernel<8, 4, 2, 4, 3, 0", "mma_attn_bf16_kernel")
             if tr is not None:     # QKV+RoPE GEMM main launch + attention core (the 120-row tail launch of the GEMM is not in the sum)
-                res["mma_kernel"].update(traffic=tr, traffic_unit=TUNIT, traffic_source=src,
+                res["mma_kernel"].update(traffic=tr, traffic_unit=TUNIT, traffic_source=src, traffic_stale=bool(stale),
                                          algorithmic_bytes_per_launch=int(2 * (B * L * 3072 + 9216 * 3072 + 3 * B * L * 3072) + 4 * B * L * 3072 * 2))
         if core is not None:
             pairs = L * (L + 1) // 2 + NV * max(0, (N_TXT - 17 + NV) - (6 + NV))
             cfl, cby = 4.0 * 96 * pairs * B * 32, 4.0 * B * L * 3072 * 2
-            tr, src = pmc_traffic("mma_attn_bf16_kernel")
+            tr, src, stale = pmc_traffic("mma_attn_bf16_kernel")
             res["mma_core"] = {"kernel": f"mma_attn_core (span-driven softmax(QK^T)V) B{B} H32 L{L}", "bound": "hbm",
                                "achieved": round(cby / core / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": round(cby / core / 1e6 / PEAK_HBM_GBS, 4), "traffic": tr, "avg_launch_ms": round(core, 4),
@@ -438,7 +455,7 @@ def main():
                                "mfma_tflops": round(cfl / core / 1e9, 1), "mfma_frac": round(cfl / core / 1e9 / PEAK_BF16_TFLOPS, 4),
                                "note": "219 FLOP/B: just on the HBM side of the ridge (312 FLOP/B); both fractions are given"}
             if src:
-                res["mma_core"].update(traffic_unit=TUNIT, traffic_source=src)
+                res["mma_core"].update(traffic_unit=TUNIT, traffic_source=src, traffic_stale=bool(stale))
         if world == 1 and not args.no_cpu_baseline:
             thr = _cpu_threads()
             res["cpu_baseline"] = cpu_baseline(model.state_dict(), model.media_token_id, thr)

@@ -442,7 +442,7 @@ int aki_decode_chain_fwd(const aki_decode_chain_args* args, void* stream);
  *                       (< 0 or >= V: ignored row), *n_valid (device int32) is an INPUT - the number of scored rows of the
  *                       whole batch.  With it the lm_head and the loss run chunk by chunk and the [B, L, V] logits tensor
  *                       is never formed (src/helpers.py:594-603 + train/losses.py:83-116).
- * aki_grad_sqnorm       *out (+)= sum g^2 over a bf16 gradient buffer (n % 8 == 0)
+ * aki_grad_sqnorm       *out (+)= sum g^2 over a gradient buffer (n % 8 == 0; dtype AKI_DT_BF16, or AKI_DT_F32 for the fp32 exchange)
  * aki_adamw_step        fp32 master weights p, moments m, v; bf16 gradients g -> updated p/m/v and bf16 weights w16.
  *                       g is scaled by gscale (1/world, 1/grad_accum) and, when sqnorm != NULL and max_norm > 0, clipped by
  *                       min(1, max_norm / (sqrt(*sqnorm) * gscale + 1e-6))  (torch.nn.utils.clip_grad_norm_ semantics).
@@ -489,6 +489,10 @@ int aki_grad_sqnorm(const void* g, size_t n, float* out, int32_t accumulate, int
                     void* stream);
 int aki_adamw_step(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* the same update from FP32 gradients: the reference's DDP path under `--precision amp_bf16` keeps fp32 parameters, so the gradients
+ * it all-reduces and its optimizer consumes are fp32 (train/train.py:311-312, train/train_utils.py:56-65) - AkiTrainer(reduce_dtype=float32) */
+int aki_adamw_step_g32(float* p, float* m, float* v, const float* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
 /* aki_quant_rows_fp8 - q[r][c] = e4m3(y[r][c] / scale[r]), scale[r] = max_c |y[r][c]| / 448, with y = x (bf16 [rows, cols])
  * or, when rms_weight != NULL, y = Phi3RMSNorm(x; rms_weight, rms_eps) (HF:phi3/modeling_phi3.py:266-284) - the input side

@@ -189,3 +189,51 @@ def test_sharded_exchange_world2_reduce_scatter_then_all_gather():
     for i, (st, n) in enumerate(zip(starts, sizes)):
         want = -((1 + 2) * (i + 1) + 2 * 1)
         assert bool((w0[st: st + n] == want).all()), (i, w0[st: st + 4], want)
+
+
+def _flat32_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aki_amd.dp import FlatGradReducer
+    n = 64
+    p = torch.nn.Parameter(torch.zeros(n))
+    q = torch.nn.Parameter(torch.zeros(n))
+    spans = [(p, 0, n), (q, n, 2 * n)]
+    flat = torch.zeros(2 * n, dtype=torch.bfloat16)
+    flat32 = torch.full((2 * n,), 7.0, dtype=torch.float32)          # stale content must be overwritten, not added to
+    red = FlatGradReducer(flat, spans, bucket_bytes=n * 2, group=None, flat32=flat32)
+    assert len(red.buckets) == 2
+    # rank 0 holds 1.0, rank 1 holds 1.5 * 2^-8: the exact sum 1.005859375 is not a bf16 number (a bf16 sum gives 1.0078125)
+    flat.fill_(1.0 if rank == 0 else 1.5 * 2.0 ** -8)
+    red.notify(q)
+    red.notify(p)
+    red.finish()
+    first = flat32.clone()
+    # an fp32 accumulation window: flat32 already holds the local sum, nothing is copied in
+    flat32.fill_(float(rank + 1) + 2.0 ** -20)
+    red.copy_in = False
+    red.notify(q)
+    red.notify(p)
+    red.finish()
+    ret[rank] = (first, flat32.clone(), flat.float().clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_flat_grad_reducer_fp32_exchange_world2():
+    """AkiTrainer(reduce_dtype=torch.float32) - the reference's DDP arithmetic under amp_bf16 (fp32 gradients all-reduced in fp32,
+    train/train.py:311-312): every bucket of the bf16 gradient buffer is widened into the fp32 buffer when it is launched, the
+    collective sums the fp32 slices, the bf16 buffer is left as the backward wrote it.  The sum equals the exact fp32 sum of the
+    ranks' bf16 gradients - a value a bf16 exchange cannot represent."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_flat32_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        first, second, local = ret[r]
+        assert bool((first == 1.0 + 1.5 * 2.0 ** -8).all())
+        assert float(torch.tensor(1.0 + 1.5 * 2.0 ** -8).to(torch.bfloat16)) != 1.0 + 1.5 * 2.0 ** -8
+        assert bool((second == 3.0 + 2.0 ** -19).all())
+        assert bool((local == (1.0 if r == 0 else 1.5 * 2.0 ** -8)).all()), "the bf16 buffer must stay as the backward left it"

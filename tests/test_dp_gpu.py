@@ -284,3 +284,59 @@ def test_two_rank_gradient_accumulation_matches_single_process(shard):
     assert abs(g0 - float(tr.grad_norm())) < 0.03 * float(tr.grad_norm()) + 1e-3, (g0, float(tr.grad_norm()))
     diff = (w0 - wref).abs()
     assert float(diff.mean()) < 2e-4 and float(diff.max()) <= 2 * 2 ** -7, (float(diff.mean()), float(diff.max()))
+
+
+def _fp32_exchange_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from aki_amd.trainer import AkiTrainer
+    m, vx, lx, am, lab = _setup()
+    default = AkiTrainer(m, lr=0.0)
+    assert default.shard, "more than one rank: the optimizer state is sharded unless the caller asks for the plain replica"
+    m, vx, lx, am, lab = _setup()
+    tr = AkiTrainer(m, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1, bucket_bytes=1 << 20, shard_optimizer=False, reduce_dtype=torch.float32)
+    assert tr.g32 is not None and not tr.shard and len(tr.reducer.buckets) >= 3
+    sl = slice(0, 2) if rank == 0 else slice(1, 2)        # different samples per rank (_setup's halves are copies of each other)
+    tr.zero_grad()
+    out = m(vx[sl], lx[sl], attention_mask=am[sl], labels=lab[sl])
+    tr.backward(out.loss)
+    torch.cuda.synchronize()
+    g_local, g_sum = tr.g16.float().cpu(), tr.g32.cpu()
+    tr.optimizer_step()
+    ret[rank] = (g_local, g_sum, _weights_in_param_order(tr), float(tr.grad_norm()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_fp32_gradient_exchange_two_ranks_is_the_exact_fp32_sum():
+    """AkiTrainer(reduce_dtype=torch.float32): what the reference's DDP path exchanges under `--precision amp_bf16` (fp32 parameters,
+    fp32 .grad, fp32 all-reduce: train/train.py:311-312, train/train_utils.py:56-65).  Two ranks (gloo, one GPU): after backward
+    the fp32 buffer of both ranks holds exactly float(g_rank0) + float(g_rank1) of the bf16 gradients the HIP backward wrote, the
+    bf16 buffers still hold the local gradients, and the optimizer (fp32-gradient AdamW) leaves both replicas with the same
+    weights.  Also: with more than one rank the optimizer state is sharded by default."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_fp32_exchange_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    (g0, s0, w0, n0), (g1, s1, w1, n1) = ret[0], ret[1]
+    assert torch.equal(s0, s1) and torch.equal(s0, g0 + g1)
+    assert float((g0 - g1).abs().max()) > 0.0, "the ranks saw different samples"
+    assert torch.equal(w0, w1) and n0 == n1
+    assert abs(n0 - float((s0 / 2).double().norm())) < 1e-5 * max(1.0, n0)
+
+
+def test_fp32_gradient_path_alone_equals_the_bf16_path():
+    """One rank: the fp32 buffer is just the widened bf16 gradients, so sqnorm + AdamW from fp32 gradients reproduce the bf16-gradient
+    step bit for bit - the two kernels differ in nothing but the load."""
+    from aki_amd.trainer import AkiTrainer
+    res = []
+    for rd in (None, torch.float32):
+        m, vx, lx, am, lab = _setup()
+        tr = AkiTrainer(m, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1, bucket_bytes=1 << 20, reduce_dtype=rd)
+        losses = [float(tr.train_step(vx, lx, attention_mask=am, labels=lab)) for _ in range(2)]
+        res.append((_weights_in_param_order(tr), losses, float(tr.grad_norm())))
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0])

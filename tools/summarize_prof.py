@@ -44,6 +44,10 @@ for k, cs in pmc.items():
         e["mfma_busy_frac_of_simd_cycles"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4), 4)
     out.append(e)
 out.sort(key=lambda e: e["kernel"])
+# which tree these counters were measured on: bench.py prints "traffic_stale": true when the running tree's kernels differ
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aki_amd.build import csrc_hash
+out.insert(0, {"kernel": "__meta__", "csrc_tree_hash": csrc_hash()})
 json.dump(out, open(dst + "_pmc_summary.json", "w"), indent=1)
 for e in out:
     print(json.dumps(e))

@@ -21,7 +21,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--layers", type=int, default=32)
-    ap.add_argument("--shard-optimizer", action="store_true", help="ZeRO/FSDP-style: reduce-scatter grads, 1/world optimizer state")
+    ap.add_argument("--shard-optimizer", action="store_true", help="ZeRO/FSDP-style: reduce-scatter grads, 1/world optimizer state (the default with more than one rank)")
+    ap.add_argument("--no-shard-optimizer", action="store_true", help="plain DDP replica: all-reduce, every rank updates everything")
+    ap.add_argument("--reduce-dtype", choices=["bf16", "fp32"], default="bf16", help="fp32 = the reference's DDP arithmetic under amp_bf16 (twice the bytes)")
     ap.add_argument("--shard-params", action="store_true", help="FSDP FULL_SHARD equivalent: weights, gradients and optimizer state sharded (AkiShardedTrainer)")
     ap.add_argument("--gpus", type=int, default=1, help="ranks of the job; without a launcher (WORLD_SIZE unset) --gpus N > 1 starts the N ranks itself")
     ap.add_argument("--bucket-mb", type=int, default=512, help="gradient bucket size; xGMI is point-to-point, few large messages")
@@ -66,7 +68,7 @@ def main():
         tr.shard = True
         tr.reducer = type("R", (), {"finish": staticmethod(lambda: None), "active": False, "buckets": tr.all_units})()
     else:
-        tr = AkiTrainer(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=1.0, shard_optimizer=a.shard_optimizer,
+        tr = AkiTrainer(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=1.0, shard_optimizer=(True if a.shard_optimizer else False if a.no_shard_optimizer else None), reduce_dtype=(torch.float32 if a.reduce_dtype == "fp32" else None),
                         bucket_bytes=a.bucket_mb << 20, exchange_when_alone=a.exchange_when_alone)
     B, L = a.batch, bench.N_TXT - 1 + bench.NV
     vx, ids, am = bench.synth_batch(B, dev, torch.bfloat16, model.media_token_id, seed=1000 + rank)
@@ -109,10 +111,9 @@ def main():
             losses.append(float(out.loss))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_min = elapsed
     if world > 1:
-        tt = torch.tensor([elapsed], device="cpu" if gloo else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, elapsed_min = bench.rank_spread(elapsed, "cpu" if gloo else dev)
     # the whole exchange on its own: every bucket back to back, nothing else on the GPU
     exch_ms = 0.0
     if tr.reducer.active:
@@ -125,6 +126,10 @@ def main():
             tr.reducer.finish()
             torch.cuda.synchronize()
         exch_ms = (time.perf_counter() - t1) / 3 * 1e3
+    # bytes one rank hands to the collectives per step (the all-gather of weights under optimizer / parameter sharding included)
+    exchange_dtype = str(getattr(tr, "reduce_dtype", torch.bfloat16)).replace("torch.", "")
+    esz = 4 if exchange_dtype == "float32" else 2
+    exchange_bytes = tr.numel * esz + (tr.numel * 2 if getattr(tr, "shard", False) else 0) + (2 * tr.numel * 2 if a.shard_params else 0)
     if rank == 0:
         n_lm = sum(p.numel() for n_, p in model.named_parameters() if n_.startswith("lang_model.") and "embed_tokens" not in n_)
         # 6 FLOP per parameter per token (fwd 2 + bwd 4) for the decoder + head, + the frozen tower's forward and the connector
@@ -132,16 +137,17 @@ def main():
         ms = elapsed / a.steps * 1e3
         print(json.dumps({
             "metric": "training tokens/s, AKI-4B pre-training step (fwd+bwd+all-reduce+clip+AdamW)", "value": round(B * world * L * a.steps / elapsed, 1),
-            "unit": "tokens/s", "n_gpus": world, "rccl_ranks": ranks_seen, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+            "unit": "tokens/s", "n_gpus": world, "rccl_ranks": ranks_seen, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
+            "ms_per_step_rank_min": round(elapsed_min / a.steps * 1e3, 2), "ms_per_step_rank_max": round(ms, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "AKI-4B pre-training step, BASELINE configs[2]: 336px image + 512-token prompt per sample, batch 8 per GPU, "
                                    "bf16 compute / fp32 master weights; random-init weights", "global_batch": B * world, "seq_len": L,
-                       "parallelism": f"dp{world}" + ("+sharded-params" if a.shard_params else "+sharded-optimizer" if a.shard_optimizer else ""), "bucket_mb": a.bucket_mb,
-                       "gradient_exchange": ("per-unit all-gather of weights (x2) + reduce-scatter of gradients" if a.shard_params else ("reduce-scatter + all-gather" if tr.shard else "all-reduce") + " of bf16 gradients, in place in the flat buffer"),
+                       "parallelism": f"dp{world}" + ("+sharded-params" if a.shard_params else "+sharded-optimizer" if getattr(tr, "shard", False) else ""), "bucket_mb": a.bucket_mb,
+                       "gradient_exchange": ("per-unit all-gather of weights (x2) + reduce-scatter of gradients" if a.shard_params else ("reduce-scatter + all-gather" if tr.shard else "all-reduce") + f" of {exchange_dtype} gradients, in place in the flat buffer"),
                        "layers": a.layers},
             "exchange_ms": round(exch_ms, 3), "exchange_exposed_ms": round(parts["exchange_exposed"] / a.steps, 3),
             "overlap_frac": (round(1.0 - min(1.0, (parts["exchange_exposed"] / a.steps) / exch_ms), 3) if exch_ms > 0 else None),
-            "buckets": len(tr.reducer.buckets),
+            "buckets": len(tr.reducer.buckets), "exchange_bytes": int(exchange_bytes), "exchange_dtype": exchange_dtype,
             "parts_ms": {k: round(v / a.steps, 2) for k, v in parts.items()}, "losses": [round(x, 4) for x in losses],
             "trainable_params": tr.numel, "lm_mfu_vs_2500TF": round(flops / (ms * 1e-3) / 2.5e15, 4),
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1), "precision": "bf16 compute, fp32 master/moments, bf16 grads", "head_chunk_rows": getattr(model.lang_model, "head_chunk_rows", 2688)}))
