@@ -104,6 +104,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+// Full LDS wait between the READS of a fold through LDS and their first use.  Round 3 met one site (the row-statistics fold of
+// gemm_bf16.hip) where the second half of a compiler-paired `ds_read2st64_b64`, consumed behind hipcc's counted `lgkmcnt(k > 0)`,
+// was used before it had arrived in 0.5 % of launches; the cause was never established, so every fold of cross-wave partials
+// through LDS now loads its values into registers, executes this, and only then adds them up (same order: bit-identical results).
+// tools/lgkm_audit.py lists what is left of the pattern (profiles/r04_lgkm_audit.txt).
+__device__ __forceinline__ void lds_reads_landed() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// ... and the values themselves made opaque behind that wait: a consumer is register arithmetic, which the "memory" clobber alone
+// does not keep from being scheduled above the wait (the decode merge's running max was).  No instruction is emitted for the ties.
+template <int N>
+__device__ __forceinline__ void lds_fold_ready(float (&v)[N]) {
+  lds_reads_landed();
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
 // ---- wave / workgroup reductions ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -487,8 +487,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* q, const T* k
   }
   __syncthreads();
   if (tid < DH) {
-    const float lt = s_l[0] + s_l[1] + s_l[2] + s_l[3];
-    const float a = s_acc[0][tid] + s_acc[1][tid] + s_acc[2][tid] + s_acc[3][tid];
+    float t[8] = {s_l[0], s_l[1], s_l[2], s_l[3], s_acc[0][tid], s_acc[1][tid], s_acc[2][tid], s_acc[3][tid]};
+    lds_fold_ready(t);
+    const float lt = t[0] + t[1] + t[2] + t[3];
+    const float a = t[4] + t[5] + t[6] + t[7];
     o[(size_t)bh * DH + tid] = (T)(lt > 0.f ? a / lt : 0.f);
   }
 }
@@ -670,19 +672,29 @@ __global__ __launch_bounds__(64) void decode_attn_split_kernel(const DecodeAttnP
   }
   __syncthreads();
   if (lane < 12) {
+    float sv[5][10];
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+      for (int e = 0; e < 10; ++e) sv[q][e] = s_mg[q][lane][e];
+    lds_reads_landed();
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+      for (int e = 0; e < 10; ++e) asm volatile("" : "+v"(sv[q][e]));
     float M5 = -INFINITY;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) M5 = fmaxf(M5, s_mg[q][lane][0]);
+    for (int q = 0; q < 5; ++q) M5 = fmaxf(M5, sv[q][0]);
     lt = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o8[e] = 0.f;
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
-      const float mq = s_mg[q][lane][0];
+      const float mq = sv[q][0];
       const float f = mq == -INFINITY ? 0.f : __expf(mq - M5);
-      lt += s_mg[q][lane][1] * f;
+      lt += sv[q][1] * f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o8[e] += s_mg[q][lane][2 + e] * f;
+      for (int e = 0; e < 8; ++e) o8[e] += sv[q][2 + e] * f;
     }
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     u32x4 ov;

@@ -484,20 +484,29 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
   if (lane < 12) {
+    float sv[5][10];
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+      for (int e = 0; e < 10; ++e) sv[q][e] = s_mg[(q * 12 + lane) * 10 + e];
+    lds_reads_landed();
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+      for (int e = 0; e < 10; ++e) asm volatile("" : "+v"(sv[q][e]));
     float M5 = -INFINITY;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) M5 = fmaxf(M5, s_mg[(q * 12 + lane) * 10]);
+    for (int q = 0; q < 5; ++q) M5 = fmaxf(M5, sv[q][0]);
     lt = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o8[e] = 0.f;
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
-      const float* sm = s_mg + (q * 12 + lane) * 10;
-      const float mq = sm[0];
+      const float mq = sv[q][0];
       const float f = mq == -INFINITY ? 0.f : __expf(mq - M5);
-      lt += sm[1] * f;
+      lt += sv[q][1] * f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o8[e] += sm[2 + e] * f;
+      for (int e = 0; e < 8; ++e) o8[e] += sv[q][2 + e] * f;
     }
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     u32x4 ov;

@@ -189,9 +189,13 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* part, b
   red[gl][cl] = s0 + s1;
   __syncthreads();
   if (gl == 0 && c < cols) {
+    float t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = red[i][cl];
+    lds_fold_ready(t);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += red[i][cl];
+    for (int i = 0; i < 16; ++i) s += t[i];
     if (accumulate) s += bf16_bits_to_f32(out[c]);
     ((__bf16*)out)[c] = (__bf16)s;
   }
@@ -235,8 +239,13 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const bf16_t* x, float
   for (int e = 0; e < 8; ++e) red[rl][(threadIdx.x & 7) * 8 + e] = acc[e];
   __syncthreads();
   if (threadIdx.x < 64) {
+    float t[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t[i] = red[i][threadIdx.x];
+    lds_fold_ready(t);
     float s = 0.f;
-    for (int i = 0; i < 32; ++i) s += red[i][threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += t[i];
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c < cols) part[(size_t)blockIdx.y * cols + c] = s;
   }
