@@ -579,7 +579,7 @@ static inline size_t chain_cnt_bytes(int n_layers, int H) { return aki_align_up(
 static inline size_t chain_vec_elems(int d, int H, int F) { return aki_align_up((size_t)(3 * H * 96 + H * 96 + d + F + 2 * d) * 2 + 256, 256) / 2; }   // one copy
 
 #ifdef AKI_LAB_HOOKS
-static int g_chain_sleep = 8, g_chain_xrep = CH_XREP_USED, g_chain_nflags = CH_FLAGS, g_chain_nowait = 0, g_chain_nb = 0;
+static int g_chain_sleep = 8, g_chain_xrep = CH_XREP_USED, g_chain_nflags = CH_FLAGS, g_chain_nowait = 0, g_chain_nb = 0, g_chain_lds_pad = 0;
 #endif
 
 static void chain_split(int H, int cap, int max_keys, int& S, int& T) {
@@ -648,9 +648,16 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   // weight stream (1.28 ms) with wrong logits, while the 2-layer graph test of the time happened to pass.
   // tests/test_decode_gpu.py now compares a FULL-DEPTH graph replay with the five-launch path, and every timing tool checks logits.
   hipLaunchKernelGGL(chain_zero_kernel, dim3((unsigned)((cb / 16 + 255) / 256)), dim3(256), 0, stream, (u32x4*)ws, (int)(cb / 16));
-  constexpr int SMEM = 16384 + 64;       // x (<= 8192 bf16) + the norm's partial sums; the attention phase carves 4 x 3 KiB of it
+  int SMEM = 16384 + 64;                 // x (<= 8192 bf16) + the norm's partial sums; the attention phase carves 4 x 3 KiB of it
+#ifdef AKI_LAB_HOOKS
+  SMEM += g_chain_lds_pad;               // lab: unused LDS that limits the workgroups resident per CU (160 KiB / SMEM)
+#endif
   const dim3 grid((unsigned)a->n_layers * (unsigned)p.wg_layer), block(256);
-#define AKI_CHAIN_LAUNCH(W8V, A, B, C, D) hipLaunchKernelGGL((decode_chain_kernel<6, 16, W8V, A, B, C, D>), grid, block, SMEM, stream, p)
+#define AKI_CHAIN_LAUNCH(W8V, A, B, C, D)                                                                                                   \
+  do {                                                                                                                                      \
+    if (SMEM > 48 * 1024) (void)hipFuncSetAttribute((const void*)decode_chain_kernel<6, 16, W8V, A, B, C, D>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); \
+    hipLaunchKernelGGL((decode_chain_kernel<6, 16, W8V, A, B, C, D>), grid, block, SMEM, stream, p);                                         \
+  } while (0)
   if (w8) AKI_CHAIN_LAUNCH(true, CH_NBQ, CH_NBO, CH_NBG, CH_NBD);
 #ifdef AKI_LAB_HOOKS
   else if (g_chain_nb == 1) AKI_CHAIN_LAUNCH(false, 8, 8, 8, 8);
@@ -676,6 +683,7 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
 #ifdef AKI_LAB_HOOKS
 // Lab build only: poll period (x 64 cycles), copies of the hand-off vectors (1..8), READY flags per phase (1..32), and
 // nowait = 1: no dependency waits at all (WRONG results - the time of the bare weight stream in this workgroup structure).
+extern "C" void aki_lab_set_chain_lds(int pad_bytes) { aki::g_chain_lds_pad = pad_bytes < 0 ? 0 : (pad_bytes > 140 * 1024 ? 140 * 1024 : pad_bytes); }
 // preset of batches per workgroup (qkv, o_proj, gate_up, down): 0 product {2,2,2,2}, 1 {8,8,8,8}, 2 {4,2,8,2}, 3 {8,2,8,4}, 4 {4,4,4,4}, 5 {16,4,16,4}, 6 {8,2,16,2}, 7 {1,1,1,1}, 8 {8,4,16,4}, 9 {2,1,4,1}, 10 {4,2,4,2}, 11 {2,2,4,2}
 extern "C" void aki_lab_set_chain_nb(int preset) { aki::g_chain_nb = (preset >= 0 && preset <= 11) ? preset : 0; }
 extern "C" void aki_lab_set_chain(int sleep_n, int xrep, int nflags, int nowait) {

@@ -709,6 +709,10 @@ int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, h
 #ifdef AKI_ATTN_SPLITS
     splits = AKI_ATTN_SPLITS;
 #endif
+#ifdef AKI_LAB_HOOKS
+    if (g_attn_variant == 6) splits = 1;     // ONE workgroup per (batch, head) pair: K/V cross the fabric once, half the resident slots stay empty at B*H = 256
+    if (g_attn_variant == 7) splits = 3;
+#endif
     const int s_l2 = a->L / AKI_ATTN_L2_ROWS;   // long sequences: more splits per pair, fewer pairs in flight per L2
     if (splits < s_l2) splits = s_l2;
     p.splits = splits < 1 ? 1 : (splits > p.nqt ? p.nqt : splits);

@@ -249,9 +249,10 @@ class Phi3DecoderLayer(nn.Module):
 
     def folds(self, h) -> bool:
         """Inference in bf16: both RMSNorms are folded into the GEMMs around them (forward_folded).  Not under parameter
-        sharding (train_ops.CACHE_WT is False there): the gain-folded weight copies are full-size and would stay resident on every
+        sharding (train_ops.sharded(weight)): the gain-folded weight copies are full-size and would stay resident on every
         rank, which is what FULL_SHARD exists to avoid - an evaluation forward then takes the unfolded path."""
-        return h.dtype == torch.bfloat16 and self._fp8 is None and T.CACHE_WT and not _ag(h, *self.parameters())
+        return (h.dtype == torch.bfloat16 and self._fp8 is None and T.CACHE_WT and not T.sharded(self.self_attn.qkv_proj.weight)
+                and not _ag(h, *self.parameters()))
 
     def train(self, mode: bool = True):
         if mode:

@@ -224,7 +224,14 @@ def adamw_step(p32, m, v, g, w16, sqnorm, max_norm, gscale, lr, beta1, beta2, ep
 # ---- transposed-weight cache -------------------------------------------------------------------------------------
 _EPOCH = 0            # bumped by the trainer after every optimizer step (the kernels write weights through raw pointers)
 _WT = {}
-CACHE_WT = True       # False under sharded parameters: a cache of transposed weights would re-materialise what sharding released
+CACHE_WT = True       # kill switch for every cached weight transform (tools flip it); sharded parameters opt out one by one, below
+
+
+def sharded(w) -> bool:
+    """Does this weight belong to a parameter-sharded unit (AkiShardedTrainer)?  A cached transform of it (transposed copy,
+    gain-folded copy) would keep full-size what sharding releases after every use - such weights are never cached.  Per weight:
+    until round 4 constructing a sharded trainer switched the caches off for every model of the process, for good."""
+    return getattr(w, "_aki_unit", None) is not None
 
 
 def bump_weight_epoch() -> None:
@@ -237,7 +244,7 @@ def _weight_t(w: torch.Tensor) -> torch.Tensor:
     """W [N,K] -> W^T [K, pad64(N)] (zero padded), cached until the weights change: the trainer bumps the epoch after every
     optimizer step (its kernels write through raw pointers), in-place torch updates show up in `_version`.  Temporaries (the
     lm_head's concatenated weight is a new tensor every forward) would pile up without a trainer, hence the size cap."""
-    if not CACHE_WT or not (isinstance(w, torch.nn.Parameter) or hasattr(w, "_aki_grad") or getattr(w, "_aki_cacheable", False)):
+    if not CACHE_WT or sharded(w) or not (isinstance(w, torch.nn.Parameter) or hasattr(w, "_aki_grad") or getattr(w, "_aki_cacheable", False)):
         # a temporary (slice / concatenation built inside a forward): its (data_ptr, _version) says nothing about its content -
         # the allocator recycles the address and a fresh tensor is always version 0 - so it is transposed every time
         return transpose(w if w.stride(1) == 1 else w.contiguous())

@@ -440,8 +440,7 @@ class AkiShardedTrainer:
         self.numel = sum(u.numel for u in self.all_units)
         self._last = None                  # unit whose reduce-scatter is in flight
         self.enabled = True
-        T.CACHE_WT = False
-        T.bump_weight_epoch()
+        T.bump_weight_epoch()            # (cached transforms of these weights: train_ops.sharded() keeps them out of the caches)
 
     # ---- hooks ---------------------------------------------------------------------------------------------------------
     def _after_forward(self, u, out):
