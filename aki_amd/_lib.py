@@ -150,6 +150,7 @@ SIGNATURES = {
     "aki_grad_sqnorm_workspace_bytes": (C.c_size_t, []),
     "aki_grad_sqnorm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_adamw_step": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p] + [C.c_float] * 7 + [C.c_int32, C.c_void_p]),
+    "aki_adamw_step_t": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p] + [C.c_float] * 7 + [C.c_int32, C.c_int32, C.c_void_p]),
     "aki_adamw_step_g32": (C.c_int, [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p] + [C.c_float] * 7 + [C.c_int32, C.c_void_p]),
     "aki_quant_rows_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "aki_splice_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -73,6 +73,8 @@ int ce_rows_launch(const void* logits, const int64_t* targets, const int* n_vali
                    int ldl, int lddl, float gscale, hipStream_t s);
 size_t grad_sqnorm_ws_bytes();
 int grad_sqnorm_launch(const void* g, size_t n, float* out, int accumulate, void* ws, size_t ws_bytes, bool g32, hipStream_t s);
+int adamw_t_launch(float* p, float* m, float* v, const void* g, void* w16, void* wT, int N, int K, int ldT, const float* sqnorm, float max_norm,
+                   float gscale, float lr, float beta1, float beta2, float eps, float wd, int step, bool g32, hipStream_t s);
 int adamw_launch(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
                  float lr, float beta1, float beta2, float eps, float wd, int step, bool g32, hipStream_t s);
 }  // namespace aki
@@ -528,6 +530,16 @@ int aki_adamw_step(float* p, float* m, float* v, const void* g, void* w16, size_
   AKI_CLEAR_ERR();
   AKI_CHECK_ARG(p && m && v && g && w16 && n > 0 && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f);
   return adamw_launch(p, m, v, g, w16, n, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step, false, (hipStream_t)stream);
+}
+
+int aki_adamw_step_t(float* p, float* m, float* v, const void* g, void* w16, void* wT, int32_t N, int32_t K, int32_t ldT, const float* sqnorm,
+                     float max_norm, float gscale, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                     int32_t grad_dtype, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(p && m && v && g && w16 && wT && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f);
+  if (grad_dtype != AKI_DT_BF16 && grad_dtype != AKI_DT_F32) return AKI_ERR_UNSUPPORTED;
+  return adamw_t_launch(p, m, v, g, w16, wT, N, K, ldT, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step, grad_dtype == AKI_DT_F32,
+                        (hipStream_t)stream);
 }
 
 int aki_adamw_step_g32(float* p, float* m, float* v, const float* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,

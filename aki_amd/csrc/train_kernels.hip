@@ -610,6 +610,81 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamwParams a) {
   }
 }
 
+// The same update for ONE 2-D weight [N, K] that also leaves W^T [K, ldT] (ldT = N padded to x64, padding columns zero) - the operand the
+// backward's input-gradient GEMMs read (train_ops._weight_t).  The bf16 weights are being written anyway: turning each 64 x 64 tile through LDS
+// costs one more 2-byte store per element and saves the separate aki_transpose pass over every weight after every optimizer step (read + write).
+struct AdamwTParams {
+  float* p; float* m; float* v; const void* g; bf16_t* w16; bf16_t* wT; int N, K, ldT;
+  const float* sqnorm; float max_norm, gscale, lr, beta1, beta2, eps, wd, bc1, bc2;
+};
+
+template <bool G32>
+__global__ __launch_bounds__(256) void adamw_t_kernel(const AdamwTParams a) {
+  __shared__ bf16_t tile[64][66];
+  float clip = 1.f;
+  if (a.sqnorm && a.max_norm > 0.f) clip = fminf(1.f, a.max_norm / (sqrtf(*a.sqnorm) * a.gscale + 1e-6f));
+  const float gs = a.gscale * clip;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 16 * i, c = c0 + tx * 4;
+    u32x2 wo = {0u, 0u};
+    if (r < a.N && c < a.K) {                     // K is a multiple of 4: a 4-column run is inside the row or outside it
+      const size_t idx = (size_t)r * a.K + c;
+      float gin[4];
+      if constexpr (G32) {
+        *(f32x4*)&gin[0] = *(const f32x4*)((const float*)a.g + idx);
+      } else {
+        const u32x2 gv = *(const u32x2*)((const bf16_t*)a.g + idx);
+        gin[0] = bf16_lo(gv[0]); gin[1] = bf16_hi(gv[0]); gin[2] = bf16_lo(gv[1]); gin[3] = bf16_hi(gv[1]);
+      }
+      float p[4], m[4], v[4];
+      *(f32x4*)&p[0] = *(const f32x4*)(a.p + idx);
+      *(f32x4*)&m[0] = *(const f32x4*)(a.m + idx);
+      *(f32x4*)&v[0] = *(const f32x4*)(a.v + idx);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {               // the arithmetic of adamw_kernel, operation for operation
+        const float g = gin[j] * gs;
+        p[j] *= 1.f - a.lr * a.wd;
+        m[j] = a.beta1 * m[j] + (1.f - a.beta1) * g;
+        v[j] = a.beta2 * v[j] + (1.f - a.beta2) * g * g;
+        p[j] -= a.lr * (m[j] / a.bc1) / (sqrtf(v[j] / a.bc2) + a.eps);
+      }
+      *(f32x4*)(a.p + idx) = *(f32x4*)&p[0];
+      *(f32x4*)(a.m + idx) = *(f32x4*)&m[0];
+      *(f32x4*)(a.v + idx) = *(f32x4*)&v[0];
+      wo = u32x2{pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3])};
+      *(u32x2*)(a.w16 + idx) = wo;
+    }
+    *(unsigned*)&tile[ty + 16 * i][tx * 4] = wo[0];            // rows >= N / columns >= K: zeros (the padding of W^T)
+    *(unsigned*)&tile[ty + 16 * i][tx * 4 + 2] = wo[1];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 16 * i, r = r0 + tx * 4;            // output row c of W^T, output columns r..r+3
+    if (c >= a.K || r >= a.ldT) continue;
+    const unsigned lo = tile[tx * 4][ty + 16 * i] | ((unsigned)tile[tx * 4 + 1][ty + 16 * i] << 16);
+    const unsigned hi = tile[tx * 4 + 2][ty + 16 * i] | ((unsigned)tile[tx * 4 + 3][ty + 16 * i] << 16);
+    *(u32x2*)(a.wT + (size_t)c * a.ldT + r) = u32x2{lo, hi};
+  }
+}
+
+int adamw_t_launch(float* p, float* m, float* v, const void* g, void* w16, void* wT, int N, int K, int ldT, const float* sqnorm, float max_norm,
+                   float gscale, float lr, float beta1, float beta2, float eps, float wd, int step, bool g32, hipStream_t s) {
+  if (N <= 0 || K <= 0 || K % 4 || ldT % 64 || ldT < N || step < 1) return AKI_ERR_INVALID_ARG;
+  if ((((size_t)p | (size_t)m | (size_t)v) & 15) || ((size_t)w16 & 7) || ((size_t)wT & 7) || ((size_t)g & (g32 ? 15 : 7))) return AKI_ERR_ALIGNMENT;
+  AdamwTParams a = {p, m, v, g, (bf16_t*)w16, (bf16_t*)wT, N, K, ldT, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, wd,
+                    1.f - powf(beta1, (float)step), 1.f - powf(beta2, (float)step)};
+  const dim3 grid((K + 63) / 64, ldT / 64);
+  AKI_CLEAR_ERR();
+  if (g32) hipLaunchKernelGGL(adamw_t_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(adamw_t_kernel<false>, grid, dim3(256), 0, s, a);
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
+}
+
 int adamw_launch(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
                  float lr, float beta1, float beta2, float eps, float wd, int step, bool g32, hipStream_t s) {
   if (n % 8 || step < 1) return AKI_ERR_INVALID_ARG;

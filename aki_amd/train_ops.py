@@ -221,6 +221,20 @@ def adamw_step(p32, m, v, g, w16, sqnorm, max_norm, gscale, lr, beta1, beta2, ep
                float(beta1), float(beta2), float(eps), float(wd), int(step), _stream()), "aki_adamw_step")
 
 
+def adamw_step_t(p32, m, v, g, w16, wT, N, K, sqnorm, max_norm, gscale, lr, beta1, beta2, eps, wd, step) -> None:
+    """adamw_step for one 2-D weight [N, K] (flat views of N*K elements) that also writes W^T into wT [K, pad64(N)]."""
+    _dev(p32, m, v, g, w16, wT, sqnorm)
+    L.check(L.load().aki_adamw_step_t(_ptr(p32), _ptr(m), _ptr(v), _ptr(g), _ptr(w16), _ptr(wT), int(N), int(K), int(wT.shape[1]), _ptr(sqnorm),
+                                      float(max_norm), float(gscale), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
+                                      L.AKI_DT_F32 if g.dtype == torch.float32 else _BF16, _stream()), "aki_adamw_step_t")
+
+
+def register_weight_t(w: torch.Tensor, wT: torch.Tensor) -> None:
+    """Hand the cache a transposed copy somebody else made of the CURRENT weights (the trainer's AdamW pass): _weight_t(w) returns it
+    until the next epoch bump."""
+    _WT[(w.data_ptr(), tuple(w.shape), w._version, _EPOCH)] = wT
+
+
 # ---- transposed-weight cache -------------------------------------------------------------------------------------
 _EPOCH = 0            # bumped by the trainer after every optimizer step (the kernels write weights through raw pointers)
 _WT = {}

@@ -22,7 +22,8 @@ from .dp import FlatGradReducer
 class AkiTrainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                  max_grad_norm: float = 1.0, bucket_bytes: int = 512 << 20, group=None, shard_optimizer: Optional[bool] = None,
-                 exchange_when_alone: bool = False, clip_every_microbatch: bool = False, reduce_dtype: Optional[torch.dtype] = None):
+                 exchange_when_alone: bool = False, clip_every_microbatch: bool = False, reduce_dtype: Optional[torch.dtype] = None,
+                 emit_transposes: bool = True):
         """shard_optimizer: keep fp32 master weights and moments only for this rank's 1/world slice of every gradient
         bucket (reduce-scatter + all-gather instead of all-reduce) - the memory behaviour of the reference's FSDP launch
         configs (train/distributed.py:170-243, scripts/run_train.sh:23) for the optimizer state.  Default (None): ON whenever
@@ -36,7 +37,10 @@ class AkiTrainer:
         exchanged bytes and one more flat buffer (4 bytes per parameter).
         exchange_when_alone: run the collectives even when the process group has a single rank (identities) - a one-GPU
         box then exercises the real RCCL reduce-scatter / all-gather / all-reduce entry points and stream hand-off.
-        clip_every_microbatch: single-rank parity only (see backward())."""
+        clip_every_microbatch: single-rank parity only (see backward()).
+        emit_transposes: (unsharded optimizer only) the AdamW pass of every 2-D weight also writes W^T, the operand of the backward's
+        input-gradient GEMMs, into a buffer this trainer owns - instead of one aki_transpose launch per weight after every optimizer step
+        (a read and a write of all 7.8 GB of bf16 weights: 3 ms of the 150 ms step).  Same arithmetic: weights bit-identical either way."""
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
@@ -119,6 +123,23 @@ class AkiTrainer:
         for b_ in model.buffers():
             if b_.dtype == torch.float32 and b_.dim() > 0:
                 pass                               # RoPE tables etc. stay f32 (the kernels take f32 cos/sin)
+        # W^T emitted by the optimizer pass: 2-D trainable weights with K % 4 == 0, when this rank updates every element itself
+        self.t_jobs = []                         # (param, flat lo, flat hi, N, K, W^T view)
+        if emit_transposes and not self.shard:
+            tot = 0
+            elig = []
+            # the weights the backward transposes: nn.Linear weights that go through train_ops.linear / QkvRopeFn (not embeddings; not the
+            # lm_head, whose chunked head + loss node reads its weight segments in place)
+            lin = {id(m.weight) for n_, m in model.named_modules() if isinstance(m, torch.nn.Linear) and "lm_head" not in n_}
+            for p, lo, hi in spans:
+                if id(p) in lin and p.dim() == 2 and p.shape[1] % 4 == 0 and lo % 8 == 0:
+                    N_, K_ = int(p.shape[0]), int(p.shape[1])
+                    ldT = (N_ + 63) // 64 * 64
+                    elig.append((p, lo, hi, N_, K_, tot, ldT))
+                    tot += K_ * ldT
+            if elig:
+                self.wT = torch.zeros(tot, dtype=torch.bfloat16, device=dev)
+                self.t_jobs = [(p, lo, hi, N_, K_, self.wT[o: o + K_ * ldT].view(K_, ldT)) for p, lo, hi, N_, K_, o, ldT in elig]
         T.bump_weight_epoch()
 
     # ---- one step ---------------------------------------------------------------------------------------------------
@@ -201,15 +222,35 @@ class AkiTrainer:
             first = False
         if self.shard:                           # every rank holds the sum over its own slices: one scalar all-reduce
             dist.all_reduce(self.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
-        for lo, hi, so, decay in self.owned:
-            n = hi - lo
-            T.adamw_step(self.master[so:so + n], self.m[so:so + n], self.v[so:so + n], g[lo:hi], self.w16[lo:hi],
-                         self.sqnorm, self.max_grad_norm, gscale, self.lr, self.betas[0], self.betas[1], self.eps, decay,
-                         self.step_count)
+        hp = (self.sqnorm, self.max_grad_norm, gscale, self.lr, self.betas[0], self.betas[1], self.eps)
+        if self.t_jobs:
+            # unsharded: state offsets = flat offsets.  2-D weights go through the transposing kernel one by one, everything between them
+            # (1-D parameters, alignment gaps) through the flat kernel, segment by segment (weight decay differs)
+            jobs = iter(self.t_jobs)
+            job = next(jobs, None)
+            for s0, s1, decay in self.segments:
+                at = s0
+                while job is not None and job[1] < s1:
+                    p_, lo, hi, N_, K_, wT = job
+                    if lo > at:
+                        T.adamw_step(self.master[at:lo], self.m[at:lo], self.v[at:lo], g[at:lo], self.w16[at:lo], *hp, decay, self.step_count)
+                    T.adamw_step_t(self.master[lo:hi], self.m[lo:hi], self.v[lo:hi], g[lo:hi], self.w16[lo:hi], wT, N_, K_, *hp, decay,
+                                   self.step_count)
+                    at = (hi + 7) // 8 * 8
+                    job = next(jobs, None)
+                if s1 > at:
+                    T.adamw_step(self.master[at:s1], self.m[at:s1], self.v[at:s1], g[at:s1], self.w16[at:s1], *hp, decay, self.step_count)
+        else:
+            for lo, hi, so, decay in self.owned:
+                n = hi - lo
+                T.adamw_step(self.master[so:so + n], self.m[so:so + n], self.v[so:so + n], g[lo:hi], self.w16[lo:hi], *hp, decay,
+                             self.step_count)
         self.reducer.all_gather_weights(self.w16)
         if self.g32 is None:
             self.gacc = None                     # the fp32 accumulator of a finished window (15.6 GB for AKI-4B) is not kept
         T.bump_weight_epoch()
+        for p_, lo, hi, N_, K_, wT in self.t_jobs:             # the transposes of the weights just written
+            T.register_weight_t(p_, wT)
 
     # ---- checkpoint / resume (train/train_utils.py:395-460 saves model + optimizer state; the I/O itself is out of scope) ----
     def refresh_master(self) -> None:

@@ -489,6 +489,12 @@ int aki_grad_sqnorm(const void* g, size_t n, float* out, int32_t accumulate, int
                     void* stream);
 int aki_adamw_step(float* p, float* m, float* v, const void* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* aki_adamw_step for ONE 2-D weight [N, K] (K % 4 == 0) that also writes W^T [K, ldT] (ldT = N rounded up to x64, padding columns zero) -
+ * what aki_transpose would make of the updated bf16 weight, in the same pass (the backward's input-gradient GEMMs read W^T).
+ * grad_dtype: AKI_DT_BF16 or AKI_DT_F32. */
+int aki_adamw_step_t(float* p, float* m, float* v, const void* g, void* w16, void* wT, int32_t N, int32_t K, int32_t ldT, const float* sqnorm,
+                     float max_norm, float gscale, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                     int32_t grad_dtype, void* stream);
 /* the same update from FP32 gradients: the reference's DDP path under `--precision amp_bf16` keeps fp32 parameters, so the gradients
  * it all-reduces and its optimizer consumes are fp32 (train/train.py:311-312, train/train_utils.py:56-65) - AkiTrainer(reduce_dtype=float32) */
 int aki_adamw_step_g32(float* p, float* m, float* v, const float* g, void* w16, size_t n, const float* sqnorm, float max_norm, float gscale,

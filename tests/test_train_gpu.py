@@ -682,3 +682,30 @@ def test_mma_attention_backward_random_masks(seed):
     close(dq, qr.grad, tol=3e-2, what=f"dq (seed {seed})")
     close(dk, kr.grad, tol=3e-2, what=f"dk (seed {seed})")
     close(dv, vr.grad, tol=3e-2, what=f"dv (seed {seed})")
+
+
+def test_adamw_emits_the_transposed_weights_and_changes_nothing_else():
+    """AkiTrainer(emit_transposes=True, the default without optimizer sharding): the AdamW pass of every nn.Linear weight also writes W^T
+    (aki_adamw_step_t) and registers it with the transposed-weight cache, so the next backward launches no aki_transpose for them.
+    (1) after every optimizer step each registered W^T equals aki_transpose of the bf16 weight bit for bit (padding columns zero);
+    (2) losses, gradient norms and weights over three steps are bit-identical to a trainer with the emission off; (3) the cache
+    serves the emitted buffers - the same storage - to the backward."""
+    from aki_amd import train_ops as T
+    from aki_amd.trainer import AkiTrainer
+    res = {}
+    for emit in (False, True):
+        _, _, m, _, (vx, lx, am, lab) = _tiny_train_setup()
+        tr = AkiTrainer(m, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1, max_grad_norm=1.0, emit_transposes=emit)
+        assert bool(tr.t_jobs) == emit
+        losses, norms = [], []
+        for _ in range(3):
+            losses.append(float(tr.train_step(vx, lx, attention_mask=am, labels=lab)))
+            norms.append(float(tr.grad_norm()))
+            if emit:
+                assert len(tr.t_jobs) >= 4 * len(m.lang_model.model.layers)
+                for p_, lo, hi, N_, K_, wT in tr.t_jobs:
+                    assert torch.equal(wT, T.transpose(p_.detach())), f"W^T of a {tuple(p_.shape)} weight differs from aki_transpose"
+                    assert T._weight_t(p_).data_ptr() == wT.data_ptr(), "the cache does not serve the emitted transpose"
+        res[emit] = (losses, norms, torch.cat([p.detach().float().reshape(-1).cpu() for p in tr.params]))
+    assert res[False][0] == res[True][0] and res[False][1] == res[True][1]
+    assert torch.equal(res[False][2], res[True][2])

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--shard-optimizer", action="store_true", help="ZeRO/FSDP-style: reduce-scatter grads, 1/world optimizer state (the default with more than one rank)")
+    ap.add_argument("--no-emit-transposes", action="store_true", help="A/B: one aki_transpose per weight after every optimizer step instead of W^T out of the AdamW pass")
     ap.add_argument("--no-shard-optimizer", action="store_true", help="plain DDP replica: all-reduce, every rank updates everything")
     ap.add_argument("--reduce-dtype", choices=["bf16", "fp32"], default="bf16", help="fp32 = the reference's DDP arithmetic under amp_bf16 (twice the bytes)")
     ap.add_argument("--shard-params", action="store_true", help="FSDP FULL_SHARD equivalent: weights, gradients and optimizer state sharded (AkiShardedTrainer)")
@@ -68,7 +69,7 @@ def main():
         tr.shard = True
         tr.reducer = type("R", (), {"finish": staticmethod(lambda: None), "active": False, "buckets": tr.all_units})()
     else:
-        tr = AkiTrainer(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=1.0, shard_optimizer=(True if a.shard_optimizer else False if a.no_shard_optimizer else None), reduce_dtype=(torch.float32 if a.reduce_dtype == "fp32" else None),
+        tr = AkiTrainer(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=1.0, shard_optimizer=(True if a.shard_optimizer else False if a.no_shard_optimizer else None), reduce_dtype=(torch.float32 if a.reduce_dtype == "fp32" else None), emit_transposes=not a.no_emit_transposes,
                         bucket_bytes=a.bucket_mb << 20, exchange_when_alone=a.exchange_when_alone)
     B, L = a.batch, bench.N_TXT - 1 + bench.NV
     vx, ids, am = bench.synth_batch(B, dev, torch.bfloat16, model.media_token_id, seed=1000 + rank)
