@@ -197,6 +197,10 @@ def load_lab() -> C.CDLL:
     lib.aki_lab_set_chain.argtypes = [C.c_int] * 4
     lib.aki_lab_set_chain_nb.restype = None
     lib.aki_lab_set_chain_nb.argtypes = [C.c_int]
+    lib.aki_lab_set_chain_touch.restype = None
+    lib.aki_lab_set_chain_touch.argtypes = [C.c_int]
+    lib.aki_lab_set_chain_stamps.restype = None
+    lib.aki_lab_set_chain_stamps.argtypes = [C.c_void_p, C.c_int]
     lib.aki_lab_set_chain_lds.restype = None
     lib.aki_lab_set_chain_lds.argtypes = [C.c_int]
     return lib

@@ -26,6 +26,8 @@
 // Arithmetic = decode.hip's, row for row: one wave owns whole weight rows, lane l takes 16-byte chunks l, l+64, ... of a row
 // in ascending order, the same xor-shuffle reduction, the same epilogue formulas, the same split-KV attention (same tiles,
 // same merge order) - a chained step reproduces the five-launch step bit for bit (tests/test_decode_gpu.py).
+#include <type_traits>
+
 #include "aki_device.h"
 
 namespace aki {
@@ -58,6 +60,16 @@ __device__ __forceinline__ float cdot16_w8(const u32x4 w, const u32x4 x0, const 
   return acc;
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_chain_impl(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_chain_impl<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for_chain(F&& f) { static_for_chain_impl<0, N>(f); }
+
 #define AKI_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 // pointers that arrive through the layer table are generic to the compiler: say "global" or every load is a flat_load
 typedef const __attribute__((address_space(1))) u32x4* gptr_u32x4;
@@ -80,7 +92,11 @@ constexpr int CH_PHASES = 5;             // [0] qkv [1] attention (per-head merg
 // Two each: 576 / 192 / 1024 / 384 workgroups per layer.  More batches cut the x traffic (the bare stream runs 1.41 ms per token at two,
 // 1.20 ms at {8,4,16,4}) but every batch after the first is loaded AFTER the dependency wait, on the critical path of its phase:
 // with the waits in, {1,1,1,1} 1.90, {2,2,2,2} 1.80, {4,4,4,4} 2.40, {8,4,16,4} 3.04 ms per token (tools/decode_chain_regimes.py).
-constexpr int CH_NBQ = 2, CH_NBO = 2, CH_NBG = 2, CH_NBD = 2;
+constexpr int CH_NBQ = 2, CH_NBO = 2, CH_NBG = 4, CH_NBD = 2;
+// ... of which this many are requested BEFORE the wait (register slots): with both batches of qkv / o_proj on chip when their input arrives, those phases
+// take x staging + 1.2 us instead of + 4 us (tools/decode_chain_edges.py); gate_up is bandwidth-bound whatever is prefetched; 1.78 -> 1.62 ms per token.
+constexpr int CH_PFQ = 2, CH_PFO = 2, CH_PFG = 2, CH_PFD = 1;
+constexpr int CH_TOUCH = 0;
 constexpr int CH_XREP = 8;               // room for copies of every hand-off vector: consumer j reads copy j % xrep
 constexpr int CH_XREP_USED = 2;          // copies in use: with 100-200 consumers per phase two spread the readers enough, and every copy is
                                          // one more write-through store per producing lane (8 copies: +35 us per token)
@@ -101,7 +117,22 @@ struct ChainParams {
   int n_qkv, n_attn, n_o, n_gu, n_down, wg_layer;
   int sleep_n, xrep, nflags, nowait;   // product: 8, CH_XREP_USED, CH_FLAGS, 0; the lab library can change them (aki_lab_set_chain)
   int nbq, nbo, nbg, nbd;              // batches of 4 x FPW features per workgroup of the qkv / o_proj / gate_up / down phases
+  int touch;                           // 1: a waiting workgroup pulls the batches it holds no registers for towards L2 / the Infinity Cache
+#ifdef AKI_LAB_HOOKS
+  unsigned long long* stamps;          // lab: [phase 0..4][workgroup < 2048][8] wall-clock stamps (100 MHz) of layer `stamp_layer`
+  int stamp_layer;
+#endif
 };
+
+#ifdef AKI_LAB_HOOKS
+#define AKI_CHAIN_STAMP(p, layer, phase, wg, k)                                                                   \
+  do {                                                                                                            \
+    if ((p).stamps && (layer) == (p).stamp_layer && threadIdx.x == 0 && (wg) < 2048)                              \
+      (p).stamps[((size_t)(phase) * 2048 + (wg)) * 8 + (k)] = wall_clock64();                                     \
+  } while (0)
+#else
+#define AKI_CHAIN_STAMP(p, layer, phase, wg, k) do { } while (0)
+#endif
 
 // ---- hand-off primitives ------------------------------------------------------------------------------------------------
 // Vector loads of handed-off bytes: buffer_load_dwordx4 ... sc1 (aux 16), 16-byte aligned offsets.
@@ -163,7 +194,7 @@ __device__ __forceinline__ void chain_publish(unsigned* sync, int idx, int n) {
 // vector through the fabric (sc1), and at one batch per workgroup those reads were 15 % of all bytes moved - the weight stream
 // ran at exactly 6.3 TB/s / 1.15 with the dependency waits switched off (tools/decode_chain_ab.py).  Batch 0 is loaded before the
 // wait; batch b+1 as soon as the dot products have released the registers of batch b, under its reduction and epilogue.
-template <int NR, int KC, bool SWIGLU, bool NORM, bool W8, int NB>
+template <int NR, int KC, bool SWIGLU, bool NORM, bool W8, int NB, int PF>
 __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_wg, const void* w, const float* w_scale, int K, int n_out,
                                            const bf16_t* x, int x_rep, const bf16_t* norm_w, const bf16_t* residual, int res_rep, bf16_t* y,
                                            int y_reps, unsigned* wait_sync, unsigned* done_sync, unsigned code, char* sx, float* s_red) {
@@ -172,23 +203,46 @@ __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_w
   constexpr int nb = NB;
   const int fbase = wg * (4 * FPW * nb) + wave * FPW;
   const size_t row_bytes = W8 ? (size_t)K : (size_t)K * 2;
-  u32x4 wv[NR][KC];
-  float wsc[NR];
-  auto issue = [&](int f0) {
+  // PF batches are requested before the wait (register slots b % PF); with PF = NB nothing is left to load once the input is there
+  static_assert(PF >= 1 && PF <= NB, "prefetch depth");
+  u32x4 wv[PF][NR][KC];
+  float wsc[PF][NR];
+  auto issue = [&](int f0, auto slot_c) {
+    constexpr int SL = decltype(slot_c)::value;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int f = min(f0 + (r % FPW), n_out - 1);
       const int row = (SWIGLU && r >= FPW) ? n_out + f : f;
       const char* wr = (const char*)w + (size_t)row * row_bytes;
-      wsc[r] = W8 ? ((gptr_f32)w_scale)[row] : 1.f;
+      wsc[SL][r] = W8 ? ((gptr_f32)w_scale)[row] : 1.f;
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) wv[r][kc] = __builtin_nontemporal_load(AKI_G128(wr + (size_t)(lane + 64 * kc) * 16));
+      for (int kc = 0; kc < KC; ++kc) wv[SL][r][kc] = __builtin_nontemporal_load(AKI_G128(wr + (size_t)(lane + 64 * kc) * 16));
     }
   };
-  // (2) the weight loads of this wave's first batch, before anything that depends on another workgroup
-  issue(fbase);
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 0);
+  // (2) the weight loads of this wave's first PF batches, before anything that depends on another workgroup
+  static_for_chain<PF>([&](auto b_c) { issue(fbase + decltype(b_c)::value * 4 * FPW, b_c); });
+  // (2b) the batches beyond the register slots: one dword per 128-byte line, default cache policy, result unused - the lines travel
+  // HBM -> Infinity Cache -> this XCD's L2 while the workgroup waits, and the real (nt) loads after the wait find them on the die
+  unsigned touched = 0;
+  if constexpr (PF < NB) {
+    if (p.touch) {
+#pragma unroll
+      for (int b = PF; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int f = min(fbase + b * 4 * FPW + (r % FPW), n_out - 1);
+          const int row = (SWIGLU && r >= FPW) ? n_out + f : f;
+          const char* wr = (const char*)w + (size_t)row * row_bytes;
+#pragma unroll
+          for (int o = 0; o < KC * 1024; o += 64 * 128)
+            if (o + lane * 128 < KC * 1024) touched |= *(volatile const __attribute__((address_space(1))) unsigned*)(wr + o + lane * 128);
+        }
+    }
+  }
   // (3) the producer phase has published
   chain_wait(p, wait_sync, wg, code);
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 1);
   // (4) x -> LDS.  Handed-off bytes: sc1 loads only, from this workgroup's copy of the vector.
   const int nchunk = K / 8;
   x += (size_t)(x_rep ? (wg % p.xrep) * p.rep_stride : 0);
@@ -233,8 +287,11 @@ __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_w
     for (int c = tid; c < nchunk; c += 256) *(u32x4*)(sx + (size_t)c * 16) = ld_sc1_b128(rx, c * 16);
   }
   __syncthreads();
-#pragma unroll
-  for (int b = 0; b < nb; ++b) {
+  asm volatile("" :: "v"(touched));    // the touch loads are older than the x loads above: nothing waits here
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 2);
+  static_for_chain<NB>([&](auto b_c) {
+    constexpr int b = decltype(b_c)::value;
+    constexpr int SL = b % PF;
     const int f0 = fbase + b * 4 * FPW;
     unsigned long long res_bits = 0;
     if (residual != nullptr && lane == 0 && f0 < n_out) {            // in flight under the dot products
@@ -246,24 +303,24 @@ __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_w
     float acc[NR];
     float sc[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) { acc[r] = 0.f; sc[r] = wsc[r]; }
+    for (int r = 0; r < NR; ++r) { acc[r] = 0.f; sc[r] = wsc[SL][r]; }
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       const int c = lane + 64 * kc;
       if constexpr (W8) {
         const u32x4 x0 = *(const u32x4*)(sx + (size_t)(2 * c) * 16), x1 = *(const u32x4*)(sx + (size_t)(2 * c + 1) * 16);
 #pragma unroll
-        for (int r = 0; r < NR; ++r) acc[r] = cdot16_w8(wv[r][kc], x0, x1, acc[r]);
+        for (int r = 0; r < NR; ++r) acc[r] = cdot16_w8(wv[SL][r][kc], x0, x1, acc[r]);
       } else {
         const u32x4 xc = *(const u32x4*)(sx + (size_t)c * 16);
 #pragma unroll
-        for (int r = 0; r < NR; ++r) acc[r] = cdot8(wv[r][kc], xc, acc[r]);
+        for (int r = 0; r < NR; ++r) acc[r] = cdot8(wv[SL][r][kc], xc, acc[r]);
       }
     }
     // the next batch's loads, as soon as the registers are free (the barrier keeps the scheduler from renaming them upwards)
     asm volatile("" : "+v"(acc[0]));
     __builtin_amdgcn_sched_barrier(0);
-    if (b + 1 < nb) issue(f0 + 4 * FPW);
+    if constexpr (b + PF < NB) issue(f0 + PF * 4 * FPW, std::integral_constant<int, SL>{});
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       float v = acc[r];
@@ -293,8 +350,10 @@ __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_w
         }
       }
     }
-  }
+  });
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 3);
   chain_publish(done_sync, wg, n_wg);
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 5);
 }
 
 // ---- the attention phase: decode.hip's decode_attn_split_kernel<true>, one (head, split) item per WAVE ---------------------
@@ -343,6 +402,7 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
     }
   };
   unsigned touch0 = 0, touch1 = 0;
+  AKI_CHAIN_STAMP(p, layer, 1, wg, 0);
   if (work) {                                            // the cache does not depend on this token's qkv: in flight under the wait
     issue_k(k_begin);
     const int rows = min(64, k_end - k_begin);
@@ -351,6 +411,7 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
     if ((lane + 64) * 128 < rows * 192) touch1 = *(gptr_u32)(vt + (lane + 64) * 128);
   }
   chain_wait(p, wait_sync, wg, code);
+  AKI_CHAIN_STAMP(p, layer, 1, wg, 1);
   if (!live) return;                                     // no workgroup barrier below this line
   if (work) {
     if (lane < 48) {
@@ -380,6 +441,7 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: its LDS operations complete in order
     __builtin_amdgcn_wave_barrier();
+    AKI_CHAIN_STAMP(p, layer, 1, wg, 2);
     // the touches are consumed here (never true): the loads stay, their wait falls where the tile's lines are needed anyway
     if (touch0 == 0x7fc0dead && touch1 == 0x7fc0beef && p.scale < 0.f) l = 1.f;
     for (int t = 0; t < p.T; ++t) {
@@ -433,6 +495,7 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
       acc[e] += __shfl_xor(acc[e], 32);
     }
   }
+  AKI_CHAIN_STAMP(p, layer, 1, wg, 3);
   if (lane == 0) { __hip_atomic_store(part, m, AKI_RLX_AGENT); __hip_atomic_store(part + 1, l, AKI_RLX_AGENT); }
   if (lane < 12) {
 #pragma unroll
@@ -442,6 +505,7 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
   unsigned prev = 0;
   if (lane == 0) prev = __hip_atomic_fetch_add(p.attn_cnt + layer * p.H + h, 1u, AKI_RLX_AGENT);
   prev = __shfl(prev, 0);
+  AKI_CHAIN_STAMP(p, layer, 1, wg, 4);
   if (prev != (unsigned)(p.S - 1)) return;
   asm volatile("" ::: "memory");
   // the last arriver of head h merges the S partials (decode.hip's order: five split slots per pass, the slots then meet in LDS)
@@ -519,6 +583,9 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   chain_arrive(done_sync, h, p.H, lane);                 // one arrival per head
+#ifdef AKI_LAB_HOOKS
+  if (p.stamps && layer == p.stamp_layer && lane == 0) p.stamps[((size_t)1 * 2048 + 1024 + h) * 8 + 5] = wall_clock64();
+#endif
 }
 
 __global__ __launch_bounds__(256) void chain_zero_kernel(u32x4* p, int n16) {
@@ -527,7 +594,7 @@ __global__ __launch_bounds__(256) void chain_zero_kernel(u32x4* p, int n16) {
 }
 
 // KCD = d / 512, KCF = F / 512 (bf16) - the register arrays are static; W8 halves both.
-template <int KCD, int KCF, bool W8, int NBQ, int NBO, int NBG, int NBD>
+template <int KCD, int KCF, bool W8, int NBQ, int NBO, int NBG, int NBD, int PFQ = 1, int PFO = 1, int PFG = 1, int PFDN = 1>
 __global__ __launch_bounds__(256) void decode_chain_kernel(const ChainParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_red = (float*)(smem + 16384);
@@ -548,7 +615,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(const ChainParams p) 
   constexpr int NRF = W8 ? 2 : 1;          // rows per wave on the K = F matrix
   constexpr int KF = W8 ? KCF / 2 : KCF;
   if (r < p.n_qkv) {
-    chain_gemv<NRD, KD, false, true, W8, NBQ>(p, r, p.n_qkv, ly.w_qkv, ly.s_qkv, p.d, 3 * p.H * 96, h0, h0_rep, (const bf16_t*)ly.norm1, nullptr, 0, p.qkv,
+    chain_gemv<NRD, KD, false, true, W8, NBQ, PFQ>(p, r, p.n_qkv, ly.w_qkv, ly.s_qkv, p.d, 3 * p.H * 96, h0, h0_rep, (const bf16_t*)ly.norm1, nullptr, 0, p.qkv,
                                           CH_XREP, prev_down, sy + 0 * CH_SYNC_WORDS, code | 1u, sx, s_red);
     return;
   }
@@ -559,18 +626,18 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(const ChainParams p) 
   }
   r -= p.n_attn;
   if (r < p.n_o) {
-    chain_gemv<NRD, KD, false, false, W8, NBO>(p, r, p.n_o, ly.w_o, ly.s_o, p.H * 96, p.d, p.attn_o, 1, nullptr, h0, h0_rep, p.h1, CH_XREP,
+    chain_gemv<NRD, KD, false, false, W8, NBO, PFO>(p, r, p.n_o, ly.w_o, ly.s_o, p.H * 96, p.d, p.attn_o, 1, nullptr, h0, h0_rep, p.h1, CH_XREP,
                                            sy + 1 * CH_SYNC_WORDS, sy + 2 * CH_SYNC_WORDS, code | 3u, sx, s_red);
     return;
   }
   r -= p.n_o;
   if (r < p.n_gu) {
-    chain_gemv<NRD, KD, true, true, W8, NBG>(p, r, p.n_gu, ly.w_gate_up, ly.s_gate_up, p.d, p.F, p.h1, 1, (const bf16_t*)ly.norm2, nullptr, 0, p.act,
+    chain_gemv<NRD, KD, true, true, W8, NBG, PFG>(p, r, p.n_gu, ly.w_gate_up, ly.s_gate_up, p.d, p.F, p.h1, 1, (const bf16_t*)ly.norm2, nullptr, 0, p.act,
                                          CH_XREP, sy + 2 * CH_SYNC_WORDS, sy + 3 * CH_SYNC_WORDS, code | 4u, sx, s_red);
     return;
   }
   r -= p.n_gu;
-  chain_gemv<NRF, KF, false, false, W8, NBD>(p, r, p.n_down, ly.w_down, ly.s_down, p.F, p.d, p.act, 1, nullptr, p.h1, 1, h2, last ? 1 : CH_XREP,
+  chain_gemv<NRF, KF, false, false, W8, NBD, PFDN>(p, r, p.n_down, ly.w_down, ly.s_down, p.F, p.d, p.act, 1, nullptr, p.h1, 1, h2, last ? 1 : CH_XREP,
                                          sy + 3 * CH_SYNC_WORDS, sy + 4 * CH_SYNC_WORDS, code | 5u, sx, s_red);
 }
 
@@ -579,7 +646,8 @@ static inline size_t chain_cnt_bytes(int n_layers, int H) { return aki_align_up(
 static inline size_t chain_vec_elems(int d, int H, int F) { return aki_align_up((size_t)(3 * H * 96 + H * 96 + d + F + 2 * d) * 2 + 256, 256) / 2; }   // one copy
 
 #ifdef AKI_LAB_HOOKS
-static int g_chain_sleep = 8, g_chain_xrep = CH_XREP_USED, g_chain_nflags = CH_FLAGS, g_chain_nowait = 0, g_chain_nb = 0, g_chain_lds_pad = 0;
+static int g_chain_sleep = 8, g_chain_xrep = CH_XREP_USED, g_chain_nflags = CH_FLAGS, g_chain_nowait = 0, g_chain_nb = 0, g_chain_lds_pad = 0, g_chain_stamp_layer = -1, g_chain_touch = -1;
+static unsigned long long* g_chain_stamps = nullptr;
 #endif
 
 static void chain_split(int H, int cap, int max_keys, int& S, int& T) {
@@ -624,9 +692,9 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   p.hbuf = v;
   p.part = (float*)(ws + cb + 256 + chain_vec_elems(d, H, F) * 2 * CH_XREP);
   const int rd = w8 ? 4 : 2, rf = w8 ? 2 : 1;     // rows per wave and batch (see the kernel)
-  p.nbq = CH_NBQ; p.nbo = CH_NBO; p.nbg = CH_NBG; p.nbd = CH_NBD;
+  p.nbq = CH_NBQ; p.nbo = CH_NBO; p.nbg = w8 ? 2 : CH_NBG; p.nbd = CH_NBD;
 #ifdef AKI_LAB_HOOKS
-  static const int presets[][4] = {{CH_NBQ, CH_NBO, CH_NBG, CH_NBD}, {8, 8, 8, 8}, {4, 2, 8, 2}, {8, 2, 8, 4}, {4, 4, 4, 4}, {16, 4, 16, 4}, {8, 2, 16, 2}, {1, 1, 1, 1}, {8, 4, 16, 4}, {2, 1, 4, 1}, {4, 2, 4, 2}, {2, 2, 4, 2}};
+  const int presets[][4] = {{CH_NBQ, CH_NBO, w8 ? 2 : CH_NBG, CH_NBD}, {8, 8, 8, 8}, {4, 2, 8, 2}, {8, 2, 8, 4}, {4, 4, 4, 4}, {16, 4, 16, 4}, {8, 2, 16, 2}, {1, 1, 1, 1}, {8, 4, 16, 4}, {2, 1, 4, 1}, {4, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 2, 2}, {2, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 4}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 2}, {2, 2, 4, 4}, {4, 2, 8, 4}, {2, 2, 4, 2}, {4, 4, 8, 4}};
   const int* ps = presets[w8 ? 0 : g_chain_nb];
   p.nbq = ps[0]; p.nbo = ps[1]; p.nbg = ps[2]; p.nbd = ps[3];
 #endif
@@ -637,9 +705,11 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   p.n_gu = wgs(F, rd / 2, p.nbg);
   p.n_down = wgs(d, rf, p.nbd);
   p.wg_layer = p.n_qkv + p.n_attn + p.n_o + p.n_gu + p.n_down;
-  p.sleep_n = 8; p.xrep = CH_XREP_USED; p.nflags = CH_FLAGS; p.nowait = 0;
+  p.sleep_n = 8; p.xrep = CH_XREP_USED; p.nflags = CH_FLAGS; p.nowait = 0; p.touch = CH_TOUCH;
 #ifdef AKI_LAB_HOOKS
   p.sleep_n = g_chain_sleep; p.xrep = g_chain_xrep; p.nflags = g_chain_nflags; p.nowait = g_chain_nowait;
+  if (g_chain_touch >= 0) p.touch = g_chain_touch;
+  p.stamps = g_chain_stamps; p.stamp_layer = g_chain_stamp_layer;
 #endif
   AKI_CLEAR_ERR();
   // Every polled word is zeroed by the call itself, by a KERNEL of this library.  hipMemsetAsync was used first: eager calls
@@ -658,7 +728,12 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
     if (SMEM > 48 * 1024) (void)hipFuncSetAttribute((const void*)decode_chain_kernel<6, 16, W8V, A, B, C, D>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); \
     hipLaunchKernelGGL((decode_chain_kernel<6, 16, W8V, A, B, C, D>), grid, block, SMEM, stream, p);                                         \
   } while (0)
-  if (w8) AKI_CHAIN_LAUNCH(true, CH_NBQ, CH_NBO, CH_NBG, CH_NBD);
+#define AKI_CHAIN_LAUNCH2(W8V, A, B, C, D, PA, PB, PC, PD)                                                                                   \
+  do {                                                                                                                                      \
+    if (SMEM > 48 * 1024) (void)hipFuncSetAttribute((const void*)decode_chain_kernel<6, 16, W8V, A, B, C, D, PA, PB, PC, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); \
+    hipLaunchKernelGGL((decode_chain_kernel<6, 16, W8V, A, B, C, D, PA, PB, PC, PD>), grid, block, SMEM, stream, p);                         \
+  } while (0)
+  if (w8) AKI_CHAIN_LAUNCH(true, 2, 2, 2, 2);
 #ifdef AKI_LAB_HOOKS
   else if (g_chain_nb == 1) AKI_CHAIN_LAUNCH(false, 8, 8, 8, 8);
   else if (g_chain_nb == 2) AKI_CHAIN_LAUNCH(false, 4, 2, 8, 2);
@@ -671,8 +746,20 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   else if (g_chain_nb == 9) AKI_CHAIN_LAUNCH(false, 2, 1, 4, 1);
   else if (g_chain_nb == 10) AKI_CHAIN_LAUNCH(false, 4, 2, 4, 2);
   else if (g_chain_nb == 11) AKI_CHAIN_LAUNCH(false, 2, 2, 4, 2);
+  else if (g_chain_nb == 12) AKI_CHAIN_LAUNCH2(false, 2, 2, 2, 2, 2, 2, 2, 2);      // batches requested before the wait: qkv, o, gate_up, down
+  else if (g_chain_nb == 13) AKI_CHAIN_LAUNCH2(false, 2, 2, 4, 2, 2, 2, 2, 2);
+  else if (g_chain_nb == 14) AKI_CHAIN_LAUNCH2(false, 2, 2, 4, 2, 2, 2, 2, 1);
+  else if (g_chain_nb == 15) AKI_CHAIN_LAUNCH2(false, 2, 2, 8, 2, 2, 2, 2, 1);
+  else if (g_chain_nb == 16) AKI_CHAIN_LAUNCH2(false, 2, 2, 4, 4, 2, 2, 2, 1);
+  else if (g_chain_nb == 17) AKI_CHAIN_LAUNCH2(false, 2, 2, 4, 2, 2, 2, 1, 2);
+  else if (g_chain_nb == 18) AKI_CHAIN_LAUNCH2(false, 2, 2, 8, 2, 2, 2, 2, 2);
+  else if (g_chain_nb == 19) AKI_CHAIN_LAUNCH2(false, 2, 2, 4, 2, 2, 2, 1, 1);
+  else if (g_chain_nb == 20) AKI_CHAIN_LAUNCH2(false, 2, 2, 4, 4, 2, 2, 1, 1);
+  else if (g_chain_nb == 21) AKI_CHAIN_LAUNCH2(false, 4, 2, 8, 4, 2, 2, 2, 1);
+  else if (g_chain_nb == 22) AKI_CHAIN_LAUNCH2(false, 2, 2, 4, 2, 1, 1, 1, 1);
+  else if (g_chain_nb == 23) AKI_CHAIN_LAUNCH2(false, 4, 4, 8, 4, 1, 1, 1, 1);
 #endif
-  else AKI_CHAIN_LAUNCH(false, CH_NBQ, CH_NBO, CH_NBG, CH_NBD);
+  else AKI_CHAIN_LAUNCH2(false, CH_NBQ, CH_NBO, CH_NBG, CH_NBD, CH_PFQ, CH_PFO, CH_PFG, CH_PFD);
 #undef AKI_CHAIN_LAUNCH
   AKI_LAUNCH_CHECK();
   return AKI_OK;
@@ -683,13 +770,17 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
 #ifdef AKI_LAB_HOOKS
 // Lab build only: poll period (x 64 cycles), copies of the hand-off vectors (1..8), READY flags per phase (1..32), and
 // nowait = 1: no dependency waits at all (WRONG results - the time of the bare weight stream in this workgroup structure).
+// device buffer of 5 x 2048 x 8 uint64 (or NULL) and the layer whose workgroups stamp their wall clock into it (tools/decode_chain_edges.py)
+extern "C" void aki_lab_set_chain_stamps(void* buf, int layer) { aki::g_chain_stamps = (unsigned long long*)buf; aki::g_chain_stamp_layer = layer; }
 extern "C" void aki_lab_set_chain_lds(int pad_bytes) { aki::g_chain_lds_pad = pad_bytes < 0 ? 0 : (pad_bytes > 140 * 1024 ? 140 * 1024 : pad_bytes); }
 // preset of batches per workgroup (qkv, o_proj, gate_up, down): 0 product {2,2,2,2}, 1 {8,8,8,8}, 2 {4,2,8,2}, 3 {8,2,8,4}, 4 {4,4,4,4}, 5 {16,4,16,4}, 6 {8,2,16,2}, 7 {1,1,1,1}, 8 {8,4,16,4}, 9 {2,1,4,1}, 10 {4,2,4,2}, 11 {2,2,4,2}
-extern "C" void aki_lab_set_chain_nb(int preset) { aki::g_chain_nb = (preset >= 0 && preset <= 11) ? preset : 0; }
+extern "C" void aki_lab_set_chain_nb(int preset) { aki::g_chain_nb = (preset >= 0 && preset <= 23) ? preset : 0; }
 extern "C" void aki_lab_set_chain(int sleep_n, int xrep, int nflags, int nowait) {
   aki::g_chain_sleep = sleep_n < 0 ? 0 : sleep_n;
   aki::g_chain_xrep = xrep < 1 ? 1 : (xrep > aki::CH_XREP ? aki::CH_XREP : xrep);
   aki::g_chain_nflags = nflags < 1 ? 1 : (nflags > aki::CH_FLAGS ? aki::CH_FLAGS : nflags);
   aki::g_chain_nowait = nowait ? 1 : 0;
 }
+// -1: the product setting; 0 / 1: touch loads of the batches beyond the register slots off / on.
+extern "C" void aki_lab_set_chain_touch(int touch) { aki::g_chain_touch = touch; }
 #endif

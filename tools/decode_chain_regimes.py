@@ -6,7 +6,10 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-PRESETS = {0: "{2,2,2,2}", 4: "{4,4,4,4}", 7: "{1,1,1,1}", 8: "{8,4,16,4}", 9: "{2,1,4,1}", 10: "{4,2,4,2}"}
+# batches per workgroup {qkv, o, gate_up, down} / batches requested before the wait
+PRESETS = {0: "product", 14: "{2,2,4,2}/{2,2,2,1}", 19: "{2,2,4,2}/{2,2,1,1}", 20: "{2,2,4,4}/{2,2,1,1}",
+           21: "{4,2,8,4}/{2,2,2,1}", 22: "{2,2,4,2}/{1,1,1,1}", 23: "{4,4,8,4}/{1,1,1,1}", 12: "{2,2,2,2}/{2,2,2,2}"}
+TOUCH = (0, 1)    # touch loads of the batches beyond the register slots while the workgroup waits
 
 
 def main():
@@ -43,12 +46,13 @@ def main():
         lm.model.use_decode_chain = True
     with _lib.use_lab(0) as lab, torch.no_grad():
         for preset, pname in PRESETS.items():
-            for copies in ((2, 8) if preset in (0, 4, 7) else (2,)):
-                for nowait in (0, 1):
+            for touch in (TOUCH if preset not in (0, 12) else (0,)):
+                for copies, nowait in ((2, 0),):
                     lab.aki_lab_set_chain(8, copies, 32, nowait)
                     lab.aki_lab_set_chain_nb(preset)
-                    r = {"preset": pname, "copies": copies, "nowait": nowait}
-                    for cap in (L + 136, L + 400):
+                    lab.aki_lab_set_chain_touch(touch if preset else -1)
+                    r = {"preset": pname, "touch": touch, "copies": copies, "nowait": nowait}
+                    for cap in (L + 136,):
                         out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=cap)
                         cache = out.past_key_values
                         ids = out.logits[:, -1].float().argmax(-1)
