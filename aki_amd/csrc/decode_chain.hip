@@ -98,8 +98,8 @@ constexpr int CH_NBQ = 2, CH_NBO = 2, CH_NBG = 4, CH_NBD = 2;
 constexpr int CH_PFQ = 2, CH_PFO = 2, CH_PFG = 2, CH_PFD = 1;
 constexpr int CH_TOUCH = 0;
 constexpr int CH_XREP = 8;               // room for copies of every hand-off vector: consumer j reads copy j % xrep
-constexpr int CH_XREP_USED = 2;          // copies in use: with 100-200 consumers per phase two spread the readers enough, and every copy is
-                                         // one more write-through store per producing lane (8 copies: +35 us per token)
+constexpr int CH_XREP_USED = 1;          // copies in use: every copy is one more write-through store per producing lane, and at the product's
+                                         // 100-600 consumers per phase one copy reads fastest (1 / 2 / 4 copies: 1.66 / 1.68 / 1.71 ms per token)
 constexpr unsigned CH_SPIN_LIMIT = 200000u;
 
 struct ChainParams {
@@ -149,14 +149,14 @@ __device__ __forceinline__ void chain_wait(const ChainParams& p, unsigned* sync,
   if (threadIdx.x == 0 && sync != nullptr && !p.nowait) {
     unsigned* flag = sync + (CH_SHARDS + 1 + (wg % p.nflags)) * 32;
     unsigned spins = 0;
+    auto give_up = [&]() {
+      __hip_atomic_store(p.err, code, AKI_RLX_AGENT);
+      for (int i = 0; i < p.n_layers * CH_PHASES; ++i)
+        for (int f = 0; f < CH_FLAGS; ++f) __hip_atomic_store(p.sync + (size_t)i * CH_SYNC_WORDS + (CH_SHARDS + 1 + f) * 32, 2u, AKI_RLX_AGENT);
+    };
     while (__hip_atomic_load(flag, AKI_RLX_AGENT) == 0u) {
       for (int i = 0; i < p.sleep_n; ++i) __builtin_amdgcn_s_sleep(1);
-      if (++spins > CH_SPIN_LIMIT) {
-        __hip_atomic_store(p.err, code, AKI_RLX_AGENT);
-        for (int i = 0; i < p.n_layers * CH_PHASES; ++i)
-          for (int f = 0; f < CH_FLAGS; ++f) __hip_atomic_store(p.sync + (size_t)i * CH_SYNC_WORDS + (CH_SHARDS + 1 + f) * 32, 2u, AKI_RLX_AGENT);
-        break;
-      }
+      if (++spins > CH_SPIN_LIMIT) { give_up(); break; }
     }
   }
   __syncthreads();
@@ -352,7 +352,10 @@ __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_w
     }
   });
   AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 3);
-  chain_publish(done_sync, wg, n_wg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chain_publish, with a stamp between the drain and the arrival
+  __syncthreads();
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 4);
+  if (threadIdx.x < 64) chain_arrive(done_sync, wg, n_wg, threadIdx.x);
   AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 5);
 }
 
@@ -594,8 +597,8 @@ __global__ __launch_bounds__(256) void chain_zero_kernel(u32x4* p, int n16) {
 }
 
 // KCD = d / 512, KCF = F / 512 (bf16) - the register arrays are static; W8 halves both.
-template <int KCD, int KCF, bool W8, int NBQ, int NBO, int NBG, int NBD, int PFQ = 1, int PFO = 1, int PFG = 1, int PFDN = 1>
-__global__ __launch_bounds__(256) void decode_chain_kernel(const ChainParams p) {
+template <int KCD, int KCF, bool W8, int NBQ, int NBO, int NBG, int NBD, int PFQ = 1, int PFO = 1, int PFG = 1, int PFDN = 1, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void decode_chain_kernel(const ChainParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_red = (float*)(smem + 16384);
   char* sx = smem;
@@ -694,8 +697,8 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   const int rd = w8 ? 4 : 2, rf = w8 ? 2 : 1;     // rows per wave and batch (see the kernel)
   p.nbq = CH_NBQ; p.nbo = CH_NBO; p.nbg = w8 ? 2 : CH_NBG; p.nbd = CH_NBD;
 #ifdef AKI_LAB_HOOKS
-  const int presets[][4] = {{CH_NBQ, CH_NBO, w8 ? 2 : CH_NBG, CH_NBD}, {8, 8, 8, 8}, {4, 2, 8, 2}, {8, 2, 8, 4}, {4, 4, 4, 4}, {16, 4, 16, 4}, {8, 2, 16, 2}, {1, 1, 1, 1}, {8, 4, 16, 4}, {2, 1, 4, 1}, {4, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 2, 2}, {2, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 4}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 2}, {2, 2, 4, 4}, {4, 2, 8, 4}, {2, 2, 4, 2}, {4, 4, 8, 4}};
-  const int* ps = presets[w8 ? 0 : g_chain_nb];
+  const int presets[][4] = {{CH_NBQ, CH_NBO, w8 ? 2 : CH_NBG, CH_NBD}, {8, 8, 8, 8}, {4, 2, 8, 2}, {8, 2, 8, 4}, {4, 4, 4, 4}, {16, 4, 16, 4}, {8, 2, 16, 2}, {1, 1, 1, 1}, {8, 4, 16, 4}, {2, 1, 4, 1}, {4, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 2, 2}, {2, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 4}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 2}, {2, 2, 4, 4}, {4, 2, 8, 4}, {2, 2, 4, 2}, {4, 4, 8, 4}, {2, 2, 4, 2}};
+  const int* ps = presets[(w8 && (g_chain_nb < 12 || g_chain_nb > 14)) ? 0 : g_chain_nb];
   p.nbq = ps[0]; p.nbo = ps[1]; p.nbg = ps[2]; p.nbd = ps[3];
 #endif
   auto wgs = [&](int n_out, int fpw, int nb) { return (n_out + 4 * fpw * nb - 1) / (4 * fpw * nb); };
@@ -728,11 +731,22 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
     if (SMEM > 48 * 1024) (void)hipFuncSetAttribute((const void*)decode_chain_kernel<6, 16, W8V, A, B, C, D>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); \
     hipLaunchKernelGGL((decode_chain_kernel<6, 16, W8V, A, B, C, D>), grid, block, SMEM, stream, p);                                         \
   } while (0)
+#define AKI_CHAIN_LAUNCH3(W8V, A, B, C, D, PA, PB, PC, PD, OC)                                                                               \
+  do {                                                                                                                                      \
+    if (SMEM > 48 * 1024) (void)hipFuncSetAttribute((const void*)decode_chain_kernel<6, 16, W8V, A, B, C, D, PA, PB, PC, PD, OC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); \
+    hipLaunchKernelGGL((decode_chain_kernel<6, 16, W8V, A, B, C, D, PA, PB, PC, PD, OC>), grid, block, SMEM, stream, p);                     \
+  } while (0)
 #define AKI_CHAIN_LAUNCH2(W8V, A, B, C, D, PA, PB, PC, PD)                                                                                   \
   do {                                                                                                                                      \
     if (SMEM > 48 * 1024) (void)hipFuncSetAttribute((const void*)decode_chain_kernel<6, 16, W8V, A, B, C, D, PA, PB, PC, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); \
     hipLaunchKernelGGL((decode_chain_kernel<6, 16, W8V, A, B, C, D, PA, PB, PC, PD>), grid, block, SMEM, stream, p);                         \
   } while (0)
+#ifdef AKI_LAB_HOOKS
+  if (w8 && g_chain_nb == 12) AKI_CHAIN_LAUNCH2(true, 2, 2, 2, 2, 2, 2, 2, 2);
+  else if (w8 && g_chain_nb == 13) AKI_CHAIN_LAUNCH2(true, 2, 2, 4, 2, 2, 2, 2, 2);
+  else if (w8 && g_chain_nb == 14) AKI_CHAIN_LAUNCH2(true, 2, 2, 4, 2, 2, 2, 2, 1);
+  else
+#endif
   if (w8) AKI_CHAIN_LAUNCH(true, 2, 2, 2, 2);
 #ifdef AKI_LAB_HOOKS
   else if (g_chain_nb == 1) AKI_CHAIN_LAUNCH(false, 8, 8, 8, 8);
@@ -758,6 +772,7 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   else if (g_chain_nb == 21) AKI_CHAIN_LAUNCH2(false, 4, 2, 8, 4, 2, 2, 2, 1);
   else if (g_chain_nb == 22) AKI_CHAIN_LAUNCH2(false, 2, 2, 4, 2, 1, 1, 1, 1);
   else if (g_chain_nb == 23) AKI_CHAIN_LAUNCH2(false, 4, 4, 8, 4, 1, 1, 1, 1);
+  else if (g_chain_nb == 24) AKI_CHAIN_LAUNCH3(false, 2, 2, 4, 2, 2, 2, 2, 1, 4);   // the product's batches held to 128 VGPRs (4 workgroups per CU; spills)
 #endif
   else AKI_CHAIN_LAUNCH2(false, CH_NBQ, CH_NBO, CH_NBG, CH_NBD, CH_PFQ, CH_PFO, CH_PFG, CH_PFD);
 #undef AKI_CHAIN_LAUNCH
@@ -774,7 +789,7 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
 extern "C" void aki_lab_set_chain_stamps(void* buf, int layer) { aki::g_chain_stamps = (unsigned long long*)buf; aki::g_chain_stamp_layer = layer; }
 extern "C" void aki_lab_set_chain_lds(int pad_bytes) { aki::g_chain_lds_pad = pad_bytes < 0 ? 0 : (pad_bytes > 140 * 1024 ? 140 * 1024 : pad_bytes); }
 // preset of batches per workgroup (qkv, o_proj, gate_up, down): 0 product {2,2,2,2}, 1 {8,8,8,8}, 2 {4,2,8,2}, 3 {8,2,8,4}, 4 {4,4,4,4}, 5 {16,4,16,4}, 6 {8,2,16,2}, 7 {1,1,1,1}, 8 {8,4,16,4}, 9 {2,1,4,1}, 10 {4,2,4,2}, 11 {2,2,4,2}
-extern "C" void aki_lab_set_chain_nb(int preset) { aki::g_chain_nb = (preset >= 0 && preset <= 23) ? preset : 0; }
+extern "C" void aki_lab_set_chain_nb(int preset) { aki::g_chain_nb = (preset >= 0 && preset <= 24) ? preset : 0; }
 extern "C" void aki_lab_set_chain(int sleep_n, int xrep, int nflags, int nowait) {
   aki::g_chain_sleep = sleep_n < 0 ? 0 : sleep_n;
   aki::g_chain_xrep = xrep < 1 ? 1 : (xrep > aki::CH_XREP ? aki::CH_XREP : xrep);

@@ -28,18 +28,15 @@ def main():
     L = a.prompt
     x = torch.randn(1, L, cfg.hidden_size, device=dev, dtype=torch.bfloat16) * 0.5
     table = ops.MaskTable.from_host([[(4, 148, 4, 148)]], torch.ones(1, L, dtype=torch.bool).numpy(), [L], dev)
-    # (sleep, copies, flags, nowait, preset of batches per workgroup: 0 product {8,4,16,4}, 1 {8,8,8,8}, 2 {4,2,8,2}, 3 {8,2,8,4}, 4 {4,4,4,4},
-    #  5 {16,4,16,4}, 6 {8,2,16,2}, 7 {1,1,1,1})
-    settings = [("product {8,4,16,4} 2 copies", (8, 2, 32, 0, 0)), ("{8,8,8,8} 8 copies", (8, 8, 32, 0, 1)), ("{8,8,8,8} 2 copies", (8, 2, 32, 0, 1)),
-                ("{4,2,8,2} 2 copies", (8, 2, 32, 0, 2)), ("{8,2,8,4} 2 copies", (8, 2, 32, 0, 3)), ("{4,4,4,4} 2 copies", (8, 2, 32, 0, 4)),
-                ("{16,4,16,4} 2 copies", (8, 2, 32, 0, 5)), ("{8,2,16,2} 2 copies", (8, 2, 32, 0, 6)), ("product, 1 copy", (8, 1, 32, 0, 0)),
-                ("product, nowait (wrong results)", (8, 2, 32, 1, 0))]
+    # (s_sleep(1) x N per poll, copies of the hand-off vectors, READY flags per phase, nowait) on the product's batches
+    settings = [("product: sleep 8, 1 copy, 32 flags", (8, 1, 32, 0)), ("sleep 2", (2, 1, 32, 0)), ("sleep 16", (16, 1, 32, 0)), ("2 copies", (8, 2, 32, 0)),
+                ("4 copies", (8, 4, 32, 0)), ("16 flags", (8, 1, 16, 0)), ("nowait (wrong results): the bare weight stream", (8, 1, 32, 1))]
     res = {name: [] for name, _ in settings}
     with _lib.use_lab(0) as lab, torch.no_grad():
         for _ in range(a.rounds):
             for name, knobs in settings:
                 lab.aki_lab_set_chain(*knobs[:4])
-                lab.aki_lab_set_chain_nb(knobs[4])
+                lab.aki_lab_set_chain_nb(0)
                 out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=L + a.steps + 16)
                 cache = out.past_key_values
                 nxt = out.logits[:, -1].float().argmax(-1)
@@ -54,7 +51,7 @@ def main():
                 res[name].append(round((time.perf_counter() - t0) * 1e3 / a.steps, 4))
                 if not knobs[3]:
                     cache.chain.check()
-        lab.aki_lab_set_chain(8, 2, 32, 0)
+        lab.aki_lab_set_chain(8, 1, 32, 0)
         lab.aki_lab_set_chain_nb(0)
     for name, _ in settings:
         print(f"{name:45s} ms/token {res[name]}")

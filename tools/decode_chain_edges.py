@@ -11,6 +11,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layer", type=int, default=16)
     ap.add_argument("--preset", type=int, default=0)
+    ap.add_argument("--dump", default=None, help="save the raw stamps [phase][workgroup][slot] (.npy)")
+    ap.add_argument("--fp8", action="store_true", help="e4m3 weights through the chain (the product runs them on five launches per layer)")
     a = ap.parse_args()
     from aki_amd import ops, _lib
     from aki_amd.phi3 import Phi3ForCausalLM, make_phi3_config
@@ -19,6 +21,9 @@ def main():
     for p in lm.parameters():
         p.data.normal_(0, 0.02)
     lm = lm.to("cuda").to(torch.bfloat16).eval()
+    if a.fp8:
+        lm.enable_fp8()
+        lm.model.decode_chain_w8 = True
     L = 655
     x = torch.randn(1, L, cfg.hidden_size, device="cuda", dtype=torch.bfloat16) * 0.5
     table = ops.MaskTable.from_host([[(4, 148, 4, 148)]], torch.ones(1, L, dtype=torch.bool).numpy(), [L], "cuda")
@@ -37,6 +42,8 @@ def main():
         lab.aki_lab_set_chain_stamps(None, -1)
         lab.aki_lab_set_chain_nb(0)
     s = stamps.cpu().numpy().astype(np.float64) / 100.0          # microseconds
+    if a.dump:
+        np.save(a.dump, stamps.cpu().numpy())
     t0 = s[s > 0].min()
     s = np.where(s > 0, s - t0, np.nan)
     rep = {}

@@ -7,9 +7,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 # batches per workgroup {qkv, o, gate_up, down} / batches requested before the wait
-PRESETS = {0: "product", 14: "{2,2,4,2}/{2,2,2,1}", 19: "{2,2,4,2}/{2,2,1,1}", 20: "{2,2,4,4}/{2,2,1,1}",
+PRESETS = {0: "product", 24: "{2,2,4,2}/{2,2,2,1} at 128 VGPRs", 14: "{2,2,4,2}/{2,2,2,1}", 19: "{2,2,4,2}/{2,2,1,1}", 20: "{2,2,4,4}/{2,2,1,1}",
            21: "{4,2,8,4}/{2,2,2,1}", 22: "{2,2,4,2}/{1,1,1,1}", 23: "{4,4,8,4}/{1,1,1,1}", 12: "{2,2,2,2}/{2,2,2,2}"}
-TOUCH = (0, 1)    # touch loads of the batches beyond the register slots while the workgroup waits
+NOWAIT = 1 if '--nowait' in sys.argv else 0     # 1: the bare weight stream of each structure (wrong results, nothing checked)
+ALL = {i: f'preset {i}' for i in range(1, 25)}
+TOUCH = (0,)    # touch loads of the batches beyond the register slots while the workgroup waits
 
 
 def main():
@@ -45,9 +47,9 @@ def main():
             ids = l_.float().argmax(-1)
         lm.model.use_decode_chain = True
     with _lib.use_lab(0) as lab, torch.no_grad():
-        for preset, pname in PRESETS.items():
-            for touch in (TOUCH if preset not in (0, 12) else (0,)):
-                for copies, nowait in ((2, 0),):
+        for preset, pname in ((ALL if NOWAIT else PRESETS).items()):
+            for touch in ((0,) if NOWAIT else TOUCH if preset not in (0, 12) else (0,)):
+                for copies, nowait in ((1, NOWAIT),):
                     lab.aki_lab_set_chain(8, copies, 32, nowait)
                     lab.aki_lab_set_chain_nb(preset)
                     lab.aki_lab_set_chain_touch(touch if preset else -1)
@@ -62,7 +64,7 @@ def main():
                         ch = cache.chain
                         r[f"eager_chain_only_cap{cap}"] = T(lambda: ch.step(h, cos, sin, cache.cache_len, cache.valid_bits, cache.capacity))
                         st = DecodeGraph(lm, cache)
-                        if cap == L + 136:
+                        if cap == L + 136 and not nowait:
                             out2 = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=cap)
                             c2, i2 = out2.past_key_values, out2.logits[:, -1].float().argmax(-1)
                             s2 = DecodeGraph(lm, c2)
@@ -83,8 +85,9 @@ def main():
                             ch.check()
                     rows.append(r)
                     print(json.dumps(r), flush=True)
-        lab.aki_lab_set_chain(8, 2, 32, 0)
+        lab.aki_lab_set_chain(8, 1, 32, 0)
         lab.aki_lab_set_chain_nb(0)
+        lab.aki_lab_set_chain_touch(-1)
 
 
 if __name__ == "__main__":

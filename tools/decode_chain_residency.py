@@ -51,7 +51,7 @@ def main():
                     ch = cache.chain
                     r["nowait_ms" if nowait else "ms"] = T(lambda: ch.step(h, cos, sin, cache.cache_len, cache.valid_bits, cache.capacity))
                 print(json.dumps(r), flush=True)
-        lab.aki_lab_set_chain(8, 2, 32, 0)
+        lab.aki_lab_set_chain(8, 1, 32, 0)
         lab.aki_lab_set_chain_nb(0)
         lab.aki_lab_set_chain_lds(0)
 
