@@ -40,17 +40,20 @@ namespace aki {
 // issued in front of K Q^T of tile j, so a wave's matrix work comes in one burst of 24 MFMAs per tile that covers its own LDS
 // fragment reads, and its softmax VALU sits alone between two bursts.  Same results bit for bit; measured 6-9 % SLOWER than the
 // plain loop on one box (B8 L655: 68.3 vs 64.3 us; B4 L4096: 670 vs 617 us; tools/attn_ab.py) - kept as a recorded experiment.
-template <int NW, int MODE>      // MODE 0: plain tile loop (product); 1: software-pipelined; 2: software-pipelined + 8-wave ping-pong (NW = 8); 3: plain, DMA issued behind the score MFMAs
+template <int NW, int MODE>      // MODE 0: plain tile loop (product); 1: software-pipelined; 2: software-pipelined + 8-wave ping-pong (NW = 8); 3: plain, DMA issued behind the score MFMAs; 4 (lab): plain, per-stage arrival counters in LDS instead of the tile barrier
 __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnParams p) {
   constexpr bool SWP = MODE == 1 || MODE == 2;
   static_assert(MODE != 2 || NW == 8, "the ping-pong loop is written for two groups of four waves");
   constexpr int BQ = NW * 32;
   constexpr int NT = NW * 64;
   constexpr int NCH = (64 * 12 + NT - 1) / NT;  // 16-B chunks per thread per tile (K and V each)
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * KTILE + NSTAGE * VTILE + MAX_VB_WORDS * 8];
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * KTILE + NSTAGE * VTILE + MAX_VB_WORDS * 8 + (MODE == 4 ? 64 : 0)];
   char* const sK = smem;
   char* const sV = smem + NSTAGE * KTILE;
   unsigned long long* const sVB = (unsigned long long*)(smem + NSTAGE * KTILE + NSTAGE * VTILE);
+  // MODE 4: sCnt[s] = waves whose pieces of the tile in stage s have landed, sCnt[NSTAGE + s] = waves that have finished reading it
+  // (both per rank, monotonic inside a rank, zeroed between the rank-end barriers)
+  unsigned* const sCnt = (unsigned*)(smem + NSTAGE * KTILE + NSTAGE * VTILE + MAX_VB_WORDS * 8);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,6 +135,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     if (p.vbits) vbw = p.vbits[(size_t)b * p.nwords + w];
     else vbw = (w * 64 + 64 <= L) ? ~0ull : ((1ull << (L - w * 64)) - 1ull);
     sVB[w] = vbw;
+  }
+  if constexpr (MODE == 4) {
+    if (tid < 2 * NSTAGE) sCnt[tid] = 0u;
+    __syncthreads();                                // also orders the valid words: this mode has no barrier in its tile loop
   }
   const aki_mma_rect* const rects_b = p.rects + (size_t)b * p.max_rects;
   auto rect_at = [&](int i) -> aki_mma_rect {       // wave-uniform: one s_load_dwordx4 through the scalar cache
@@ -473,11 +480,21 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
     // tile j's pieces are older than tile j+1's 2*NCH: wait for them, then make it a workgroup-wide fact
     if (j + 1 < jend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (MODE == 4) {
+      // this wave's pieces of tile j are in LDS: say so, then wait for the other waves' pieces of THIS tile only - nobody waits
+      // for a wave that is still computing tile j-1 (hypothesis of VERDICT r3 item 4: the tile barrier makes every wave pay for the
+      // slowest block of its rank)
+      if (lane == 0) __hip_atomic_fetch_add(sCnt + stage, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned want = (unsigned)NW * (unsigned)(j / NSTAGE + 1);
+      while (__hip_atomic_load(sCnt + stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) { }
+      asm volatile("" ::: "memory");
+    } else {
+      __builtin_amdgcn_s_barrier();
+    }
     // DMA of tile j+2 into the stage read in iteration j-1.  MODE 3 (lab): issued BEHIND the score MFMAs instead of here - a piece
     // costs the issuing wave 60-185 cycles (MI355X guide, cycle constants), six of them in front of the K fragment reads are a
     // good part of the ~730 cycles between the barrier and the first MFMA (profiles/r01i_attn_phase_cycles.txt)
-    constexpr bool DMA_LATE = (MODE == 3);
+    constexpr bool DMA_LATE = (MODE == 3 || MODE == 4);
     const int dma_stage = stage >= 1 ? stage - 1 : NSTAGE - 1;
     if (!DMA_LATE && j + 2 < jend) issue_tile(j + 2, dma_stage);
     const int c0 = j * 64;
@@ -558,7 +575,15 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[ks], s1, 0, 0, 0);
       }
-      if (DMA_LATE && j + 2 < jend) issue_tile(j + 2, dma_stage);
+      if (DMA_LATE && j + 2 < jend) {
+        if constexpr (MODE == 4) {   // the stage held tile j-1: every wave must have finished reading it
+          if (j >= 1) {
+            const unsigned wantf = (unsigned)NW * (unsigned)((j - 1) / NSTAGE + 1);
+            while (__hip_atomic_load(sCnt + NSTAGE + dma_stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < wantf) { }
+          }
+        }
+        issue_tile(j + 2, dma_stage);
+      }
       // The V^T fragments do not depend on the softmax: issue their transposed reads now, they land under the VALU work.
       u32x2 vlo[4][3], vhi[4][3];
       {
@@ -605,6 +630,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
                      "+v"(vlo[2][0]), "+v"(vhi[2][0]), "+v"(vlo[2][1]), "+v"(vhi[2][1]), "+v"(vlo[2][2]), "+v"(vhi[2][2]),
                      "+v"(vlo[3][0]), "+v"(vhi[3][0]), "+v"(vlo[3][1]), "+v"(vhi[3][1]), "+v"(vlo[3][2]), "+v"(vhi[3][2]));
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MODE == 4) {     // every LDS read of this tile has returned (the wait above): its stage may be overwritten
+        if (lane == 0) __hip_atomic_fetch_add(sCnt + NSTAGE + stage, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
 #pragma unroll
       for (int ks4 = 0; ks4 < 4; ++ks4) {
         bf16x8 pf;
@@ -616,8 +644,19 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
         }
       }
-    } else if (DMA_LATE && j + 2 < jend) {
-      issue_tile(j + 2, dma_stage);
+    } else {
+      if constexpr (MODE == 4) {     // a skipped tile is "read" at once
+        if (lane == 0) __hip_atomic_fetch_add(sCnt + NSTAGE + stage, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (DMA_LATE && j + 2 < jend) {
+        if constexpr (MODE == 4) {
+          if (j >= 1) {
+            const unsigned wantf = (unsigned)NW * (unsigned)((j - 1) / NSTAGE + 1);
+            while (__hip_atomic_load(sCnt + NSTAGE + dma_stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < wantf) { }
+          }
+        }
+        issue_tile(j + 2, dma_stage);
+      }
     }
     vb_next = valid_word(j + 1);
     if (++stage == NSTAGE) stage = 0;
@@ -632,6 +671,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   const float l_tot = halves_sum(l_part);
   const bool dead = !(l_tot > 0.f);
   __syncthreads();                       // every wave is done reading the ring
+  if constexpr (MODE == 4) {
+    if (tid < 2 * NSTAGE) sCnt[tid] = 0u;   // the next rank counts from zero (ordered by the barrier at the end of this epilogue)
+  }
   constexpr int OROW = 208;              // 192 B + 16: the 8-B writes of 32 rows land 2-way instead of 8-way conflicted
   char* const sO = sK + wave * (32 * OROW);
   {
@@ -676,7 +718,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
 // an A/B in one process (tools/attn_ab.py).  It is not part of the product library: as compiled by hipcc it is 1.7x SLOWER
 // than this kernel ("64-row attention core").
 int attn_core64_bf16(const aki_mma_attn_core_args* a, hipStream_t stream);
-int g_attn_variant = 0;   // 0 / 1 = this kernel, 2 = the 64-row kernel, 3 = this kernel with the software-pipelined tile loop (lab: 6-9 % slower), 4 = 8-wave ping-pong on the software-pipelined loop
+int g_attn_variant = 0;   // 0 / 1 = this kernel, 2 = the 64-row kernel, 3 = this kernel with the software-pipelined tile loop (lab: 6-9 % slower), 4 = 8-wave ping-pong on the software-pipelined loop, 5 = DMA behind the score MFMAs, 6 / 7 = one / three workgroups per pair, 8 = LDS arrival counters instead of the tile barrier
 #endif
 
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -727,6 +769,7 @@ int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, h
 #ifdef AKI_LAB_HOOKS
   if (g_attn_variant == 3) hipLaunchKernelGGL((mma_attn_bf16_kernel<NW, 1>), dim3(a->B * a->H * p.splits), dim3(NW * 64), 0, stream, p);
   else if (g_attn_variant == 5) hipLaunchKernelGGL((mma_attn_bf16_kernel<NW, 3>), dim3(a->B * a->H * p.splits), dim3(NW * 64), 0, stream, p);
+  else if (g_attn_variant == 8) hipLaunchKernelGGL((mma_attn_bf16_kernel<NW, 4>), dim3(a->B * a->H * p.splits), dim3(NW * 64), 0, stream, p);
   else if (g_attn_variant == 4) {
     // 8-wave ping-pong (lab): one 512-thread workgroup per CU, ranks of eight 32-row blocks
     constexpr int NW8 = 8;
