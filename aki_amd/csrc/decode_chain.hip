@@ -97,7 +97,6 @@ constexpr int CH_NBQ = 2, CH_NBO = 2, CH_NBG = 4, CH_NBD = 2;
 // take x staging + 1.2 us instead of + 4 us (tools/decode_chain_edges.py); gate_up is bandwidth-bound whatever is prefetched; 1.78 -> 1.62 ms per token.
 constexpr int CH_PFQ = 2, CH_PFO = 2, CH_PFG = 2, CH_PFD = 1;
 constexpr int CH_TOUCH = 0;
-constexpr int CH_PRIO = 0;
 constexpr int CH_XREP = 8;               // room for copies of every hand-off vector: consumer j reads copy j % xrep
 constexpr int CH_XREP_USED = 1;          // copies in use: every copy is one more write-through store per producing lane, and at the product's
                                          // 100-600 consumers per phase one copy reads fastest (1 / 2 / 4 copies: 1.66 / 1.68 / 1.71 ms per token)
@@ -118,7 +117,6 @@ struct ChainParams {
   int n_qkv, n_attn, n_o, n_gu, n_down, wg_layer;
   int sleep_n, xrep, nflags, nowait;   // product: 8, CH_XREP_USED, CH_FLAGS, 0; the lab library can change them (aki_lab_set_chain)
   int nbq, nbo, nbg, nbd;              // batches of 4 x FPW features per workgroup of the qkv / o_proj / gate_up / down phases
-  int prio;                            // 1: a wave that has seen its flag runs at s_setprio(3) (its loads, stores and arrival issue ahead of prefetching waves)
   int touch;                           // 1: a waiting workgroup pulls the batches it holds no registers for towards L2 / the Infinity Cache
 #ifdef AKI_LAB_HOOKS
   unsigned long long* stamps;          // lab: [phase 0..4][workgroup < 2048][8] wall-clock stamps (100 MHz) of layer `stamp_layer`
@@ -244,7 +242,6 @@ __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_w
   }
   // (3) the producer phase has published
   chain_wait(p, wait_sync, wg, code);
-  if (p.prio) __builtin_amdgcn_s_setprio(3);
   AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 1);
   // (4) x -> LDS.  Handed-off bytes: sc1 loads only, from this workgroup's copy of the vector.
   const int nchunk = K / 8;
@@ -417,7 +414,6 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
     if ((lane + 64) * 128 < rows * 192) touch1 = *(gptr_u32)(vt + (lane + 64) * 128);
   }
   chain_wait(p, wait_sync, wg, code);
-  if (p.prio) __builtin_amdgcn_s_setprio(3);
   AKI_CHAIN_STAMP(p, layer, 1, wg, 1);
   if (!live) return;                                     // no workgroup barrier below this line
   if (work) {
@@ -712,10 +708,10 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   p.n_gu = wgs(F, rd / 2, p.nbg);
   p.n_down = wgs(d, rf, p.nbd);
   p.wg_layer = p.n_qkv + p.n_attn + p.n_o + p.n_gu + p.n_down;
-  p.sleep_n = 8; p.xrep = CH_XREP_USED; p.nflags = CH_FLAGS; p.nowait = 0; p.touch = CH_TOUCH; p.prio = CH_PRIO;
+  p.sleep_n = 8; p.xrep = CH_XREP_USED; p.nflags = CH_FLAGS; p.nowait = 0; p.touch = CH_TOUCH;
 #ifdef AKI_LAB_HOOKS
   p.sleep_n = g_chain_sleep; p.xrep = g_chain_xrep; p.nflags = g_chain_nflags; p.nowait = g_chain_nowait;
-  if (g_chain_touch >= 0) { p.touch = g_chain_touch & 1; p.prio = (g_chain_touch >> 1) & 1; }      // lab: touch | prio << 1
+  if (g_chain_touch >= 0) p.touch = g_chain_touch;
   p.stamps = g_chain_stamps; p.stamp_layer = g_chain_stamp_layer;
 #endif
   AKI_CLEAR_ERR();
