@@ -96,6 +96,9 @@ constexpr int CH_NBQ = 2, CH_NBO = 2, CH_NBG = 4, CH_NBD = 2;
 // ... of which this many are requested BEFORE the wait (register slots): with both batches of qkv / o_proj on chip when their input arrives, those phases
 // take x staging + 1.2 us instead of + 4 us (tools/decode_chain_edges.py); gate_up is bandwidth-bound whatever is prefetched; 1.78 -> 1.62 ms per token.
 constexpr int CH_PFQ = 2, CH_PFO = 2, CH_PFG = 2, CH_PFD = 1;
+// e4m3 weights (half the bytes, 24 VALU operations per 16 weights to widen them): ONE batch per workgroup, requested before the wait - that chain is
+// all dependency latency and the second batch's dot products (2 us) sat on it: {1,1,1,1} 1.37 ms per token, {2,2,2,2}/{2,2,2,2} 1.48, five launches 1.46
+// (tools/decode_chain_w8.py).
 constexpr int CH_TOUCH = 0;
 constexpr int CH_XREP = 8;               // room for copies of every hand-off vector: consumer j reads copy j % xrep
 constexpr int CH_XREP_USED = 1;          // copies in use: every copy is one more write-through store per producing lane, and at the product's
@@ -695,11 +698,14 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   p.hbuf = v;
   p.part = (float*)(ws + cb + 256 + chain_vec_elems(d, H, F) * 2 * CH_XREP);
   const int rd = w8 ? 4 : 2, rf = w8 ? 2 : 1;     // rows per wave and batch (see the kernel)
-  p.nbq = CH_NBQ; p.nbo = CH_NBO; p.nbg = w8 ? 2 : CH_NBG; p.nbd = CH_NBD;
+  p.nbq = w8 ? 1 : CH_NBQ; p.nbo = w8 ? 1 : CH_NBO; p.nbg = w8 ? 1 : CH_NBG; p.nbd = w8 ? 1 : CH_NBD;
 #ifdef AKI_LAB_HOOKS
-  const int presets[][4] = {{CH_NBQ, CH_NBO, w8 ? 2 : CH_NBG, CH_NBD}, {8, 8, 8, 8}, {4, 2, 8, 2}, {8, 2, 8, 4}, {4, 4, 4, 4}, {16, 4, 16, 4}, {8, 2, 16, 2}, {1, 1, 1, 1}, {8, 4, 16, 4}, {2, 1, 4, 1}, {4, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 2, 2}, {2, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 4}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 2}, {2, 2, 4, 4}, {4, 2, 8, 4}, {2, 2, 4, 2}, {4, 4, 8, 4}, {2, 2, 4, 2}};
-  const int* ps = presets[(w8 && (g_chain_nb < 12 || g_chain_nb > 14)) ? 0 : g_chain_nb];
+  const int presets[][4] = {{w8 ? 1 : CH_NBQ, w8 ? 1 : CH_NBO, w8 ? 1 : CH_NBG, w8 ? 1 : CH_NBD}, {8, 8, 8, 8}, {4, 2, 8, 2}, {8, 2, 8, 4}, {4, 4, 4, 4}, {16, 4, 16, 4}, {8, 2, 16, 2}, {1, 1, 1, 1}, {8, 4, 16, 4}, {2, 1, 4, 1}, {4, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 2, 2}, {2, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 4}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 2}, {2, 2, 4, 4}, {4, 2, 8, 4}, {2, 2, 4, 2}, {4, 4, 8, 4}, {2, 2, 4, 2}};
+  const int* ps = presets[(w8 && g_chain_nb != 9 && g_chain_nb != 20 && g_chain_nb != 21 && (g_chain_nb < 12 || g_chain_nb > 14)) ? 0 : g_chain_nb];
   p.nbq = ps[0]; p.nbo = ps[1]; p.nbg = ps[2]; p.nbd = ps[3];
+  if (w8 && g_chain_nb == 20) { p.nbq = 1; p.nbo = 1; p.nbg = 2; p.nbd = 1; }
+  if (w8 && g_chain_nb == 21) { p.nbq = 1; p.nbo = 1; p.nbg = 1; p.nbd = 2; }
+  if (w8 && g_chain_nb == 7) { p.nbq = 2; p.nbo = 2; p.nbg = 2; p.nbd = 2; }
 #endif
   auto wgs = [&](int n_out, int fpw, int nb) { return (n_out + 4 * fpw * nb - 1) / (4 * fpw * nb); };
   p.n_qkv = wgs(3 * H * 96, rd, p.nbq);
@@ -745,9 +751,13 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   if (w8 && g_chain_nb == 12) AKI_CHAIN_LAUNCH2(true, 2, 2, 2, 2, 2, 2, 2, 2);
   else if (w8 && g_chain_nb == 13) AKI_CHAIN_LAUNCH2(true, 2, 2, 4, 2, 2, 2, 2, 2);
   else if (w8 && g_chain_nb == 14) AKI_CHAIN_LAUNCH2(true, 2, 2, 4, 2, 2, 2, 2, 1);
+  else if (w8 && g_chain_nb == 7) AKI_CHAIN_LAUNCH2(true, 2, 2, 2, 2, 1, 1, 1, 1);
+  else if (w8 && g_chain_nb == 9) AKI_CHAIN_LAUNCH2(true, 2, 1, 4, 1, 2, 1, 4, 1);
+  else if (w8 && g_chain_nb == 20) AKI_CHAIN_LAUNCH2(true, 1, 1, 2, 1, 1, 1, 2, 1);
+  else if (w8 && g_chain_nb == 21) AKI_CHAIN_LAUNCH2(true, 1, 1, 1, 2, 1, 1, 1, 2);
   else
 #endif
-  if (w8) AKI_CHAIN_LAUNCH(true, 2, 2, 2, 2);
+  if (w8) AKI_CHAIN_LAUNCH2(true, 1, 1, 1, 1, 1, 1, 1, 1);
 #ifdef AKI_LAB_HOOKS
   else if (g_chain_nb == 1) AKI_CHAIN_LAUNCH(false, 8, 8, 8, 8);
   else if (g_chain_nb == 2) AKI_CHAIN_LAUNCH(false, 4, 2, 8, 2);

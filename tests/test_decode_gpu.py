@@ -424,7 +424,6 @@ def test_decode_chain_is_bit_identical_to_the_per_layer_launches(prompt, steps, 
     lm, cfg = _full_width_lm(3)
     if fp8:
         lm.enable_fp8()
-        lm.model.decode_chain_w8 = True            # off by default (slower than five launches with e4m3 weights); still must be right
     x = (torch.randn(1, prompt, cfg.hidden_size, generator=torch.Generator().manual_seed(1)) * 0.5).to(torch.bfloat16).to(DEV)
     am = np.ones((1, prompt), dtype=bool)
     am[0, 3:9] = False                                        # a hole in the prompt: the valid-column bits are honoured
@@ -485,14 +484,17 @@ def test_decode_chain_graph_replay_and_poisoned_workspace():
     assert torch.equal(res["eager"], res["graph"])
 
 
-def test_decode_chain_full_depth_graph_replay_equals_the_five_launch_path():
-    """All 32 layers at Phi-3.5-mini's width, hipGraph replay, 10 greedy steps: the logits of every replayed step equal the
-    five-launch-per-layer path bit for bit.  (This is the check round 4 was missing when the chain's arrival counters were zeroed
+@pytest.mark.parametrize("fp8", [False, True])
+def test_decode_chain_full_depth_graph_replay_equals_the_five_launch_path(fp8):
+    """All 32 layers at Phi-3.5-mini's width, hipGraph replay, 10 greedy steps, bf16 and e4m3 weights (each has its own instance of the
+    chain kernel): the logits of every replayed step equal the five-launch-per-layer path bit for bit.  (This is the check round 4 was missing when the chain's arrival counters were zeroed
     by a captured hipMemsetAsync node: under replay the block held a constant non-zero pattern, no workgroup waited for its
     producers, and the step ran at the bare weight stream's speed with wrong logits - while a 2-layer graph test passed.)"""
     from aki_amd import ops
     from aki_amd.phi3 import DecodeGraph
     lm, cfg = _full_width_lm(32, seed=5)
+    if fp8:
+        lm.enable_fp8()
     prompt, steps = 655, 10
     x = (torch.randn(1, prompt, cfg.hidden_size, generator=torch.Generator().manual_seed(4)) * 0.5).to(torch.bfloat16).to(DEV)
     table = ops.MaskTable.from_host([[(6, 150, 150, 638)]], np.ones((1, prompt), dtype=bool), [prompt], DEV)
