@@ -100,6 +100,7 @@ constexpr int CH_PFQ = 2, CH_PFO = 2, CH_PFG = 2, CH_PFD = 1;
 // all dependency latency and the second batch's dot products (2 us) sat on it: {1,1,1,1} 1.37 ms per token, {2,2,2,2}/{2,2,2,2} 1.48, five launches 1.46
 // (tools/decode_chain_w8.py).
 constexpr int CH_TOUCH = 0;
+constexpr int CH_QKV_BY_HEAD = 1;
 constexpr int CH_XREP = 8;               // room for copies of every hand-off vector: consumer j reads copy j % xrep
 constexpr int CH_XREP_USED = 1;          // copies in use: every copy is one more write-through store per producing lane, and at the product's
                                          // 100-600 consumers per phase one copy reads fastest (1 / 2 / 4 copies: 1.66 / 1.68 / 1.71 ms per token)
@@ -113,6 +114,9 @@ struct ChainParams {
   int d, H, F, cap, S, T; float scale, eps;
   unsigned* sync;         // [n_layers][CH_PHASES][CH_SYNC_WORDS], then [n_layers][H] attention tickets: zeroed by the launch function
   unsigned* attn_cnt;     // a ticket per (layer, head): nothing is re-armed inside the launch
+  unsigned* head_sync;    // [n_layers][H][2 lines]: arrivals of the 96 / rows-per-workgroup x 3 qkv workgroups that produce head h's q, k, v and
+                          // the head's READY flag (qkv_by_head): an attention item waits for ITS head's 18 producers, not for the phase's 576
+  int qkv_by_head;        // wgs per (section, head) of the qkv phase when its workgroups are laid out head-major, else 0 (one flag for the phase)
   unsigned* err;          // sticky error word (outside the zeroed block)
   bf16_t* qkv; bf16_t* attn_o; bf16_t* h1; bf16_t* act; bf16_t* hbuf;   // hand-off vectors (copy 0); hbuf = 2 x d
   int rep_stride;         // elements between the copies of a hand-off vector
@@ -200,11 +204,20 @@ __device__ __forceinline__ void chain_publish(unsigned* sync, int idx, int n) {
 template <int NR, int KC, bool SWIGLU, bool NORM, bool W8, int NB, int PF>
 __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_wg, const void* w, const float* w_scale, int K, int n_out,
                                            const bf16_t* x, int x_rep, const bf16_t* norm_w, const bf16_t* residual, int res_rep, bf16_t* y,
-                                           int y_reps, unsigned* wait_sync, unsigned* done_sync, unsigned code, char* sx, float* s_red) {
+                                           int y_reps, unsigned* wait_sync, unsigned* done_sync, unsigned code, char* sx, float* s_red,
+                                           int head_per = 0, unsigned* head_sync = nullptr) {
   constexpr int FPW = SWIGLU ? NR / 2 : NR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int nb = NB;
-  const int fbase = wg * (4 * FPW * nb) + wave * FPW;
+  // qkv phase, head-major (head_per = workgroups per 96 rows): workgroup -> (head, section q / k / v, slice) so that the producers of one
+  // head's q, k and v are 3 x head_per consecutive workgroups with an arrival counter of their own
+  int fbase = wg * (4 * FPW * nb) + wave * FPW;
+  int head_of_wg = 0;
+  if (head_per > 0) {
+    head_of_wg = wg / (3 * head_per);
+    const int part = wg - head_of_wg * 3 * head_per, sec = part / head_per, sub = part - sec * head_per;
+    fbase = sec * (n_out / 3) + head_of_wg * 96 + sub * (4 * FPW * nb) + wave * FPW;
+  }
   const size_t row_bytes = W8 ? (size_t)K : (size_t)K * 2;
   // PF batches are requested before the wait (register slots b % PF); with PF = NB nothing is left to load once the input is there
   static_assert(PF >= 1 && PF <= NB, "prefetch depth");
@@ -358,7 +371,14 @@ __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_w
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chain_publish, with a stamp between the drain and the arrival
   __syncthreads();
   AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 4);
-  if (threadIdx.x < 64) chain_arrive(done_sync, wg, n_wg, threadIdx.x);
+  if (head_per > 0) {             // one counter per head: 3 x head_per arrivals, the last one raises the head's flag
+    if (threadIdx.x == 0) {
+      unsigned* hs = head_sync + (size_t)head_of_wg * 64;
+      if (__hip_atomic_fetch_add(hs, 1u, AKI_RLX_AGENT) + 1u == (unsigned)(3 * head_per)) __hip_atomic_store(hs + 32, 1u, AKI_RLX_AGENT);
+    }
+  } else if (threadIdx.x < 64) {
+    chain_arrive(done_sync, wg, n_wg, threadIdx.x);
+  }
   AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 5);
 }
 
@@ -416,7 +436,22 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
     if (lane * 128 < rows * 192) touch0 = *(gptr_u32)(vt + lane * 128);
     if ((lane + 64) * 128 < rows * 192) touch1 = *(gptr_u32)(vt + (lane + 64) * 128);
   }
-  chain_wait(p, wait_sync, wg, code);
+  if (p.qkv_by_head && !p.nowait) {
+    // per wave: the flag of THIS item's head (lane 0 polls; a wave is one item and nothing below is a workgroup barrier)
+    if (live && lane == 0) {
+      const unsigned* flag = p.head_sync + ((size_t)layer * p.H + h) * 64 + 32;
+      unsigned spins = 0;
+      while (__hip_atomic_load(flag, AKI_RLX_AGENT) == 0u) {
+        for (int i = 0; i < p.sleep_n; ++i) __builtin_amdgcn_s_sleep(1);
+        if (++spins > CH_SPIN_LIMIT) { __hip_atomic_store(p.err, code, AKI_RLX_AGENT); break; }
+        if ((spins & 63u) == 0u && __hip_atomic_load(p.err, AKI_RLX_AGENT) != 0u) break;      // somebody gave up: drain
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    chain_wait(p, wait_sync, wg, code);
+  }
   AKI_CHAIN_STAMP(p, layer, 1, wg, 1);
   if (!live) return;                                     // no workgroup barrier below this line
   if (work) {
@@ -622,7 +657,8 @@ __global__ __launch_bounds__(256, OCC) void decode_chain_kernel(const ChainParam
   constexpr int KF = W8 ? KCF / 2 : KCF;
   if (r < p.n_qkv) {
     chain_gemv<NRD, KD, false, true, W8, NBQ, PFQ>(p, r, p.n_qkv, ly.w_qkv, ly.s_qkv, p.d, 3 * p.H * 96, h0, h0_rep, (const bf16_t*)ly.norm1, nullptr, 0, p.qkv,
-                                          CH_XREP, prev_down, sy + 0 * CH_SYNC_WORDS, code | 1u, sx, s_red);
+                                          CH_XREP, prev_down, sy + 0 * CH_SYNC_WORDS, code | 1u, sx, s_red, p.qkv_by_head,
+                                          p.head_sync + (size_t)layer * p.H * 64);
     return;
   }
   r -= p.n_qkv;
@@ -648,7 +684,7 @@ __global__ __launch_bounds__(256, OCC) void decode_chain_kernel(const ChainParam
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-static inline size_t chain_cnt_bytes(int n_layers, int H) { return aki_align_up((size_t)n_layers * ((size_t)CH_PHASES * CH_SYNC_WORDS + H) * 4, 256); }
+static inline size_t chain_cnt_bytes(int n_layers, int H) { return aki_align_up((size_t)n_layers * ((size_t)CH_PHASES * CH_SYNC_WORDS + H + (size_t)H * 64) * 4, 256); }
 static inline size_t chain_vec_elems(int d, int H, int F) { return aki_align_up((size_t)(3 * H * 96 + H * 96 + d + F + 2 * d) * 2 + 256, 256) / 2; }   // one copy
 
 #ifdef AKI_LAB_HOOKS
@@ -687,7 +723,8 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   char* ws = (char*)a->workspace;
   const size_t cb = chain_cnt_bytes(a->n_layers, H);
   p.sync = (unsigned*)ws;
-  p.attn_cnt = p.sync + (size_t)a->n_layers * CH_PHASES * CH_SYNC_WORDS;
+  p.head_sync = p.sync + (size_t)a->n_layers * CH_PHASES * CH_SYNC_WORDS;          // 128-byte lines first, the tickets behind them
+  p.attn_cnt = p.head_sync + (size_t)a->n_layers * H * 64;
   p.err = (unsigned*)(ws + cb);
   bf16_t* v = (bf16_t*)(ws + cb + 256);
   p.rep_stride = (int)chain_vec_elems(d, H, F);
@@ -714,10 +751,14 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   p.n_gu = wgs(F, rd / 2, p.nbg);
   p.n_down = wgs(d, rf, p.nbd);
   p.wg_layer = p.n_qkv + p.n_attn + p.n_o + p.n_gu + p.n_down;
+  {
+    const int rows_wg = 4 * rd * p.nbq;                 // rows of w_qkv per workgroup
+    p.qkv_by_head = (CH_QKV_BY_HEAD && 96 % rows_wg == 0) ? 96 / rows_wg : 0;
+  }
   p.sleep_n = 8; p.xrep = CH_XREP_USED; p.nflags = CH_FLAGS; p.nowait = 0; p.touch = CH_TOUCH;
 #ifdef AKI_LAB_HOOKS
   p.sleep_n = g_chain_sleep; p.xrep = g_chain_xrep; p.nflags = g_chain_nflags; p.nowait = g_chain_nowait;
-  if (g_chain_touch >= 0) p.touch = g_chain_touch;
+  if (g_chain_touch >= 0) { p.touch = g_chain_touch & 1; if (g_chain_touch & 2) p.qkv_by_head = 0; }      // lab: touch | (one flag for the whole qkv phase) << 1
   p.stamps = g_chain_stamps; p.stamp_layer = g_chain_stamp_layer;
 #endif
   AKI_CLEAR_ERR();

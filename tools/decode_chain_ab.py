@@ -30,13 +30,15 @@ def main():
     table = ops.MaskTable.from_host([[(4, 148, 4, 148)]], torch.ones(1, L, dtype=torch.bool).numpy(), [L], dev)
     # (s_sleep(1) x N per poll, copies of the hand-off vectors, READY flags per phase, nowait) on the product's batches
     settings = [("product: sleep 8, 1 copy, 32 flags", (8, 1, 32, 0)), ("sleep 2", (2, 1, 32, 0)), ("sleep 16", (16, 1, 32, 0)), ("2 copies", (8, 2, 32, 0)),
-                ("4 copies", (8, 4, 32, 0)), ("16 flags", (8, 1, 16, 0)), ("nowait (wrong results): the bare weight stream", (8, 1, 32, 1))]
+                ("4 copies", (8, 4, 32, 0)), ("16 flags", (8, 1, 16, 0)), ("one READY flag for the whole qkv phase (attention waits for all 576 producers)", (8, 1, 32, 0, 2)),
+                ("nowait (wrong results): the bare weight stream", (8, 1, 32, 1))]
     res = {name: [] for name, _ in settings}
     with _lib.use_lab(0) as lab, torch.no_grad():
         for _ in range(a.rounds):
             for name, knobs in settings:
                 lab.aki_lab_set_chain(*knobs[:4])
                 lab.aki_lab_set_chain_nb(0)
+                lab.aki_lab_set_chain_touch(knobs[4] if len(knobs) > 4 else -1)
                 out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=L + a.steps + 16)
                 cache = out.past_key_values
                 nxt = out.logits[:, -1].float().argmax(-1)
@@ -53,6 +55,7 @@ def main():
                     cache.chain.check()
         lab.aki_lab_set_chain(8, 1, 32, 0)
         lab.aki_lab_set_chain_nb(0)
+        lab.aki_lab_set_chain_touch(-1)
     for name, _ in settings:
         print(f"{name:45s} ms/token {res[name]}")
     print(json.dumps(res))
