@@ -16,7 +16,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 13
+AKI_ABI_VERSION = 14
 
 
 class AkiError(RuntimeError):
@@ -157,6 +157,8 @@ SIGNATURES = {
     "aki_splice_fwd": (C.c_int, [C.POINTER(SpliceArgs), C.c_void_p]),
     "aki_mma_mask_dense": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p]),
+    "aki_greedy_pick": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "aki_sft_collate_pad": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32] + [C.c_void_p] * 4),
     "aki_mma_mask_to_table_workspace_bytes": (C.c_size_t, [C.c_int32] * 2),
     "aki_mma_mask_to_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),

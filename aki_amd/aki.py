@@ -219,6 +219,26 @@ class AKI(VLMWithLanguageStream):
         done = torch.zeros(B, dtype=torch.bool, device=lang_x.device)
         eos_t = torch.tensor(sorted(eos_ids), dtype=torch.long, device=lang_x.device) if eos_ids else None
         stepper = None
+        if use_graph and not do_sample and logits.is_cuda and logits.dtype == torch.bfloat16:
+            # Greedy: the pick (argmax, pad for finished rows, append, eos check, cache_len advance) is one launch INSIDE the replayed
+            # step, so a token is one graph replay; the host looks at the finished flags every 8th token instead of syncing per token.
+            from . import ops
+            from .phi3 import DecodeGraph
+            done8 = torch.zeros(B, dtype=torch.uint8, device=lang_x.device)
+            done_at = torch.full((B,), -1, dtype=torch.int32, device=lang_x.device)
+            pick = dict(pad_token_id=pad_id, eos_ids=eos_t, done=done8, tokens=tokens, start_len=cache.cache_len.clone(), done_at=done_at)
+            stepper = DecodeGraph(self.lang_model, cache, greedy=pick)
+            ops.greedy_pick(logits.contiguous(), stepper.ids, cache_len=cache.cache_len, advance=False, **pick)      # token 0, from the prefill
+            steps = 1
+            for t in range(1, max_new_tokens):
+                if eos_t is not None and t % 8 == 0 and bool(done8.all()):
+                    break
+                stepper.step_greedy()
+                steps = t + 1
+            if eos_t is not None and bool(done8.all()):
+                steps = int(done_at.max()) + 1
+            self._post_forward_hook()
+            return tokens[:, :steps]
         if use_graph:
             from .phi3 import DecodeGraph
             stepper = DecodeGraph(self.lang_model, cache)

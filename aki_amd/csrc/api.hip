@@ -37,6 +37,8 @@ int splice_launch(const aki_splice_args* a, hipStream_t s);
 int mask_dense_launch(const aki_mma_rect* rects, int max_rects, const uint64_t* vbits, const int* seq_lens, int B, int L,
                       int64_t* out, hipStream_t s);
 int im2col_launch(const void* pix, void* out, int N, int S, int P, int Kp, int dtype, hipStream_t s);
+int greedy_pick_launch(const void* logits, int B, int V, int ld, const int64_t* eos, int n_eos, int64_t pad, unsigned char* done, int64_t* ids,
+                       int64_t* tokens, int tokens_ld, int* cache_len, const int* start_len, int advance, int* done_at, hipStream_t s);
 int sft_collate_launch(const int64_t* ids, const int64_t* labels, const int64_t* mask, const int* offsets, int B, int T_out,
                        int64_t pad_id, int64_t ignore_index, int left, int64_t* out_ids, int64_t* out_labels, int64_t* out_mask,
                        hipStream_t s);
@@ -585,6 +587,16 @@ int aki_sft_collate_pad(const int64_t* ids, const int64_t* labels, const int64_t
   AKI_CHECK_ARG((!out_labels || labels) && (!out_mask || attention_mask));
   return sft_collate_launch(ids, labels, attention_mask, offsets, B, T_out, pad_token_id, ignore_index, padding_side, out_ids, out_labels,
                             out_mask, (hipStream_t)stream);
+}
+
+int aki_greedy_pick(const void* logits, int32_t B, int32_t V, int64_t ld, const int64_t* eos_ids, int32_t n_eos, int64_t pad_token_id,
+                    uint8_t* done, int64_t* next_ids, int64_t* tokens, int32_t tokens_ld, int32_t* cache_len, const int32_t* start_len,
+                    int32_t advance, int32_t* done_at, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(logits && next_ids && B > 0 && V > 0 && ld >= V && ld < (1ll << 31) && n_eos >= 0 && (n_eos == 0 || eos_ids));
+  AKI_CHECK_ARG((!tokens || tokens_ld > 0) && (!advance || cache_len) && (advance == 0 || advance == 1));
+  return greedy_pick_launch(logits, B, V, (int)ld, eos_ids, n_eos, pad_token_id, done, next_ids, tokens, tokens_ld, cache_len, start_len, advance,
+                            done_at, (hipStream_t)stream);
 }
 
 size_t aki_mma_mask_to_table_workspace_bytes(int32_t B, int32_t L) {

@@ -837,4 +837,86 @@ int decode_attn_launch(const void* q, const void* kc, const void* vc, void* o, c
   return AKI_OK;
 }
 
+
+// ---- greedy token pick: what the reference's generate loop does between two decode steps (HF GenerationMixin greedy branch:
+// argmax over the vocabulary, finished rows take pad_token_id, append, eos check; src/aki.py:136-209 hands its kwargs to it) as
+// ONE launch that can sit inside the replayed step - the loop's five small launches and its per-token host sync were 4 % of a token.
+// Ties go to the lower index and a NaN outranks every number (torch.argmax's ordering).
+struct PickParams {
+  const bf16_t* logits; int B, V, ld;
+  const int64_t* eos; int n_eos; int64_t pad;
+  unsigned char* done; int64_t* ids; int64_t* tokens; int tokens_ld;
+  int* cache_len; const int* start_len; int advance; int* done_at;
+};
+
+__device__ __forceinline__ bool pick_better(float a, int ia, float b, int ib) {
+  const bool na = a != a, nb = b != b;
+  if (na != nb) return na;
+  if (na) return ia < ib;
+  return a > b || (a == b && ia < ib);
+}
+
+__global__ __launch_bounds__(256) void greedy_pick_kernel(const PickParams p) {
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_t* row = p.logits + (size_t)b * p.ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  const bool vec = ((p.ld & 7) == 0) && ((((uintptr_t)p.logits) & 15) == 0);
+  const int nvec = vec ? p.V / 8 : 0;
+  for (int c = tid; c < nvec; c += 256) {
+    const u32x4 v = *(const u32x4*)(row + (size_t)c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = bf16_lo(v[e]), hi = bf16_hi(v[e]);
+      if (pick_better(lo, c * 8 + 2 * e, best, bi)) { best = lo; bi = c * 8 + 2 * e; }
+      if (pick_better(hi, c * 8 + 2 * e + 1, best, bi)) { best = hi; bi = c * 8 + 2 * e + 1; }
+    }
+  }
+  for (int i = nvec * 8 + tid; i < p.V; i += 256) {
+    const float x = bf16_bits_to_f32(row[i]);
+    if (pick_better(x, i, best, bi)) { best = x; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (pick_better(ov, oi, best, bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { s_v[wave] = best; s_i[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (pick_better(s_v[w], s_i[w], best, bi)) { best = s_v[w]; bi = s_i[w]; }
+    const bool was_done = p.done != nullptr && p.done[b] != 0;
+    const int64_t nxt = was_done ? p.pad : (int64_t)bi;
+    int t = 0;
+    if (p.cache_len != nullptr) {
+      t = p.cache_len[b] + p.advance - (p.start_len ? p.start_len[b] : 0);
+      if (p.advance) p.cache_len[b] += 1;
+    }
+    if (p.tokens != nullptr && t >= 0 && t < p.tokens_ld) p.tokens[(size_t)b * p.tokens_ld + t] = nxt;
+    p.ids[b] = nxt;
+    if (p.done != nullptr && !was_done) {
+      bool hit = false;
+      for (int i = 0; i < p.n_eos; ++i) hit = hit || p.eos[i] == nxt;
+      if (hit) {
+        p.done[b] = 1;
+        if (p.done_at) p.done_at[b] = t;
+      }
+    }
+  }
+}
+
+int greedy_pick_launch(const void* logits, int B, int V, int ld, const int64_t* eos, int n_eos, int64_t pad, unsigned char* done, int64_t* ids,
+                       int64_t* tokens, int tokens_ld, int* cache_len, const int* start_len, int advance, int* done_at, hipStream_t s) {
+  PickParams p = {(const bf16_t*)logits, B, V, ld, eos, n_eos, pad, done, ids, tokens, tokens_ld, cache_len, start_len, advance, done_at};
+  AKI_CLEAR_ERR();
+  hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(256), 0, s, p);
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
+}
+
 }  // namespace aki

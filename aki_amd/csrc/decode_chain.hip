@@ -95,7 +95,7 @@ constexpr int CH_PHASES = 5;             // [0] qkv [1] attention (per-head merg
 constexpr int CH_NBQ = 2, CH_NBO = 2, CH_NBG = 4, CH_NBD = 2;
 // ... of which this many are requested BEFORE the wait (register slots): with both batches of qkv / o_proj on chip when their input arrives, those phases
 // take x staging + 1.2 us instead of + 4 us (tools/decode_chain_edges.py); gate_up is bandwidth-bound whatever is prefetched; 1.78 -> 1.62 ms per token.
-constexpr int CH_PFQ = 2, CH_PFO = 2, CH_PFG = 2, CH_PFD = 1;
+constexpr int CH_PFQ = 2, CH_PFO = 2, CH_PFG = 2, CH_PFD = 2;
 // e4m3 weights (half the bytes, 24 VALU operations per 16 weights to widen them): ONE batch per workgroup, requested before the wait - that chain is
 // all dependency latency and the second batch's dot products (2 us) sat on it: {1,1,1,1} 1.37 ms per token, {2,2,2,2}/{2,2,2,2} 1.48, five launches 1.46
 // (tools/decode_chain_w8.py).

@@ -510,6 +510,28 @@ class DecodeChain:
             raise AkiError(f"decode chain: a dependency wait gave up (layer {code >> 8}, phase {code & 255}); the step's output is invalid")
 
 
+def greedy_pick(logits: torch.Tensor, next_ids: torch.Tensor, pad_token_id: int = 0, eos_ids: Optional[torch.Tensor] = None,
+                done: Optional[torch.Tensor] = None, tokens: Optional[torch.Tensor] = None, cache_len: Optional[torch.Tensor] = None,
+                start_len: Optional[torch.Tensor] = None, advance: bool = False, done_at: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The step between two decode steps of a greedy `generate` as one launch (aki_greedy_pick; HF GenerationMixin's greedy branch):
+    next_ids[b] = pad if done[b] else argmax(logits[b]); tokens[b, t] = next with t = cache_len[b] + advance - start_len[b]; rows whose
+    next is an eos id become done (done_at[b] = t); advance: cache_len += 1.  logits: bf16 [B, V] (row stride >= V); next_ids / tokens /
+    eos_ids int64; done uint8; cache_len / start_len / done_at int32.  Capturable: no host value is read."""
+    if logits.dtype != torch.bfloat16 or logits.dim() != 2 or logits.stride(1) != 1:
+        raise AkiError("greedy_pick takes bf16 logits [B, V] with unit column stride")
+    B, V = logits.shape
+    for t_, dt in ((next_ids, torch.int64), (tokens, torch.int64), (eos_ids, torch.int64), (done, torch.uint8), (cache_len, torch.int32),
+                   (start_len, torch.int32), (done_at, torch.int32)):
+        if t_ is not None and (t_.dtype != dt or not t_.is_contiguous() or t_.device != logits.device):
+            raise AkiError(f"greedy_pick: a {dt} contiguous tensor on {logits.device} is expected, got {t_.dtype} {tuple(t_.shape)}")
+    if tokens is not None and (tokens.dim() != 2 or tokens.shape[0] != B):
+        raise AkiError("greedy_pick: tokens is [B, max_new_tokens]")
+    L.check(L.load().aki_greedy_pick(_ptr(logits), B, V, logits.stride(0), _ptr(eos_ids), 0 if eos_ids is None else eos_ids.numel(),
+                                          int(pad_token_id), _ptr(done), _ptr(next_ids), _ptr(tokens), 0 if tokens is None else tokens.shape[1],
+                                          _ptr(cache_len), _ptr(start_len), 1 if advance else 0, _ptr(done_at), _stream()), "aki_greedy_pick")
+    return next_ids
+
+
 def decode_linear(x: torch.Tensor, w: torch.Tensor, rms_weight: torch.Tensor, eps: float, act: int = ACT_NONE,
                   bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = act(rmsnorm(x; rms_weight, eps) W^T + bias) [+ residual] for the few rows of a decode step: one weight-streaming

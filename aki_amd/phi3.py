@@ -131,13 +131,16 @@ class DecodeGraph:
     tensors advanced inside the graph, so no per-step host value is baked in - except the LongRoPE table choice, which
     is re-captured if the sequence crosses `original_max_position_embeddings`."""
 
-    def __init__(self, lm: "Phi3ForCausalLM", cache: AkiKVCache):
+    def __init__(self, lm: "Phi3ForCausalLM", cache: AkiKVCache, greedy: Optional[dict] = None):
+        """greedy (optional): the arguments of ops.greedy_pick except logits / next_ids / cache_len / advance - the pick then sits INSIDE the
+        replayed step and writes the next step's input ids itself: one replay per token (`step_greedy`), nothing else on the stream."""
         self.lm, self.cache = lm, cache
         B = cache.cache_len.shape[0]
         self.ids = torch.zeros((B,), dtype=torch.long, device=cache.cache_len.device)
         self.graph = None
         self.logits = None
         self._long = None
+        self.greedy = greedy
 
     def _capture(self):
         lm, cache = self.lm, self.cache
@@ -152,10 +155,24 @@ class DecodeGraph:
         cache.host_len = saved_host
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.logits = lm.decode_step(input_ids=self.ids, past_key_values=cache)
+            if self.greedy is None:
+                self.logits = lm.decode_step(input_ids=self.ids, past_key_values=cache)
+            else:                                   # the pick advances cache_len itself: one launch less per token
+                self.logits = lm.decode_step(input_ids=self.ids, past_key_values=cache, advance=False)
+                ops.greedy_pick(self.logits, self.ids, cache_len=cache.cache_len, advance=True, **self.greedy)
         cache.host_len = saved_host
 
-    def step(self, ids: torch.Tensor) -> torch.Tensor:
+    def step_greedy(self) -> torch.Tensor:
+        """One token of a greedy generation: replay; the ids picked by the previous replay (or placed in `self.ids` by the caller) go in,
+        the ids picked from this step's logits are left in `self.ids` (and in greedy['tokens'])."""
+        if self.greedy is None:
+            raise ops.AkiError("DecodeGraph was built without a greedy pick")
+        self._ready()
+        self.graph.replay()
+        self.cache.host_len += 1
+        return self.ids
+
+    def _ready(self):
         if self.cache.host_len + 1 > self.cache.capacity:
             raise ops.AkiError(f"KV cache is full: {self.cache.host_len} of {self.cache.capacity} rows used; size it with "
                                "lang_model(..., use_cache=True, cache_capacity=prompt_len + max_new_tokens)")
@@ -164,6 +181,11 @@ class DecodeGraph:
         if self.graph is None or use_long != self._long:
             self._long = use_long
             self._capture()
+
+    def step(self, ids: torch.Tensor) -> torch.Tensor:
+        if self.greedy is not None:
+            raise ops.AkiError("this DecodeGraph picks its own next ids: use step_greedy()")
+        self._ready()
         self.ids.copy_(ids)
         self.graph.replay()
         self.cache.host_len += 1
@@ -384,8 +406,9 @@ class Phi3Model(nn.Module):
             return h
         return self.norm(h)
 
-    def decode(self, inputs_embeds, cache):
-        """inputs_embeds [B, d]: the embeddings of the tokens appended at index cache.cache_len[b]."""
+    def decode(self, inputs_embeds, cache, advance: bool = True):
+        """inputs_embeds [B, d]: the embeddings of the tokens appended at index cache.cache_len[b].  advance=False leaves cache_len to the
+        caller (ops.greedy_pick folds the increment into its launch)."""
         if cache.host_len + 1 > cache.capacity and not torch.cuda.is_current_stream_capturing():
             # host_len is a host-side upper bound of max(cache_len): the guard costs no sync.  The append kernels write row
             # cache_len[b] and read cos/sin row cache_len[b] unconditionally - one step further corrupts the next (b, h) slab.
@@ -405,7 +428,8 @@ class Phi3Model(nn.Module):
         else:
             for layer in self.layers:
                 h = layer.decode(h, cos, sin, cache)
-        cache.cache_len += 1
+        if advance:
+            cache.cache_len += 1
         return h                                    # PRE-norm: the head applies self.norm inside its GEMV
 
     use_decode_chain = True                         # False: the five-launch-per-layer path (A/B and the bit-identity tests)
@@ -602,12 +626,12 @@ class Phi3ForCausalLM(nn.Module):
         steps = [self.decode_step(inputs_embeds=inputs_embeds[:, t], past_key_values=cache) for t in range(inputs_embeds.shape[1])]
         return CausalLMOutputWithPast(loss=None, logits=torch.stack(steps, dim=1), past_key_values=cache)
 
-    def decode_step(self, input_ids=None, inputs_embeds=None, past_key_values=None):
+    def decode_step(self, input_ids=None, inputs_embeds=None, past_key_values=None, advance: bool = True):
         """One greedy-decoding step: new token ids [B] (or their embeddings [B, d]) -> logits [B, V'].  After the prefill
         the reference's mask is all ones (src/aki_generation.py:58-62): the token attends to everything cached."""
         if inputs_embeds is None:
             inputs_embeds = self.get_input_embeddings()(input_ids)
-        h = self.model.decode(inputs_embeds.reshape(inputs_embeds.shape[0], -1), past_key_values)
+        h = self.model.decode(inputs_embeds.reshape(inputs_embeds.shape[0], -1), past_key_values, advance=advance)
         norm = self.model.norm
         if getattr(self, "_fp8_head", None) is not None and h.shape[0] == 1:
             wq, ws, b, n = self._fp8_head

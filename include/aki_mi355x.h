@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 13
+#define AKI_ABI_VERSION 14
 
 typedef enum {
   AKI_OK = 0,
@@ -535,6 +535,19 @@ int aki_mma_mask_to_table(const int64_t* mask, int32_t B, int32_t L, int32_t max
 int aki_sft_collate_pad(const int64_t* ids, const int64_t* labels, const int64_t* attention_mask, const int32_t* offsets, int32_t B,
                         int32_t T_out, int64_t pad_token_id, int64_t ignore_index, int32_t padding_side, int64_t* out_ids,
                         int64_t* out_labels, int64_t* out_mask, void* stream);
+
+/* aki_greedy_pick - the step between two decode steps of a greedy `generate` (HF GenerationMixin's greedy branch, which
+ * src/aki.py:136-209 drives through src/aki_generation.py:36-86): per row b of bf16 logits [B, ld], V columns used,
+ *   next = done[b] ? pad_token_id : argmax_v logits[b, v]     (ties: the lower index; a NaN outranks every number - torch.argmax)
+ *   t = cache_len[b] + advance - start_len[b]                 (0 when cache_len is NULL; start_len NULL = zeros)
+ *   tokens[b, t] = next (when tokens != NULL and 0 <= t < tokens_ld);  next_ids[b] = next
+ *   a row that was not done and whose next is one of eos_ids becomes done (done[b] = 1, done_at[b] = t)
+ *   advance = 1: cache_len[b] += 1 (the decode step's own advance, folded into this launch)
+ * done / tokens / cache_len / start_len / done_at may be NULL.  One launch, no host value: it sits inside the replayed hipGraph
+ * of a decode step, so a greedy token is one replay and the host looks at `done` every few tokens. */
+int aki_greedy_pick(const void* logits, int32_t B, int32_t V, int64_t ld, const int64_t* eos_ids, int32_t n_eos, int64_t pad_token_id,
+                    uint8_t* done, int64_t* next_ids, int64_t* tokens, int32_t tokens_ld, int32_t* cache_len, const int32_t* start_len,
+                    int32_t advance, int32_t* done_at, void* stream);
 
 #ifdef __cplusplus
 }

@@ -258,6 +258,63 @@ def test_generate_graph_replay_equals_eager(dtype):
     assert torch.equal(eager, graph)
 
 
+def test_generate_graph_greedy_stops_at_eos_like_the_eager_loop():
+    """bf16, hipGraph: the greedy pick runs inside the replayed step and the host looks at the finished flags every 8th token - the
+    returned tokens (pads behind an EOS, truncation at the step where the last row finished) must equal the eager loop's, which syncs
+    on every token like HF's (GenerationMixin greedy branch)."""
+    m, g = build_tiny(torch.bfloat16)
+    vx, lx, am, _ = batch(g, torch.bfloat16)
+    pad = gen.TINY["pad_token_id"]
+    free = m.generate(vx, lx, attention_mask=am, max_new_tokens=20, eos_token_id=[], use_graph=False)
+    assert free.shape[1] == 20
+    graph_free = m.generate(vx, lx, attention_mask=am, max_new_tokens=20, eos_token_id=[], use_graph=True)
+    assert torch.equal(free, graph_free)
+    for eos in ([int(free[0, 3])], [int(free[0, 11]), int(free[-1, 2])], sorted(set(free[:, 5].tolist()))):
+        eager = m.generate(vx, lx, attention_mask=am, max_new_tokens=20, eos_token_id=eos, pad_token_id=pad, use_graph=False)
+        graph = m.generate(vx, lx, attention_mask=am, max_new_tokens=20, eos_token_id=eos, pad_token_id=pad, use_graph=True)
+        assert eager.shape == graph.shape and torch.equal(eager, graph), (eos, eager.shape, graph.shape)
+
+
+def test_greedy_pick_kernel_against_torch():
+    """aki_greedy_pick: argmax with torch's ordering (lower index on ties, NaN first), pad for finished rows, append at
+    t = cache_len + advance - start_len, eos -> done / done_at, cache_len advance; strided logits rows."""
+    from aki_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, V, ld = 5, 32064, 32064 + 64
+    buf = torch.randn(B, ld, generator=g).to(torch.bfloat16)
+    buf[0, 777] = buf[0, 31000] = 9.5                       # a tie: the lower index wins
+    buf[1, 12345] = float("nan")                            # NaN outranks every number
+    buf[2, V:] = 50.0                                       # beyond V: never looked at
+    buf[3, V - 1] = 40.0                                    # the last column counts
+    buf = buf.to(DEV)
+    logits = buf[:, :V]
+    want = logits.float().argmax(-1)
+    assert int(want[0]) == 777 and int(want[1]) == 12345 and int(want[3]) == V - 1
+    eos = torch.tensor([int(want[3]), 5], dtype=torch.long, device=DEV)
+    done = torch.tensor([0, 0, 1, 0, 0], dtype=torch.uint8, device=DEV)
+    ids = torch.full((B,), -7, dtype=torch.long, device=DEV)
+    tokens = torch.full((B, 6), -1, dtype=torch.long, device=DEV)
+    cache_len = torch.tensor([10, 11, 12, 13, 14], dtype=torch.int32, device=DEV)
+    start = torch.tensor([8, 11, 12, 10, 20], dtype=torch.int32, device=DEV)      # t = 3, 1, 1, 4, -5 (outside: not stored)
+    done_at = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+    ops.greedy_pick(logits, ids, pad_token_id=99, eos_ids=eos, done=done, tokens=tokens, cache_len=cache_len, start_len=start, advance=True,
+                    done_at=done_at)
+    exp = want.clone()
+    exp[2] = 99
+    assert ids.tolist() == exp.tolist()
+    assert cache_len.tolist() == [11, 12, 13, 14, 15]
+    t = [3, 1, 1, 4]
+    for b in range(4):
+        row = tokens[b].tolist()
+        assert row[t[b]] == int(exp[b]) and all(v == -1 for i, v in enumerate(row) if i != t[b])
+    assert tokens[4].tolist() == [-1] * 6
+    assert done.tolist() == [0, 0, 1, 1, 0] and done_at.tolist() == [-1, -1, -1, 4, -1]
+    # the minimal form: ids only, unaligned width (scalar tail path)
+    small = torch.randn(2, 1001, generator=g).to(torch.bfloat16).to(DEV)
+    out = ops.greedy_pick(small, torch.empty(2, dtype=torch.long, device=DEV))
+    assert out.tolist() == small.float().argmax(-1).tolist()
+
+
 @pytest.mark.parametrize("M", [1, 8])
 @pytest.mark.parametrize("act", ["none", "swiglu"])
 def test_decode_linear_fused_rmsnorm(M, act):
