@@ -5,17 +5,19 @@
 // Why.  At batch 1 a decode step is 7.4 GB of weights read once; decode.hip runs it as 5 launches per layer, and every launch
 // of that chain is a latency chain of its own - launch, stage x, first weight round trip, reduce, store, drain - during which
 // HBM idles: the three K = 3072 GEMVs are ONE batch of loads per wave (10.7 us for 19-57 MB), 1.96 ms per token = 0.47 of the
-// HBM peak.  Weights do not depend on activations.  Here a workgroup issues its weight loads FIRST and only then
+// HBM peak.  Weights do not depend on activations.  Here a workgroup requests its weights FIRST and only then
 // waits for its input vector, so the stream runs ahead of the dependency chain by everything the register files of the
-// resident workgroups hold (~40-50 MB chip-wide), across phase AND layer seams.
+// resident workgroups hold (~60 MB chip-wide), across phase AND layer seams.  1.64 ms per greedy token (0.59 of the peak).
 //
 // How.  grid = n_layers x (qkv | attention | o_proj | gate_up | down) workgroups in DISPATCH ORDER = dependency order.  A
-// workgroup: (1) finds its (layer, phase, slice) from blockIdx, (2) issues every weight load of its slice (non-temporal,
-// 12-16 x 16 B per lane), (3) one lane polls the producer phase's arrival counter (relaxed agent-scope loads + s_sleep),
-// (4) stages its input vector from the hand-off buffer into LDS (RMSNorm fused where the layer has one), (5) dot products
-// out of registers, wave reduce, epilogue (SwiGLU / residual), (6) publishes: outputs stored write-through (sc1), every
-// storing wave drains vmcnt, barrier, one lane adds 1 to its phase's counter.  (cdna_hip_programming.md Guideline 16, R1 +
-// counter form; every handed-off byte is stored sc1 and loaded sc1, so no acquire fence is needed.)
+// workgroup: (1) finds its (layer, phase, slice) from blockIdx, (2) requests the weights of its first CH_PF* batches (non-temporal
+// loads into register slots), (3) one lane polls a READY flag of its producer phase (relaxed agent-scope loads + s_sleep; attention
+// items poll the flag of THEIR HEAD's 18 qkv workgroups), (4) stages its input vector from the hand-off buffer into LDS (RMSNorm
+// fused where the layer has one), (5) dot products out of registers, batch by batch, the next batch requested as a slot frees;
+// wave reduce, epilogue (SwiGLU / residual), (6) publishes: outputs stored write-through (sc1), every storing wave drains
+// vmcnt, barrier, one arrival on a sharded counter whose completer raises the phase's replicated flags.
+// (cdna_hip_programming.md Guideline 16, R1 + counter form; every handed-off byte is stored sc1 and loaded sc1, so no acquire
+// fence is needed.)
 //
 // Progress.  A workgroup only ever waits for workgroups with SMALLER block indices.  The dispatcher hands out workgroups of
 // a grid in index order (per XCD queue), so every workgroup a resident one waits for is resident or finished: the lowest
@@ -737,7 +739,7 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   const int rd = w8 ? 4 : 2, rf = w8 ? 2 : 1;     // rows per wave and batch (see the kernel)
   p.nbq = w8 ? 1 : CH_NBQ; p.nbo = w8 ? 1 : CH_NBO; p.nbg = w8 ? 1 : CH_NBG; p.nbd = w8 ? 1 : CH_NBD;
 #ifdef AKI_LAB_HOOKS
-  const int presets[][4] = {{w8 ? 1 : CH_NBQ, w8 ? 1 : CH_NBO, w8 ? 1 : CH_NBG, w8 ? 1 : CH_NBD}, {8, 8, 8, 8}, {4, 2, 8, 2}, {8, 2, 8, 4}, {4, 4, 4, 4}, {16, 4, 16, 4}, {8, 2, 16, 2}, {1, 1, 1, 1}, {8, 4, 16, 4}, {2, 1, 4, 1}, {4, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 2, 2}, {2, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 4}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 2}, {2, 2, 4, 4}, {4, 2, 8, 4}, {2, 2, 4, 2}, {4, 4, 8, 4}, {2, 2, 4, 2}};
+  const int presets[][4] = {{w8 ? 1 : CH_NBQ, w8 ? 1 : CH_NBO, w8 ? 1 : CH_NBG, w8 ? 1 : CH_NBD}, {8, 8, 8, 8}, {4, 2, 8, 2}, {8, 2, 8, 4}, {4, 4, 4, 4}, {16, 4, 16, 4}, {8, 2, 16, 2}, {1, 1, 1, 1}, {8, 4, 16, 4}, {2, 1, 4, 1}, {4, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 2, 2}, {2, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 4}, {2, 2, 4, 2}, {2, 2, 8, 2}, {2, 2, 4, 2}, {2, 2, 4, 4}, {4, 2, 8, 4}, {2, 2, 4, 2}, {4, 4, 8, 4}, {2, 2, 4, 2}, {2, 2, 4, 2}, {2, 2, 4, 2}};
   const int* ps = presets[(w8 && g_chain_nb != 9 && g_chain_nb != 20 && g_chain_nb != 21 && (g_chain_nb < 12 || g_chain_nb > 14)) ? 0 : g_chain_nb];
   p.nbq = ps[0]; p.nbo = ps[1]; p.nbg = ps[2]; p.nbd = ps[3];
   if (w8 && g_chain_nb == 20) { p.nbq = 1; p.nbo = 1; p.nbg = 2; p.nbd = 1; }
@@ -823,7 +825,9 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   else if (g_chain_nb == 21) AKI_CHAIN_LAUNCH2(false, 4, 2, 8, 4, 2, 2, 2, 1);
   else if (g_chain_nb == 22) AKI_CHAIN_LAUNCH2(false, 2, 2, 4, 2, 1, 1, 1, 1);
   else if (g_chain_nb == 23) AKI_CHAIN_LAUNCH2(false, 4, 4, 8, 4, 1, 1, 1, 1);
-  else if (g_chain_nb == 24) AKI_CHAIN_LAUNCH3(false, 2, 2, 4, 2, 2, 2, 2, 1, 4);   // the product's batches held to 128 VGPRs (4 workgroups per CU; spills)
+  else if (g_chain_nb == 24) AKI_CHAIN_LAUNCH3(false, 2, 2, 4, 2, 2, 2, 2, 1, 4);
+  else if (g_chain_nb == 25) AKI_CHAIN_LAUNCH2(false, 2, 2, 4, 2, 2, 2, 4, 2);   // every weight of every phase before the wait: ~250 VGPRs, 2 workgroups per CU
+  else if (g_chain_nb == 26) AKI_CHAIN_LAUNCH2(false, 2, 2, 4, 2, 2, 2, 3, 2);   // the product's batches held to 128 VGPRs (4 workgroups per CU; spills)
 #endif
   else AKI_CHAIN_LAUNCH2(false, CH_NBQ, CH_NBO, CH_NBG, CH_NBD, CH_PFQ, CH_PFO, CH_PFG, CH_PFD);
 #undef AKI_CHAIN_LAUNCH
@@ -840,7 +844,7 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
 extern "C" void aki_lab_set_chain_stamps(void* buf, int layer) { aki::g_chain_stamps = (unsigned long long*)buf; aki::g_chain_stamp_layer = layer; }
 extern "C" void aki_lab_set_chain_lds(int pad_bytes) { aki::g_chain_lds_pad = pad_bytes < 0 ? 0 : (pad_bytes > 140 * 1024 ? 140 * 1024 : pad_bytes); }
 // preset of batches per workgroup (qkv, o_proj, gate_up, down): 0 product {2,2,2,2}, 1 {8,8,8,8}, 2 {4,2,8,2}, 3 {8,2,8,4}, 4 {4,4,4,4}, 5 {16,4,16,4}, 6 {8,2,16,2}, 7 {1,1,1,1}, 8 {8,4,16,4}, 9 {2,1,4,1}, 10 {4,2,4,2}, 11 {2,2,4,2}
-extern "C" void aki_lab_set_chain_nb(int preset) { aki::g_chain_nb = (preset >= 0 && preset <= 24) ? preset : 0; }
+extern "C" void aki_lab_set_chain_nb(int preset) { aki::g_chain_nb = (preset >= 0 && preset <= 26) ? preset : 0; }
 extern "C" void aki_lab_set_chain(int sleep_n, int xrep, int nflags, int nowait) {
   aki::g_chain_sleep = sleep_n < 0 ? 0 : sleep_n;
   aki::g_chain_xrep = xrep < 1 ? 1 : (xrep > aki::CH_XREP ? aki::CH_XREP : xrep);

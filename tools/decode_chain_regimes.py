@@ -7,10 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 # batches per workgroup {qkv, o, gate_up, down} / batches requested before the wait
-PRESETS = {0: "product", 12: "{2,2,2,2}/{2,2,2,2}", 13: "{2,2,4,2}/{2,2,2,2}", 14: "{2,2,4,2}/{2,2,2,1}", 16: "{2,2,4,4}/{2,2,2,1}", 17: "{2,2,4,2}/{2,2,1,2}", 19: "{2,2,4,2}/{2,2,1,1}",
+PRESETS = {0: "product", 25: "{2,2,4,2}/{2,2,4,2} (2 workgroups per CU)", 26: "{2,2,4,2}/{2,2,3,2} (2 per CU)", 12: "{2,2,2,2}/{2,2,2,2}", 13: "{2,2,4,2}/{2,2,2,2}", 14: "{2,2,4,2}/{2,2,2,1}", 16: "{2,2,4,4}/{2,2,2,1}", 17: "{2,2,4,2}/{2,2,1,2}", 19: "{2,2,4,2}/{2,2,1,1}",
            21: "{4,2,8,4}/{2,2,2,1}", 22: "{2,2,4,2}/{1,1,1,1}", 23: "{4,4,8,4}/{1,1,1,1}", 12: "{2,2,2,2}/{2,2,2,2}"}
 NOWAIT = 1 if '--nowait' in sys.argv else 0     # 1: the bare weight stream of each structure (wrong results, nothing checked)
-ALL = {i: f'preset {i}' for i in range(1, 25)}
+ALL = {i: f'preset {i}' for i in range(1, 27)}
 TOUCH = (0,)    # touch loads of the batches beyond the register slots while the workgroup waits
 
 
