@@ -78,6 +78,26 @@ def main():
             st.step_greedy()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / a.steps
+        # the same token without a graph: five eager launches per token when the chain is on (the host runs ahead, nothing syncs)
+        out_e = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=L + 2 * a.steps + 8)
+        cache_e = out_e.past_key_values
+        tokens_e = torch.full((B, n_tok), -1, dtype=torch.long, device=dev)
+        pick_e = dict(pad_token_id=0, eos_ids=None, done=None, tokens=tokens_e, start_len=cache_e.cache_len.clone(), done_at=None)
+        ids_e = torch.zeros(B, dtype=torch.long, device=dev)
+        ops.greedy_pick(out_e.logits[:, -1].contiguous(), ids_e, cache_len=cache_e.cache_len, advance=False, **pick_e)
+
+        def eager_token():
+            lg = lm.decode_step(input_ids=ids_e, past_key_values=cache_e, advance=False)
+            ops.greedy_pick(lg, ids_e, cache_len=cache_e.cache_len, advance=True, **pick_e)
+        for _ in range(4):
+            eager_token()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            eager_token()
+        torch.cuda.synchronize()
+        ms_e = (time.perf_counter() - t0) * 1e3 / a.steps
+        res["eager_greedy_pick"] = {"ms_per_token": round(ms_e, 4), "tokens_differing_from_the_graph": int((tokens_e[:, :9] != tokens[:, :9]).sum())}
         ref_st, nxt, want = DecodeGraph(lm, ref_cache), out.logits[:, -1].float().argmax(-1), []
         for _ in range(9):
             want.append(nxt)
