@@ -91,28 +91,30 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_nc_bf16_kernel(const AttnNcPa
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1e30f, l_part = 0.f;
 
-  u32x4 kreg[NCH], vreg[NCH];
-  auto load_tile = [&](int j) {
+  // K/V tiles go global -> LDS directly (global_load_lds, 16 B per lane, lane-linear LDS image = rows at their padded pitch): nothing of
+  // the next tile is held in registers while this one is computed (the register-staged form kept 24 VGPRs for it; with the V fragments
+  // fetched in two halves the DH = 72 kernel fits 170 VGPRs = three waves per SIMD, and SigLIP's 640 workgroups are ONE round of 768
+  // slots instead of 1.25 rounds of 512).  Lanes that map to a row's pad chunks are switched off: the pads were zeroed once.
+  constexpr int KCP = KROW / 16, VCP = VROW / 16;            // chunks per row pitch
+  constexpr int KN = (64 * KCP + NT - 1) / NT, VN = (64 * VCP + NT - 1) / NT;
+  auto issue_tile = [&](int j, int buf) {
     const int c0 = j * 64;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * NT;
-      if (NCH * NT == NCHUNK || c < NCHUNK) {
-        const int kr = c / CPR, kc = c - kr * CPR;
+    for (int i = 0; i < KN; ++i) {
+      const int c = i * NT + tid;
+      const int kr = c / KCP, kc = c - kr * KCP;
+      if (kc < CPR && c < 64 * KCP) {
         const size_t trow = (size_t)min(c0 + kr, Lk - 1);
-        kreg[i] = *(const u32x4*)(kb + trow * p.k_st * 2 + kc * 16);
-        vreg[i] = *(const u32x4*)(vb + trow * p.v_st * 2 + kc * 16);
+        __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(kb + trow * p.k_st * 2 + kc * 16), AKI_LDS_PTR(sK + buf * KTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
       }
     }
-  };
-  auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * NT;
-      if (NCH * NT == NCHUNK || c < NCHUNK) {
-        const int kr = c / CPR, kc = c - kr * CPR;
-        *(u32x4*)(sK + buf * KTILE + kr * KROW + kc * 16) = kreg[i];
-        *(u32x4*)(sV + buf * VTILE + kr * VROW + kc * 16) = vreg[i];
+    for (int i = 0; i < VN; ++i) {
+      const int c = i * NT + tid;
+      const int kr = c / VCP, kc = c - kr * VCP;
+      if (kc < CPR && c < 64 * VCP) {
+        const size_t trow = (size_t)min(c0 + kr, Lk - 1);
+        __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(vb + trow * p.v_st * 2 + kc * 16), AKI_LDS_PTR(sV + buf * VTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
       }
     }
   };
@@ -121,13 +123,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_nc_bf16_kernel(const AttnNcPa
   const int voff = (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
   const int jend = (Lk + 63) >> 6;
 
-  load_tile(0);
-  store_tile(0);
+  __syncthreads();                     // the pad zeroing above is in LDS before any DMA piece lands beside it
+  issue_tile(0, 0);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing pending at loop entry (see mma_attn_bf16.hip)
   __syncthreads();
 
   for (int j = 0; j < jend; ++j) {
-    if (j + 1 < jend) load_tile(j + 1);
+    if (j + 1 < jend) issue_tile(j + 1, (j + 1) & 1);      // the other buffer: every wave passed the barrier that ended tile j-1
     const int c0 = j * 64;
     const char* Kb = sK + (j & 1) * KTILE;
     const char* Vb = sV + (j & 1) * VTILE;
@@ -148,19 +150,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_nc_bf16_kernel(const AttnNcPa
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[ks], s1, 0, 0, 0);
     }
-    // The V^T fragments do not depend on the softmax: issue their transposed reads now, they land under the VALU work.
+    // The V^T fragments do not depend on the softmax: the transposed reads of the first 32 keys are issued now and land under the VALU
+    // work; those of keys 32-63 follow behind the first half's P V MFMAs (all four at once cost 24 more VGPRs - the third wave per SIMD).
     typedef __attribute__((ext_vector_type(8))) short s16x8;
-    s16x8 vfr[4][DT];
-#pragma unroll
-    for (int ks4 = 0; ks4 < 4; ++ks4)
+    auto read_v = [&](int ks4, s16x8 (&dst)[DT]) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const char* va = Vb + voff + ks4 * 16 * VROW + dt * 64;
         const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va));
         const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + 8 * VROW));
         const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        vfr[ks4][dt] = vv;
+        dst[dt] = vv;
       }
+    };
+    s16x8 vfa[2][DT];
+    read_v(0, vfa[0]);
+    read_v(1, vfa[1]);
     __builtin_amdgcn_sched_barrier(0);
     if (c0 + 64 > Lk) {   // last tile: keys >= Lk are masked (prefix in register order, see mma_attn_bf16.hip count_le)
       const int x = Lk - 1 - c0 - 4 * h;
@@ -197,16 +202,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_nc_bf16_kernel(const AttnNcPa
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
 #pragma unroll
-    for (int ks4 = 0; ks4 < 4; ++ks4) {
+    for (int ks4 = 0; ks4 < 2; ++ks4) {
       bf16x8 pf;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pf[e] = (__bf16)((ks4 < 2) ? s0[8 * (ks4 & 1) + e] : s1[8 * (ks4 & 1) + e]);
+      for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s0[8 * ks4 + e];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr[ks4][dt]), pf, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfa[ks4][dt]), pf, o[dt], 0, 0, 0);
     }
-    if (j + 1 < jend) store_tile((j + 1) & 1);
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      s16x8 vfb[2][DT];
+      read_v(2, vfb[0]);
+      read_v(3, vfb[1]);
+#pragma unroll
+      for (int ks4 = 0; ks4 < 2; ++ks4) {
+        bf16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s1[8 * ks4 + e];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfb[ks4][dt]), pf, o[dt], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of tile j+1 have landed ...
+    __syncthreads();                                         // ... and so have everybody's; tile j's buffer is free
   }
 
   const float l_tot = halves_sum(l_part);
