@@ -11,7 +11,16 @@ def short(n):
     return n if len(n) < 110 else n[:107] + "..."
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+def newest(pattern):
+    """One rocprofv3 run per directory is expected; a directory merged back from several gpurun calls holds several (one file per
+    process id): take the newest and say so, never an average over builds."""
+    found = sorted(glob.glob(pattern), key=os.path.getmtime)
+    if len(found) > 1:
+        print(f"summarize_prof: {len(found)} runs under {os.path.dirname(os.path.dirname(pattern))}: using the newest, {found[-1]}", file=sys.stderr)
+    return found[-1:]
+
+
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats[0]))) if stats else []
 with open(dst + "_kernel_stats.csv", "w") as f:
     w = csv.writer(f)
@@ -21,7 +30,7 @@ with open(dst + "_kernel_stats.csv", "w") as f:
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in glob.glob(os.path.join(src, "pmc_*")):
-    for fcsv in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for fcsv in newest(os.path.join(d, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(fcsv)):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = []
