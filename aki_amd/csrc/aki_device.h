@@ -18,6 +18,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 typedef uint16_t bf16_t;  // storage type on the host side of the ABI
 
+// Decode attention (decode.hip, decode_chain.hip - the two must split a cache identically: their outputs are compared bit for bit): a
+// (head, split) item takes T 64-key tiles with T = ceil(B * H * tiles / AKI_DEC_ITEMS); every tile after an item's first is a serial
+// round trip behind the item's dependency, so items stay one tile long up to this many of them.
+#ifndef AKI_DEC_ITEMS
+#define AKI_DEC_ITEMS 2048
+#endif
 #define AKI_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define AKI_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 

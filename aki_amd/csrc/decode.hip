@@ -794,7 +794,7 @@ int decode_attn_split_launch(const void* q_or_qkv, const float* cos, const float
                              void* ws, size_t ws_bytes, hipStream_t s) {
   if (max_keys <= 0 || max_keys > cap) max_keys = cap;
   const int tiles = (max_keys + 63) / 64;
-  int T = (int)(((size_t)B * H * tiles + 2047) / 2048);
+  int T = (int)(((size_t)B * H * tiles + AKI_DEC_ITEMS - 1) / AKI_DEC_ITEMS);
   if (T < 1) T = 1;
   const int S = (tiles + T - 1) / T;
   if (ws == nullptr || ws_bytes < dec_cnt_bytes(B, H) + (size_t)B * H * S * DEC_PSTRIDE * 4) return AKI_ERR_WORKSPACE;
