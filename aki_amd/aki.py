@@ -220,20 +220,31 @@ class AKI(VLMWithLanguageStream):
         eos_t = torch.tensor(sorted(eos_ids), dtype=torch.long, device=lang_x.device) if eos_ids else None
         stepper = None
         if use_graph and not do_sample and logits.is_cuda and logits.dtype == torch.bfloat16:
-            # Greedy: the pick (argmax, pad for finished rows, append, eos check, cache_len advance) is one launch INSIDE the replayed
-            # step, so a token is one graph replay; the host looks at the finished flags every 8th token instead of syncing per token.
+            # Greedy: the pick (argmax, pad for finished rows, append, eos check, cache_len advance) is one launch behind the decode step
+            # (inside the replayed graph where there is one); the host looks at the finished flags every 8th token instead of syncing
+            # per token.
             from . import ops
             from .phi3 import DecodeGraph
             done8 = torch.zeros(B, dtype=torch.uint8, device=lang_x.device)
             done_at = torch.full((B,), -1, dtype=torch.int32, device=lang_x.device)
             pick = dict(pad_token_id=pad_id, eos_ids=eos_t, done=done8, tokens=tokens, start_len=cache.cache_len.clone(), done_at=done_at)
-            stepper = DecodeGraph(self.lang_model, cache, greedy=pick)
-            ops.greedy_pick(logits.contiguous(), stepper.ids, cache_len=cache.cache_len, advance=False, **pick)      # token 0, from the prefill
+            ids = torch.zeros(B, dtype=torch.long, device=lang_x.device)
+            ops.greedy_pick(logits.contiguous(), ids, cache_len=cache.cache_len, advance=False, **pick)      # token 0, from the prefill
             steps = 1
             for t in range(1, max_new_tokens):
                 if eos_t is not None and t % 8 == 0 and bool(done8.all()):
                     break
-                stepper.step_greedy()
+                if stepper is not None:
+                    stepper.step_greedy()
+                else:
+                    # One sequence on the one-launch decode chain is five launches per token: the host runs far ahead of them and a
+                    # hipGraph would only add its capture (about 12 ms per call, 7 tokens' worth).  Anything else - batches, the
+                    # five-launch-per-layer path - is ~165 launches per token and is captured after its first eager step.
+                    lg = self.lang_model.decode_step(input_ids=ids, past_key_values=cache, advance=False)
+                    ops.greedy_pick(lg, ids, cache_len=cache.cache_len, advance=True, **pick)
+                    if getattr(cache, "chain", None) is None:
+                        stepper = DecodeGraph(self.lang_model, cache, greedy=pick)
+                        stepper.ids.copy_(ids)
                 steps = t + 1
             if eos_t is not None and bool(done8.all()):
                 steps = int(done_at.max()) + 1

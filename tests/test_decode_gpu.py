@@ -541,6 +541,36 @@ def test_decode_chain_graph_replay_and_poisoned_workspace():
     assert torch.equal(res["eager"], res["graph"])
 
 
+def test_generate_on_the_decode_chain_equals_generate_on_the_captured_five_launch_steps():
+    """`AKI.generate`, one sample, a full-width 2-layer decoder behind a small vision tower: with the one-launch decode chain the greedy
+    loop runs eagerly (five launches per token, no graph), without it the steps are captured into a hipGraph after the first eager one -
+    two code paths in aki.py::generate.  Logits are bit-identical between the two decode implementations, so the tokens must be equal:
+    all of them, and with an EOS in the middle (pads behind it, truncation)."""
+    from aki_amd.factory import build_aki
+    from aki_amd.phi3 import make_phi3_config
+    from aki_amd.siglip import make_siglip_config
+    m = build_aki(lm_config=make_phi3_config(num_hidden_layers=2), vis_config=make_siglip_config(num_hidden_layers=1, image_size=224),
+                  dtype=torch.bfloat16, device=DEV, seed=3).eval()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n_txt = 40
+    ids = torch.randint(3, 32000, (1, n_txt), generator=g)
+    ids[0, 0], ids[0, 6] = 1, m.media_token_id
+    vx = ((torch.rand((1, 1, 1, 3, 224, 224), generator=g) - 0.5) / 0.5).to(DEV, torch.bfloat16)
+    ids, am = ids.to(DEV), torch.ones(1, n_txt, dtype=torch.long, device=DEV)
+    outs = {}
+    for chained in (True, False):
+        m.lang_model.model.use_decode_chain = chained
+        outs[chained] = m.generate(vx, ids, attention_mask=am, max_new_tokens=24, do_sample=False, eos_token_id=[])
+    assert outs[True].shape == (1, 24) and torch.equal(outs[True], outs[False])
+    eos = [int(outs[True][0, 13])]
+    first = int((outs[True][0] == eos[0]).nonzero()[0])
+    for chained in (True, False):
+        m.lang_model.model.use_decode_chain = chained
+        got = m.generate(vx, ids, attention_mask=am, max_new_tokens=24, do_sample=False, eos_token_id=eos)
+        assert got.shape == (1, first + 1) and torch.equal(got[0], outs[True][0, : first + 1]), (chained, got.shape, first)
+    m.lang_model.model.use_decode_chain = True
+
+
 @pytest.mark.parametrize("fp8", [False, True])
 def test_decode_chain_full_depth_graph_replay_equals_the_five_launch_path(fp8):
     """All 32 layers at Phi-3.5-mini's width, hipGraph replay, 10 greedy steps, bf16 and e4m3 weights (each has its own instance of the
