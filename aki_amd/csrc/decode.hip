@@ -793,8 +793,11 @@ int decode_attn_split_launch(const void* q_or_qkv, const float* cos, const float
                              const uint64_t* vbits, int nwords, int B, int H, int cap, int max_keys, float scale, bool fused,
                              void* ws, size_t ws_bytes, hipStream_t s) {
   if (max_keys <= 0 || max_keys > cap) max_keys = cap;
-  const int tiles = (max_keys + 63) / 64;
-  int T = (int)(((size_t)B * H * tiles + AKI_DEC_ITEMS - 1) / AKI_DEC_ITEMS);
+  // Tiles per item from the cache CAPACITY, items per head from max_keys: a launch sized for the keys cached so far (eager steps) and one
+  // sized for the whole cache (a captured step) then cut the keys at the same places and differ only by trailing empty items, whose
+  // partials (m = -inf, l = 0) fold exactly - eager and replayed steps give the same bits at any cache size.
+  const int tiles = (max_keys + 63) / 64, tiles_cap = (cap + 63) / 64;
+  int T = (int)(((size_t)B * H * tiles_cap + AKI_DEC_ITEMS - 1) / AKI_DEC_ITEMS);
   if (T < 1) T = 1;
   const int S = (tiles + T - 1) / T;
   if (ws == nullptr || ws_bytes < dec_cnt_bytes(B, H) + (size_t)B * H * S * DEC_PSTRIDE * 4) return AKI_ERR_WORKSPACE;

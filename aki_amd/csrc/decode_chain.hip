@@ -696,8 +696,8 @@ static unsigned long long* g_chain_stamps = nullptr;
 
 static void chain_split(int H, int cap, int max_keys, int& S, int& T) {
   if (max_keys <= 0 || max_keys > cap) max_keys = cap;
-  const int tiles = (max_keys + 63) / 64;
-  T = (int)(((size_t)H * tiles + AKI_DEC_ITEMS - 1) / AKI_DEC_ITEMS);
+  const int tiles = (max_keys + 63) / 64, tiles_cap = (cap + 63) / 64;     // decode.hip's rule: T from the capacity, S from max_keys
+  T = (int)(((size_t)H * tiles_cap + AKI_DEC_ITEMS - 1) / AKI_DEC_ITEMS);
   if (T < 1) T = 1;
   S = (tiles + T - 1) / T;
 }

@@ -541,6 +541,37 @@ def test_decode_chain_graph_replay_and_poisoned_workspace():
     assert torch.equal(res["eager"], res["graph"])
 
 
+@pytest.mark.parametrize("chained", [True, False])
+def test_decode_replayed_steps_equal_eager_steps_in_a_cache_larger_than_4096_keys(chained):
+    """A captured decode step sizes its attention launch for the whole cache, an eager one for the keys cached so far.  Beyond 2048
+    (head, tile) items the split takes two tiles per item: that count now comes from the CAPACITY in both cases, so the two launches
+    cut the keys at the same places and differ only by trailing empty items - eager and replayed logits are equal bit for bit.  (A
+    4096-token soak of the chain, tools/decode_chain_soak.py, found the replayed continuation leaving the eager one at token 128 when the
+    count still came from the keys cached so far.)"""
+    from aki_amd import ops
+    from aki_amd.phi3 import DecodeGraph
+    lm, cfg = _full_width_lm(2, seed=9)
+    lm.model.use_decode_chain = chained
+    prompt, cap, steps = 200, 4400, 5
+    x = (torch.randn(1, prompt, cfg.hidden_size, generator=torch.Generator().manual_seed(2)) * 0.5).to(torch.bfloat16).to(DEV)
+    table = ops.MaskTable.from_host([[(4, 40, 40, prompt - 8)]], np.ones((1, prompt), dtype=bool), [prompt], DEV)
+    res = {}
+    with torch.no_grad():
+        for mode in ("eager", "graph"):
+            out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=cap)
+            cache, ids = out.past_key_values, out.logits[:, -1].float().argmax(-1)
+            st = DecodeGraph(lm, cache) if mode == "graph" else None
+            logits = []
+            for _ in range(steps):
+                lg = st.step(ids) if st is not None else lm.decode_step(input_ids=ids, past_key_values=cache)
+                logits.append(lg.clone())
+                ids = lg.float().argmax(-1)
+            res[mode] = torch.stack(logits)
+            assert (getattr(cache, "chain", None) is not None) == chained
+    lm.model.use_decode_chain = True
+    assert torch.equal(res["eager"], res["graph"]), f"{int((res['eager'] != res['graph']).sum())} logits differ between eager and replayed steps"
+
+
 def test_generate_on_the_decode_chain_equals_generate_on_the_captured_five_launch_steps():
     """`AKI.generate`, one sample, a full-width 2-layer decoder behind a small vision tower: with the one-launch decode chain the greedy
     loop runs eagerly (five launches per token, no graph), without it the steps are captured into a hipGraph after the first eager one -
