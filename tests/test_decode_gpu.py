@@ -541,8 +541,8 @@ def test_decode_chain_graph_replay_and_poisoned_workspace():
     assert torch.equal(res["eager"], res["graph"])
 
 
-@pytest.mark.parametrize("chained", [True, False])
-def test_decode_replayed_steps_equal_eager_steps_in_a_cache_larger_than_4096_keys(chained):
+@pytest.mark.parametrize("chained,batch,prompt,cap", [(True, 1, 200, 4400), (False, 1, 200, 4400), (False, 8, 150, 700)])
+def test_decode_replayed_steps_equal_eager_steps_in_a_cache_larger_than_4096_keys(chained, batch, prompt, cap):
     """A captured decode step sizes its attention launch for the whole cache, an eager one for the keys cached so far.  Beyond 2048
     (head, tile) items the split takes two tiles per item: that count now comes from the CAPACITY in both cases, so the two launches
     cut the keys at the same places and differ only by trailing empty items - eager and replayed logits are equal bit for bit.  (A
@@ -552,9 +552,9 @@ def test_decode_replayed_steps_equal_eager_steps_in_a_cache_larger_than_4096_key
     from aki_amd.phi3 import DecodeGraph
     lm, cfg = _full_width_lm(2, seed=9)
     lm.model.use_decode_chain = chained
-    prompt, cap, steps = 200, 4400, 5
-    x = (torch.randn(1, prompt, cfg.hidden_size, generator=torch.Generator().manual_seed(2)) * 0.5).to(torch.bfloat16).to(DEV)
-    table = ops.MaskTable.from_host([[(4, 40, 40, prompt - 8)]], np.ones((1, prompt), dtype=bool), [prompt], DEV)
+    steps = 5                      # (batch 8: 8 x 32 heads x 11 tiles of a 700-key cache are already more than 2048 items)
+    x = (torch.randn(batch, prompt, cfg.hidden_size, generator=torch.Generator().manual_seed(2)) * 0.5).to(torch.bfloat16).to(DEV)
+    table = ops.MaskTable.from_host([[(4, 40, 40, prompt - 8)]] * batch, np.ones((batch, prompt), dtype=bool), [prompt] * batch, DEV)
     res = {}
     with torch.no_grad():
         for mode in ("eager", "graph"):
