@@ -16,7 +16,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 14
+AKI_ABI_VERSION = 15
 
 
 class AkiError(RuntimeError):
@@ -159,6 +159,9 @@ SIGNATURES = {
                                      C.c_void_p]),
     "aki_greedy_pick": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "aki_greedy_pick_embed": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+                                        C.c_void_p]),
     "aki_sft_collate_pad": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32] + [C.c_void_p] * 4),
     "aki_mma_mask_to_table_workspace_bytes": (C.c_size_t, [C.c_int32] * 2),
     "aki_mma_mask_to_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
@@ -205,6 +208,8 @@ def load_lab() -> C.CDLL:
     lib.aki_lab_set_chain_stamps.argtypes = [C.c_void_p, C.c_int]
     lib.aki_lab_set_chain_lds.restype = None
     lib.aki_lab_set_chain_lds.argtypes = [C.c_int]
+    lib.aki_lab_set_chain_fault.restype = None
+    lib.aki_lab_set_chain_fault.argtypes = [C.c_int, C.c_int]
     return lib
 
 

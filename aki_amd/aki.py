@@ -30,6 +30,25 @@ def sample_next(logits: torch.Tensor, temperature: float = 1.0, top_k: int = 0, 
     return torch.multinomial(x.softmax(dim=-1), 1, generator=generator).squeeze(-1)
 
 
+def _embedding_tables(emb: nn.Module, logits: torch.Tensor):
+    """(weight, additional weight or None, max_original_id) when ops.greedy_pick can gather the picked token's embedding row itself
+    (bf16 tables that hold a row for every logit column), else None: the module's own forward is used."""
+    w = getattr(emb, "weight", None)
+    if w is None or w.dtype != torch.bfloat16 or not w.is_contiguous() or w.device != logits.device or w.shape[1] % 8:
+        return None
+    n_add = int(getattr(emb, "num_additional_embeddings", 0) or 0)
+    if n_add > 0:
+        extra, max_orig = emb.additional_embedding.weight, int(emb.max_original_id)
+        if extra.dtype != torch.bfloat16 or not extra.is_contiguous() or extra.device != w.device or w.shape[0] <= max_orig:
+            return None
+        rows = max_orig + 1 + extra.shape[0]
+    elif type(emb) is nn.Embedding or hasattr(emb, "max_original_id"):
+        extra, max_orig, rows = None, w.shape[0] - 1, w.shape[0]
+    else:
+        return None
+    return (w, extra, max_orig) if logits.shape[-1] <= rows else None
+
+
 class AKI(VLMWithLanguageStream):
     def __init__(self, vision_encoder: nn.Module, lang_model: nn.Module, vis_feature_dim: int, initial_tokenizer_len: int,
                  pad_token_id: int, decoder_layers_attr_name: str = None, gradient_checkpointing: bool = False,
@@ -218,51 +237,108 @@ class AKI(VLMWithLanguageStream):
         tokens = torch.full((B, max_new_tokens), pad_id, dtype=torch.long, device=lang_x.device)
         done = torch.zeros(B, dtype=torch.bool, device=lang_x.device)
         eos_t = torch.tensor(sorted(eos_ids), dtype=torch.long, device=lang_x.device) if eos_ids else None
+        lm = self.lang_model
+        # The one-launch decode chain (one sequence, decode_chain.hip) bounds every dependency wait; a wait that gives up leaves garbage in that
+        # step's output and a sticky error word.  Both loops below read the word wherever they synchronise anyway (every 8th token) and once at the
+        # end; on an error the tokens after the last verified point are decoded again on the five-launch-per-layer path: nothing unverified is
+        # ever returned (lm.decode_verified switches the chain off for this cache and warns).
+        chained = lambda: getattr(cache, "chain", None) is not None
         stepper = None
         if use_graph and not do_sample and logits.is_cuda and logits.dtype == torch.bfloat16:
-            # Greedy: the pick (argmax, pad for finished rows, append, eos check, cache_len advance) is one launch behind the decode step
-            # (inside the replayed graph where there is one); the host looks at the finished flags every 8th token instead of syncing
-            # per token.
+            # Greedy: the pick (argmax, pad for finished rows, append, eos check, cache_len advance, the next step's embedding row) is one launch
+            # behind the decode step (inside the replayed graph where there is one); the host looks at the finished flags every 8th token
+            # instead of syncing per token.
             from . import ops
             from .phi3 import DecodeGraph
             done8 = torch.zeros(B, dtype=torch.uint8, device=lang_x.device)
             done_at = torch.full((B,), -1, dtype=torch.int32, device=lang_x.device)
-            pick = dict(pad_token_id=pad_id, eos_ids=eos_t, done=done8, tokens=tokens, start_len=cache.cache_len.clone(), done_at=done_at)
+            start_len, host_len0 = cache.cache_len.clone(), cache.host_len
+            pick = dict(pad_token_id=pad_id, eos_ids=eos_t, done=done8, tokens=tokens, start_len=start_len, done_at=done_at)
             ids = torch.zeros(B, dtype=torch.long, device=lang_x.device)
-            ops.greedy_pick(logits.contiguous(), ids, cache_len=cache.cache_len, advance=False, **pick)      # token 0, from the prefill
-            steps = 1
-            for t in range(1, max_new_tokens):
-                if eos_t is not None and t % 8 == 0 and bool(done8.all()):
+            emb_mod = lm.get_input_embeddings()
+            embed = _embedding_tables(emb_mod, logits)
+            nxt_emb = None if embed is None else torch.empty((B, emb_mod.weight.shape[1]), dtype=torch.bfloat16, device=lang_x.device)
+            pick_e = pick if embed is None else dict(pick, embed=embed, next_embeds=nxt_emb)
+            ops.greedy_pick(logits.contiguous(), ids, cache_len=cache.cache_len, advance=False, **pick_e)      # token 0, from the prefill
+            t, t_ok = 1, 1                                  # tokens[:, :t_ok] are verified (token 0 comes from the prefill, not from the chain)
+            while True:
+                ok = True
+                while t < max_new_tokens:
+                    if t % 8 == 0 and (eos_t is not None or chained()):
+                        if chained() and not lm.decode_verified(cache):
+                            ok = False
+                            break
+                        t_ok = t
+                        if eos_t is not None and bool(done8.all()):
+                            break
+                    if stepper is not None:
+                        stepper.step_greedy()
+                    else:
+                        # One sequence on the one-launch decode chain is four launches per token (counter zeroing, chain, head, pick + embedding):
+                        # the host runs far ahead of them and a hipGraph would only add its capture (about 12 ms per call, 7 tokens' worth).
+                        # Anything else - batches, the five-launch-per-layer path - is ~165 launches per token and is captured after its first
+                        # eager step.
+                        if nxt_emb is not None:
+                            lg = lm.decode_step(inputs_embeds=nxt_emb, past_key_values=cache, advance=False)
+                        else:
+                            lg = lm.decode_step(input_ids=ids, past_key_values=cache, advance=False)
+                        ops.greedy_pick(lg, ids, cache_len=cache.cache_len, advance=True, **pick_e)
+                        if not chained():
+                            stepper = DecodeGraph(lm, cache, greedy=pick)
+                            stepper.ids.copy_(ids)
+                    t += 1
+                if ok and chained() and not lm.decode_verified(cache):
+                    ok = False
+                if ok:
                     break
-                if stepper is not None:
-                    stepper.step_greedy()
-                else:
-                    # One sequence on the one-launch decode chain is five launches per token: the host runs far ahead of them and a
-                    # hipGraph would only add its capture (about 12 ms per call, 7 tokens' worth).  Anything else - batches, the
-                    # five-launch-per-layer path - is ~165 launches per token and is captured after its first eager step.
-                    lg = self.lang_model.decode_step(input_ids=ids, past_key_values=cache, advance=False)
-                    ops.greedy_pick(lg, ids, cache_len=cache.cache_len, advance=True, **pick)
-                    if getattr(cache, "chain", None) is None:
-                        stepper = DecodeGraph(self.lang_model, cache, greedy=pick)
-                        stepper.ids.copy_(ids)
-                steps = t + 1
+                # recovery (one sequence - the chain runs no batches): back to the last verified token, then on without the chain
+                t = t_ok
+                cache.cache_len.copy_(start_len + (t_ok - 1))
+                cache.host_len = host_len0 + (t_ok - 1)
+                tokens[:, t_ok:] = pad_id
+                done8.zero_()                               # the loop would have ended at a verified check had the row been finished
+                done_at.fill_(-1)
+                ids.copy_(tokens[:, t_ok - 1])
+                if nxt_emb is not None:
+                    nxt_emb.copy_(emb_mod(ids))
+            steps = t
             if eos_t is not None and bool(done8.all()):
                 steps = int(done_at.max()) + 1
             self._post_forward_hook()
             return tokens[:, :steps]
         if use_graph:
             from .phi3 import DecodeGraph
-            stepper = DecodeGraph(self.lang_model, cache)
-        for t in range(max_new_tokens):
-            nxt = sample_next(logits, temperature, top_k, top_p, rng) if do_sample else logits.float().argmax(dim=-1)
-            nxt = torch.where(done, torch.full_like(nxt, pad_id), nxt)
-            tokens[:, t] = nxt
-            if eos_t is not None:
-                done = done | (nxt[:, None] == eos_t[None, :]).any(-1)
-                if bool(done.all()):
-                    tokens = tokens[:, : t + 1]
-                    break
-            if t + 1 < max_new_tokens:
-                logits = stepper.step(nxt) if stepper is not None else self.lang_model.decode_step(input_ids=nxt, past_key_values=cache)
+            stepper = DecodeGraph(lm, cache)
+        t, n_out = 0, max_new_tokens
+        ck = None                                           # the state at the last verified point of a chained decode
+        while True:
+            ok = True
+            while t < max_new_tokens:
+                if t % 8 == 0 and (t == 0 or chained()):
+                    if chained() and not lm.decode_verified(cache):
+                        ok = False
+                        break
+                    ck = (t, logits.clone(), done.clone(), cache.cache_len.clone(), cache.host_len)
+                nxt = sample_next(logits, temperature, top_k, top_p, rng) if do_sample else logits.float().argmax(dim=-1)
+                nxt = torch.where(done, torch.full_like(nxt, pad_id), nxt)
+                tokens[:, t] = nxt
+                t += 1
+                if eos_t is not None:
+                    done = done | (nxt[:, None] == eos_t[None, :]).any(-1)
+                    if bool(done.all()):
+                        n_out = t
+                        break
+                if t < max_new_tokens:
+                    logits = stepper.step(nxt) if stepper is not None else lm.decode_step(input_ids=nxt, past_key_values=cache)
+            if ok and chained() and not lm.decode_verified(cache):
+                ok = False
+            if ok:
+                break
+            t, logits, done, cl, cache.host_len = ck
+            cache.cache_len.copy_(cl)
+            tokens[:, t:] = pad_id
+            n_out, stepper = max_new_tokens, None           # a graph captured around the chain is gone with it
+            if use_graph:
+                stepper = DecodeGraph(lm, cache)
         self._post_forward_hook()
-        return tokens
+        return tokens[:, :n_out]

@@ -38,7 +38,8 @@ int mask_dense_launch(const aki_mma_rect* rects, int max_rects, const uint64_t* 
                       int64_t* out, hipStream_t s);
 int im2col_launch(const void* pix, void* out, int N, int S, int P, int Kp, int dtype, hipStream_t s);
 int greedy_pick_launch(const void* logits, int B, int V, int ld, const int64_t* eos, int n_eos, int64_t pad, unsigned char* done, int64_t* ids,
-                       int64_t* tokens, int tokens_ld, int* cache_len, const int* start_len, int advance, int* done_at, hipStream_t s);
+                       int64_t* tokens, int tokens_ld, int* cache_len, const int* start_len, int advance, int* done_at, const void* emb_main,
+                       const void* emb_extra, int64_t max_original_id, int d, void* emb_out, hipStream_t s);
 int sft_collate_launch(const int64_t* ids, const int64_t* labels, const int64_t* mask, const int* offsets, int B, int T_out,
                        int64_t pad_id, int64_t ignore_index, int left, int64_t* out_ids, int64_t* out_labels, int64_t* out_mask,
                        hipStream_t s);
@@ -596,7 +597,23 @@ int aki_greedy_pick(const void* logits, int32_t B, int32_t V, int64_t ld, const 
   AKI_CHECK_ARG(logits && next_ids && B > 0 && V > 0 && ld >= V && ld < (1ll << 31) && n_eos >= 0 && (n_eos == 0 || eos_ids));
   AKI_CHECK_ARG((!tokens || tokens_ld > 0) && (!advance || cache_len) && (advance == 0 || advance == 1));
   return greedy_pick_launch(logits, B, V, (int)ld, eos_ids, n_eos, pad_token_id, done, next_ids, tokens, tokens_ld, cache_len, start_len, advance,
-                            done_at, (hipStream_t)stream);
+                            done_at, nullptr, nullptr, 0, 0, nullptr, (hipStream_t)stream);
+}
+
+int aki_greedy_pick_embed(const void* logits, int32_t B, int32_t V, int64_t ld, const int64_t* eos_ids, int32_t n_eos, int64_t pad_token_id,
+                          uint8_t* done, int64_t* next_ids, int64_t* tokens, int32_t tokens_ld, int32_t* cache_len, const int32_t* start_len,
+                          int32_t advance, int32_t* done_at, const void* embed_weight, const void* additional_weight, int64_t max_original_id,
+                          int64_t num_additional, int32_t d, void* next_embeds, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(logits && next_ids && B > 0 && V > 0 && ld >= V && ld < (1ll << 31) && n_eos >= 0 && (n_eos == 0 || eos_ids));
+  AKI_CHECK_ARG((!tokens || tokens_ld > 0) && (!advance || cache_len) && (advance == 0 || advance == 1));
+  AKI_CHECK_ARG(embed_weight && next_embeds && d > 0 && d % 8 == 0 && max_original_id >= 0 && num_additional >= 0);
+  AKI_CHECK_ARG((((uintptr_t)embed_weight | (uintptr_t)additional_weight | (uintptr_t)next_embeds) & 15) == 0);
+  // every id the pick can produce has a row: V' = original rows + additional rows (DecoupledLinear's output width), pad included
+  AKI_CHECK_ARG((int64_t)V <= max_original_id + 1 + (additional_weight ? num_additional : 0) && pad_token_id >= 0 &&
+                pad_token_id <= max_original_id + (additional_weight ? num_additional : 0));
+  return greedy_pick_launch(logits, B, V, (int)ld, eos_ids, n_eos, pad_token_id, done, next_ids, tokens, tokens_ld, cache_len, start_len, advance,
+                            done_at, embed_weight, additional_weight, max_original_id, d, next_embeds, (hipStream_t)stream);
 }
 
 size_t aki_mma_mask_to_table_workspace_bytes(int32_t B, int32_t L) {

@@ -850,6 +850,9 @@ struct PickParams {
   const int64_t* eos; int n_eos; int64_t pad;
   unsigned char* done; int64_t* ids; int64_t* tokens; int tokens_ld;
   int* cache_len; const int* start_len; int advance; int* done_at;
+  // optional: the NEXT decode step's input row, gathered here (DecoupledEmbedding, src/helpers.py:350-492: ids above max_original_id index the
+  // additional table) so that a greedy token needs no embedding launch
+  const bf16_t* emb_main; const bf16_t* emb_extra; int64_t max_original_id; int d; bf16_t* emb_out;
 };
 
 __device__ __forceinline__ bool pick_better(float a, int ia, float b, int ib) {
@@ -862,6 +865,7 @@ __device__ __forceinline__ bool pick_better(float a, int ia, float b, int ib) {
 __global__ __launch_bounds__(256) void greedy_pick_kernel(const PickParams p) {
   __shared__ float s_v[4];
   __shared__ int s_i[4];
+  __shared__ int64_t s_next;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bf16_t* row = p.logits + (size_t)b * p.ld;
   float best = -INFINITY;
@@ -902,6 +906,7 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const PickParams p) {
     }
     if (p.tokens != nullptr && t >= 0 && t < p.tokens_ld) p.tokens[(size_t)b * p.tokens_ld + t] = nxt;
     p.ids[b] = nxt;
+    s_next = nxt;
     if (p.done != nullptr && !was_done) {
       bool hit = false;
       for (int i = 0; i < p.n_eos; ++i) hit = hit || p.eos[i] == nxt;
@@ -911,11 +916,21 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const PickParams p) {
       }
     }
   }
+  if (p.emb_out != nullptr) {
+    __syncthreads();
+    const int64_t nxt = s_next;
+    const bool extra = p.emb_extra != nullptr && nxt > p.max_original_id;
+    const bf16_t* src = extra ? p.emb_extra + (size_t)(nxt - p.max_original_id - 1) * p.d : p.emb_main + (size_t)nxt * p.d;
+    bf16_t* dst = p.emb_out + (size_t)b * p.d;
+    for (int c = tid; c < p.d / 8; c += 256) *(u32x4*)(dst + (size_t)c * 8) = *(const u32x4*)(src + (size_t)c * 8);
+  }
 }
 
 int greedy_pick_launch(const void* logits, int B, int V, int ld, const int64_t* eos, int n_eos, int64_t pad, unsigned char* done, int64_t* ids,
-                       int64_t* tokens, int tokens_ld, int* cache_len, const int* start_len, int advance, int* done_at, hipStream_t s) {
-  PickParams p = {(const bf16_t*)logits, B, V, ld, eos, n_eos, pad, done, ids, tokens, tokens_ld, cache_len, start_len, advance, done_at};
+                       int64_t* tokens, int tokens_ld, int* cache_len, const int* start_len, int advance, int* done_at, const void* emb_main,
+                       const void* emb_extra, int64_t max_original_id, int d, void* emb_out, hipStream_t s) {
+  PickParams p = {(const bf16_t*)logits, B, V, ld, eos, n_eos, pad, done, ids, tokens, tokens_ld, cache_len, start_len, advance, done_at,
+                  (const bf16_t*)emb_main, (const bf16_t*)emb_extra, max_original_id, d, (bf16_t*)emb_out};
   AKI_CLEAR_ERR();
   hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(256), 0, s, p);
   AKI_LAUNCH_CHECK();

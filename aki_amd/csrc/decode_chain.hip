@@ -22,8 +22,14 @@
 // Progress.  A workgroup only ever waits for workgroups with SMALLER block indices.  The dispatcher hands out workgroups of
 // a grid in index order (per XCD queue), so every workgroup a resident one waits for is resident or finished: the lowest
 // unfinished index is always resident with all its producers finished.  Every spin is bounded all the same: a poller that
-// gives up writes its code to the error word, releases every counter of the launch (so the rest drains in microseconds)
-// and the host wrapper raises - a broken assumption is a loud error, never a hung GPU.
+// gives up writes its code to the error word and releases every counter of the launch (so the rest drains in microseconds);
+// that step's output is garbage.  The host reads the word wherever it synchronises and at the end of a generation, switches the
+// chain off for that KV cache and decodes the unverified tokens again on the five-launch path (Phi3ForCausalLM.decode_verified,
+// AKI.generate; ops.DecodeChain.check raises): a broken assumption costs a warning and time, never a hung GPU or a wrong token.
+// ONE CHAIN IN FLIGHT PER DEVICE: the argument needs the lowest unfinished index to be resident; two chain launches running
+// side by side (two streams, two processes) can fill the CUs with each other's waiters, and then only the bounded spin ends
+// them.  ops.DecodeChain.step serialises chain launches of one process across streams; processes sharing a GPU are the caller's
+// to keep apart (the error word still catches it).
 //
 // Arithmetic = decode.hip's, row for row: one wave owns whole weight rows, lane l takes 16-byte chunks l, l+64, ... of a row
 // in ascending order, the same xor-shuffle reduction, the same epilogue formulas, the same split-KV attention (same tiles,
@@ -130,6 +136,7 @@ struct ChainParams {
 #ifdef AKI_LAB_HOOKS
   unsigned long long* stamps;          // lab: [phase 0..4][workgroup < 2048][8] wall-clock stamps (100 MHz) of layer `stamp_layer`
   int stamp_layer;
+  unsigned fault_code;                 // lab: the wait with this code (layer << 8 | phase) gives up at once (fault injection for the host's recovery path)
 #endif
 };
 
@@ -163,6 +170,10 @@ __device__ __forceinline__ void chain_wait(const ChainParams& p, unsigned* sync,
       for (int i = 0; i < p.n_layers * CH_PHASES; ++i)
         for (int f = 0; f < CH_FLAGS; ++f) __hip_atomic_store(p.sync + (size_t)i * CH_SYNC_WORDS + (CH_SHARDS + 1 + f) * 32, 2u, AKI_RLX_AGENT);
     };
+#ifdef AKI_LAB_HOOKS
+    if (p.fault_code != 0u && code == p.fault_code) give_up();
+    else
+#endif
     while (__hip_atomic_load(flag, AKI_RLX_AGENT) == 0u) {
       for (int i = 0; i < p.sleep_n; ++i) __builtin_amdgcn_s_sleep(1);
       if (++spins > CH_SPIN_LIMIT) { give_up(); break; }
@@ -692,6 +703,8 @@ static inline size_t chain_vec_elems(int d, int H, int F) { return aki_align_up(
 #ifdef AKI_LAB_HOOKS
 static int g_chain_sleep = 8, g_chain_xrep = CH_XREP_USED, g_chain_nflags = CH_FLAGS, g_chain_nowait = 0, g_chain_nb = 0, g_chain_lds_pad = 0, g_chain_stamp_layer = -1, g_chain_touch = -1;
 static unsigned long long* g_chain_stamps = nullptr;
+static unsigned g_chain_fault_code = 0;
+static int g_chain_fault_skip = 0;
 #endif
 
 static void chain_split(int H, int cap, int max_keys, int& S, int& T) {
@@ -762,6 +775,8 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   p.sleep_n = g_chain_sleep; p.xrep = g_chain_xrep; p.nflags = g_chain_nflags; p.nowait = g_chain_nowait;
   if (g_chain_touch >= 0) { p.touch = g_chain_touch & 1; if (g_chain_touch & 2) p.qkv_by_head = 0; }      // lab: touch | (one flag for the whole qkv phase) << 1
   p.stamps = g_chain_stamps; p.stamp_layer = g_chain_stamp_layer;
+  p.fault_code = 0;
+  if (g_chain_fault_code != 0u && g_chain_fault_skip-- == 0) { p.fault_code = g_chain_fault_code; g_chain_fault_code = 0; }     // one shot
 #endif
   AKI_CLEAR_ERR();
   // Every polled word is zeroed by the call itself, by a KERNEL of this library.  hipMemsetAsync was used first: eager calls
@@ -851,6 +866,9 @@ extern "C" void aki_lab_set_chain(int sleep_n, int xrep, int nflags, int nowait)
   aki::g_chain_nflags = nflags < 1 ? 1 : (nflags > aki::CH_FLAGS ? aki::CH_FLAGS : nflags);
   aki::g_chain_nowait = nowait ? 1 : 0;
 }
+// Fault injection: the chain launch number `skip` from now (0 = the next one) treats the wait `code` = layer << 8 | phase (phase 1 qkv, 3 o_proj,
+// 4 gate_up, 5 down; layer >= 1 for phase 1) as given up at once - error word set, every flag raised, garbage output.  One shot; code 0 disarms.
+extern "C" void aki_lab_set_chain_fault(int code, int skip) { aki::g_chain_fault_code = (unsigned)code; aki::g_chain_fault_skip = skip < 0 ? 0 : skip; }
 // -1: the product setting; 0 / 1: touch loads of the batches beyond the register slots off / on.
 extern "C" void aki_lab_set_chain_touch(int touch) { aki::g_chain_touch = touch; }
 #endif

@@ -7,6 +7,7 @@ CPU tensors or a missing library raise :class:`aki_amd._lib.AkiError`.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -448,6 +449,10 @@ def decode_attn_fused(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, c
     return o
 
 
+_CHAIN_LAST = {}                      # device index -> the torch stream of the last chain launch
+_CHAIN_LOCK = threading.Lock()
+
+
 class DecodeChain:
     """The whole decoder stack of a batch-1 decode step as ONE launch (aki_decode_chain_fwd, decode_chain.hip): a device-resident
     table of per-layer pointers + the workspace with the hand-off vectors and arrival counters.  Built once per (model weights,
@@ -495,7 +500,15 @@ class DecodeChain:
                               self.ws_ptr, self.ws_bytes, self.n_layers, 0 if col_valid_bits is None else col_valid_bits.shape[-1], d, H, Dh, F,
                               cap, int(max_keys), self.scale, self.eps, L.AKI_DT_W8A16 if self.w8 else L.AKI_DT_BF16, 0)
         end = _TAP.begin(("decode_chain", self.n_layers)) if (_TAP is not None and _TAP.want(("decode_chain",))) else None
-        L.check(L.load().aki_decode_chain_fwd(C.byref(a), _stream()), "aki_decode_chain_fwd")
+        cur = torch.cuda.current_stream()
+        with _CHAIN_LOCK:
+            # one chain in flight per device (decode_chain.hip, "Progress"): a launch on another stream than the previous chain launch first
+            # lets that stream finish.  Same stream = ordered by the stream; nothing to do (the common case: one comparison).
+            last = _CHAIN_LAST.get(cur.device_index)
+            if last is not None and last.cuda_stream != cur.cuda_stream and not torch.cuda.is_current_stream_capturing():
+                last.synchronize()
+            _CHAIN_LAST[cur.device_index] = cur
+            L.check(L.load().aki_decode_chain_fwd(C.byref(a), cur.cuda_stream), "aki_decode_chain_fwd")
         if end is not None:
             end.record()
         return self.h_out
@@ -512,11 +525,15 @@ class DecodeChain:
 
 def greedy_pick(logits: torch.Tensor, next_ids: torch.Tensor, pad_token_id: int = 0, eos_ids: Optional[torch.Tensor] = None,
                 done: Optional[torch.Tensor] = None, tokens: Optional[torch.Tensor] = None, cache_len: Optional[torch.Tensor] = None,
-                start_len: Optional[torch.Tensor] = None, advance: bool = False, done_at: Optional[torch.Tensor] = None) -> torch.Tensor:
+                start_len: Optional[torch.Tensor] = None, advance: bool = False, done_at: Optional[torch.Tensor] = None,
+                embed=None, next_embeds: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The step between two decode steps of a greedy `generate` as one launch (aki_greedy_pick; HF GenerationMixin's greedy branch):
     next_ids[b] = pad if done[b] else argmax(logits[b]); tokens[b, t] = next with t = cache_len[b] + advance - start_len[b]; rows whose
     next is an eos id become done (done_at[b] = t); advance: cache_len += 1.  logits: bf16 [B, V] (row stride >= V); next_ids / tokens /
-    eos_ids int64; done uint8; cache_len / start_len / done_at int32.  Capturable: no host value is read."""
+    eos_ids int64; done uint8; cache_len / start_len / done_at int32.  Capturable: no host value is read.
+    embed = (weight [rows, d], additional_weight [extra, d] or None, max_original_id) with next_embeds bf16 [B, d]: the picked token's
+    embedding row (DecoupledEmbedding's two tables, src/helpers.py:440-492) is written to next_embeds in the same launch - the input of the next
+    decode step."""
     if logits.dtype != torch.bfloat16 or logits.dim() != 2 or logits.stride(1) != 1:
         raise AkiError("greedy_pick takes bf16 logits [B, V] with unit column stride")
     B, V = logits.shape
@@ -526,9 +543,23 @@ def greedy_pick(logits: torch.Tensor, next_ids: torch.Tensor, pad_token_id: int 
             raise AkiError(f"greedy_pick: a {dt} contiguous tensor on {logits.device} is expected, got {t_.dtype} {tuple(t_.shape)}")
     if tokens is not None and (tokens.dim() != 2 or tokens.shape[0] != B):
         raise AkiError("greedy_pick: tokens is [B, max_new_tokens]")
-    L.check(L.load().aki_greedy_pick(_ptr(logits), B, V, logits.stride(0), _ptr(eos_ids), 0 if eos_ids is None else eos_ids.numel(),
-                                          int(pad_token_id), _ptr(done), _ptr(next_ids), _ptr(tokens), 0 if tokens is None else tokens.shape[1],
-                                          _ptr(cache_len), _ptr(start_len), 1 if advance else 0, _ptr(done_at), _stream()), "aki_greedy_pick")
+    common = (_ptr(logits), B, V, logits.stride(0), _ptr(eos_ids), 0 if eos_ids is None else eos_ids.numel(), int(pad_token_id), _ptr(done),
+              _ptr(next_ids), _ptr(tokens), 0 if tokens is None else tokens.shape[1], _ptr(cache_len), _ptr(start_len), 1 if advance else 0,
+              _ptr(done_at))
+    if embed is None:
+        L.check(L.load().aki_greedy_pick(*common, _stream()), "aki_greedy_pick")
+        return next_ids
+    w, extra, max_orig = embed
+    d = w.shape[1]
+    for t_ in (w, extra, next_embeds):
+        if t_ is not None and (t_.dtype != torch.bfloat16 or not t_.is_contiguous() or t_.device != logits.device or t_.shape[-1] != d):
+            raise AkiError("greedy_pick: embedding tables and next_embeds are contiguous bf16 [*, d] on the logits' device")
+    if next_embeds is None or next_embeds.numel() != B * d:
+        raise AkiError("greedy_pick: next_embeds is [B, d]")
+    if w.shape[0] <= max_orig:
+        raise AkiError("greedy_pick: the embedding table has fewer than max_original_id + 1 rows")
+    L.check(L.load().aki_greedy_pick_embed(*common, _ptr(w), _ptr(extra), int(max_orig), 0 if extra is None else extra.shape[0], d,
+                                           _ptr(next_embeds), _stream()), "aki_greedy_pick_embed")
     return next_ids
 
 

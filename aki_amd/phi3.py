@@ -10,6 +10,7 @@ The modality-mutual mask arrives as an ``ops.MaskTable`` (rectangles + valid bit
 from __future__ import annotations
 
 import math
+import warnings
 from types import SimpleNamespace
 from typing import Optional
 
@@ -101,6 +102,7 @@ class AkiKVCache:
         self.grid_keys = capacity                                               # host bound of n_keys sizing the decode grid
         self.attn_ws_rows = B
         self.chain, self.chain_sig = None, None                                 # ops.DecodeChain of the one-launch step (batch 1)
+        self.chain_disabled = False                                             # set when a chained step failed its check (decode_verified)
 
     def get_seq_length(self, layer_idx=0):
         return int(self.cache_len.max())
@@ -432,6 +434,20 @@ class Phi3Model(nn.Module):
             cache.cache_len += 1
         return h                                    # PRE-norm: the head applies self.norm inside its GEMV
 
+    _weights_version = 0                            # bumped whenever parameters may have been re-allocated (part of the chain's signature)
+
+    def _apply(self, fn, *a, **kw):
+        self._weights_version += 1
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._weights_version += 1
+        return super().load_state_dict(*a, **kw)
+
+    def _load_from_state_dict(self, *a, **kw):      # reached when a PARENT module loads (assign=True swaps the parameter objects)
+        self._weights_version += 1
+        return super()._load_from_state_dict(*a, **kw)
+
     use_decode_chain = True                         # False: the five-launch-per-layer path (A/B and the bit-identity tests)
     decode_chain_w8 = True                          # e4m3 weights: one batch per workgroup, 1.37 ms per token against 1.46 on five launches
                                                     # (1.55 vs 1.46 ms per token: half the bytes, the same dependency latencies)
@@ -439,13 +455,16 @@ class Phi3Model(nn.Module):
     def _decode_chain(self, h, cache):
         """The one-launch decode step when it applies: one sequence, bf16 stream, Phi-3.5-mini's dimensions, every layer either
         bf16 or fully e4m3-quantised (the fp8 configuration's weight-only GEMVs).  Built once per (weights, KV cache)."""
-        if not self.use_decode_chain or h.shape[0] != 1 or h.dtype != torch.bfloat16 or not h.is_cuda:
+        if not self.use_decode_chain or cache.chain_disabled or h.shape[0] != 1 or h.dtype != torch.bfloat16 or not h.is_cuda:
             return None
         l0, ll = self.layers[0], self.layers[-1]
         chain = getattr(cache, "chain", None)
         # a cheap signature per step (module attribute lookups cost ~1 us each; the full scan below runs only when it changes):
         # re-allocated weights (model.to / a new quantisation) or KV tensors (beam re-ordering) move these pointers
-        sig = (l0.self_attn.qkv_proj.weight.data_ptr(), ll.mlp.down_proj.weight.data_ptr(), id(l0._fp8), id(ll._fp8), cache.k[0].data_ptr(),
+        # (ends of the stack), and everything that re-allocates parameters in between - Module._apply (.to / .half / .cuda), load_state_dict,
+        # a new quantisation - bumps `_weights_version`.  Assigning a new tensor to one middle layer's `.data` by hand is not seen:
+        # build a fresh cache (a new prefill) after surgery of that kind.
+        sig = (l0.self_attn.qkv_proj.weight.data_ptr(), ll.mlp.down_proj.weight.data_ptr(), self._weights_version, cache.k[0].data_ptr(),
                cache.k[-1].data_ptr(), len(self.layers))
         if chain is not None and chain.sig == sig:
             return chain
@@ -520,6 +539,7 @@ class Phi3ForCausalLM(nn.Module):
         tests/test_full_depth_gpu.py).  `head=False` keeps the lm_head in bf16, `residual_writers=False` also
         o_proj and down_proj (the projections whose output IS the residual stream): qkv and gate_up - 62 % of the decoder's
         GEMM work - then still run on the fp8 MFMA path."""
+        self.model._weights_version += 1
         if not enable:
             for layer in self.model.layers:
                 layer._fp8 = None
@@ -623,8 +643,30 @@ class Phi3ForCausalLM(nn.Module):
             inputs_embeds = self.get_input_embeddings()(input_ids)
         if inputs_embeds.dim() == 2:
             inputs_embeds = inputs_embeds[:, None]
-        steps = [self.decode_step(inputs_embeds=inputs_embeds[:, t], past_key_values=cache) for t in range(inputs_embeds.shape[1])]
+        T_new = inputs_embeds.shape[1]
+        steps = [self.decode_step(inputs_embeds=inputs_embeds[:, t], past_key_values=cache) for t in range(T_new)]
+        if not self.decode_verified(cache):          # a chained step failed its check: the same steps again, five launches per layer
+            cache.cache_len -= T_new
+            cache.host_len -= T_new
+            steps = [self.decode_step(inputs_embeds=inputs_embeds[:, t], past_key_values=cache) for t in range(T_new)]
         return CausalLMOutputWithPast(loss=None, logits=torch.stack(steps, dim=1), past_key_values=cache)
+
+    def decode_verified(self, cache) -> bool:
+        """True when every decode step taken on `cache` so far is valid.  The one-launch decode chain (one sequence; decode_chain.hip) bounds
+        its dependency waits, and a wait that gives up leaves garbage in that step's output and a sticky error word: this reads the word (a
+        device synchronisation - callers do it where they synchronise anyway).  On an error the chain is switched off for this cache (later
+        steps take the five-launch-per-layer path), a warning is issued and False is returned: the caller must discard every step since its
+        last verified point and run them again (rewind cache.cache_len / cache.host_len; the K/V rows are simply overwritten)."""
+        chain = getattr(cache, "chain", None)
+        if chain is None:
+            return True
+        code = chain.error_code()
+        if code == 0:
+            return True
+        cache.chain, cache.chain_disabled = None, True
+        warnings.warn(f"decode chain: a dependency wait gave up (layer {code >> 8}, phase {code & 255}); the steps since the last verified "
+                      "token are decoded again on the per-layer path, which this KV cache now stays on", RuntimeWarning, stacklevel=2)
+        return False
 
     def decode_step(self, input_ids=None, inputs_embeds=None, past_key_values=None, advance: bool = True):
         """One greedy-decoding step: new token ids [B] (or their embeddings [B, d]) -> logits [B, V'].  After the prefill

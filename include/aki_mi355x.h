@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 14
+#define AKI_ABI_VERSION 15
 
 typedef enum {
   AKI_OK = 0,
@@ -548,6 +548,16 @@ int aki_sft_collate_pad(const int64_t* ids, const int64_t* labels, const int64_t
 int aki_greedy_pick(const void* logits, int32_t B, int32_t V, int64_t ld, const int64_t* eos_ids, int32_t n_eos, int64_t pad_token_id,
                     uint8_t* done, int64_t* next_ids, int64_t* tokens, int32_t tokens_ld, int32_t* cache_len, const int32_t* start_len,
                     int32_t advance, int32_t* done_at, void* stream);
+
+/* aki_greedy_pick_embed - aki_greedy_pick + the embedding lookup of the token it picked (`DecoupledEmbedding.forward`,
+ * src/helpers.py:440-492, which HF's generate loop runs at the top of the next step): next_embeds[b, :] = bf16 row `next` of embed_weight
+ * [max_original_id + 1 or more rows, d], or row `next - max_original_id - 1` of additional_weight [num_additional, d] when
+ * next > max_original_id (additional_weight NULL: one table).  d % 8 == 0, 16-byte aligned tables; V may not exceed the number of rows.
+ * next_embeds is what the following decode step takes as h_in: a greedy token is decode chain + head + this launch. */
+int aki_greedy_pick_embed(const void* logits, int32_t B, int32_t V, int64_t ld, const int64_t* eos_ids, int32_t n_eos, int64_t pad_token_id,
+                          uint8_t* done, int64_t* next_ids, int64_t* tokens, int32_t tokens_ld, int32_t* cache_len, const int32_t* start_len,
+                          int32_t advance, int32_t* done_at, const void* embed_weight, const void* additional_weight, int64_t max_original_id,
+                          int64_t num_additional, int32_t d, void* next_embeds, void* stream);
 
 #ifdef __cplusplus
 }
