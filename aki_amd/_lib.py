@@ -69,7 +69,35 @@ class LinearArgs(C.Structure):
                 ("w2", C.c_void_p), ("w2_row0", C.c_int32), ("w2_rows", C.c_int32),
                 ("row_scale", C.c_void_p), ("row_shift", C.c_void_p), ("col_shift", C.c_void_p), ("stats_rstd", C.c_void_p),
                 ("stats_mean", C.c_void_p), ("stats_eps", C.c_float), ("stats_workspace", C.c_void_p),
-                ("stats_workspace_bytes", C.c_size_t)]
+                ("stats_workspace_bytes", C.c_size_t), ("splitk_workspace", C.c_void_p), ("splitk_workspace_bytes", C.c_size_t)]
+
+
+class DecoderLayer(C.Structure):
+    _fields_ = [("w_qkv", C.c_void_p), ("w_o", C.c_void_p), ("w_gate_up", C.c_void_p), ("w_down", C.c_void_p), ("k_cache", C.c_void_p),
+                ("v_cache", C.c_void_p)]
+
+
+class DecoderStackArgs(C.Structure):
+    _fields_ = [("layers", C.POINTER(DecoderLayer)), ("n_layers", C.c_int32), ("h_in", C.c_void_p), ("h_out", C.c_void_p), ("rstd_out", C.c_void_p),
+                ("cos", C.c_void_p), ("sin", C.c_void_p), ("position_ids", C.c_void_p), ("pos_rows", C.c_int32), ("rects", C.c_void_p),
+                ("col_valid_bits", C.c_void_p), ("seq_lens", C.c_void_p), ("max_rects", C.c_int32), ("B", C.c_int32), ("H", C.c_int32),
+                ("L", C.c_int32), ("Dh", C.c_int32), ("d", C.c_int32), ("F", C.c_int32), ("kv_capacity", C.c_int32), ("scale", C.c_float),
+                ("rms_eps", C.c_float), ("dead_rows", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("stats_workspace", C.c_void_p), ("stats_workspace_bytes", C.c_size_t), ("splitk_workspace", C.c_void_p),
+                ("splitk_workspace_bytes", C.c_size_t)]
+
+
+class SiglipLayer(C.Structure):
+    _fields_ = [("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p), ("c_qkv", C.c_void_p), ("w_out", C.c_void_p), ("b_out", C.c_void_p),
+                ("w_fc1", C.c_void_p), ("b_fc1", C.c_void_p), ("c_fc1", C.c_void_p), ("w_fc2", C.c_void_p), ("b_fc2", C.c_void_p)]
+
+
+class SiglipStackArgs(C.Structure):
+    _fields_ = [("layers", C.POINTER(SiglipLayer)), ("n_layers", C.c_int32), ("h_in", C.c_void_p), ("h_out", C.c_void_p), ("fc1_out", C.c_void_p),
+                ("N", C.c_int32), ("L", C.c_int32), ("E", C.c_int32), ("heads", C.c_int32), ("I", C.c_int32), ("Ip", C.c_int32),
+                ("act", C.c_int32), ("ln_eps", C.c_float), ("scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("stats_workspace", C.c_void_p), ("stats_workspace_bytes", C.c_size_t), ("splitk_workspace", C.c_void_p),
+                ("splitk_workspace_bytes", C.c_size_t)]
 
 
 class SpliceArgs(C.Structure):
@@ -109,6 +137,7 @@ SIGNATURES = {
     "aki_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "aki_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "aki_linear_stats_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "aki_linear_splitk_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "aki_linear_stats_counter_bytes": (C.c_size_t, [C.c_int32]),
     "aki_row_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "aki_rmsnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -159,6 +188,10 @@ SIGNATURES = {
                                      C.c_void_p]),
     "aki_greedy_pick": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "aki_decoder_stack_workspace_bytes": (C.c_size_t, [C.c_int32] * 7),
+    "aki_decoder_stack_fwd": (C.c_int, [C.POINTER(DecoderStackArgs), C.c_void_p]),
+    "aki_siglip_stack_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
+    "aki_siglip_stack_fwd": (C.c_int, [C.POINTER(SiglipStackArgs), C.c_void_p]),
     "aki_greedy_pick_embed": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
                                         C.c_void_p]),
@@ -208,6 +241,8 @@ def load_lab() -> C.CDLL:
     lib.aki_lab_set_chain_stamps.argtypes = [C.c_void_p, C.c_int]
     lib.aki_lab_set_chain_lds.restype = None
     lib.aki_lab_set_chain_lds.argtypes = [C.c_int]
+    lib.aki_lab_set_small_m.restype = None
+    lib.aki_lab_set_small_m.argtypes = [C.c_int, C.c_int]
     lib.aki_lab_set_chain_fault.restype = None
     lib.aki_lab_set_chain_fault.argtypes = [C.c_int, C.c_int]
     return lib

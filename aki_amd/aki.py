@@ -225,11 +225,10 @@ class AKI(VLMWithLanguageStream):
         table = new_inputs["attention_mask"]
         L = new_inputs["inputs_embeds"].shape[1]
         out = self.lang_model(inputs_embeds=new_inputs["inputs_embeds"], attention_mask=table, use_cache=True,
-                              cache_capacity=L + max_new_tokens)
+                              cache_capacity=L + max_new_tokens, last_token_logits=True)
         cache = out.past_key_values
         B = lang_x.shape[0]
-        last = (cache.cache_len.long() - 1).clamp_(min=0)
-        logits = out.logits[torch.arange(B, device=lang_x.device), last]          # logits of each sample's last real token
+        logits = out.logits[:, 0]                                                  # logits of each sample's last real token
         if num_beams > 1:
             tokens = self._beam_search(cache, logits, num_beams, max_new_tokens, eos_ids, pad_id, length_penalty, early_stopping)
             self._post_forward_hook()

@@ -46,7 +46,10 @@ int sft_collate_launch(const int64_t* ids, const int64_t* labels, const int64_t*
 size_t mask_to_table_ws_bytes(int B, int L);
 int mask_to_table_launch(const int64_t* mask, int B, int L, int max_rects, aki_mma_rect* rects, uint64_t* vbits, int* seq_lens,
                          int* status, void* ws, hipStream_t s);
+size_t linear_splitk_plan_ws_bytes(int M, int N, int K);
 #ifdef AKI_LAB_HOOKS
+extern int g_sm_variant;
+extern int g_sm_ksplit;
 extern int g_force_tile;
 extern int g_deep_ring;
 extern int g_pipe;
@@ -114,6 +117,8 @@ void aki_lab_set_gemm_tile(int mode) {
   mode &= 255;
   aki::g_force_tile = (mode >= 1 && mode <= 5) ? mode : 0;
 }
+// small-M tile variant (gemm_bf16.hip: launch_variant; -1 = the planner) and its K split, for every bf16 GEMM launch
+void aki_lab_set_small_m(int variant, int ksplit) { aki::g_sm_variant = variant; aki::g_sm_ksplit = ksplit < 1 ? 1 : ksplit; }
 // 0 = product choice, 1 = 32-row attention core (two waves per SIMD), 2 = 64-row core (one wave per SIMD)
 void aki_lab_set_attn_variant(int v) { aki::g_attn_variant = v; }
 // device pointer to two int64: every bf16 GEMM launch then leaves {shader cycles, 100 MHz wall ticks} of its workgroup 0 there
@@ -221,6 +226,7 @@ int aki_mma_attn_fwd(const aki_mma_attn_args* a, void* ws, size_t ws_bytes, void
 // ---- linear ------------------------------------------------------------------------------------------
 size_t aki_linear_stats_counter_bytes(int32_t M) { return M > 0 ? linear_stats_cnt_bytes(M) : 0; }
 size_t aki_linear_stats_workspace_bytes(int32_t M, int32_t N_out) { return (M > 0 && N_out > 0) ? aki_align_up(linear_stats_ws_bytes(M, N_out), 256) : 0; }
+size_t aki_linear_splitk_workspace_bytes(int32_t M, int32_t N, int32_t K) { return (M > 0 && N > 0 && K > 0) ? aki_align_up(linear_splitk_plan_ws_bytes(M, N, K), 256) : 0; }
 
 int aki_row_stats(const void* x, int32_t rows, int32_t cols, int32_t ldx, float eps, float* rstd, float* mean, int32_t dtype, void* stream) {
   AKI_CLEAR_ERR();

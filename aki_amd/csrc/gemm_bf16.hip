@@ -110,6 +110,11 @@ struct GemmParams {
   float* st_mean;
   float* st_part;      // [slots][2][M] partial sums (sum of squares, sum), slot = tile column * WN + wave column
   unsigned* st_cnt;    // [tiles_m] arrival counters, zero between launches
+  // Split-K (template SK; small-M launches, see plan_small_m): workgroup t = tile * ksplit + slice walks K-steps [slice * nk / ksplit, (slice + 1) * nk / ksplit)
+  int ksplit;
+  float* sk_part;      // [tiles][ksplit][BN * BM] f32 partial accumulators in fragment order (16 B per lane: coalesced)
+  size_t sk_bytes;     // bytes behind sk_part (host side: does the planned split fit?)
+  unsigned* sk_cnt;    // [tiles] arrival tickets, zero between launches
 #ifdef AKI_LAB_HOOKS
   int probe_block;          // lab: which workgroup stamps (default 0)
   long long* clock_probe;   // lab: 32 int64: {shader cycles, 100 MHz ticks} of workgroup 0, [2..17] phase sums of the PIPE 3 loop, [18] prologue, [19] epilogue cycles
@@ -133,8 +138,9 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 // FP8: e4m3 operands through v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate).  A 128-byte
 // LDS row then holds BK = 128 k-values instead of 64, so staging, swizzle and the epilogues are byte-for-byte the same; the
 // per-row dequantisation scales (one per token, one per weight row) multiply the f32 accumulators before the epilogue.
-template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false, int NST = 2, int PIPE = 0>
+template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false, int NST = 2, int PIPE = 0, int SK = 0>
 __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16_kernel(const GemmParams p) {
+  static_assert(!SK || (!FP8 && PIPE <= 1), "split-K: bf16, the plain K loops and the mid-step-barrier pipeline");
   constexpr int BK = FP8 ? 128 : 64, ES = FP8 ? 1 : 2, NWAVES = WN * WM;
   constexpr int WROWS = NF * 16;      // features per wave
   constexpr int BN = WN * WROWS;      // features per block tile
@@ -156,10 +162,24 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   // kernel actually ran at (tools/gemm_clock.py)
   long long probe_c0 = 0, probe_w0 = 0;
   if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) { probe_c0 = clock64(); probe_w0 = wall_clock64(); }
+  // probe_block == -2: EVERY workgroup stamps the 100 MHz wall clock (one time base for the whole chip) at its start, K-loop begin, K-loop end and
+  // exit into clock_probe[4 * blockIdx.x + 0..3] - the launch's timeline (dispatch ramp, stragglers, fold tails): tools/small_m_timeline.py
+#define AKI_WG_STAMP(k) do { if (p.probe_block == -2 && tid == 0 && p.clock_probe) p.clock_probe[4 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
+  AKI_WG_STAMP(0);
+#else
+#define AKI_WG_STAMP(k) do { } while (0)
 #endif
 
   // ---- tile id: XCD-contiguous chunks, grouped so concurrently running tiles of an XCD share operand panels ----
-  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  int ksp = 0, kt0 = 0;                           // split-K: this workgroup's slice of K and its first K-step
+  int nk = p.K / (FP8 ? 128 : 64);
+  if constexpr (SK) {                             // the slices of a tile are neighbours in the remapped order: same XCD, same L2
+    ksp = t % p.ksplit;
+    t /= p.ksplit;
+    kt0 = ksp * nk / p.ksplit;
+    nk = (ksp + 1) * nk / p.ksplit - kt0;
+  }
   constexpr int GM = 8;
   const int per_group = GM * p.tiles_n;
   const int group = t / per_group;
@@ -206,6 +226,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       const int xrow = min(m0 + row - BN, p.M - 1);
       src[j] = (const char*)p.x + (size_t)xrow * p.ldx * ES + chunk * 16;
     }
+    if constexpr (SK) src[j] += (size_t)kt0 * 128;
   }
 
   auto stage = [&](int s, int kt) {
@@ -228,7 +249,6 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   const int wbase = (wn * WROWS + l15) * 128;
   const int xbase = BN * 128 + (wm * WTOK + l15) * 128;
 
-  const int nk = p.K / BK;
   // ---- epilogue operands (bias, folded-norm scale / shift / column sums).  Their fetch is a DRAM-latency round trip that
   // nothing in the epilogue can hide; small tiles (several short launches per layer, spare registers) issue it here, under
   // the first K-step's DMA wait, the 256^2 tiles (at the register limit) right after the K loop, ahead of the residual
@@ -310,6 +330,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   long long probe_l0 = 0, probe_l1 = 0;                  // K-loop begin / end of workgroup 0 -> clock_probe[18] = prologue, [19] = epilogue cycles
   if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) probe_l0 = clock64();
 #endif
+  AKI_WG_STAMP(1);
   if constexpr (PIPE == 3) {
     // One wave per SIMD with a hand-placed stream (lab).  Four waves, wave tile 128 features x 128 tokens: 256 accumulator registers
     // in the AGPR half of the file, the fragments of both k32 halves (128 VGPRs) in the other - a third fewer LDS fragment bytes
@@ -758,6 +779,51 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
 #ifdef AKI_LAB_HOOKS
   if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) probe_l1 = clock64();
 #endif
+  AKI_WG_STAMP(2);
+  if constexpr (SK) {
+    // Split-K fold, deterministic and without a second launch.  Every slice writes its f32 accumulators in fragment order (one 16-byte
+    // store per lane and block: 1 KiB per wave-instruction, write-through), drains, and draws a ticket (cdna_hip_programming.md
+    // Guideline 16, ticket form - the protocol of the row statistics below).  The LAST slice to arrive - whichever it is - reads all
+    // `ksplit` partials back in slice order, its own included, and adds them up in that order: the sum does not depend on the arrival
+    // order, so a launch is bit-reproducible.  It then runs the ordinary epilogue (residual, statistics, ...); the others are done.
+    if (p.ksplit > 1) {
+      __shared__ unsigned sk_last;
+      constexpr int TILE_BYTES = BN * BM * 4;
+      float* const tile_base = p.sk_part + (size_t)t * p.ksplit * (BN * BM);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tile_base, (short)0, p.ksplit * TILE_BYTES, 0x00020000);
+      const int lane_off = (wave * NF * NT * 64 + lane) * 16;
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[n][m]), rs, ksp * TILE_BYTES + lane_off + (n * NT + m) * 1024, 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.sk_cnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sk_last = (old == (unsigned)p.ksplit - 1u) ? 1u : 0u;
+        if (old == (unsigned)p.ksplit - 1u) __hip_atomic_store(p.sk_cnt + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again when the launch ends
+      }
+      __syncthreads();
+#ifdef AKI_LAB_HOOKS
+      if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) {
+        p.clock_probe[0] = clock64() - probe_c0; p.clock_probe[1] = wall_clock64() - probe_w0;
+        p.clock_probe[18] = probe_l0 - probe_c0; p.clock_probe[19] = clock64() - probe_l1; p.clock_probe[22] = sk_last;
+      }
+#endif
+      if (sk_last == 0u) { AKI_WG_STAMP(3); return; }
+      for (int i = 0; i < p.ksplit; ++i) {
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+          for (int m = 0; m < NT; ++m) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, i * TILE_BYTES + lane_off + (n * NT + m) * 1024, 0, 16));
+            if (i == 0) acc[n][m] = v;
+            else acc[n][m] += v;
+          }
+      }
+    }
+  }
   if constexpr (FP8) {   // dequantise: acc[feature][token] *= sw[weight row] * sx[token]
     float sxm[NT];
 #pragma unroll
@@ -897,6 +963,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       p.clock_probe[20] = probe_s - probe_l1;            // cos / sin staging
     }
 #endif
+    AKI_WG_STAMP(3);
     return;
   }
 
@@ -1157,17 +1224,20 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
     p.clock_probe[19] = clock64() - probe_l1;
   }
 #endif
+  AKI_WG_STAMP(3);
 }
+#undef AKI_WG_STAMP
 
 #ifdef AKI_LAB_HOOKS
+int g_sm_variant = -1, g_sm_ksplit = 1;              // set by aki_lab_set_small_m: force a small-M tile variant (launch_variant) and its K split
 int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0;   // set by aki_lab_set_gemm_tile (lab build only); g_pipe: 0 off, 1 on, 2 on without the residual prefetch
 long long* g_clock_probe = nullptr;                  // set by aki_lab_set_clock_probe
 int g_probe_block = 0;                               // set by aki_lab_set_probe_block
 #else
-static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0;
+static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0, g_sm_variant = -1, g_sm_ksplit = 1;
 #endif
 
-template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, int PIPE = 0>
+template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, int PIPE = 0, int SK = 0>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
   constexpr int SMEM = (PIPE >= 4 && PIPE <= 7) ? (BN > BM ? 3 * BN + 2 * BM : 3 * BM + 2 * BN) * 128   // PIPE 4-7: three + two tiles
@@ -1175,7 +1245,7 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   static_assert(SMEM <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return AKI_ERR_LAUNCH;
     attr_set = true;
   }
@@ -1188,7 +1258,8 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.clock_probe = g_clock_probe;
   p.probe_block = g_probe_block;
 #endif
-  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE>), dim3(p.tiles_m * p.tiles_n), dim3(WN * WM * 64), SMEM, stream, p);
+  const int slices = SK ? (p.ksplit > 1 ? p.ksplit : (p.ksplit = 1)) : 1;
+  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE, SK>), dim3(p.tiles_m * p.tiles_n * slices), dim3(WN * WM * 64), SMEM, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }
@@ -1285,8 +1356,123 @@ static int launch_big(GemmParams& p, hipStream_t stream) {
   return launch_gemm<8, 4, 2, 4, EPI, ACT, FP8>(p, stream);
 }
 
+// ---- small M (one-sample prefill: M = 655 / 207; one image through the SigLIP tower: M = 576) --------------------------------------
+// Tile variants on the plain K loops (two stages, or a ring of NST stages with NST - 1 tiles in flight), each optionally with the K range split
+// over `ksplit` workgroups (EPI_PLAIN without activation).  What these launches lack is not FLOPs but requests in flight: a 128 x 128 tile on
+// the two-stage loop has ONE 32 KiB tile outstanding per workgroup and pays the memory latency every K-step (o_proj at M = 655: 144
+// workgroups x 48 steps x ~2000 cycles = 46 us for 12 GFLOP).
+//   id  features x tokens  stages  LDS      per CU
+//   0   128 x 128          2       64 KiB   2          5   128 x 64   3   72 KiB   2
+//   1   128 x 128          3       96 KiB   1          6   64 x 128   3   72 KiB   2
+//   2   128 x 128          4       128 KiB  1          7   64 x 64    4   64 KiB   2
+//   3   128 x 96           2       56 KiB   2          8   128 x 64   2   48 KiB   3
+//   4   128 x 96           3       84 KiB   1          9   64 x 128   4   96 KiB   1
+constexpr int kSmallMVariants = 16;
+struct SmallMTile { int bn, bm, lds_kib; };
+static const SmallMTile kSmallMTiles[kSmallMVariants] = {{128, 128, 64}, {128, 128, 96}, {128, 128, 128}, {128, 96, 56}, {128, 96, 84},
+                                                        {128, 64, 72}, {64, 128, 72}, {64, 64, 64}, {128, 64, 48}, {64, 128, 96},
+                                                        // 10-15: the mid-step-barrier pipeline (PIPE 1: fragments double-buffered in registers, reads and DMA issue spread between the MFMAs)
+                                                        {128, 128, 64}, {128, 96, 56}, {256, 128, 96}, {128, 128, 64}, {256, 64, 80}, {128, 256, 96}};
+size_t linear_splitk_cnt_bytes() { return size_t(64) << 10; }     // 16 384 tile tickets, at the front of the split-K workspace
+size_t linear_splitk_ws_bytes(int variant, int ksplit, int M, int n_out) {
+  if (ksplit <= 1 || variant < 0 || variant >= kSmallMVariants) return 0;
+  const SmallMTile& tl = kSmallMTiles[variant];
+  const size_t tiles = (size_t)((M + tl.bm - 1) / tl.bm) * ((n_out + tl.bn - 1) / tl.bn);
+  return linear_splitk_cnt_bytes() + tiles * ksplit * tl.bn * tl.bm * sizeof(float);
+}
+
+// The planner's choice for a bf16 GEMM with few rows (17 .. 1024: a one-sample prefill, one image through the tower): tile variant (-1: none, the
+// ordinary plans) and K split.  From tools/small_m_sweep.py on cold operands (profiles/r05_small_m_sweep.txt, us per launch, planner before -> now):
+//   plain, N <= 4096, K >= 2304 (o_proj / down / SigLIP fc2): 128 x 96 (M > 256) or 128 x 64 tiles, K split 3 ways when the tiles alone
+//     leave the 512 two-per-CU slots under-filled - M 655: o_proj 46.6 -> 37.2, down 97.2 -> 59.4; M 207: 27.1 -> 24.5, 47.1 -> 38.5; fc2 26.9 -> 22.7.
+//     Deeper rings, 256-wide tiles and the register-pipelined loop on these tiles all lost: one 4-wave workgroup per CU serialises DMA wait,
+//     fragment reads and MFMAs (1200-1450 cycles per K-step for 384-512 of MFMA work, warm or cold), two per CU overlap them, and the
+//     launch's fixed costs (prologue 1.5 us, fold / statistics tails 3-15 us) are then as long as the K loop (tools/small_m_timeline.py).
+//   QKV + RoPE: 128 x 96 tiles (M > 256: 57.8 -> 48.5) or the same on a three-stage ring (M 207: 46.5 -> 31.0).
+//   gate_up + SwiGLU, M <= 256: 128 x 128 on a three-stage ring (47.4 -> 36.8); above that the 256 x 256 tile stays (76 us at M 655).
+static void plan_small_m(int epi, int M, int n_out, int K, bool can_split, int& variant, int& ksplit) {
+  variant = -1; ksplit = 1;
+  if (M < 17 || M > 1024 || g_force_tile) return;
+  const int nk = K / 64;
+  if (epi == EPI_QKV_ROPE8) { variant = M > 256 ? 3 : 4; return; }
+  if (epi == EPI_SWIGLU) { if (M <= 256 && nk >= 8) variant = 1; return; }
+  if (n_out > 4096 || nk < 36 || !can_split) return;
+  const int v = M > 256 ? 3 : 5;
+  const SmallMTile& tl = kSmallMTiles[v];
+  const long tiles = (long)((M + tl.bm - 1) / tl.bm) * ((n_out + tl.bn - 1) / tl.bn);
+  const int ks = (int)(512 / tiles) < 3 ? (int)(512 / tiles) : 3;
+  if (ks < 2) return;
+  variant = v; ksplit = ks;
+}
+size_t linear_splitk_plan_ws_bytes(int M, int N, int K) {
+  int v, ks;
+  plan_small_m(EPI_PLAIN, M, N, K, true, v, ks);
+  return linear_splitk_ws_bytes(v, ks, M, N);
+}
+
+template <int EPI, int ACT>
+static int launch_variant(GemmParams& p, int variant, int ksplit, hipStream_t stream) {
+  constexpr int SKV = (EPI == EPI_PLAIN && ACT == 0) ? 1 : 0;
+  p.ksplit = SKV ? ksplit : 1;
+  switch (variant) {
+    case 0: return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 2, 0, SKV>(p, stream);
+    case 1: return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 3, 0, SKV>(p, stream);
+    case 2: return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 4, 0, SKV>(p, stream);
+    case 3: return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 2, 0, SKV>(p, stream);
+    case 4: return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 3, 0, SKV>(p, stream);
+    case 5: return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 3, 0, SKV>(p, stream);
+    case 6: return launch_gemm<2, 4, 2, 2, EPI, ACT, false, 3, 0, SKV>(p, stream);
+    case 7: return launch_gemm<2, 2, 2, 2, EPI, ACT, false, 4, 0, SKV>(p, stream);
+    case 8: return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 2, 0, SKV>(p, stream);
+    case 9: return launch_gemm<2, 4, 2, 2, EPI, ACT, false, 4, 0, SKV>(p, stream);
+    case 10: return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
+    case 11: return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
+    case 12: return launch_gemm<8, 4, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
+    case 13: return launch_gemm<8, 4, 1, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);     // two waves, wave tile 128 features x 64 tokens
+    case 14: return launch_gemm<8, 2, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
+    case 15:
+      if constexpr (EPI != EPI_QKV_ROPE8) return launch_gemm<4, 4, 2, 4, EPI, ACT, false, 2, 1, SKV>(p, stream);
+      break;
+  }
+  return AKI_ERR_UNSUPPORTED;
+}
+
+// the variants plan_small_m hands out (the product library instantiates these and no others)
+template <int EPI, int ACT>
+static int launch_small_m(GemmParams& p, int variant, int ksplit, hipStream_t stream) {
+  p.ksplit = ksplit;
+  if constexpr (EPI == EPI_QKV_ROPE8) {
+    if (variant == 3) return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 2, 0, 0>(p, stream);
+    if (variant == 4) return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 3, 0, 0>(p, stream);
+  } else if constexpr (EPI == EPI_SWIGLU) {
+    if (variant == 1) return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 3, 0, 0>(p, stream);
+  } else if constexpr (ACT == 0) {
+    if (variant == 3) return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 2, 0, 1>(p, stream);
+    if (variant == 5) return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 3, 0, 1>(p, stream);
+  }
+  return AKI_ERR_UNSUPPORTED;
+}
+
 template <int EPI, int ACT, bool FP8 = false>
 static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
+#ifdef AKI_LAB_HOOKS
+  if constexpr (!FP8) {
+    if (g_sm_variant >= 0) {                       // lab: forced small-M variant
+      int ks = g_sm_ksplit;
+      if (ks > 1 && (p.sk_part == nullptr || ks > p.K / 64)) ks = 1;
+      return launch_variant<EPI, ACT>(p, g_sm_variant, ks, stream);
+    }
+  }
+#endif
+  if constexpr (!FP8 && (EPI != EPI_PLAIN || ACT == 0)) {
+    if (g_sm_variant != -2 && (p.w2 == nullptr)) {        // (lab: -2 = the plans as they were before the small-M planner)
+      int v, ks;
+      const int n_out = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
+      plan_small_m(EPI, p.M, n_out, p.K, p.sk_part != nullptr, v, ks);
+      if (v >= 0 && ks > 1 && p.sk_bytes < linear_splitk_ws_bytes(v, ks, p.M, n_out) - linear_splitk_cnt_bytes()) v = -1;
+      if (v >= 0 && !(EPI == EPI_PLAIN && p.row_shift != nullptr)) return launch_small_m<EPI, ACT>(p, v, ks, stream);
+    }
+  }
   if (plan == 1) return launch_small<EPI, ACT, FP8>(p, stream);
   if (plan == 0) return launch_big<EPI, ACT, FP8>(p, stream);
   if constexpr (EPI == EPI_PLAIN && !FP8) {
@@ -1357,6 +1543,14 @@ int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
   if (a->act == AKI_ACT_SWIGLU) {
     if (a->bias) return AKI_ERR_UNSUPPORTED;
     return run_planned<EPI_SWIGLU, 0>(p, plan_tiles(a->M, n_out, 128, 64), stream);
+  }
+  if (a->splitk_workspace && a->splitk_workspace_bytes > linear_splitk_cnt_bytes() && !(((uintptr_t)a->splitk_workspace) & 255)) {
+    p.sk_cnt = (unsigned*)a->splitk_workspace;
+    p.sk_part = (float*)((char*)a->splitk_workspace + linear_splitk_cnt_bytes());
+    p.sk_bytes = a->splitk_workspace_bytes - linear_splitk_cnt_bytes();
+#ifdef AKI_LAB_HOOKS
+    if (g_sm_variant >= 0 && a->splitk_workspace_bytes < linear_splitk_ws_bytes(g_sm_variant, g_sm_ksplit, a->M, n_out)) p.sk_part = nullptr;
+#endif
   }
   const int plan = plan_tiles(a->M, n_out, 256, 128, 0.25, true, a->K / 64);
   switch (a->act) {

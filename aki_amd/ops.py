@@ -140,6 +140,23 @@ def _stats_ws(M: int, n_out: int, dev) -> torch.Tensor:
     return hit
 
 
+_SPLITK_WS = {}
+SPLITK_WS_MIN_BYTES = 0          # tools / tests: a floor for the split-K workspace (the lab library's forced splits need more than the planner's)
+
+
+def _splitk_ws(M: int, N: int, K: int, dev) -> Optional[torch.Tensor]:
+    """Split-K workspace (tickets + f32 partial tiles; include/aki_mi355x.h): zero-filled once per (device, stream), None when the
+    library never splits this shape."""
+    need = max(int(L.load().aki_linear_splitk_workspace_bytes(M, N, K)), SPLITK_WS_MIN_BYTES)
+    if need == 0:
+        return None
+    key = (torch.device(dev).index, torch.cuda.current_stream().cuda_stream)
+    hit = _SPLITK_WS.get(key)
+    if hit is None or hit.numel() < need:
+        hit = _SPLITK_WS[key] = torch.zeros(max(need, 32 << 20), dtype=torch.uint8, device=dev)
+    return hit
+
+
 def new_stats(M: int, dev, ln: bool = False) -> RowStats:
     return RowStats(torch.empty((M,), dtype=torch.float32, device=dev), torch.empty((M,), dtype=torch.float32, device=dev) if ln else None)
 
@@ -250,6 +267,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         sws = _stats_ws(M, n_out, dev)
         a.stats_rstd, a.stats_mean, a.stats_eps = _ptr(stats_out.rstd), _ptr(stats_out.mean), float(stats_eps)
         a.stats_workspace, a.stats_workspace_bytes = sws.data_ptr(), sws.numel()
+    if act == ACT_NONE and M <= 2048 and x.dtype == torch.bfloat16:
+        sk = _splitk_ws(M, N, K, dev)
+        if sk is not None:
+            a.splitk_workspace, a.splitk_workspace_bytes = sk.data_ptr(), sk.numel()
     end = _TAP.begin(("linear", M, N, K, act)) if (_TAP is not None and _TAP.want(("linear", M, N, K, act))) else None
     L.check(lib.aki_linear_fwd(C.byref(a), _stream()), "aki_linear_fwd")
     if end is not None:
@@ -581,6 +602,100 @@ def decode_linear(x: torch.Tensor, w: torch.Tensor, rms_weight: torch.Tensor, ep
     a = L.LinearArgs(_ptr(x2), _ptr(w), _ptr(bias), _ptr(r2), _ptr(o2), M, N, K, x2.stride(0), w.stride(0), o2.stride(0),
                      0 if r2 is None else r2.stride(0), 0, act, _dt(x))
     L.check(L.load().aki_decode_linear_fwd(C.byref(a), _ptr(rms_weight), float(eps), _stream()), "aki_decode_linear_fwd")
+    return out
+
+
+# ---- layer loops in one C call (csrc/stack.hip) -------------------------------------------------------------------------
+_SCRATCH = {}
+
+
+def _scratch(nbytes: int, dev) -> torch.Tensor:
+    """Uninitialised scratch per (device, stream), 256-byte aligned: launches that use it are stream-ordered."""
+    key = (torch.device(dev).index, torch.cuda.current_stream().cuda_stream)
+    hit = _SCRATCH.get(key)
+    if hit is None or hit.numel() < nbytes + 256:
+        hit = _SCRATCH[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+    return hit
+
+
+def stack_enabled() -> bool:
+    """The one-call layer loops hide the individual launches from the event tap (bench.py brackets single GEMMs): off while one is installed."""
+    return _TAP is None
+
+
+class LayerTable:
+    """A host array of per-layer pointer structs for the stack calls, rebuilt only when a pointer changes."""
+
+    def __init__(self, struct):
+        self.struct, self.key, self.arr, self.keep = struct, None, None, None
+
+    def get(self, rows):
+        """rows: per layer a tuple of tensors / None in the struct's field order."""
+        key = tuple(0 if t_ is None else t_.data_ptr() for r in rows for t_ in r)
+        if key != self.key:
+            n = len(self.struct._fields_)
+            arr = (self.struct * len(rows))()
+            for i, r in enumerate(rows):
+                arr[i] = self.struct(*key[i * n:(i + 1) * n])
+            self.key, self.arr, self.keep = key, arr, rows
+        return self.arr
+
+
+def decoder_stack(table_arr, n_layers: int, h: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, mask: MaskTable, num_heads: int, head_dim: int,
+                  inter: int, scale: float, eps: float, position_ids: Optional[torch.Tensor] = None, kv_capacity: int = 0,
+                  dead_rows: int = DEAD_ROWS_UNIFORM):
+    """All decoder layers of a bf16 inference forward in ONE call (aki_decoder_stack_fwd): h [B, L, d] raw residual stream -> (h_out, 1/rms of
+    its rows).  `table_arr`: LayerTable of L.DecoderLayer (gain-folded w_qkv / w_gate_up, w_o, w_down, KV cache tensors or None)."""
+    dev = _dev(h, cos, sin)
+    B, Lq, d = h.shape
+    if h.dtype != torch.bfloat16 or not h.is_contiguous():
+        raise AkiError("decoder_stack: h is a contiguous bf16 [B, L, d] tensor")
+    lib = L.load()
+    cos = cos.to(torch.float32).reshape(-1, head_dim).contiguous()
+    sin = sin.to(torch.float32).reshape(-1, head_dim).contiguous()
+    pos = None if position_ids is None else position_ids.to(torch.int32).expand(B, Lq).contiguous()
+    M = B * Lq
+    out = torch.empty_like(h)
+    rstd = torch.empty((M,), dtype=torch.float32, device=dev)
+    keep = 1 if kv_capacity else 0
+    need = int(lib.aki_decoder_stack_workspace_bytes(B, num_heads, Lq, head_dim, d, inter, keep))
+    ws = _scratch(need, dev)
+    off = (-ws.data_ptr()) % 256
+    sws = _stats_ws(M, d, dev)
+    sk = None
+    if M <= 2048:
+        for K_ in (num_heads * head_dim, inter):          # o_proj, down: one buffer (it only ever grows) serves both
+            sk = _splitk_ws(M, d, K_, dev) or sk
+    a = L.DecoderStackArgs(table_arr, n_layers, _ptr(h), _ptr(out), _ptr(rstd), _ptr(cos), _ptr(sin), _ptr(pos), cos.shape[0], _ptr(mask.rects),
+                           _ptr(mask.col_valid_bits), _ptr(mask.seq_lens), mask.max_rects, B, num_heads, Lq, head_dim, d, inter,
+                           int(kv_capacity), float(scale), float(eps), dead_rows, ws.data_ptr() + off, ws.numel() - off, sws.data_ptr(), sws.numel(),
+                           None if sk is None else sk.data_ptr(), 0 if sk is None else sk.numel())
+    L.check(lib.aki_decoder_stack_fwd(C.byref(a), _stream()), "aki_decoder_stack_fwd")
+    return out, RowStats(rstd)
+
+
+def siglip_stack(table_arr, n_layers: int, h: torch.Tensor, fc1_out: torch.Tensor, heads: int, inter: int, act: int, eps: float,
+                 scale: float) -> torch.Tensor:
+    """All SigLIP encoder layers of a bf16 inference forward in ONE call (aki_siglip_stack_fwd): h [N, L, E] -> h_out.  `fc1_out` [N*L, Ip]:
+    the K-padded fc1 output buffer whose pad columns are zero."""
+    dev = _dev(h, fc1_out)
+    N, Lq, E = h.shape
+    if h.dtype != torch.bfloat16 or not h.is_contiguous() or not fc1_out.is_contiguous():
+        raise AkiError("siglip_stack: contiguous bf16 tensors")
+    lib = L.load()
+    M, Ip = N * Lq, fc1_out.shape[-1]
+    out = torch.empty_like(h)
+    need = int(lib.aki_siglip_stack_workspace_bytes(N, Lq, E, heads))
+    ws = _scratch(need, dev)
+    off = (-ws.data_ptr()) % 256
+    sws = _stats_ws(M, E, dev)
+    sk = None
+    if M <= 2048:
+        for K_ in (E, Ip):                                # out-proj, fc2
+            sk = _splitk_ws(M, E, K_, dev) or sk
+    a = L.SiglipStackArgs(table_arr, n_layers, _ptr(h), _ptr(out), _ptr(fc1_out), N, Lq, E, heads, inter, Ip, act, float(eps), float(scale), ws.data_ptr() + off,
+                          ws.numel() - off, sws.data_ptr(), sws.numel(), None if sk is None else sk.data_ptr(), 0 if sk is None else sk.numel())
+    L.check(lib.aki_siglip_stack_fwd(C.byref(a), _stream()), "aki_siglip_stack_fwd")
     return out
 
 

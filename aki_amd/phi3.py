@@ -92,8 +92,8 @@ class AkiKVCache:
     and appended to by the decode kernels.  Lengths and positions live on the device so a decode step never syncs."""
 
     def __init__(self, n_layers, B, H, Dh, capacity, dtype, device):
-        self.k = [torch.empty((B, H, capacity, Dh), dtype=dtype, device=device) for _ in range(n_layers)]
-        self.v = [torch.empty((B, H, capacity, Dh), dtype=dtype, device=device) for _ in range(n_layers)]
+        kv = torch.empty((2, n_layers, B, H, capacity, Dh), dtype=dtype, device=device)      # one allocation, per-layer views
+        self.k, self.v = list(kv[0].unbind(0)), list(kv[1].unbind(0))
         self.capacity = capacity
         self.cache_len = torch.zeros((B,), dtype=torch.int32, device=device)   # tokens cached per sample
         self.valid_bits = None                                                  # uint64 words of the prompt's 1-D mask
@@ -395,9 +395,12 @@ class Phi3Model(nn.Module):
         if self.fold_norms and all(layer.folds(h) for layer in self.layers) and not _ag(h, self.norm.weight):
             # every RMSNorm of the stack rides on the GEMM before it (statistics) and after it (gain, scale): the only pass over
             # the residual stream that is not a GEMM is this one, for the embeddings no kernel of ours produced
-            st = ops.row_stats(h, self.norm.variance_epsilon)
-            for layer in self.layers:
-                h, st = layer(h, cos, sin, table, position_ids, cache, stats=st)     # through __call__: module hooks (weight gathering) run
+            if self._can_stack(h):
+                h, st = self._forward_stack(h, cos, sin, table, position_ids, cache)
+            else:
+                st = ops.row_stats(h, self.norm.variance_epsilon)
+                for layer in self.layers:
+                    h, st = layer(h, cos, sin, table, position_ids, cache, stats=st)     # through __call__: module hooks (weight gathering) run
             if self.defer_final_norm:
                 self.final_stats = st            # the head folds the final norm the same way
                 return h
@@ -407,6 +410,39 @@ class Phi3Model(nn.Module):
         if self.skip_final_norm:                 # the fp8 head fuses the final RMSNorm into its quantiser
             return h
         return self.norm(h)
+
+    use_layer_stack = True                          # the folded inference forward as ONE C call (csrc/stack.hip) instead of 4-5 Python-issued launches per layer
+
+    def _can_stack(self, h) -> bool:
+        """The layer loop may run inside the library when nothing in Python has to happen between layers: no module hooks (the sharded
+        trainer gathers weights there), no event tap on single launches, one epsilon for every norm, contiguous weights."""
+        if not (self.use_layer_stack and ops.stack_enabled() and h.is_cuda and h.is_contiguous() and h.dim() == 3):
+            return False
+        eps = self.norm.variance_epsilon
+        for ly in self.layers:
+            if ly._forward_hooks or ly._forward_pre_hooks or ly.input_layernorm.variance_epsilon != eps or ly.post_attention_layernorm.variance_epsilon != eps:
+                return False
+        return True
+
+    def _forward_stack(self, h, cos, sin, table, position_ids, cache):
+        """= the loop over Phi3DecoderLayer.forward_folded, issued by aki_decoder_stack_fwd: same launches, same arguments."""
+        rows = []
+        for ly in self.layers:
+            at, mlp, n1, n2 = ly.self_attn, ly.mlp, ly.input_layernorm, ly.post_attention_layernorm
+            wq = ly._prep.get("qkv", [at.qkv_proj.weight, n1.weight], lambda: ops.fold_gain(at.qkv_proj.weight, n1.weight), T._EPOCH)
+            wg = ly._prep.get("gate_up", [mlp.gate_up_proj.weight, n2.weight], lambda: ops.fold_gain(mlp.gate_up_proj.weight, n2.weight), T._EPOCH)
+            rows.append((wq, at.o_proj.weight, wg, mlp.down_proj.weight, None if cache is None else cache.k[at.layer_idx],
+                         None if cache is None else cache.v[at.layer_idx]))
+        for r in rows:
+            for t_ in r[:4]:
+                if not t_.is_contiguous():
+                    raise ops.AkiError("decoder stack: weights must be contiguous")
+        if getattr(self, "_stack_table", None) is None:
+            self._stack_table = ops.LayerTable(ops.L.DecoderLayer)
+        at0 = self.layers[0].self_attn
+        return ops.decoder_stack(self._stack_table.get(rows), len(rows), h, cos, sin, table, at0.num_heads, at0.head_dim,
+                                 self.layers[0].mlp.down_proj.weight.shape[1], at0.scaling, self.norm.variance_epsilon, position_ids,
+                                 0 if cache is None else cache.capacity)
 
     def decode(self, inputs_embeds, cache, advance: bool = True):
         """inputs_embeds [B, d]: the embeddings of the tokens appended at index cache.cache_len[b].  advance=False leaves cache_len to the
@@ -580,9 +616,12 @@ class Phi3ForCausalLM(nn.Module):
         return ops.linear(h, w, bias=b, row_scale=st.rstd)[..., :n]
 
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, labels=None, position_ids=None,
-                use_cache=False, past_key_values=None, cache_capacity=None, **kwargs):
+                use_cache=False, past_key_values=None, cache_capacity=None, last_token_logits=False, **kwargs):
         """Prefill / full forward.  With use_cache=True the returned past_key_values is an AkiKVCache holding the
-        rotated keys and the values of every layer (capacity = cache_capacity or L + 256)."""
+        rotated keys and the values of every layer (capacity = cache_capacity or L + 256).
+        last_token_logits=True (prefill of `generate`, which reads nothing else; HF's `logits_to_keep=1` for a right-padded batch): logits is
+        [B, 1, V'] - the head runs on each sample's last valid token only, a weight-streaming GEMV instead of an L-row GEMM against the
+        197 MB head."""
         if past_key_values is not None:
             return self._continue(input_ids, inputs_embeds, past_key_values, labels)
         if inputs_embeds is None:
@@ -615,9 +654,18 @@ class Phi3ForCausalLM(nn.Module):
             # weight (so the output carries no logits; train/losses.py:110-115 only reads [0] = loss)
             loss = T.fused_head_ce(h, self.lm_head, labels, chunk=getattr(self, "head_chunk_rows", 2688))
             return CausalLMOutputWithPast(loss=loss, logits=None, past_key_values=None)
-        logits = self._head(h) if head_stats is None else self._head_folded(h, head_stats)
+        counts = None if cache is None else table.token_counts(B, h.device)
+        if last_token_logits and cache is not None and labels is None and h.dtype == torch.bfloat16 and (head_stats is not None or fp8_head):
+            # h is the raw stream here (final norm deferred to the head): gather the B rows, then the decode step's head
+            rows = (counts.long() - 1).clamp_(min=0) + torch.arange(B, device=h.device) * L
+            logits = self._head_rows(h.reshape(B * L, -1).index_select(0, rows)).unsqueeze(1)
+            self._pre_norm_h = None
+        else:
+            logits = self._head(h) if head_stats is None else self._head_folded(h, head_stats)
+            if last_token_logits and cache is not None:
+                logits = logits[torch.arange(B, device=h.device), (counts.long() - 1).clamp_(min=0)].unsqueeze(1)
         if cache is not None:
-            cache.cache_len.copy_(table.token_counts(B, h.device))
+            cache.cache_len.copy_(counts)
             if table.col_valid_bits is not None:
                 # decode appends right after each sample's last valid token (overwriting stacking padding), so only holes INSIDE the prompt stay masked
                 nw = table.col_valid_bits.shape[1]
@@ -674,6 +722,11 @@ class Phi3ForCausalLM(nn.Module):
         if inputs_embeds is None:
             inputs_embeds = self.get_input_embeddings()(input_ids)
         h = self.model.decode(inputs_embeds.reshape(inputs_embeds.shape[0], -1), past_key_values, advance=advance)
+        return self._head_rows(h)
+
+    def _head_rows(self, h):
+        """lm_head(norm(h)) for a few rows of the RAW residual stream [B, d] (a decode step; the last prompt token of a prefill): the final
+        RMSNorm is applied inside the weight-streaming GEMV."""
         norm = self.model.norm
         if getattr(self, "_fp8_head", None) is not None and h.shape[0] == 1:
             wq, ws, b, n = self._fp8_head

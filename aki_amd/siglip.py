@@ -126,6 +126,16 @@ class SiglipAttention(nn.Module):
 _HBUF = {}      # (leading shape, padded width, dtype, device, stream) -> K-padded fc1 output buffer shared by all layers
 
 
+def _fc1_buffer(lead, Kp, x):
+    key = (tuple(lead), Kp, x.dtype, x.device, torch.cuda.current_stream().cuda_stream)
+    hbuf = _HBUF.get(key)
+    if hbuf is None:
+        if len(_HBUF) > 8:
+            _HBUF.clear()
+        hbuf = _HBUF[key] = torch.zeros((*lead, Kp), dtype=x.dtype, device=x.device)
+    return hbuf
+
+
 class SiglipMLP(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -144,12 +154,7 @@ class SiglipMLP(nn.Module):
         # fc1 writes into a K-padded buffer; the pad columns must be finite zeros for fc2 (zero weights there).  The buffer
         # is kept per shape: fc1 overwrites columns [:inter] every call and nothing ever writes the pad columns, so they are
         # zeroed once instead of a 40 MB fill per layer and step (stream-ordered reuse: the next fc1 runs after this fc2).
-        key = (tuple(lead), Kp, x.dtype, x.device, torch.cuda.current_stream().cuda_stream)
-        hbuf = _HBUF.get(key)
-        if hbuf is None:
-            if len(_HBUF) > 8:
-                _HBUF.clear()
-            hbuf = _HBUF[key] = torch.zeros((*lead, Kp), dtype=x.dtype, device=x.device)
+        hbuf = _fc1_buffer(lead, Kp, x)
         if st is None:
             ops.linear(x, self.fc1.weight, bias=self.fc1.bias, act=self.act, out=hbuf[..., :inter])
         else:
@@ -195,6 +200,8 @@ class SiglipEncoder(nn.Module):
     def forward(self, h):
         if self.fold_norms and h.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (
                 h.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            if self._can_stack(h):
+                return self._forward_stack(h)
             st = ops.row_stats(h, self.layers[0].layer_norm1.eps, ln=True)      # the embeddings' statistics: the one extra pass
             for i, layer in enumerate(self.layers):
                 h, st = layer(h, stats=st, want_stats=i + 1 < len(self.layers))
@@ -202,6 +209,49 @@ class SiglipEncoder(nn.Module):
         for layer in self.layers:
             h = layer(h)
         return h
+
+
+def _siglip_can_stack(self, h) -> bool:
+    if not (self.use_layer_stack and ops.stack_enabled() and h.is_cuda and h.dim() == 3 and h.is_contiguous()):
+        return False
+    l0 = self.layers[0]
+    for ly in self.layers:
+        if (ly._forward_hooks or ly._forward_pre_hooks or ly.layer_norm1.eps != l0.layer_norm1.eps or ly.layer_norm2.eps != l0.layer_norm1.eps
+                or ly.mlp.act != l0.mlp.act or ly.mlp.fc1.bias is None or ly.self_attn.q_proj.bias is None):
+            return False
+    return True
+
+
+def _siglip_forward_stack(self, h):
+    """= the loop over SiglipEncoderLayer.forward_folded, issued by aki_siglip_stack_fwd: same launches, same arguments."""
+    rows = []
+    for ly in self.layers:
+        at, mlp = ly.self_attn, ly.mlp
+        ps = [at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, at.q_proj.bias, at.k_proj.bias, at.v_proj.bias, ly.layer_norm1.weight, ly.layer_norm1.bias]
+        wqkv, bqkv, cqkv = at._prep.get("qkv_ln", ps, lambda: fold_layernorm(torch.cat([p.detach() for p in ps[:3]], 0),
+                                                                              torch.cat([p.detach() for p in ps[3:6]], 0), ly.layer_norm1), _epoch(ps))
+        ln2 = ly.layer_norm2
+        w1, b1, c1 = mlp._prep.get("fc1_ln", [mlp.fc1.weight, mlp.fc1.bias, ln2.weight, ln2.bias],
+                                   lambda: fold_layernorm(mlp.fc1.weight.detach(), mlp.fc1.bias.detach(), ln2),
+                                   _epoch([mlp.fc1.weight, mlp.fc1.bias, ln2.weight, ln2.bias]))
+        w2 = mlp._prep.get("w2", [mlp.fc2.weight], lambda: ops.pad_k(mlp.fc2.weight.detach()), _epoch([mlp.fc2.weight]))
+        rows.append((wqkv, bqkv, cqkv, at.out_proj.weight, at.out_proj.bias, w1, b1, c1, w2, mlp.fc2.bias))
+    for r in rows:
+        for t_ in r:
+            if t_ is not None and not t_.is_contiguous():
+                raise ops.AkiError("siglip stack: weights must be contiguous")
+    l0 = self.layers[0]
+    inter = l0.mlp.fc1.weight.shape[0]
+    hbuf = _fc1_buffer(h.shape[:-1], (inter + 63) // 64 * 64, h)
+    if getattr(self, "_stack_table", None) is None:
+        self._stack_table = ops.LayerTable(ops.L.SiglipLayer)
+    return ops.siglip_stack(self._stack_table.get(rows), len(rows), h, hbuf, l0.self_attn.num_heads, inter, l0.mlp.act, l0.layer_norm1.eps,
+                            l0.self_attn.scale)
+
+
+SiglipEncoder.use_layer_stack = True       # the folded inference forward as ONE C call (csrc/stack.hip) instead of 5 Python-issued launches per layer
+SiglipEncoder._can_stack = _siglip_can_stack
+SiglipEncoder._forward_stack = _siglip_forward_stack
 
 
 class SiglipVisionTransformer(nn.Module):

@@ -238,10 +238,18 @@ typedef struct {
   float stats_eps;
   void* stats_workspace;
   size_t stats_workspace_bytes;
+  /* Split-K workspace (optional; bf16, act NONE).  Launches with few rows (a one-sample prefill: M = 655 / 207 against N = 3072) have
+   * too few output tiles to fill the chip; given this buffer the library may split the K range of a tile over several workgroups
+   * whose f32 partial sums meet here and are added in a FIXED order by the last one to arrive (bit-reproducible).  256-byte aligned,
+   * aki_linear_splitk_workspace_bytes(M, N, K) bytes or more (0: this shape is never split), ZERO-FILLED ONCE by the caller (tickets
+   * at its front, put back to zero by every launch; launches sharing it must be stream-ordered).  NULL / too small: no split. */
+  void* splitk_workspace;
+  size_t splitk_workspace_bytes;
 } aki_linear_args;
 
 int aki_linear_fwd(const aki_linear_args* args, void* stream);
 size_t aki_linear_stats_workspace_bytes(int32_t M, int32_t N_out);
+size_t aki_linear_splitk_workspace_bytes(int32_t M, int32_t N, int32_t K);
 size_t aki_linear_stats_counter_bytes(int32_t M);
 /* aki_row_stats - the same statistics for a tensor no GEMM of this library produced (the first block's input): rstd[m] (and,
  * when mean != NULL, mean[m]) of x [rows, cols] bf16. */
@@ -548,6 +556,97 @@ int aki_sft_collate_pad(const int64_t* ids, const int64_t* labels, const int64_t
 int aki_greedy_pick(const void* logits, int32_t B, int32_t V, int64_t ld, const int64_t* eos_ids, int32_t n_eos, int64_t pad_token_id,
                     uint8_t* done, int64_t* next_ids, int64_t* tokens, int32_t tokens_ld, int32_t* cache_len, const int32_t* start_len,
                     int32_t advance, int32_t* done_at, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layer loops issued from ONE call (host code; csrc/stack.hip).  A one-sample prefill - the shape the reference's callers run
+ * (local_demo.py:75-87, eval_cv_bench/eval.py:92-104) - is ~400 launches of 10-70 us: issued one by one from Python the HOST was 9 ms
+ * of a 15 ms first token.  These two functions issue, on `stream`, exactly the launches of the per-layer entry points above, in
+ * the order of HF:phi3/modeling_phi3.py `Phi3Model.forward` (:287-328 per layer) and HF:siglip/modeling_siglip.py:329-354 -
+ * bf16 inference with the normalisations folded into the GEMMs (aki_linear_args: row_scale / row_shift / stats_*).
+ *
+ * aki_decoder_stack_fwd: per layer  q,k,v = RoPE(rstd (h W_qkv'^T)) -> span attention -> h1 = h + o W_o^T -> act = SwiGLU(rstd1 (h1 W_gu'^T))
+ * -> h2 = h1 + act W_down^T, every h-writing GEMM leaving 1/rms of its rows for the next one.  W' = W diag(RMSNorm gain), prepared by the
+ * caller.  k_cache / v_cache ([B,H,kv_capacity,Dh], all layers or none): rotated keys and values are written there (KV-cache prefill).
+ *   h_in, h_out [B*L, d] bf16 (may not alias); rstd_out [B*L] f32 or NULL: 1/rms(h_out) for the final norm folded into the head;
+ *   workspace: aki_decoder_stack_workspace_bytes() bytes, 256-byte aligned, scratch; stats_workspace / splitk_workspace as in
+ *   aki_linear_args (zero-filled once by the caller; splitk optional).  `layers` is a HOST array. */
+typedef struct {
+  const void* w_qkv;     /* [3*H*Dh, d] */
+  const void* w_o;       /* [d, H*Dh] */
+  const void* w_gate_up; /* [2F, d] */
+  const void* w_down;    /* [d, F] */
+  void* k_cache;
+  void* v_cache;
+} aki_decoder_layer;
+
+typedef struct {
+  const aki_decoder_layer* layers;
+  int32_t n_layers;
+  const void* h_in;
+  void* h_out;
+  float* rstd_out;
+  const float* cos;
+  const float* sin;
+  const int32_t* position_ids;
+  int32_t pos_rows;
+  const aki_mma_rect* rects;
+  const uint64_t* col_valid_bits;
+  const int32_t* seq_lens;
+  int32_t max_rects;
+  int32_t B, H, L, Dh, d, F;
+  int32_t kv_capacity;   /* rows per (batch, head) of the caches; 0 with no caches */
+  float scale;
+  float rms_eps;
+  int32_t dead_rows;
+  void* workspace;
+  size_t workspace_bytes;
+  void* stats_workspace;
+  size_t stats_workspace_bytes;
+  void* splitk_workspace;
+  size_t splitk_workspace_bytes;
+} aki_decoder_stack_args;
+
+size_t aki_decoder_stack_workspace_bytes(int32_t B, int32_t H, int32_t L, int32_t Dh, int32_t d, int32_t F, int32_t keep_kv);
+int aki_decoder_stack_fwd(const aki_decoder_stack_args* args, void* stream);
+
+/* aki_siglip_stack_fwd: per layer  qkv = LN1(h) W_qkv^T + b (folded: rstd (h W'^T - mean c) + b') -> 16-head attention read in place out
+ * of qkv -> h1 = h + out_proj -> fc1 + GELU with LN2 folded, into fc1_out -> h2 = h1 + fc2.  W', b', c = fold of the LayerNorm gain /
+ * bias into the weight (see aki_linear_args), prepared by the caller; w_fc2 is K-padded to Ip (a multiple of 64) with zero columns.
+ *   h_in, h_out [N*L, E] bf16; fc1_out [N*L, Ip] bf16, caller-owned, its pad columns [I, Ip) ZERO (nothing here writes them);
+ *   workspace: aki_siglip_stack_workspace_bytes() bytes, 256-byte aligned, scratch.  `layers` is a HOST array. */
+typedef struct {
+  const void* w_qkv;  /* [3E, E] */
+  const void* b_qkv;  /* [3E] */
+  const float* c_qkv; /* [3E] f32 */
+  const void* w_out;  /* [E, E] */
+  const void* b_out;  /* [E] or NULL */
+  const void* w_fc1;  /* [I, E] */
+  const void* b_fc1;  /* [I] */
+  const float* c_fc1; /* [roundup(I, 4)] f32 */
+  const void* w_fc2;  /* [E, Ip] */
+  const void* b_fc2;  /* [E] or NULL */
+} aki_siglip_layer;
+
+typedef struct {
+  const aki_siglip_layer* layers;
+  int32_t n_layers;
+  const void* h_in;
+  void* h_out;
+  void* fc1_out;
+  int32_t N, L, E, heads, I, Ip;
+  int32_t act;       /* AKI_ACT_GELU_TANH (SigLIP) or AKI_ACT_GELU_ERF */
+  float ln_eps;
+  float scale;       /* softmax scale, (E / heads)^-0.5 as the caller's module computed it */
+  void* workspace;
+  size_t workspace_bytes;
+  void* stats_workspace;
+  size_t stats_workspace_bytes;
+  void* splitk_workspace;
+  size_t splitk_workspace_bytes;
+} aki_siglip_stack_args;
+
+size_t aki_siglip_stack_workspace_bytes(int32_t N, int32_t L, int32_t E, int32_t heads);
+int aki_siglip_stack_fwd(const aki_siglip_stack_args* args, void* stream);
 
 /* aki_greedy_pick_embed - aki_greedy_pick + the embedding lookup of the token it picked (`DecoupledEmbedding.forward`,
  * src/helpers.py:440-492, which HF's generate loop runs at the top of the next step): next_embeds[b, :] = bf16 row `next` of embed_weight

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/aki_mi355x.h but not exported"
-    assert lib.aki_abi_version() == 14
+    assert lib.aki_abi_version() == 15
     exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "debug" not in exported and "aki_lab_" not in exported, "lab / debug hooks must not ship in the product library"
     assert b"aligned" in lib.aki_strerror(-3)
@@ -42,7 +42,9 @@ def test_library_exports_every_declared_symbol(lib):
 
 STRUCTS = {"aki_mma_rect": "MmaRect", "aki_mma_attn_core_args": "MmaAttnCoreArgs", "aki_mma_attn_args": "MmaAttnArgs",
            "aki_attn_args": "AttnArgs", "aki_linear_args": "LinearArgs", "aki_splice_args": "SpliceArgs",
-           "aki_attn_bwd_args": "AttnBwdArgs", "aki_decode_chain_layer": "DecodeChainLayer", "aki_decode_chain_args": "DecodeChainArgs"}
+           "aki_attn_bwd_args": "AttnBwdArgs", "aki_decode_chain_layer": "DecodeChainLayer", "aki_decode_chain_args": "DecodeChainArgs",
+           "aki_decoder_layer": "DecoderLayer", "aki_decoder_stack_args": "DecoderStackArgs", "aki_siglip_layer": "SiglipLayer",
+           "aki_siglip_stack_args": "SiglipStackArgs"}
 
 
 def header_structs():

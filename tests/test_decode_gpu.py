@@ -719,7 +719,7 @@ def test_forward_from_past_key_values_recovers_from_a_decode_chain_give_up():
     lm, cfg = _full_width_lm(2, seed=7)
     g = torch.Generator().manual_seed(2)
     x = (torch.randn(1, 70, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
-    new = torch.randint(3, 32000, (1, 6), generator=g).to(DEV)
+    new = torch.randint(3, cfg.vocab_size, (1, 6), generator=g).to(DEV)
     table = ops.MaskTable.causal(1, 70, DEV)
     outs = {}
     with _lib.use_lab(0) as lab, torch.no_grad():

@@ -1,0 +1,92 @@
+"""The layer loops issued from one C call (csrc/stack.hip: aki_decoder_stack_fwd, aki_siglip_stack_fwd) against the per-layer Python loops
+they replace (phi3.py / siglip.py forward_folded): the same launches with the same arguments, so every output is compared BIT FOR BIT -
+hidden states, the folded final statistics' effect on the logits, and the KV cache a prefill leaves behind."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _lm(n_layers, seed, **kw):
+    from aki_amd.phi3 import Phi3ForCausalLM, make_phi3_config
+    torch.manual_seed(seed)
+    cfg = make_phi3_config(num_hidden_layers=n_layers, vocab_size=2048, pad_token_id=0, eos_token_id=2, **kw)
+    lm = Phi3ForCausalLM(cfg)
+    g = torch.Generator().manual_seed(seed)
+    for n, p in lm.named_parameters():
+        p.data.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g) if p.dim() == 1 else torch.randn(p.shape, generator=g) * 0.02)
+    return lm.to(DEV).to(torch.bfloat16).eval(), cfg
+
+
+@pytest.mark.parametrize("B,L,width", [(1, 655, "full"), (1, 207, "full"), (2, 150, "small"), (3, 64, "small")])
+@pytest.mark.parametrize("use_cache", [False, True])
+def test_decoder_stack_equals_the_per_layer_loop(B, L, width, use_cache):
+    from aki_amd import ops
+    kw = {} if width == "full" else dict(hidden_size=384, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=4)
+    lm, cfg = _lm(3, seed=11, **kw)
+    g = torch.Generator().manual_seed(L)
+    x = (torch.randn(B, L, cfg.hidden_size, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    lens = [L - 7 * b for b in range(B)]
+    mask = np.zeros((B, L), dtype=bool)
+    for b in range(B):
+        mask[b, : lens[b]] = True
+    rects = [[(3, min(40, lens[b] // 2), min(40, lens[b] // 2), lens[b] - 5)] for b in range(B)]
+    table = ops.MaskTable.from_host(rects, mask, lens, DEV)
+    out = {}
+    for stack in (True, False):
+        lm.model.use_layer_stack = stack
+        with torch.no_grad():
+            o = lm(inputs_embeds=x, attention_mask=table, use_cache=use_cache, cache_capacity=L + 9)
+        out[stack] = (o.logits.clone(), o.past_key_values)
+    lm.model.use_layer_stack = True
+    assert torch.equal(out[True][0], out[False][0]), "logits differ between the one-call layer loop and the per-layer launches"
+    if use_cache:
+        ca, cb = out[True][1], out[False][1]
+        assert torch.equal(ca.cache_len, cb.cache_len)
+        for i in range(len(ca.k)):
+            assert torch.equal(ca.k[i][:, :, :L], cb.k[i][:, :, :L]) and torch.equal(ca.v[i][:, :, :L], cb.v[i][:, :, :L]), f"KV cache of layer {i}"
+
+
+def test_decoder_stack_is_skipped_when_python_must_run_between_layers():
+    """Module hooks on a layer (the sharded trainer gathers weights there) and an installed event tap switch the one-call loop off."""
+    from aki_amd import ops
+    lm, cfg = _lm(2, seed=5, hidden_size=384, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=4)
+    x = torch.zeros(1, 64, 384, dtype=torch.bfloat16, device=DEV)
+    assert lm.model._can_stack(x)
+    h = lm.model.layers[1].register_forward_pre_hook(lambda m, a: None)
+    assert not lm.model._can_stack(x)
+    h.remove()
+    ops.set_event_tap(ops.EventTap(tags=("linear",)))
+    try:
+        assert not lm.model._can_stack(x)
+    finally:
+        ops.set_event_tap(None)
+    assert lm.model._can_stack(x)
+
+
+@pytest.mark.parametrize("N,size,width", [(1, 336, "full"), (2, 224, "small"), (3, 56, "small")])
+def test_siglip_stack_equals_the_per_layer_loop(N, size, width):
+    from aki_amd.siglip import SiglipVisionTransformer, make_siglip_config
+    kw = dict(num_hidden_layers=3, image_size=size)
+    if width == "small":
+        kw.update(hidden_size=576, intermediate_size=1000, num_attention_heads=8)
+    torch.manual_seed(3)
+    vt = SiglipVisionTransformer(make_siglip_config(**kw))
+    g = torch.Generator().manual_seed(7)
+    for n, p in vt.named_parameters():
+        if "layer_norm" in n or "layernorm" in n:
+            p.data.copy_((1.0 if n.endswith("weight") else 0.0) + 0.2 * torch.randn(p.shape, generator=g))
+        elif p.dim() == 1:
+            p.data.copy_(0.1 * torch.randn(p.shape, generator=g))
+    vt = vt.to(DEV).to(torch.bfloat16).eval()
+    px = ((torch.rand((N, 3, size, size), generator=g) - 0.5) / 0.5).to(DEV, torch.bfloat16)
+    out = {}
+    for stack in (True, False):
+        vt.encoder.use_layer_stack = stack
+        with torch.no_grad():
+            out[stack] = vt(px).last_hidden_state.clone()
+    vt.encoder.use_layer_stack = True
+    assert torch.isfinite(out[True].float()).all()
+    assert torch.equal(out[True], out[False]), "SigLIP tower differs between the one-call layer loop and the per-layer launches"
