@@ -23,7 +23,7 @@ LIB = os.path.join(LIBDIR, "libaki_mi355x.so")
 # product library must not carry).  Used by the forced-tile GEMM tests and tools/siglip_gemm_bench.py only.
 LAB_LIB = os.path.join(LIBDIR, "libaki_mi355x_lab.so")
 LAB_SOURCES = ["api.hip", "gemm_bf16.hip", "gemm_tn_bf16.hip", "mma_attn_bf16.hip", "decode_chain.hip"]
-LAB_ONLY_SOURCES = ["mma_attn64_bf16.hip"]     # experiments that exist in the lab library only
+LAB_ONLY_SOURCES = []     # experiments that exist in the lab library only (none at present)
 SOURCES = ["api.hip", "gemm_bf16.hip", "gemm_tn_bf16.hip", "mma_attn_bf16.hip", "attn_nc_bf16.hip", "decode.hip", "decode_chain.hip", "train_kernels.hip", "attn_bwd_bf16.hip", "fp8_quant.hip", "simple_f32.hip", "aux_kernels.hip", "stack.hip"]
 ARCH = "gfx950"
 

@@ -346,7 +346,14 @@ __global__ __launch_bounds__(256) void mask_rows_scan_kernel(const int64_t* mask
   if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_any[wave] = any; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); any |= s_any[w]; }
+    int plo[3], phi[3], pany[3];                            // the other waves' partials into registers, ONE full wait, then the fold
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { plo[w - 1] = s_lo[w]; phi[w - 1] = s_hi[w]; pany[w - 1] = s_any[w]; }
+    lds_reads_landed();
+#pragma unroll
+    for (int w = 0; w < 3; ++w) asm volatile("" : "+v"(plo[w]), "+v"(phi[w]), "+v"(pany[w]));
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { lo = min(lo, plo[w]); hi = max(hi, phi[w]); any |= pany[w]; }
     if (hi == 0) lo = 0;
     rowinfo[(size_t)b * L + r] = make_int4(lo, hi, any, 0);
   }

@@ -714,11 +714,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
 }
 
 #ifdef AKI_LAB_HOOKS
-// Lab library only: the experimental 64-rows-per-wave core (mma_attn64_bf16.hip, one wave per SIMD) can be switched in for
-// an A/B in one process (tools/attn_ab.py).  It is not part of the product library: as compiled by hipcc it is 1.7x SLOWER
-// than this kernel ("64-row attention core").
-int attn_core64_bf16(const aki_mma_attn_core_args* a, hipStream_t stream);
-int g_attn_variant = 0;   // 0 / 1 = this kernel, 2 = the 64-row kernel, 3 = this kernel with the software-pipelined tile loop (lab: 6-9 % slower), 4 = 8-wave ping-pong on the software-pipelined loop, 5 = DMA behind the score MFMAs, 6 / 7 = one / three workgroups per pair, 8 = LDS arrival counters instead of the tile barrier
+// Lab library only: structures of this core switched in for an A/B in one process (tools/attn_ab.py).  (Variant 2 was the 64-rows-per-wave core,
+// one wave per SIMD - as compiled by hipcc 1.7x SLOWER than this kernel; its source left the tree in round 5, EXPERIMENTS.md keeps the numbers.)
+int g_attn_variant = 0;   // 0 / 1 / 2 = this kernel, 3 = this kernel with the software-pipelined tile loop (lab: 6-9 % slower), 4 = 8-wave ping-pong on the software-pipelined loop, 5 = DMA behind the score MFMAs, 6 / 7 = one / three workgroups per pair, 8 = LDS arrival counters instead of the tile barrier
 #endif
 
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -727,9 +725,6 @@ int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, h
   if ((a->L + 63) / 64 > MAX_VB_WORDS) return AKI_ERR_UNSUPPORTED;
   AKI_CHECK_ALIGN16(a->q); AKI_CHECK_ALIGN16(a->k); AKI_CHECK_ALIGN16(a->v); AKI_CHECK_ALIGN16(a->o);
   (void)ws; (void)ws_bytes;  // the bf16 path needs no scratch (kept in the signature for the f32 path)
-#ifdef AKI_LAB_HOOKS
-  if (g_attn_variant == 2) return attn_core64_bf16(a, stream);
-#endif
   constexpr int NW = 4;
   AttnParams p = {};
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.o = (bf16_t*)a->o; p.lse = a->lse;

@@ -168,8 +168,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32Params p) {
     for (int cc = 0; cc < cend; ++cc) {
       const int c = c0 + cc;
       float part = 0.f;
+      float kv[DPT];                                       // LDS reads into registers, ONE full wait, then the arithmetic (aki_device.h: lds_fold_ready)
 #pragma unroll
-      for (int i = 0; i < DPT; ++i) part = __builtin_fmaf(qr[i], sk[cc][sub * DPT + i], part);
+      for (int i = 0; i < DPT; ++i) kv[i] = sk[cc][sub * DPT + i];
+      lds_fold_ready(kv);
+#pragma unroll
+      for (int i = 0; i < DPT; ++i) part = __builtin_fmaf(qr[i], kv[i], part);
       part += __shfl_xor(part, 1);
       part += __shfl_xor(part, 2);
       bool vis = (!p.causal) | (c <= row) | ((c >= rc0) & (c < rc1));
@@ -181,8 +185,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32Params p) {
         const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 on the first visible key
         const float pr = expf(s - m_new);
         l_run = l_run * alpha + pr;
+        float vv[DPT];
 #pragma unroll
-        for (int i = 0; i < DPT; ++i) acc[i] = __builtin_fmaf(pr, sv[cc][sub * DPT + i], acc[i] * alpha);
+        for (int i = 0; i < DPT; ++i) vv[i] = sv[cc][sub * DPT + i];
+        lds_fold_ready(vv);
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) acc[i] = __builtin_fmaf(pr, vv[i], acc[i] * alpha);
         m_run = m_new;
       }
     }

@@ -28,7 +28,7 @@ def _infer_decoder_layers_attr_name(model):
 
 def build_aki(lm_config=None, vis_config=None, initial_tokenizer_len: int = 32011, pad_token_id: int = 32000,
               num_vision_tokens: int = 144, dtype=torch.bfloat16, device="cuda", init_std: Optional[float] = None,
-              seed: int = 0, media_token_id: Optional[int] = None):
+              seed: int = 0, media_token_id: Optional[int] = None, gradient_checkpointing: bool = False):
     """Random-init AKI of a given shape (defaults = AKI-4B: Phi-3.5-mini + SigLIP-so400m/14-384 + 144 latents).
     Weights ~ N(0, initializer_range) with unit norm gains, generated directly on the device."""
     lm_config = lm_config or make_phi3_config()
@@ -40,7 +40,8 @@ def build_aki(lm_config=None, vis_config=None, initial_tokenizer_len: int = 3201
     vt = vt.to_empty(device=device).to(dtype)
     model = AKI(vision_encoder=vt, lang_model=lm, vis_feature_dim=vis_config.hidden_size,
                 initial_tokenizer_len=initial_tokenizer_len, pad_token_id=pad_token_id,
-                decoder_layers_attr_name="model.layers", num_vision_tokens=num_vision_tokens)
+                decoder_layers_attr_name="model.layers", num_vision_tokens=num_vision_tokens,
+                gradient_checkpointing=gradient_checkpointing)
     model = model.to(device=device, dtype=dtype)
     std = init_std if init_std is not None else getattr(lm_config, "initializer_range", 0.02)
     g = torch.Generator(device=device).manual_seed(seed)

@@ -665,7 +665,8 @@ def decoder_stack(table_arr, n_layers: int, h: torch.Tensor, cos: torch.Tensor, 
     sk = None
     if M <= 2048:
         for K_ in (num_heads * head_dim, inter):          # o_proj, down: one buffer (it only ever grows) serves both
-            sk = _splitk_ws(M, d, K_, dev) or sk
+            got = _splitk_ws(M, d, K_, dev)
+            sk = sk if got is None else got
     a = L.DecoderStackArgs(table_arr, n_layers, _ptr(h), _ptr(out), _ptr(rstd), _ptr(cos), _ptr(sin), _ptr(pos), cos.shape[0], _ptr(mask.rects),
                            _ptr(mask.col_valid_bits), _ptr(mask.seq_lens), mask.max_rects, B, num_heads, Lq, head_dim, d, inter,
                            int(kv_capacity), float(scale), float(eps), dead_rows, ws.data_ptr() + off, ws.numel() - off, sws.data_ptr(), sws.numel(),
@@ -692,7 +693,8 @@ def siglip_stack(table_arr, n_layers: int, h: torch.Tensor, fc1_out: torch.Tenso
     sk = None
     if M <= 2048:
         for K_ in (E, Ip):                                # out-proj, fc2
-            sk = _splitk_ws(M, E, K_, dev) or sk
+            got = _splitk_ws(M, E, K_, dev)
+            sk = sk if got is None else got
     a = L.SiglipStackArgs(table_arr, n_layers, _ptr(h), _ptr(out), _ptr(fc1_out), N, Lq, E, heads, inter, Ip, act, float(eps), float(scale), ws.data_ptr() + off,
                           ws.numel() - off, sws.data_ptr(), sws.numel(), None if sk is None else sk.data_ptr(), 0 if sk is None else sk.numel())
     L.check(lib.aki_siglip_stack_fwd(C.byref(a), _stream()), "aki_siglip_stack_fwd")

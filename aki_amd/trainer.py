@@ -42,6 +42,8 @@ class AkiTrainer:
         input-gradient GEMMs, into a buffer this trainer owns - instead of one aki_transpose launch per weight after every optimizer step
         (a read and a write of all 7.8 GB of bf16 weights: 3 ms of the 150 ms step).  Same arithmetic: weights bit-identical either way."""
         self.model = model
+        if getattr(model, "_gradient_checkpointing", False) and hasattr(model, "init_gradient_checkpointing"):
+            model.init_gradient_checkpointing()  # what the reference's driver does after wrapping the model (train/train.py:315-327)
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
         self.gacc = None                         # fp32 gradient accumulator (gradient accumulation windows only)

@@ -23,6 +23,22 @@ from .utils import getattr_recursive, num_params
 ASSISTANT_TOKEN_ID = 32001  # hard-coded by the reference, src/vlm.py:490-496
 
 
+def _activate_checkpointing(module: nn.Module) -> None:
+    """Route `module.forward` through torch.utils.checkpoint while gradients are being recorded (inference and no-grad calls go straight
+    through, as do calls with a KV cache - a prefill keeps nothing for backward anyway)."""
+    import torch.utils.checkpoint as ckpt
+    inner = module.forward
+
+    def forward(*args, **kwargs):
+        if torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in args) or (
+                torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())):
+            return ckpt.checkpoint(inner, *args, use_reentrant=False, **kwargs)
+        return inner(*args, **kwargs)
+
+    module.forward = forward
+    module._ckpt_active = True
+
+
 class VLM(nn.Module):
     """Vision tower + vision tokenizer + language model under the attribute names checkpoints and the training scripts rely
     on (`vision_encoder`, `vision_tokenizer`, `lang_model`; src/vlm.py:26-103).  Construction swaps the language model's
@@ -45,9 +61,24 @@ class VLM(nn.Module):
         self.pad_token_id = pad_token_id
         self.initial_tokenizer_len = initial_tokenizer_len
         self._decouple_token_tables(n_new=len(self.special_tokens), std=getattr(cfg, "initializer_range", 0.02))
-        # accepted for signature compatibility; the HIP autograd path keeps its activations (82 GB of 288 GB at the
-        # benchmark batch) and has no recompute mode
+        # As in the reference (src/vlm.py:63, :124-127) the flag only MARKS modules; `init_gradient_checkpointing()` (below; the reference's
+        # driver calls its twin at train/train.py:315-327, AkiTrainer calls this one) switches recomputation on for the marked ones.
+        self._gradient_checkpointing = bool(gradient_checkpointing)
         self.vision_tokenizer._use_gradient_checkpointing = gradient_checkpointing
+
+    def init_gradient_checkpointing(self):
+        """Activation checkpointing for every module marked `_use_gradient_checkpointing` (src/vlm.py:360-378: non-reentrant
+        `checkpoint_wrapper` around the decoder blocks and the vision tokenizer).  Same effect here without wrapper modules - parameter
+        names and state-dict keys stay as they are: a marked module's training forward runs under `torch.utils.checkpoint` (non-reentrant),
+        so only its input is kept and its HIP forward kernels run again inside backward.  The kernels are deterministic (no float atomics), so
+        the recomputed activations - and therefore the gradients - are bit-identical to a run without checkpointing
+        (tests/test_train_gpu.py::test_gradient_checkpointing_recomputes_and_changes_nothing)."""
+        n = 0
+        for m in self.modules():
+            if getattr(m, "_use_gradient_checkpointing", False) and not getattr(m, "_ckpt_active", False):
+                _activate_checkpointing(m)
+                n += 1
+        return n
 
     def _decouple_token_tables(self, n_new: int, std: float) -> None:
         """Input embedding -> DecoupledEmbedding, output head -> DecoupledLinear; the original rows are shared with the

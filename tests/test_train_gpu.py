@@ -709,3 +709,51 @@ def test_adamw_emits_the_transposed_weights_and_changes_nothing_else():
         res[emit] = (losses, norms, torch.cat([p.detach().float().reshape(-1).cpu() for p in tr.params]))
     assert res[False][0] == res[True][0] and res[False][1] == res[True][1]
     assert torch.equal(res[False][2], res[True][2])
+
+
+def test_gradient_checkpointing_recomputes_and_changes_nothing():
+    """VERDICT r4: `gradient_checkpointing=True` used to be accepted and ignored.  Now `init_gradient_checkpointing()` (src/vlm.py:360-378;
+    called by the reference's driver at train/train.py:315-327 and by AkiTrainer) makes every marked module - the decoder blocks and the
+    vision tokenizer - run its training forward under non-reentrant torch.utils.checkpoint.  The HIP kernels are deterministic, so loss and
+    every gradient are BIT-identical with and without recomputation, the state-dict keys do not change, and the activations kept between
+    forward and backward shrink (a wider, deeper decoder than the tiny model so that the difference is measurable)."""
+    from aki_amd.factory import build_aki
+    from aki_amd.phi3 import make_phi3_config
+    from aki_amd.siglip import make_siglip_config
+    lm_cfg = dict(vocab_size=2048, hidden_size=768, intermediate_size=2048, num_hidden_layers=6, num_attention_heads=8, num_key_value_heads=8)
+    vis_cfg = dict(hidden_size=576, intermediate_size=1000, num_hidden_layers=1, num_attention_heads=8, image_size=56)
+    res, keys = {}, {}
+    for ckpt in (False, True):
+        m = build_aki(lm_config=make_phi3_config(**lm_cfg), vis_config=make_siglip_config(**vis_cfg), dtype=BF, device=DEV, seed=4,
+                      gradient_checkpointing=ckpt)
+        m.train()
+        m.set_trainable()
+        if ckpt:
+            assert m.init_gradient_checkpointing() == 7          # six decoder blocks + the vision tokenizer
+            assert m.init_gradient_checkpointing() == 0          # idempotent
+        keys[ckpt] = sorted(m.state_dict().keys())
+        g = torch.Generator().manual_seed(9)
+        B, T = 4, 200
+        lx = torch.randint(3, 2000, (B, T), generator=g)
+        lx[:, 0], lx[:, 5] = 1, m.media_token_id
+        vx = ((torch.rand((B, 1, 1, 3, 56, 56), generator=g) - 0.5) / 0.5).to(DEV, BF)
+        lx, am = lx.to(DEV), torch.ones(B, T, dtype=torch.long, device=DEV)
+        lab = lx.clone()
+        lab[:, :8] = -100
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = m(vx, lx, attention_mask=am, labels=lab)
+        torch.cuda.synchronize()
+        held = torch.cuda.memory_allocated() - base              # what the graph keeps alive between forward and backward
+        out.loss.backward()
+        torch.cuda.synchronize()
+        res[ckpt] = (float(out.loss), held, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        del m, out
+        torch.cuda.empty_cache()
+    assert keys[True] == keys[False]
+    assert res[True][0] == res[False][0], "loss differs under recomputation"
+    assert set(res[True][2]) == set(res[False][2]) and len(res[True][2]) > 40
+    for n, gr in res[False][2].items():
+        assert torch.equal(gr, res[True][2][n]), f"{n}: gradient differs under recomputation"
+    assert res[True][1] < 0.6 * res[False][1], f"activations held: {res[True][1] / 2**20:.1f} MiB with checkpointing vs {res[False][1] / 2**20:.1f} MiB"
