@@ -56,10 +56,7 @@ __device__ __forceinline__ float cdot16_w8(const u32x4 w, const u32x4 x0, const 
   const chain_bf16x8_t xa = __builtin_bit_cast(chain_bf16x8_t, x0), xb = __builtin_bit_cast(chain_bf16x8_t, x1);
 #define AKI_CW8_PAIR(word, hi, xv, i0)                                                                              \
   {                                                                                                                 \
-    const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)(word), hi);                                                \
-    chain_bf16x2_t wb;                                                                                              \
-    wb[0] = (__bf16)f2[0];                                                                                          \
-    wb[1] = (__bf16)f2[1];                                                                                          \
+    const chain_bf16x2_t wb = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((unsigned)(word), 1.0f, hi);   /* two e4m3 -> a bf16 pair in ONE instruction, exact */ \
     acc = __builtin_amdgcn_fdot2_f32_bf16(wb, __builtin_shufflevector(xv, xv, i0, i0 + 1), acc, false);             \
   }
   AKI_CW8_PAIR(w[0], false, xa, 0) AKI_CW8_PAIR(w[0], true, xa, 2) AKI_CW8_PAIR(w[1], false, xa, 4) AKI_CW8_PAIR(w[1], true, xa, 6)

@@ -138,9 +138,14 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 // FP8: e4m3 operands through v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate).  A 128-byte
 // LDS row then holds BK = 128 k-values instead of 64, so staging, swizzle and the epilogues are byte-for-byte the same; the
 // per-row dequantisation scales (one per token, one per weight row) multiply the f32 accumulators before the epilogue.
-template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false, int NST = 2, int PIPE = 0, int SK = 0>
-__global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16_kernel(const GemmParams p) {
+// KG (K groups, small-M launches with at most one tile per CU): the workgroup is KG x (WN x WM) waves; group g has its own stage buffers and walks
+// K-steps g, g + KG, ... of the tile, so a CU holds KG waves per SIMD whose DMA waits, fragment reads and MFMAs overlap (one 4-wave workgroup alone
+// serialises them: 1200-1450 cycles per K-step for 384-512 of MFMA work).  After the loop the groups' accumulators meet in LDS and are added in
+// group order by group 0, which runs the epilogue alone: an on-chip, fixed-order fold - no partial tiles in memory, no tickets, bit-reproducible.
+template <int NF, int NT, int WN, int WM, int EPI, int ACT, bool FP8 = false, int NST = 2, int PIPE = 0, int SK = 0, int KG = 1>
+__global__ __launch_bounds__(WN* WM * 64 * KG, ((NF * NT > 32 || KG > 1) ? 1 : 2)) void gemm_bf16_kernel(const GemmParams p) {
   static_assert(!SK || (!FP8 && PIPE <= 1), "split-K: bf16, the plain K loops and the mid-step-barrier pipeline");
+  static_assert(KG == 1 || (!FP8 && PIPE == 0 && NST == 2 && !SK), "K groups: bf16, the two-stage loop");
   constexpr int BK = FP8 ? 128 : 64, ES = FP8 ? 1 : 2, NWAVES = WN * WM;
   constexpr int WROWS = NF * 16;      // features per wave
   constexpr int BN = WN * WROWS;      // features per block tile
@@ -150,11 +155,14 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   constexpr int STAGE_BYTES = ROWS * 128;
   constexpr int NLD = ROWS / 8 / NWAVES;  // global_load_lds per thread per stage
   static_assert(ROWS % (8 * NWAVES) == 0 && NF % 2 == 0, "tile shape");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = threadIdx.x & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kgrp = KG > 1 ? wave_all / NWAVES : 0;                 // this wave's K group
+  const int wave = KG > 1 ? wave_all % NWAVES : wave_all;          // ... and its place in the group's WN x WM arrangement
+  const int tid = KG > 1 ? (int)threadIdx.x - kgrp * (NWAVES * 64) : (int)threadIdx.x;   // thread index inside the group (group 0 runs the epilogue)
+  char* const smem = smem_all + (KG > 1 ? kgrp * (NST * STAGE_BYTES) : 0);
   const int wn = wave % WN, wm = wave / WN;
   const int l15 = lane & 15, kg = lane >> 4;
 #ifdef AKI_LAB_HOOKS
@@ -227,13 +235,16 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
       src[j] = (const char*)p.x + (size_t)xrow * p.ldx * ES + chunk * 16;
     }
     if constexpr (SK) src[j] += (size_t)kt0 * 128;
+    if constexpr (KG > 1) src[j] += (size_t)kgrp * 128;               // group g starts at K-step g ...
   }
+  constexpr int KSTRIDE = KG * 128;                                   // ... and advances KG steps at a time (bytes per K-step of the group)
+  if constexpr (KG > 1) nk /= KG;                                     // host: the K-step count is a multiple of KG
 
   auto stage = [&](int s, int kt) {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       char* dst = smem + s * STAGE_BYTES + (j * NWAVES + wave) * 1024;
-      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[j] + (size_t)kt * 128), AKI_LDS_PTR(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(src[j] + (size_t)kt * (KG > 1 ? KSTRIDE : 128)), AKI_LDS_PTR(dst), 16, 0, 0);
     }
   };
 
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   constexpr bool RES_PF_OK = EPI == EPI_PLAIN && ACT == 0 && !FP8 && (!PIPE || PIPE == 8) && NST == 2 && RCH <= 64 && (64 % RCH == 0) && BM * RCH * 16 <= STAGE_BYTES &&
                              (PIPE != 8 || BM * RCH * 16 <= 2 * BM * 128) &&
                              (BM * RCH * 16) % (NWAVES * 1024) == 0;
-  const bool res_pf = RES_PF_OK && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && n_out >= 8;   // workgroup-uniform
+  const bool res_pf = RES_PF_OK && KG == 1 && p.residual != nullptr && p.res_wide && p.res_row_mod <= 0 && n_out >= 8;   // workgroup-uniform
   int res_off = 0;                 // where the residual tile image sits in smem
   // QKV + RoPE on the pipelined 256 x 256 tile: cos / sin rows prefetched under the last half K-step (issue_cos_sin below); workgroup-uniform
   const bool cs_pf = EPI == EPI_QKV_ROPE8 && (PIPE == 1 || PIPE == 4 || PIPE == 7) && BM == 256 && n0 / 32 < 6 * p.H && p.position_ids == nullptr && p.L >= BM;
@@ -780,6 +791,28 @@ __global__ __launch_bounds__(WN* WM * 64, (NF * NT > 32 ? 1 : 2)) void gemm_bf16
   if ((int)blockIdx.x == p.probe_block && tid == 0 && p.clock_probe) probe_l1 = clock64();
 #endif
   AKI_WG_STAMP(2);
+  if constexpr (KG > 1) {
+    // fold of the K groups through LDS, in group order (g0 + g1 + ...): the stage buffers are free once every wave has left the loop
+    static_assert(KG == 1 || BN * BM * 4 <= NST * STAGE_BYTES, "a group's accumulators fit its own stage buffers");
+    __syncthreads();
+    f32x4* const mine = (f32x4*)smem + (wave * NF * NT) * 64 + lane;             // fragment order: one 16-byte slot per lane and block
+    if (kgrp != 0) {
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) mine[(n * NT + m) * 64] = acc[n][m];
+    }
+    __syncthreads();
+    if (kgrp != 0) { AKI_WG_STAMP(3); return; }                                   // (a finished wave leaves the workgroup's barriers)
+#pragma unroll
+    for (int g = 1; g < KG; ++g) {
+      const f32x4* const theirs = (const f32x4*)(smem_all + g * (NST * STAGE_BYTES)) + (wave * NF * NT) * 64 + lane;
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc[n][m] += theirs[(n * NT + m) * 64];
+    }
+  }
   if constexpr (SK) {
     // Split-K fold, deterministic and without a second launch.  Every slice writes its f32 accumulators in fragment order (one 16-byte
     // store per lane and block: 1 KiB per wave-instruction, write-through), drains, and draws a ticket (cdna_hip_programming.md
@@ -1237,15 +1270,15 @@ int g_probe_block = 0;                               // set by aki_lab_set_probe
 static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0, g_sm_variant = -1, g_sm_ksplit = 1;
 #endif
 
-template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, int PIPE = 0, int SK = 0>
+template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, int PIPE = 0, int SK = 0, int KG = 1>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int BN = WN * NF * 16, BM = WM * NT * 16;
   constexpr int SMEM = (PIPE >= 4 && PIPE <= 7) ? (BN > BM ? 3 * BN + 2 * BM : 3 * BM + 2 * BN) * 128   // PIPE 4-7: three + two tiles
-                       : (PIPE == 8 ? (2 * BN + 4 * BM) * 128 : NST * (BN + BM) * 128);                      // PIPE 8: two weight, three token slots + a spare
+                       : (PIPE == 8 ? (2 * BN + 4 * BM) * 128 : KG * NST * (BN + BM) * 128);                 // PIPE 8: two weight, three token slots + a spare
   static_assert(SMEM <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE, SK, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return AKI_ERR_LAUNCH;
     attr_set = true;
   }
@@ -1259,7 +1292,8 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.probe_block = g_probe_block;
 #endif
   const int slices = SK ? (p.ksplit > 1 ? p.ksplit : (p.ksplit = 1)) : 1;
-  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE, SK>), dim3(p.tiles_m * p.tiles_n * slices), dim3(WN * WM * 64), SMEM, stream, p);
+  if (KG > 1 && (p.K / 64) % KG) return AKI_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE, SK, KG>), dim3(p.tiles_m * p.tiles_n * slices), dim3(WN * WM * 64 * KG), SMEM, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }
@@ -1367,12 +1401,14 @@ static int launch_big(GemmParams& p, hipStream_t stream) {
 //   2   128 x 128          4       128 KiB  1          7   64 x 64    4   64 KiB   2
 //   3   128 x 96           2       56 KiB   2          8   128 x 64   2   48 KiB   3
 //   4   128 x 96           3       84 KiB   1          9   64 x 128   4   96 KiB   1
-constexpr int kSmallMVariants = 16;
+constexpr int kSmallMVariants = 21;
 struct SmallMTile { int bn, bm, lds_kib; };
 static const SmallMTile kSmallMTiles[kSmallMVariants] = {{128, 128, 64}, {128, 128, 96}, {128, 128, 128}, {128, 96, 56}, {128, 96, 84},
                                                         {128, 64, 72}, {64, 128, 72}, {64, 64, 64}, {128, 64, 48}, {64, 128, 96},
                                                         // 10-15: the mid-step-barrier pipeline (PIPE 1: fragments double-buffered in registers, reads and DMA issue spread between the MFMAs)
-                                                        {128, 128, 64}, {128, 96, 56}, {256, 128, 96}, {128, 128, 64}, {256, 64, 80}, {128, 256, 96}};
+                                                        {128, 128, 64}, {128, 96, 56}, {256, 128, 96}, {128, 128, 64}, {256, 64, 80}, {128, 256, 96},
+                                                        // 16-20: K groups inside the workgroup (KG x 4 waves, fold through LDS): 128 x 96 x 2, 128 x 128 x 2, 128 x 64 x 2 / x 3, 64 x 64 x 4
+                                                        {128, 96, 112}, {128, 128, 128}, {128, 64, 96}, {128, 64, 144}, {64, 64, 128}};
 size_t linear_splitk_cnt_bytes() { return size_t(64) << 10; }     // 16 384 tile tickets, at the front of the split-K workspace
 size_t linear_splitk_ws_bytes(int variant, int ksplit, int M, int n_out) {
   if (ksplit <= 1 || variant < 0 || variant >= kSmallMVariants) return 0;
@@ -1433,6 +1469,11 @@ static int launch_variant(GemmParams& p, int variant, int ksplit, hipStream_t st
     case 15:
       if constexpr (EPI != EPI_QKV_ROPE8) return launch_gemm<4, 4, 2, 4, EPI, ACT, false, 2, 1, SKV>(p, stream);
       break;
+    case 16: p.ksplit = 1; return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 2, 0, 0, 2>(p, stream);
+    case 17: p.ksplit = 1; return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 2, 0, 0, 2>(p, stream);
+    case 18: p.ksplit = 1; return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 2, 0, 0, 2>(p, stream);
+    case 19: p.ksplit = 1; return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 2, 0, 0, 3>(p, stream);
+    case 20: p.ksplit = 1; return launch_gemm<2, 2, 2, 2, EPI, ACT, false, 2, 0, 0, 4>(p, stream);
   }
   return AKI_ERR_UNSUPPORTED;
 }

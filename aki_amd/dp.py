@@ -129,10 +129,15 @@ class FlatGradReducer:
     """
 
     def __init__(self, flat_grad: torch.Tensor, spans, bucket_bytes: int = 512 << 20, group=None, shard: bool = False,
-                 breaks=(), exchange_when_alone: bool = False, flat32: Optional[torch.Tensor] = None):
+                 breaks=(), exchange_when_alone: bool = False, flat32: Optional[torch.Tensor] = None,
+                 first_bucket_bytes: Optional[int] = None):
         """spans: list of (param, start, stop) element ranges inside flat_grad, in buffer order.
         exchange_when_alone: issue the collectives even in a world of one rank (they are identities there) - how the RCCL
-        entry points and the compute-stream -> communicator-stream hand-off are exercised on a single GPU."""
+        entry points and the compute-stream -> communicator-stream hand-off are exercised on a single GPU.
+        first_bucket_bytes: size of the FIRST bucket of every segment (None = bucket_bytes).  The buffer is laid out in forward order, the
+        backward pass delivers it back to front: the first bucket (vision tokenizer, embeddings, first decoder layers) is the last one to be
+        launched and its exchange is what the step waits for after the backward pass - a small one bounds that exposed tail
+        (64 MiB: about 1 ms on one xGMI link) while the others stay large."""
         self.flat, self.group, self.shard = flat_grad, group, shard
         # fp32 exchange (the reference's DDP path under amp_bf16 all-reduces fp32 .grad, train/train.py:311-312): a bucket's slice of
         # `flat` is widened into `flat32` (same length) when the bucket is launched and the collective runs on the fp32 slice; the sum
@@ -147,19 +152,21 @@ class FlatGradReducer:
         self.no_scatter = dist.is_initialized() and str(dist.get_backend(group)).lower() == "gloo"
         self._delivered = set()       # ids of parameters already counted in this accumulation window
         per = max(1, bucket_bytes // flat_grad.element_size())
+        per_first = per if first_bucket_bytes is None else max(1, min(per, first_bucket_bytes // flat_grad.element_size()))
         brk = sorted(set(int(b) for b in breaks) | {flat_grad.numel()})
         self.buckets = []             # [start, stop, n_params, pending, work, widened into flat32]
         self._owner = {}
-        cur_start, cur_n = None, 0
+        self.stamps = None            # tools/train_bench.py: {bucket index: [event at launch, event at completion]} on the compute stream
+        cur_start, cur_n, first = None, 0, True
         for i, (p, lo, hi) in enumerate(spans):
             if cur_start is None:
                 cur_start = lo
             self._owner[id(p)] = len(self.buckets)
             cur_n += 1
             nxt = spans[i + 1][1] if i + 1 < len(spans) else flat_grad.numel()   # bucket ends where the next param starts
-            if nxt - cur_start >= per or nxt in brk:
+            if nxt - cur_start >= (per_first if first else per) or nxt in brk:
                 self.buckets.append([cur_start, nxt, cur_n, cur_n, None, False])
-                cur_start, cur_n = None, 0
+                cur_start, cur_n, first = None, 0, nxt in brk
         if cur_start is not None:
             self.buckets.append([cur_start, flat_grad.numel(), cur_n, cur_n, None, False])
         if shard:
@@ -194,6 +201,10 @@ class FlatGradReducer:
             b[5] = True
         if not self.active:
             return
+        if self.stamps is not None and self.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()                                                  # compute stream: the bucket's last gradient has been written
+            self.stamps[self.buckets.index(b)] = [ev, None]
         src = self.flat if self.flat32 is None else self.flat32
         buf = src[b[0]: b[1]]
         if not self.shard or self.no_scatter:
@@ -205,9 +216,13 @@ class FlatGradReducer:
     def finish(self) -> None:
         for b in self.buckets:
             self._launch(b)
-        for b in self.buckets:
+        for i, b in enumerate(self.buckets):
             if b[4] is not None:
                 b[4].wait()
+                if self.stamps is not None and i in self.stamps and self.flat.is_cuda:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()                                          # compute stream, behind the wait: this bucket's sum is in place
+                    self.stamps[i][1] = ev
             b[3], b[4], b[5] = b[2], None, False
         self._delivered.clear()
 

@@ -14,6 +14,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import weakref
+
 import torch
 
 from . import _lib as L
@@ -232,7 +234,7 @@ def adamw_step_t(p32, m, v, g, w16, wT, N, K, sqnorm, max_norm, gscale, lr, beta
 def register_weight_t(w: torch.Tensor, wT: torch.Tensor) -> None:
     """Hand the cache a transposed copy somebody else made of the CURRENT weights (the trainer's AdamW pass): _weight_t(w) returns it
     until the next epoch bump."""
-    _WT[(w.data_ptr(), tuple(w.shape), w._version, _EPOCH)] = wT
+    _WT[(w.data_ptr(), tuple(w.shape), w._version, _EPOCH)] = (weakref.ref(w), wT)
 
 
 # ---- transposed-weight cache -------------------------------------------------------------------------------------
@@ -263,12 +265,16 @@ def _weight_t(w: torch.Tensor) -> torch.Tensor:
         # the allocator recycles the address and a fresh tensor is always version 0 - so it is transposed every time
         return transpose(w if w.stride(1) == 1 else w.contiguous())
     key = (w.data_ptr(), tuple(w.shape), w._version, _EPOCH)
-    t = _WT.get(key)
-    if t is None:
-        if len(_WT) >= 320:                  # > every 2-D weight of AKI-4B (32 x 4 + connector + heads)
-            _WT.clear()
-        t = transpose(w if w.stride(1) == 1 else w.contiguous())
-        _WT[key] = t
+    hit = _WT.get(key)
+    # The key alone cannot tell two weights apart over time: a deleted model's addresses are recycled for the next one's parameters - same
+    # shape, version 0, same epoch - and the entry would hand out ANOTHER weight's transpose (round 5: two models built in one process
+    # gave garbage input gradients for the second).  An entry therefore remembers WHICH tensor object it was made from.
+    if hit is not None and hit[0]() is w:
+        return hit[1]
+    if len(_WT) >= 320:                      # > every 2-D weight of AKI-4B (32 x 4 + connector + heads)
+        _WT.clear()
+    t = transpose(w if w.stride(1) == 1 else w.contiguous())
+    _WT[key] = (weakref.ref(w), t)
     return t
 
 

@@ -23,8 +23,10 @@ class AkiTrainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                  max_grad_norm: float = 1.0, bucket_bytes: int = 512 << 20, group=None, shard_optimizer: Optional[bool] = None,
                  exchange_when_alone: bool = False, clip_every_microbatch: bool = False, reduce_dtype: Optional[torch.dtype] = None,
-                 emit_transposes: bool = True):
-        """shard_optimizer: keep fp32 master weights and moments only for this rank's 1/world slice of every gradient
+                 emit_transposes: bool = True, first_bucket_bytes: Optional[int] = 64 << 20):
+        """first_bucket_bytes: the first gradient bucket of each segment - the parameters whose gradients the backward pass finishes LAST - is
+        this small, so that the exchange left over after the backward pass is short (dp.FlatGradReducer); None = bucket_bytes.
+        shard_optimizer: keep fp32 master weights and moments only for this rank's 1/world slice of every gradient
         bucket (reduce-scatter + all-gather instead of all-reduce) - the memory behaviour of the reference's FSDP launch
         configs (train/distributed.py:170-243, scripts/run_train.sh:23) for the optimizer state.  Default (None): ON whenever
         there is more than one rank - the AdamW pass is HBM-bound (21 ms of a 150 ms step at world 1, 24 bytes per parameter) and
@@ -66,6 +68,7 @@ class AkiTrainer:
         # therefore segment ends) are padded to multiples of 8*world so every bucket splits evenly over the ranks
         align = 8 * self.world if self.shard else 8
         per = max(1, bucket_bytes // 2)
+        per_first = per if first_bucket_bytes is None else max(1, min(per, first_bucket_bytes // 2))
         spans, off, breaks = [], 0, []
         self.segments = []                       # (start, stop, weight_decay)
         for ps, decay in groups:
@@ -73,7 +76,7 @@ class AkiTrainer:
             for p in ps:
                 spans.append((p, off, off + p.numel()))
                 off = (off + p.numel() + 7) // 8 * 8          # 16-byte aligned views
-                if off - bstart >= per:                        # the reducer closes a bucket here: pad so it splits evenly
+                if off - bstart >= (per_first if bstart == start else per):     # the reducer closes a bucket here: pad so it splits evenly
                     off = (off + align - 1) // align * align
                     bstart = off
             off = (off + align - 1) // align * align
@@ -89,7 +92,7 @@ class AkiTrainer:
         # as the fp32 accumulator of gradient-accumulation windows
         self.g32 = torch.zeros(n, dtype=torch.float32, device=dev) if self.reduce_dtype == torch.float32 else None
         self.reducer = FlatGradReducer(self.g16, spans, bucket_bytes, group, shard=self.shard, breaks=breaks,
-                                       exchange_when_alone=alone, flat32=self.g32)
+                                       exchange_when_alone=alone, flat32=self.g32, first_bucket_bytes=first_bucket_bytes)
         self.params = []
         self.span_of = {id(p): (lo, hi) for p, lo, hi in spans}
         for p, lo, hi in spans:

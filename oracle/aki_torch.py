@@ -106,6 +106,44 @@ def decoupled_linear(x, weight, bias, add_weight, add_bias, max_original_id, lin
 
 
 # ---- a6-a8: splice ---------------------------------------------------------------------------------
+def prepare_inputs_multi_image(vision_tokens, lang_x, attention_mask, lang_embeds, media_token_id, pad_token_id, num_tokens_per_vis):
+    """BUILD-DEFINED (parity unpinned: the reference raises on a second image, src/vlm.py:547-554 - BASELINE configs[3] needs four).  The
+    rule the product implements (csrc/aux_kernels.hip splice_table_kernel), restated: the k-th `<image>` placeholder at prompt index t_k is
+    replaced by that image's Nv vision tokens, so it starts at E_k = t_k + k (Nv - 1) of the spliced stream; rows [E_k, E_k + Nv) additionally
+    see columns [E_k + Nv, text_end) with text_end = spliced index of the first <|assistant|> token + 1 (src/vlm.py:556-564 applied per image);
+    everything else is causal, padded columns are masked (src/vlm.py:434-438).  Right padding, no labels."""
+    lx, am = lang_x.cpu().numpy(), attention_mask.cpu().numpy()
+    B, Nv = lx.shape[0], num_tokens_per_vis
+    embeds, masks, spans, m1d = [], [], [], []
+    for i in range(B):
+        img = [int(t) for t in np.where(lx[i] == media_token_id)[0]]
+        q = np.where(lx[i] == O.ASSISTANT_TOKEN_ID)[0]
+        q = int(q[0]) if len(q) else 0
+        parts, mparts, prev = [], [], 0
+        for k, t in enumerate(img):
+            parts += [lang_embeds[i][prev:t], vision_tokens[i][k]]
+            mparts += [am[i][prev:t], np.ones(Nv, dtype=am.dtype)]
+            prev = t + 1
+        parts.append(lang_embeds[i][prev:])
+        mparts.append(am[i][prev:])
+        e, a = torch.cat(parts, 0), np.concatenate(mparts, 0)
+        n = a.shape[0]
+        text_end = q + sum(1 for t in img if t < q) * (Nv - 1) + 1
+        rects = []
+        for k, t in enumerate(img):
+            st = t + k * (Nv - 1)
+            r = (min(st, n), min(st + Nv, n), min(st + Nv, n), min(text_end, n))
+            rects.append(r if r[1] > r[0] and r[3] > r[2] else (0, 0, 0, 0))
+        embeds.append(e)
+        masks.append(O.mask_from_spans(a, rects))
+        spans.append(rects)
+        m1d.append(a)
+    Lmax = max(e.shape[0] for e in embeds)
+    rows = [e if e.shape[0] == Lmax else torch.cat((e, torch.full((Lmax - e.shape[0], e.shape[1]), float(pad_token_id), dtype=e.dtype)), 0) for e in embeds]
+    return {"inputs_embeds": torch.stack(rows), "attention_mask": torch.from_numpy(O.stack_with_padding_2d_attention(masks)), "labels": None,
+            "spans": spans, "mask_1d": O.stack_with_padding(m1d, padding_value=0, padding_side="right"), "lengths": [e.shape[0] for e in embeds]}
+
+
 def prepare_inputs_for_forward(vision_tokens, lang_x, attention_mask, labels, lang_embeds, media_token_id, pad_token_id,
                                num_tokens_per_vis, padding_side="right"):
     """src/vlm.py:445-603 (no KV cache).  Index logic and the dense mask come from the numpy oracle (bit-exact, pinned);
@@ -233,12 +271,17 @@ def phi3_decoder_layer(h, p, cos, sin, add_mask, n_heads, eps=1e-5, fp8=None):
     return h + phi3_mlp(x, p["mlp.gate_up_proj.weight"], p["mlp.down_proj.weight"], fp8)
 
 
-def phi3_lm_forward(inputs_embeds, mask01_4d, p, n_layers, n_heads, max_original_id, theta=10000.0, eps=1e-5, fp8=None):
+def phi3_lm_forward(inputs_embeds, mask01_4d, p, n_layers, n_heads, max_original_id, theta=10000.0, eps=1e-5, fp8=None, rope=None):
     """fp8 (None or {"head": bool, "residual_writers": bool}): BASELINE configs[4], build-defined - the decoder's projections
     (and optionally the head) on e4m3 fake-quantised operands at exactly the product's quantisation points: after each fused
     RMSNorm (qkv, gate_up, head), on the attention output (o_proj) and on the SwiGLU output (down_proj)."""
     B, L, d = inputs_embeds.shape
-    cos, sin = rope_cos_sin(np.arange(L)[None], d // n_heads, theta)
+    if rope is None:
+        cos, sin = rope_cos_sin(np.arange(L)[None], d // n_heads, theta)
+    else:   # LongRoPE (HF modeling_rope_utils: inv_freq = 1 / (ext_factors * theta^(2i/d)), cos / sin scaled): {"ext_factors", "attention_scaling"}
+        c_, s_ = O.rope_cos_sin(np.arange(L)[None], d // n_heads, theta, np.asarray(rope["ext_factors"], dtype=np.float32),
+                                float(rope.get("attention_scaling", 1.0)))
+        cos, sin = torch.from_numpy(c_), torch.from_numpy(s_)
     add = invert_mask_441(mask01_4d, inputs_embeds.dtype)
     h = inputs_embeds
     for l in range(n_layers):
@@ -309,9 +352,13 @@ def aki_forward(p: Dict[str, torch.Tensor], cfg: Dict, vision_x, lang_x, attenti
     lm = _sub(p, "lang_model.")
     emb = decoupled_embedding(lang_x, lm["model.embed_tokens.weight"], lm.get("model.embed_tokens.additional_embedding.weight"),
                               cfg["max_original_id"])
-    prep = prepare_inputs_for_forward(vt, lang_x, attention_mask, labels, emb, cfg["media_token_id"], cfg["pad_token_id"],
-                                      cfg["num_vision_tokens"], "right")
+    if cfg.get("multi_image"):      # build-defined (BASELINE configs[3]); the reference's behaviour is the branch below, which raises
+        assert labels is None
+        prep = prepare_inputs_multi_image(vt, lang_x, attention_mask, emb, cfg["media_token_id"], cfg["pad_token_id"], cfg["num_vision_tokens"])
+    else:
+        prep = prepare_inputs_for_forward(vt, lang_x, attention_mask, labels, emb, cfg["media_token_id"], cfg["pad_token_id"],
+                                          cfg["num_vision_tokens"], "right")
     logits = phi3_lm_forward(prep["inputs_embeds"], prep["attention_mask"], lm, cfg["lm_layers"], cfg["lm_heads"],
-                             cfg["max_original_id"], cfg.get("rope_theta", 10000.0), cfg.get("rms_eps", 1e-5), cfg.get("fp8"))
+                             cfg["max_original_id"], cfg.get("rope_theta", 10000.0), cfg.get("rms_eps", 1e-5), cfg.get("fp8"), cfg.get("rope"))
     loss = causal_lm_loss(logits, prep["labels"]) if labels is not None else None
     return {"logits": logits, "loss": loss, "prep": prep, "vision_tokens": vt}

@@ -237,3 +237,28 @@ def test_flat_grad_reducer_fp32_exchange_world2():
         assert float(torch.tensor(1.0 + 1.5 * 2.0 ** -8).to(torch.bfloat16)) != 1.0 + 1.5 * 2.0 ** -8
         assert bool((second == 3.0 + 2.0 ** -19).all())
         assert bool((local == (1.0 if r == 0 else 1.5 * 2.0 ** -8)).all()), "the bf16 buffer must stay as the backward left it"
+
+
+def test_first_bucket_of_each_segment_is_small():
+    """The flat buffer is in forward order and the backward pass delivers it back to front, so the FIRST bucket of a segment is the last one
+    launched - what the step waits for after the backward pass.  `first_bucket_bytes` keeps that one small; the others keep
+    the large size, boundaries stay on parameter boundaries and on the segment breaks, and every parameter belongs to exactly one bucket."""
+    from aki_amd.dp import FlatGradReducer
+    sizes = [40, 40, 40, 400, 400, 400, 400, 24, 24, 24]                # two segments: seven weights, three norm gains
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+    spans, off = [], 0
+    for p in params[:7]:
+        spans.append((p, off, off + p.numel()))
+        off += p.numel()
+    brk = off
+    for p in params[7:]:
+        spans.append((p, off, off + p.numel()))
+        off += p.numel()
+    flat = torch.zeros(off, dtype=torch.bfloat16)
+    big = FlatGradReducer(flat, spans, bucket_bytes=800 * 2, breaks=[brk])
+    small = FlatGradReducer(flat, spans, bucket_bytes=800 * 2, breaks=[brk], first_bucket_bytes=100 * 2)
+    assert [tuple(b[:2]) for b in big.buckets] == [(0, 920), (920, 1720), (1720, 1792)]
+    assert [tuple(b[:2]) for b in small.buckets] == [(0, 120), (120, 920), (920, 1720), (1720, 1792)]
+    for red in (big, small):
+        assert sum(b[2] for b in red.buckets) == len(params)
+        assert all(red.buckets[red._owner[id(p)]][0] <= lo and hi <= red.buckets[red._owner[id(p)]][1] for p, lo, hi in spans)

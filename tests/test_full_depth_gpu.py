@@ -307,3 +307,62 @@ def test_aki4b_full_size_training_step_properties():
     assert l1 == l2 and n1 == n2, (l1, l2, n1, n2)
     assert torch.equal(g1, g2), f"{int((g1 != g2).sum())} gradient elements differ between two runs"
     assert torch.equal(w1, w2), "weights after three steps differ between two runs"
+
+
+@pytest.mark.timeout(3000)
+def test_config4_seq4096_four_images_whole_model_vs_oracle():
+    """BASELINE configs[3] - seq = 4096 with 4 interleaved 336 x 336 images - through `AKI.forward` at the FULL WIDTH of AKI-4B (d 3072,
+    32 heads x 96, FFN 8192, head 32011 + 2, SigLIP 1152 / 16 heads, Perceiver 6 layers, 144 latents per image) and reduced depth (2 decoder
+    + 2 SigLIP layers), bf16, against the fp32 torch oracle on the same bf16-rounded weights: four splices of 144 vision tokens, the
+    build-defined multi-image mask (four rectangles; the reference raises on a second image - parity unpinned), LongRoPE
+    with the SHORT factor set (Phi-3.5-mini: 4096 = original_max_position_embeddings, positions 0..4095), the QKV + RoPE epilogue and the
+    attention core at L = 4096, the head at M = 4096.  Yardstick: the same oracle graph in bf16."""
+    import aki_torch as OT
+    from aki_amd.factory import build_aki
+    from aki_amd.phi3 import make_phi3_config
+    from aki_amd.siglip import make_siglip_config
+    g = torch.Generator().manual_seed(21)
+    short = (1.0 + 0.15 * torch.rand(48, generator=g)).tolist()                 # Phi-3.5-mini ships 48 factors in [1.0, 1.2] for seq <= 4096
+    long_ = (1.0 + 60.0 * torch.rand(48, generator=g)).tolist()
+    lm_cfg = make_phi3_config(num_hidden_layers=2, max_position_embeddings=131072, original_max_position_embeddings=4096,
+                              rope_scaling={"type": "longrope", "short_factor": short, "long_factor": long_})
+    m = build_aki(lm_config=lm_cfg, vis_config=make_siglip_config(num_hidden_layers=2), dtype=torch.bfloat16, device=DEV, seed=17).eval()
+    m.allow_multi_image = True
+    randomize_norms_and_biases(m, seed=5)
+    rot = m.lang_model.model.rotary_emb
+    assert rot.short is not None and rot.attention_scaling > 1.0
+    N_IMG, L = 4, 4096
+    n_txt = L - N_IMG * (NV - 1)
+    ids = torch.randint(3, 31999, (1, n_txt), generator=g)
+    ids[0, 0] = 1
+    for s in (6, 900 - 143, 1800 - 286, 2700 - 429):                            # the images start at 6 / 900 / 1800 / 2700 of the spliced stream
+        ids[0, s] = m.media_token_id
+    ids[0, n_txt - 64] = 32001                                                  # <|assistant|>: where every image's unlocked columns end
+    am = torch.ones_like(ids)
+    vx = ((torch.rand((1, N_IMG, 1, 3, PX, PX), generator=g) - 0.5) / 0.5).to(torch.bfloat16)
+    with torch.no_grad():
+        got = m(vx.to(DEV), ids.to(DEV), attention_mask=am.to(DEV)).logits.float().cpu()
+    assert got.shape == (1, L, 32011 + 2) and bool(torch.isfinite(got).all())
+    p16 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    del m
+    torch.cuda.empty_cache()
+    cfg = dict(vis_layers=2, vis_heads=16, lm_layers=2, lm_heads=32, max_original_id=32010, media_token_id=32011, pad_token_id=32000,
+               num_vision_tokens=NV, multi_image=True, rope=dict(ext_factors=short, attention_scaling=rot.attention_scaling))
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    with torch.no_grad():
+        want = OT.aki_forward({k: v.float() for k, v in p16.items()}, cfg, vx.float(), ids, am)
+        ref = want["logits"]
+        assert ref.shape == got.shape and len(want["prep"]["spans"][0]) == 4 and want["prep"]["spans"][0][3] == (2700, 2844, 2844, L - 63)
+        ref16 = OT.aki_forward(p16, cfg, vx, ids, am)["logits"].float()
+    mx = max(1.0, float(ref.abs().max()))
+    e_hip, e_ref = (got - ref).abs(), (ref16 - ref).abs()
+    stats = dict(hip_max=float(e_hip.max()), hip_mean=float(e_hip.mean()), eager_bf16_max=float(e_ref.max()), eager_bf16_mean=float(e_ref.mean()),
+                 argmax_agreement_hip=float((got.argmax(-1) == ref.argmax(-1)).float().mean()),
+                 argmax_agreement_eager_bf16=float((ref16.argmax(-1) == ref.argmax(-1)).float().mean()), max_abs_ref=mx)
+    print(json.dumps(stats))
+    with open(os.path.join(ROOT, "gpurun_out", "parity_config4.json"), "w") as f:
+        json.dump(stats, f, indent=1)
+    record_parity("configs[3]: L 4096, 4 images, full width, 2+2 layers, logits", torch.bfloat16, stats["hip_max"], stats["hip_mean"], mx,
+                  "<= 1.5x mean / 2x max of the oracle's own bf16-eager error + 1e-3*max|ref|")
+    assert stats["hip_mean"] <= 1.5 * stats["eager_bf16_mean"] + 1e-3 * mx, stats
+    assert stats["hip_max"] <= 2.0 * stats["eager_bf16_max"] + 1e-2 * mx, stats

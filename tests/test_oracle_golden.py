@@ -287,3 +287,34 @@ def test_fake_quant_e4m3_oracle_is_the_plain_oracle_plus_format_noise():
     assert torch.equal(plain, same)
     rel = lambda a: float((a - plain).norm() / plain.norm())
     assert 0.0 < rel(part) < rel(full) < 0.25, (rel(part), rel(full))
+
+
+def test_multi_image_oracle_extension_reduces_to_the_reference_for_one_image():
+    """oracle/aki_torch.py::prepare_inputs_multi_image is build-defined (the reference raises on a second image); with ONE image it must be
+    the reference's splice and mask bit for bit (the pinned numpy restatement), for placeholders in front of and behind <|assistant|>, with
+    padding, and with no assistant token at all."""
+    import aki_torch as OT
+    import torch
+    g = torch.Generator().manual_seed(3)
+    T_, d, Nv = 24, 8, 5
+    for img_at, q_at, n_real in ((2, 15, 24), (0, 9, 20), (17, 6, 24), (4, None, 22)):
+        lx = torch.randint(3, 100, (1, T_), generator=g)
+        lx[0, img_at] = 500
+        if q_at is not None:
+            lx[0, q_at] = O.ASSISTANT_TOKEN_ID
+        am = torch.ones(1, T_, dtype=torch.long)
+        am[0, n_real:] = 0
+        emb, vt = torch.randn(1, T_, d, generator=g), torch.randn(1, 1, Nv, d, generator=g)
+        a = OT.prepare_inputs_for_forward(vt, lx, am, None, emb, 500, 0, Nv)
+        b = OT.prepare_inputs_multi_image(vt, lx, am, emb, 500, 0, Nv)
+        assert torch.equal(a["inputs_embeds"], b["inputs_embeds"]) and torch.equal(a["attention_mask"], b["attention_mask"]), (img_at, q_at)
+        assert np.array_equal(a["mask_1d"], b["mask_1d"])
+    # two images: both are spliced, each image's rows see [its end, <|assistant|>]
+    lx = torch.randint(3, 100, (1, T_), generator=g)
+    lx[0, 1], lx[0, 8], lx[0, 20] = 500, 500, O.ASSISTANT_TOKEN_ID
+    emb, vt = torch.randn(1, T_, d, generator=g), torch.randn(1, 2, Nv, d, generator=g)
+    b = OT.prepare_inputs_multi_image(vt, lx, torch.ones(1, T_, dtype=torch.long), emb, 500, 0, Nv)
+    assert b["inputs_embeds"].shape[1] == T_ + 2 * (Nv - 1) and b["spans"][0] == [(1, 6, 6, 29), (12, 17, 17, 29)]
+    assert torch.equal(b["inputs_embeds"][0, 12:17], vt[0, 1]) and torch.equal(b["inputs_embeds"][0, 1:6], vt[0, 0])
+    m = b["attention_mask"][0, 0]
+    assert int(m[3, 20]) == 1 and int(m[3, 29]) == 0 and int(m[14, 20]) == 1 and int(m[14, 6]) == 1 and int(m[7, 20]) == 0

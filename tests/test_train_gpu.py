@@ -720,12 +720,13 @@ def test_gradient_checkpointing_recomputes_and_changes_nothing():
     from aki_amd.factory import build_aki
     from aki_amd.phi3 import make_phi3_config
     from aki_amd.siglip import make_siglip_config
-    lm_cfg = dict(vocab_size=2048, hidden_size=768, intermediate_size=2048, num_hidden_layers=6, num_attention_heads=8, num_key_value_heads=8)
+    lm_cfg = dict(vocab_size=2048, hidden_size=768, intermediate_size=2048, num_hidden_layers=6, num_attention_heads=8, num_key_value_heads=8,
+                  pad_token_id=0)
     vis_cfg = dict(hidden_size=576, intermediate_size=1000, num_hidden_layers=1, num_attention_heads=8, image_size=56)
     res, keys = {}, {}
     for ckpt in (False, True):
         m = build_aki(lm_config=make_phi3_config(**lm_cfg), vis_config=make_siglip_config(**vis_cfg), dtype=BF, device=DEV, seed=4,
-                      gradient_checkpointing=ckpt)
+                      gradient_checkpointing=ckpt, initial_tokenizer_len=2048, pad_token_id=0, num_vision_tokens=16)
         m.train()
         m.set_trainable()
         if ckpt:
@@ -757,3 +758,23 @@ def test_gradient_checkpointing_recomputes_and_changes_nothing():
     for n, gr in res[False][2].items():
         assert torch.equal(gr, res[True][2][n]), f"{n}: gradient differs under recomputation"
     assert res[True][1] < 0.6 * res[False][1], f"activations held: {res[True][1] / 2**20:.1f} MiB with checkpointing vs {res[False][1] / 2**20:.1f} MiB"
+
+
+def test_transposed_weight_cache_survives_address_reuse():
+    """Round 5: the cache of W^T (train_ops._weight_t, the dX GEMMs' operand) was keyed by (address, shape, version, epoch) only.  Delete a
+    model, build another: the allocator hands the old addresses to the new parameters and an entry of the OLD model answered for a
+    different weight - input gradients were garbage while the loss was right.  An entry now also remembers the tensor object."""
+    from aki_amd import train_ops as T
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(64, 256, generator=g)).to(BF).to(DEV)
+    grads = []
+    for seed in (1, 2, 3, 4):
+        w = torch.nn.Parameter((torch.randn(128, 256, generator=torch.Generator().manual_seed(seed)) * 0.05).to(BF).to(DEV))
+        ptr = w.data_ptr()
+        xi = x.clone().requires_grad_(True)
+        T.linear(xi, w).float().sum().backward()
+        want = (torch.ones(64, 128, device=DEV) @ w.detach().float())
+        grads.append(ptr)
+        close(xi.grad, want, what=f"dX with weight seed {seed}")
+        del w, xi
+    assert len(set(grads)) < len(grads), "the allocator did not recycle an address: the test exercised nothing"

@@ -15,6 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def esz_of(tr):
+    import torch
+    return 4 if getattr(tr, "reduce_dtype", None) == torch.float32 else 2
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
@@ -29,6 +34,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1, help="ranks of the job; without a launcher (WORLD_SIZE unset) --gpus N > 1 starts the N ranks itself")
     ap.add_argument("--bucket-mb", type=int, default=512, help="gradient bucket size; xGMI is point-to-point, few large messages")
     ap.add_argument("--exchange-when-alone", action="store_true", help="world of one: still issue the RCCL collectives")
+    ap.add_argument("--first-bucket-mb", type=int, default=64, help="size of the first bucket of each segment (its gradients finish last: the exposed tail); 0 = like the others")
     ap.add_argument("--head-chunk", type=int, default=0, help="rows per chunk of the fused lm_head + cross-entropy (0 = default 2688: two chunks at the benchmark batch)")
     a = ap.parse_args()
     import bench
@@ -70,7 +76,8 @@ def main():
         tr.reducer = type("R", (), {"finish": staticmethod(lambda: None), "active": False, "buckets": tr.all_units})()
     else:
         tr = AkiTrainer(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=1.0, shard_optimizer=(True if a.shard_optimizer else False if a.no_shard_optimizer else None), reduce_dtype=(torch.float32 if a.reduce_dtype == "fp32" else None), emit_transposes=not a.no_emit_transposes,
-                        bucket_bytes=a.bucket_mb << 20, exchange_when_alone=a.exchange_when_alone)
+                        bucket_bytes=a.bucket_mb << 20, exchange_when_alone=a.exchange_when_alone,
+                        first_bucket_bytes=(a.first_bucket_mb << 20) if a.first_bucket_mb > 0 else None)
     B, L = a.batch, bench.N_TXT - 1 + bench.NV
     vx, ids, am = bench.synth_batch(B, dev, torch.bfloat16, model.media_token_id, seed=1000 + rank)
     labels = ids.clone()
@@ -86,6 +93,7 @@ def main():
         marks["b"] = ev(); marks["b"].record()
     tr.reducer.finish = timed_finish
     losses = []
+    bucket_rows = None
     torch.cuda.reset_peak_memory_stats()
     for it in range(a.warmup + a.steps):
         if it == a.warmup:
@@ -94,6 +102,9 @@ def main():
                 dist.barrier()
             t0 = time.perf_counter()
         e = [ev() for _ in range(4)]
+        last_step = it == a.warmup + a.steps - 1
+        if last_step and getattr(tr.reducer, "active", False) and hasattr(tr.reducer, "stamps"):
+            tr.reducer.stamps = {}                     # the last timed step also stamps every bucket (two event records per bucket)
         e[0].record()
         tr.zero_grad()
         out = model(vx, ids, attention_mask=am, labels=labels)
@@ -110,6 +121,17 @@ def main():
                 parts[k] += e[i].elapsed_time(e[i + 1])
             parts["exchange_exposed"] += marks["a"].elapsed_time(marks["b"])
             losses.append(float(out.loss))
+            if last_step and getattr(tr.reducer, "stamps", None):
+                # per bucket, on this rank's compute-stream clock, relative to the start of the backward pass: when its last gradient was written
+                # (= when its collective was handed to the communicator stream) and when its sum was in place; the backward pass itself ends at
+                # `backward_compute_end_ms`.  Buckets are in buffer (= forward) order: the backward pass launches them last to first.
+                bucket_rows = {"backward_compute_end_ms": round(e[1].elapsed_time(marks["a"]), 3), "buckets": []}
+                for i, b in enumerate(tr.reducer.buckets):
+                    st = tr.reducer.stamps.get(i)
+                    if st and st[0] is not None and st[1] is not None:
+                        bucket_rows["buckets"].append({"index": i, "MiB": round((b[1] - b[0]) * esz_of(tr) / 2**20, 1), "launched_ms": round(e[1].elapsed_time(st[0]), 3),
+                                                       "complete_ms": round(e[1].elapsed_time(st[1]), 3)})
+                tr.reducer.stamps = None
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed_min = elapsed
@@ -148,7 +170,7 @@ def main():
                        "layers": a.layers},
             "exchange_ms": round(exch_ms, 3), "exchange_exposed_ms": round(parts["exchange_exposed"] / a.steps, 3),
             "overlap_frac": (round(1.0 - min(1.0, (parts["exchange_exposed"] / a.steps) / exch_ms), 3) if exch_ms > 0 else None),
-            "buckets": len(tr.reducer.buckets), "exchange_bytes": int(exchange_bytes), "exchange_dtype": exchange_dtype,
+            "buckets": len(tr.reducer.buckets), "bucket_timeline": bucket_rows, "exchange_bytes": int(exchange_bytes), "exchange_dtype": exchange_dtype,
             "parts_ms": {k: round(v / a.steps, 2) for k, v in parts.items()}, "losses": [round(x, 4) for x in losses],
             "trainable_params": tr.numel, "lm_mfu_vs_2500TF": round(flops / (ms * 1e-3) / 2.5e15, 4),
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1), "precision": "bf16 compute, fp32 master/moments, bf16 grads", "head_chunk_rows": getattr(model.lang_model, "head_chunk_rows", 2688)}))
