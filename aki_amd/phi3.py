@@ -54,8 +54,9 @@ class Phi3RotaryTables(nn.Module):
         self.orig_max = int(_cfg_get(config, "original_max_position_embeddings", config.max_position_embeddings))
         self.max_pos = int(config.max_position_embeddings)
         if rs and rs.get("rope_type", rs.get("type")) == "longrope":
-            self.short = torch.tensor(rs["short_factor"], dtype=torch.float32)
-            self.long = torch.tensor(rs["long_factor"], dtype=torch.float32)
+            # (explicit device: the factory builds the module tree under torch.device("meta"), and these are plain attributes, not buffers)
+            self.short = torch.tensor(rs["short_factor"], dtype=torch.float32, device="cpu")
+            self.long = torch.tensor(rs["long_factor"], dtype=torch.float32, device="cpu")
         f = self.max_pos / self.orig_max
         self.attention_scaling = 1.0 if (self.short is None or f <= 1.0) else math.sqrt(1 + math.log(f) / math.log(self.orig_max))
         self._cache = {}
@@ -69,7 +70,7 @@ class Phi3RotaryTables(nn.Module):
         key = (n_pos, use_long, str(device))
         if key not in self._cache:
             d = self.head_dim
-            base = self.theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d)
+            base = self.theta ** (torch.arange(0, d, 2, dtype=torch.float32, device="cpu") / d)
             if self.short is not None:
                 base = (self.long if use_long else self.short) * base
             inv = (1.0 / base).to(device)
