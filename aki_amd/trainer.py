@@ -34,9 +34,15 @@ class AkiTrainer:
         reference's plain DDP replica (every rank updates everything).
         reduce_dtype: None / bfloat16 exchanges the bf16 gradients where the backward kernels left them (the reference's FSDP
         default, train/distributed.py:160-167 `reduce_dtype=bf16`); float32 widens every bucket into an fp32 buffer, sums in fp32
-        across ranks and lets the optimizer consume the fp32 sum - the arithmetic of the reference's DDP path under
-        `--precision amp_bf16` (fp32 parameters and gradients: train/train.py:311-312, train/train_utils.py:56-65) at twice the
-        exchanged bytes and one more flat buffer (4 bytes per parameter).
+        across ranks (and across the micro-batches of an accumulation window) and lets the optimizer consume the fp32 sum, at twice
+        the exchanged bytes and one more flat buffer (4 bytes per parameter).  This is an fp32 SUM OF bf16 LOCAL GRADIENTS: each
+        rank's backward kernels still write their gradient - including the in-backward accumulation of a weight used twice - rounded
+        to bf16.  The reference's DDP path under `--precision amp_bf16` (train/train.py:311-312, train/train_utils.py:56-65) keeps
+        fp32 local .grad as well; that part is not reproduced.
+        With a sharded optimizer (the default for world > 1) `state_dict()` is THIS RANK's slice: a checkpoint written by rank 0 alone
+        would drop (world - 1) / world of the optimizer state - save `full_state_dict()` (a collective that gathers master weights and
+        moments) instead, and restore it with `load_full_state_dict()` under any sharding layout; `emit_transposes` has no effect under
+        sharding (a rank does not update whole weights).
         exchange_when_alone: run the collectives even when the process group has a single rank (identities) - a one-GPU
         box then exercises the real RCCL reduce-scatter / all-gather / all-reduce entry points and stream hand-off.
         clip_every_microbatch: single-rank parity only (see backward()).
@@ -278,6 +284,33 @@ class AkiTrainer:
         self.m.copy_(sd["exp_avg"])
         self.v.copy_(sd["exp_avg_sq"])
         for lo, hi, so, _ in self.owned:                    # the forward reads the bf16 image of the restored master weights
+            self.w16[lo:hi].copy_(self.master[so: so + hi - lo])
+        self.reducer.all_gather_weights(self.w16)
+        T.bump_weight_epoch()
+
+    def full_state_dict(self, cpu: bool = True) -> dict:
+        """COLLECTIVE (every rank calls it): the whole optimizer state - fp32 master weights and both moments over the full flat layout -
+        on every rank, whatever the sharding; what rank 0 should write into a checkpoint (the reference saves a consolidated optimizer
+        state through FSDP.optim_state_dict, train/train_utils.py:292-327).  One flat tensor at a time: 4 bytes per parameter in flight."""
+        out = {"step": self.step_count, "numel": self.numel, "full": True}
+        for name, src in (("master", self.master), ("exp_avg", self.m), ("exp_avg_sq", self.v)):
+            full = torch.zeros(self.numel, dtype=torch.float32, device=src.device)
+            for lo, hi, so, _ in self.owned:
+                full[lo:hi].copy_(src[so: so + hi - lo])
+            if self.shard and self.world > 1:
+                dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)      # every element is owned by exactly one rank
+            out[name] = full.cpu() if cpu else full
+        return out
+
+    def load_full_state_dict(self, sd: dict) -> None:
+        """Restore from `full_state_dict()` under THIS trainer's sharding layout (which may differ from the saving run's)."""
+        if not sd.get("full") or sd["numel"] != self.numel:
+            raise ValueError("not a consolidated optimizer state of this model (full_state_dict())")
+        self.step_count = int(sd["step"])
+        for name, dst in (("master", self.master), ("exp_avg", self.m), ("exp_avg_sq", self.v)):
+            for lo, hi, so, _ in self.owned:
+                dst[so: so + hi - lo].copy_(sd[name][lo:hi])
+        for lo, hi, so, _ in self.owned:
             self.w16[lo:hi].copy_(self.master[so: so + hi - lo])
         self.reducer.all_gather_weights(self.w16)
         T.bump_weight_epoch()

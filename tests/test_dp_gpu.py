@@ -340,3 +340,54 @@ def test_fp32_gradient_path_alone_equals_the_bf16_path():
         res.append((_weights_in_param_order(tr), losses, float(tr.grad_norm())))
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
     assert torch.equal(res[0][0], res[1][0])
+
+
+def _default_sharded_fp32_worker(rank, world, port, shard, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from aki_amd.trainer import AkiTrainer
+    m, vx, lx, am, lab = _setup()
+    tr = AkiTrainer(m, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1, bucket_bytes=1 << 20, shard_optimizer=shard, reduce_dtype=torch.float32)
+    assert tr.shard == shard and tr.g32 is not None
+    sl = slice(0, 2) if rank == 0 else slice(1, 2)
+    for _ in range(2):
+        tr.zero_grad()
+        tr.backward(m(vx[sl], lx[sl], attention_mask=am[sl], labels=lab[sl]).loss)
+        tr.optimizer_step()
+    full = tr.full_state_dict()
+    own = tr.state_dict()
+    # a consolidated state restores into a fresh trainer of the same layout and reproduces the weights
+    m2, *_ = _setup()
+    tr2 = AkiTrainer(m2, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1, bucket_bytes=1 << 20, shard_optimizer=shard, reduce_dtype=torch.float32)
+    tr2.load_full_state_dict(full)
+    ret[rank] = (_weights_in_param_order(tr), full["master"], full["exp_avg"], full["exp_avg_sq"], int(own["master"].numel()), _weights_in_param_order(tr2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_default_multi_rank_combination_sharded_optimizer_with_fp32_exchange():
+    """the default for world > 1 is a SHARDED optimizer, and with reduce_dtype=float32 that is a reduce-scatter on the fp32 buffer
+    - a combination no test covered.  Two ranks, two steps: the sharded run ends with the weights of the replicated (all-reduce) run bit for
+    bit (same fp32 sums, same AdamW arithmetic on every element, whoever owns it), its per-rank state_dict holds about half the state, and
+    full_state_dict() - the consolidated state a checkpoint must hold - equals the replicated run's state and restores the same weights."""
+    world = 2
+    res = {}
+    for shard in (True, False):
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(_default_sharded_fp32_worker, args=(world, _free_port(), shard, ret), nprocs=world, join=True)
+        res[shard] = (ret[0], ret[1])
+    for shard in (True, False):
+        a, b = res[shard]
+        assert torch.equal(a[0], b[0]), "replicas diverged"
+        for i in (1, 2, 3):
+            assert torch.equal(a[i], b[i]), "full_state_dict differs between the ranks"
+        assert torch.equal(a[5], a[0]), "load_full_state_dict did not restore the weights"
+    sh, rep = res[True][0], res[False][0]
+    assert torch.equal(sh[0], rep[0]), "sharded optimizer (reduce-scatter of fp32 sums) and replicated optimizer (all-reduce) disagree"
+    for i in (1, 2, 3):
+        assert torch.equal(sh[i], rep[i]), "consolidated optimizer state of the sharded run differs from the replicated run's"
+    assert sh[4] < 0.7 * rep[4] and res[True][0][4] + res[True][1][4] >= rep[4]
