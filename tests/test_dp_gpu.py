@@ -370,8 +370,8 @@ def _default_sharded_fp32_worker(rank, world, port, shard, ret):
 @pytest.mark.timeout(300)
 def test_default_multi_rank_combination_sharded_optimizer_with_fp32_exchange():
     """the default for world > 1 is a SHARDED optimizer, and with reduce_dtype=float32 that is a reduce-scatter on the fp32 buffer
-    - a combination no test covered.  Two ranks, two steps: the sharded run ends with the weights of the replicated (all-reduce) run bit for
-    bit (same fp32 sums, same AdamW arithmetic on every element, whoever owns it), its per-rank state_dict holds about half the state, and
+    - a combination no test covered.  Two ranks, two steps: the sharded run ends with the weights of the replicated (all-reduce) run (same
+    fp32 sums, same AdamW arithmetic on every element, whoever owns it; the clip norm is summed in another order), its per-rank state_dict holds about half the state, and
     full_state_dict() - the consolidated state a checkpoint must hold - equals the replicated run's state and restores the same weights."""
     world = 2
     res = {}
@@ -387,7 +387,12 @@ def test_default_multi_rank_combination_sharded_optimizer_with_fp32_exchange():
             assert torch.equal(a[i], b[i]), "full_state_dict differs between the ranks"
         assert torch.equal(a[5], a[0]), "load_full_state_dict did not restore the weights"
     sh, rep = res[True][0], res[False][0]
-    assert torch.equal(sh[0], rep[0]), "sharded optimizer (reduce-scatter of fp32 sums) and replicated optimizer (all-reduce) disagree"
+    # Same fp32 gradient sums and the same AdamW arithmetic per element; the one difference is the clip norm, which the sharded run adds up
+    # per owner and all-reduces (another summation order: the clip factor differs in its last bits) - so: fp32 state equal to 1e-5, the bf16
+    # weights equal except where that last bit crosses a rounding boundary (at most one bf16 step, on a small fraction of the elements).
     for i in (1, 2, 3):
-        assert torch.equal(sh[i], rep[i]), "consolidated optimizer state of the sharded run differs from the replicated run's"
+        assert torch.allclose(sh[i], rep[i], rtol=2e-5, atol=1e-9), "consolidated optimizer state of the sharded run differs from the replicated run's"
+    dw = (sh[0].float() - rep[0].float()).abs()
+    assert float((dw > 0).float().mean()) < 0.02 and bool((dw <= 2.0 ** -7 * rep[0].float().abs() + 1e-12).all()), \
+        "sharded optimizer (reduce-scatter of fp32 sums) and replicated optimizer (all-reduce) disagree"
     assert sh[4] < 0.7 * rep[4] and res[True][0][4] + res[True][1][4] >= rep[4]

@@ -1,7 +1,10 @@
-"""BASELINE configs[3]: AKI-4B forward at seq = 4096 with 4 interleaved 336x336 images (multi-image MMA mask), bf16, one MI355X."""
+"""BASELINE configs[3]: AKI-4B forward at seq = 4096 with 4 interleaved 336x336 images (multi-image MMA mask), bf16, one MI355X.
+Per batch size: ms per forward, tokens/s, and a `roofline` object for the dominant kernel (gate_up + SwiGLU, bracketed live with HIP events on
+every 4th launch in a separate pass - the timed pass runs without probes) as in bench.py.   python tools/config4_bench.py > profiles/r05_config4_bench.json"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from aki_amd import ops
 from aki_amd.factory import build_aki
 dev = torch.device("cuda", 0)
 model = build_aki(dtype=torch.bfloat16, device=dev).eval()
@@ -29,5 +32,19 @@ for B in (1, 2, 4):
             model(vx, ids, attention_mask=am)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
-    res.append({"batch": B, "seq_len": L, "images_per_sample": N_IMG, "ms_per_forward": round(ms, 2), "tokens_per_s": round(B * L / ms * 1e3, 1)})
+        tap = ops.EventTap(tags={"linear", "mma_attn_core", "mma_attn"}, every=4,
+                           select=lambda tag: tag[0].startswith("mma_attn") or (tag[0] == "linear" and tag[4] == ops.ACT_SWIGLU))
+        ops.set_event_tap(tap)
+        for _ in range(2):
+            model(vx, ids, attention_mask=am)
+        summ = tap.summary()
+        ops.set_event_tap(None)
+    gu = [(tag, n_, ms_) for tag, (n_, ms_) in summ.items() if tag[0] == "linear"]
+    at = [(tag, n_, ms_) for tag, (n_, ms_) in summ.items() if tag[0].startswith("mma_attn")]
+    (tag, _, gms), M = gu[0], B * L
+    fl = 2.0 * M * 16384 * 3072
+    roof = {"kernel": "gemm_bf16_kernel<8,4,2,4,SWIGLU> (gate_up + SwiGLU)", "bound": "mfma", "achieved": round(fl / gms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(fl / gms / 1e9 / 2500.0, 4), "traffic": None, "avg_launch_ms": round(gms, 4), "flop_per_launch": fl}
+    res.append({"batch": B, "seq_len": L, "images_per_sample": N_IMG, "ms_per_forward": round(ms, 2), "tokens_per_s": round(B * L / ms * 1e3, 1), "roofline": roof,
+                "mma_attention_ms_per_launch": {str(t_[0]): round(t_[2], 4) for t_ in at}})
 print(json.dumps(res))

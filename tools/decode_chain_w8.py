@@ -5,7 +5,8 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-PRESETS = {0: "{1,1,1,1}/{1,1,1,1} (product)", 7: "{2,2,2,2}/{1,1,1,1}", 12: "{2,2,2,2}/{2,2,2,2}", 20: "{1,1,2,1}/{1,1,2,1}", 21: "{1,1,1,2}/{1,1,1,2}", 9: "{2,1,4,1}/{2,1,4,1}"}
+PRESETS = {0: "{1,1,1,1}/{1,1,1,1} (product)", 7: "{2,2,2,2}/{1,1,1,1}", 12: "{2,2,2,2}/{2,2,2,2}", 20: "{1,1,2,1}/{1,1,2,1}", 21: "{1,1,1,2}/{1,1,1,2}", 9: "{2,1,4,1}/{2,1,4,1}",
+           13: "{2,2,4,2}/{2,2,2,2}", 14: "{2,2,4,2}/{2,2,2,1}"}
 
 
 def main():
