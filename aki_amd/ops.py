@@ -623,11 +623,19 @@ def stack_enabled() -> bool:
     return _TAP is None
 
 
+def params_signature(tensors) -> tuple:
+    """(address, in-place version) of every tensor: changes when a parameter is re-allocated (`.to`, load_state_dict(assign=True), `.data = ...`)
+    or written in place through torch (`copy_`, an optimizer step).  Writes through raw pointers (this library's trainers) are announced by the
+    weight epoch, which callers add themselves.  ~0.25 us per tensor: cheap enough to run before every stacked forward."""
+    return tuple((t_.data_ptr(), t_._version) for t_ in tensors)
+
+
 class LayerTable:
     """A host array of per-layer pointer structs for the stack calls, rebuilt only when a pointer changes."""
 
     def __init__(self, struct):
         self.struct, self.key, self.arr, self.keep = struct, None, None, None
+        self.sig = None                 # the owner's cheap signature of everything the rows were prepared from (see params_signature)
 
     def get(self, rows):
         """rows: per layer a tuple of tensors / None in the struct's field order."""

@@ -414,6 +414,11 @@ class Phi3Model(nn.Module):
 
     use_layer_stack = True                          # the folded inference forward as ONE C call (csrc/stack.hip) instead of 4-5 Python-issued launches per layer
 
+    def train(self, mode: bool = True):
+        if mode:
+            self._stack_table = None                # it keeps the layers' gain-folded weight copies alive (~5 GB): inference only, like Phi3DecoderLayer._prep
+        return super().train(mode)
+
     def _can_stack(self, h) -> bool:
         """The layer loop may run inside the library when nothing in Python has to happen between layers: no module hooks (the sharded
         trainer gathers weights there), no event tap on single launches, one epsilon for every norm, contiguous weights."""
@@ -426,22 +431,41 @@ class Phi3Model(nn.Module):
         return True
 
     def _forward_stack(self, h, cos, sin, table, position_ids, cache):
-        """= the loop over Phi3DecoderLayer.forward_folded, issued by aki_decoder_stack_fwd: same launches, same arguments."""
-        rows = []
-        for ly in self.layers:
-            at, mlp, n1, n2 = ly.self_attn, ly.mlp, ly.input_layernorm, ly.post_attention_layernorm
-            wq = ly._prep.get("qkv", [at.qkv_proj.weight, n1.weight], lambda: ops.fold_gain(at.qkv_proj.weight, n1.weight), T._EPOCH)
-            wg = ly._prep.get("gate_up", [mlp.gate_up_proj.weight, n2.weight], lambda: ops.fold_gain(mlp.gate_up_proj.weight, n2.weight), T._EPOCH)
-            rows.append((wq, at.o_proj.weight, wg, mlp.down_proj.weight, None if cache is None else cache.k[at.layer_idx],
-                         None if cache is None else cache.v[at.layer_idx]))
-        for r in rows:
-            for t_ in r[:4]:
-                if not t_.is_contiguous():
-                    raise ops.AkiError("decoder stack: weights must be contiguous")
-        if getattr(self, "_stack_table", None) is None:
-            self._stack_table = ops.LayerTable(ops.L.DecoderLayer)
+        """= the loop over Phi3DecoderLayer.forward_folded, issued by aki_decoder_stack_fwd: same launches, same arguments.
+        The per-layer preparation (gain-folded weights out of each layer's cache, 192 pointers) costs ~0.8 ms of Python - during which the
+        GPU of a one-sample prefill sits idle - so it is redone only when a cheap signature of the weights changes: (address, in-place
+        version) of all 6 x n_layers tensors, the trainers' weight epoch, the module-level version bumped by _apply / load_state_dict."""
+        tb = getattr(self, "_stack_table", None)
+        if tb is None:
+            tb = self._stack_table = ops.LayerTable(ops.L.DecoderLayer)
+            tb.params = None
+        if tb.params is None or tb.params[0] != self._weights_version:
+            flat = []
+            for ly in self.layers:
+                flat += [ly.self_attn.qkv_proj.weight, ly.input_layernorm.weight, ly.self_attn.o_proj.weight, ly.mlp.gate_up_proj.weight,
+                         ly.post_attention_layernorm.weight, ly.mlp.down_proj.weight]
+            tb.params = (self._weights_version, flat)
+            tb.sig = None
+        sig = (T._EPOCH, self._weights_version, len(self.layers), ops.params_signature(tb.params[1]))
+        if tb.sig != sig:
+            rows = []
+            for ly in self.layers:
+                at, mlp, n1, n2 = ly.self_attn, ly.mlp, ly.input_layernorm, ly.post_attention_layernorm
+                wq = ly._prep.get("qkv", [at.qkv_proj.weight, n1.weight], lambda: ops.fold_gain(at.qkv_proj.weight, n1.weight), T._EPOCH)
+                wg = ly._prep.get("gate_up", [mlp.gate_up_proj.weight, n2.weight], lambda: ops.fold_gain(mlp.gate_up_proj.weight, n2.weight), T._EPOCH)
+                rows.append((wq, at.o_proj.weight, wg, mlp.down_proj.weight, None, None))
+            for r in rows:
+                for t_ in r[:4]:
+                    if not t_.is_contiguous():
+                        raise ops.AkiError("decoder stack: weights must be contiguous")
+            tb.get(rows)
+            tb.sig = sig
+        arr = tb.arr
+        for i, ly in enumerate(self.layers):                # the KV cache is this call's: 64 pointer stores
+            arr[i].k_cache = None if cache is None else cache.k[i].data_ptr()
+            arr[i].v_cache = None if cache is None else cache.v[i].data_ptr()
         at0 = self.layers[0].self_attn
-        return ops.decoder_stack(self._stack_table.get(rows), len(rows), h, cos, sin, table, at0.num_heads, at0.head_dim,
+        return ops.decoder_stack(arr, len(self.layers), h, cos, sin, table, at0.num_heads, at0.head_dim,
                                  self.layers[0].mlp.down_proj.weight.shape[1], at0.scaling, self.norm.variance_epsilon, position_ids,
                                  0 if cache is None else cache.capacity)
 

@@ -362,7 +362,10 @@ def _default_sharded_fp32_worker(rank, world, port, shard, ret):
     m2, *_ = _setup()
     tr2 = AkiTrainer(m2, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1, bucket_bytes=1 << 20, shard_optimizer=shard, reduce_dtype=torch.float32)
     tr2.load_full_state_dict(full)
-    ret[rank] = (_weights_in_param_order(tr), full["master"], full["exp_avg"], full["exp_avg_sq"], int(own["master"].numel()), _weights_in_param_order(tr2))
+    # per parameter, in parameter order: the flat layouts of a sharded and a replicated trainer differ in their padding
+    per_param = lambda flat: torch.cat([flat[tr.span_of[id(p)][0]: tr.span_of[id(p)][1]] for p in tr.params])
+    ret[rank] = (_weights_in_param_order(tr), per_param(full["master"]), per_param(full["exp_avg"]), per_param(full["exp_avg_sq"]),
+                 int(own["master"].numel()), _weights_in_param_order(tr2))
     dist.barrier()
     dist.destroy_process_group()
 

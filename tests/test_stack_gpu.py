@@ -90,3 +90,41 @@ def test_siglip_stack_equals_the_per_layer_loop(N, size, width):
     vt.encoder.use_layer_stack = True
     assert torch.isfinite(out[True].float()).all()
     assert torch.equal(out[True], out[False]), "SigLIP tower differs between the one-call layer loop and the per-layer launches"
+
+
+def test_stack_tables_follow_weight_changes():
+    """The one-call loops prepare their per-layer tables (gain-folded weights, pointers) once and re-check a cheap signature per call.  Every
+    way a weight can change must invalidate it: an in-place torch write, a re-allocation (`.data = ...`), a trainer-style raw write announced
+    by the weight epoch, and model.train() must drop the folded copies."""
+    from aki_amd import train_ops as T
+    lm, cfg = _lm(2, seed=3, hidden_size=384, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=4)
+    x = (torch.randn(1, 80, 384, generator=torch.Generator().manual_seed(1)) * 0.5).to(torch.bfloat16).to(DEV)
+
+    def both():
+        out = []
+        for stack in (True, False):
+            lm.model.use_layer_stack = stack
+            with torch.no_grad():
+                out.append(lm(inputs_embeds=x).logits.clone())
+        lm.model.use_layer_stack = True
+        return out
+
+    a, b = both()
+    assert torch.equal(a, b)
+    w = lm.model.layers[1].mlp.down_proj.weight
+    with torch.no_grad():
+        w.mul_(1.5)                                          # in place: version counter
+    a2, b2 = both()
+    assert torch.equal(a2, b2) and not torch.equal(a2, a)
+    g = lm.model.layers[0].input_layernorm.weight
+    g.data = (g.data * 0.5).clone()                          # re-allocated: another address (the gain is folded into the cached qkv weight)
+    a3, b3 = both()
+    assert torch.equal(a3, b3) and not torch.equal(a3, a2)
+    lm.model.layers[1].self_attn.o_proj.weight.data.view(-1)[:1000].zero_()       # a write torch does not count on the Parameter ...
+    T.bump_weight_epoch()                                    # ... announced the way the trainers announce theirs
+    a4, b4 = both()
+    assert torch.equal(a4, b4)
+    assert lm.model._stack_table is not None and lm.model._stack_table.keep is not None
+    lm.train()
+    assert lm.model._stack_table is None
+    lm.eval()
