@@ -100,6 +100,19 @@ class SiglipStackArgs(C.Structure):
                 ("splitk_workspace_bytes", C.c_size_t)]
 
 
+class PerceiverLayer(C.Structure):
+    _fields_ = [("norm_media_w", C.c_void_p), ("norm_media_b", C.c_void_p), ("norm_latents_w", C.c_void_p), ("norm_latents_b", C.c_void_p),
+                ("w_q", C.c_void_p), ("w_kv", C.c_void_p), ("w_out", C.c_void_p), ("ff_ln_w", C.c_void_p), ("ff_ln_b", C.c_void_p),
+                ("ff_w1", C.c_void_p), ("ff_w2", C.c_void_p)]
+
+
+class PerceiverStackArgs(C.Structure):
+    _fields_ = [("layers", C.POINTER(PerceiverLayer)), ("n_layers", C.c_int32), ("x", C.c_void_p), ("latents", C.c_void_p), ("norm_w", C.c_void_p),
+                ("norm_b", C.c_void_p), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("out", C.c_void_p), ("n1", C.c_int32), ("n2", C.c_int32),
+                ("D", C.c_int32), ("heads", C.c_int32), ("dim_head", C.c_int32), ("d_ff", C.c_int32), ("D_out", C.c_int32), ("scale", C.c_float),
+                ("eps", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class SpliceArgs(C.Structure):
     _fields_ = [("lang_x", C.c_void_p), ("attention_mask", C.c_void_p), ("labels", C.c_void_p),
                 ("embed_weight", C.c_void_p), ("embed_additional", C.c_void_p), ("vision_tokens", C.c_void_p),
@@ -192,6 +205,8 @@ SIGNATURES = {
     "aki_decoder_stack_fwd": (C.c_int, [C.POINTER(DecoderStackArgs), C.c_void_p]),
     "aki_siglip_stack_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
     "aki_siglip_stack_fwd": (C.c_int, [C.POINTER(SiglipStackArgs), C.c_void_p]),
+    "aki_perceiver_stack_workspace_bytes": (C.c_size_t, [C.c_int32] * 6),
+    "aki_perceiver_stack_fwd": (C.c_int, [C.POINTER(PerceiverStackArgs), C.c_void_p]),
     "aki_greedy_pick_embed": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
                                         C.c_void_p]),

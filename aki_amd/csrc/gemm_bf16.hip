@@ -845,15 +845,49 @@ __global__ __launch_bounds__(WN* WM * 64 * KG, ((NF * NT > 32 || KG > 1) ? 1 : 2
       }
 #endif
       if (sk_last == 0u) { AKI_WG_STAMP(3); return; }
-      for (int i = 0; i < p.ksplit; ++i) {
+      // The fold: sum over the slices IN SLICE ORDER, ((p0 + p1) + p2) ... - with this workgroup's own partial taken from its registers (the
+      // same bits it stored) and, for the splits the planner hands out (2 and 3), every other slice's loads in flight at once: one memory
+      // round trip instead of one per pair of slices (the fold was ~6 us of a 30 us launch, tools/small_m_timeline.py).
+      auto load_slice = [&](int i, f32x4 (&dst)[NF][NT]) {
 #pragma unroll
         for (int n = 0; n < NF; ++n)
 #pragma unroll
-          for (int m = 0; m < NT; ++m) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, i * TILE_BYTES + lane_off + (n * NT + m) * 1024, 0, 16));
-            if (i == 0) acc[n][m] = v;
-            else acc[n][m] += v;
-          }
+          for (int m = 0; m < NT; ++m)
+            dst[n][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, i * TILE_BYTES + lane_off + (n * NT + m) * 1024, 0, 16));
+      };
+      if (p.ksplit == 2) {
+        f32x4 other[NF][NT];
+        load_slice(1 - ksp, other);
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+          for (int m = 0; m < NT; ++m) acc[n][m] += other[n][m];               // p0 + p1 either way round: the addition commutes
+      } else if (p.ksplit == 3) {
+        f32x4 pa[NF][NT], pb[NF][NT];                                           // the two other slices, in slice order
+        load_slice(ksp == 0 ? 1 : 0, pa);
+        load_slice(ksp == 2 ? 1 : 2, pb);
+        if (ksp == 2) {                                                         // (p0 + p1) + own
+#pragma unroll
+          for (int n = 0; n < NF; ++n)
+#pragma unroll
+            for (int m = 0; m < NT; ++m) acc[n][m] = (pa[n][m] + pb[n][m]) + acc[n][m];
+        } else {                                                                // (own + p1) + p2  or  (p0 + own) + p2
+#pragma unroll
+          for (int n = 0; n < NF; ++n)
+#pragma unroll
+            for (int m = 0; m < NT; ++m) acc[n][m] = (acc[n][m] + pa[n][m]) + pb[n][m];
+        }
+      } else {
+        for (int i = 0; i < p.ksplit; ++i) {
+#pragma unroll
+          for (int n = 0; n < NF; ++n)
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+              const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, i * TILE_BYTES + lane_off + (n * NT + m) * 1024, 0, 16));
+              if (i == 0) acc[n][m] = v;
+              else acc[n][m] += v;
+            }
+        }
       }
     }
   }

@@ -198,4 +198,73 @@ int aki_siglip_stack_fwd(const aki_siglip_stack_args* a, void* stream) {
   return AKI_OK;
 }
 
+size_t aki_perceiver_stack_workspace_bytes(int32_t n1, int32_t n2, int32_t D, int32_t heads, int32_t dim_head, int32_t d_ff) {
+  if (n1 <= 0 || n2 <= 0 || D <= 0 || heads <= 0 || dim_head <= 0 || d_ff <= 0) return 0;
+  const size_t inner = (size_t)heads * dim_head;
+  return aki_align_up((size_t)(n1 + n2) * D * 2, 256) + aki_align_up((size_t)n2 * inner * 2, 256) + aki_align_up((size_t)(n1 + n2) * 2 * inner * 2, 256) +
+         aki_align_up((size_t)n2 * inner * 2, 256) + 2 * aki_align_up((size_t)n2 * D * 2, 256) + aki_connector_mlp_workspace_bytes(n2, D, d_ff, AKI_DT_BF16) +
+         aki_align_up((size_t)heads * dim_head * 4 + 256, 256);
+}
+
+int aki_perceiver_stack_fwd(const aki_perceiver_stack_args* a, void* stream) {
+  AKI_CLEAR_ERR();
+  AKI_CHECK_ARG(a && a->layers && a->n_layers > 0 && a->x && a->latents && a->out && a->norm_w && a->workspace);
+  AKI_CHECK_ARG(a->n1 > 0 && a->n2 > 0 && a->D > 0 && a->heads > 0 && a->dim_head > 0 && a->d_ff > 0 && a->eps > 0.f && a->scale > 0.f);
+  AKI_CHECK_ARG(!a->proj_w || a->D_out > 0);
+  for (int i = 0; i < a->n_layers; ++i) {
+    const aki_perceiver_layer& ly = a->layers[i];
+    AKI_CHECK_ARG(ly.norm_media_w && ly.norm_latents_w && ly.w_q && ly.w_kv && ly.w_out && ly.ff_ln_w && ly.ff_w1 && ly.ff_w2);
+  }
+  if (a->workspace_bytes < aki_perceiver_stack_workspace_bytes(a->n1, a->n2, a->D, a->heads, a->dim_head, a->d_ff) || ((uintptr_t)a->workspace & 255))
+    return AKI_ERR_WORKSPACE;
+  const int n1 = a->n1, n2 = a->n2, D = a->D, inner = a->heads * a->dim_head, nk = n1 + n2;
+  char* w = (char*)a->workspace;
+  char* cat = carve(w, (size_t)nk * D * 2);                 // [LN_media(x) ; LN_latents(latents)]: the keys / values' input, rows n1.. the queries' input
+  void* q = carve(w, (size_t)n2 * inner * 2);
+  char* kv = carve(w, (size_t)nk * 2 * inner * 2);
+  void* ao = carve(w, (size_t)n2 * inner * 2);
+  void* lat[2] = {carve(w, (size_t)n2 * D * 2), carve(w, (size_t)n2 * D * 2)};
+  void* mlp_ws = carve(w, aki_connector_mlp_workspace_bytes(n2, D, a->d_ff, AKI_DT_BF16));
+  void* attn_ws = w;
+  const size_t mlp_ws_bytes = aki_connector_mlp_workspace_bytes(n2, D, a->d_ff, AKI_DT_BF16), attn_ws_bytes = (size_t)inner * 4 + 256;
+  const void* cur = a->latents;
+  int rc;
+  for (int i = 0; i < a->n_layers; ++i) {
+    const aki_perceiver_layer& ly = a->layers[i];
+    // PerceiverAttention (src/helpers.py:76-102): both LayerNorms straight into the concatenated key / value input
+    rc = aki_layernorm_fwd(a->x, ly.norm_media_w, ly.norm_media_b, cat, n1, D, D, D, a->eps, AKI_DT_BF16, stream);
+    if (rc) return rc;
+    rc = aki_layernorm_fwd(cur, ly.norm_latents_w, ly.norm_latents_b, cat + (size_t)n1 * D * 2, n2, D, D, D, a->eps, AKI_DT_BF16, stream);
+    if (rc) return rc;
+    aki_linear_args qa = {};
+    qa.x = cat + (size_t)n1 * D * 2; qa.w = ly.w_q; qa.y = q; qa.M = n2; qa.N = inner; qa.K = D; qa.ldx = D; qa.ldw = D; qa.ldy = inner;
+    qa.act = AKI_ACT_NONE; qa.dtype = AKI_DT_BF16;
+    rc = aki_linear_fwd(&qa, stream);
+    if (rc) return rc;
+    aki_linear_args ka = {};
+    ka.x = cat; ka.w = ly.w_kv; ka.y = kv; ka.M = nk; ka.N = 2 * inner; ka.K = D; ka.ldx = D; ka.ldw = D; ka.ldy = 2 * inner;
+    ka.act = AKI_ACT_NONE; ka.dtype = AKI_DT_BF16;
+    rc = aki_linear_fwd(&ka, stream);
+    if (rc) return rc;
+    aki_attn_args at = {};
+    at.q = q; at.k = kv; at.v = kv + (size_t)inner * 2; at.o = ao;
+    at.q_stride_b = (int64_t)n2 * inner; at.q_stride_h = a->dim_head; at.q_stride_t = inner;
+    at.k_stride_b = at.v_stride_b = (int64_t)nk * 2 * inner; at.k_stride_h = at.v_stride_h = a->dim_head; at.k_stride_t = at.v_stride_t = 2 * inner;
+    at.B = 1; at.H = a->heads; at.Lq = n2; at.Lk = nk; at.Dh = a->dim_head; at.scale = a->scale; at.dtype = AKI_DT_BF16;
+    rc = aki_attn_fwd(&at, attn_ws, attn_ws_bytes, stream);
+    if (rc) return rc;
+    aki_linear_args oa = {};
+    oa.x = ao; oa.w = ly.w_out; oa.residual = cur; oa.y = lat[0]; oa.M = n2; oa.N = D; oa.K = inner; oa.ldx = inner; oa.ldw = inner; oa.ldy = D; oa.ldr = D;
+    oa.act = AKI_ACT_NONE; oa.dtype = AKI_DT_BF16;
+    rc = aki_linear_fwd(&oa, stream);
+    if (rc) return rc;
+    // FeedForward + residual (src/helpers.py:32-39,194)
+    rc = aki_connector_mlp_fwd(lat[0], ly.ff_ln_w, ly.ff_ln_b, ly.ff_w1, ly.ff_w2, lat[1], n2, D, a->d_ff, a->eps, AKI_DT_BF16, mlp_ws, mlp_ws_bytes, stream);
+    if (rc) return rc;
+    cur = lat[1];
+  }
+  if (a->proj_w) return aki_connector_proj_fwd(cur, a->norm_w, a->norm_b, a->proj_w, a->proj_b, a->out, n2, D, a->D_out, a->eps, AKI_DT_BF16, mlp_ws, mlp_ws_bytes, stream);
+  return aki_layernorm_fwd(cur, a->norm_w, a->norm_b, a->out, n2, D, D, D, a->eps, AKI_DT_BF16, stream);
+}
+
 }  // extern "C"

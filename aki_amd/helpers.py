@@ -122,6 +122,42 @@ class PerceiverResampler(VisionTokenizer):
                                               FeedForward(dim=dim, mult=ff_mult)]))
         self.norm = nn.LayerNorm(dim)
 
+    use_layer_stack = True      # one (sample, image) pair: the ~55 launches of the 6 layers issued by ONE C call (csrc/stack.hip: aki_perceiver_stack_fwd)
+
+    def _can_stack(self, x) -> bool:
+        if not (self.use_layer_stack and ops.stack_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()):
+            return False
+        eps = self.norm.eps
+        for attn, ff in self.layers:
+            if (attn._forward_hooks or attn._forward_pre_hooks or attn.norm_media.eps != eps or attn.norm_latents.eps != eps or ff[0].eps != eps
+                    or attn.heads != self.layers[0][0].heads or attn.dim_head != self.layers[0][0].dim_head):
+                return False
+        return True
+
+    def _forward_stack(self, x, latents):
+        """= the inference loop below for one (sample, image) pair, issued by aki_perceiver_stack_fwd: same launches, same arguments."""
+        tb = getattr(self, "_stack_table", None)
+        if tb is None:
+            tb = self._stack_table = ops.LayerTable(ops.L.PerceiverLayer)
+            tb.params = [p for p in self.layers.parameters()]
+        sig = ops.params_signature(tb.params)
+        if tb.sig != sig:
+            rows = []
+            for attn, ff in self.layers:
+                rows.append((attn.norm_media.weight, attn.norm_media.bias, attn.norm_latents.weight, attn.norm_latents.bias, attn.to_q.weight,
+                             attn.to_kv.weight, attn.to_out.weight, ff[0].weight, ff[0].bias, ff[1].weight, ff[3].weight))
+            for r in rows:
+                for t_ in r:
+                    if t_ is not None and not t_.is_contiguous():
+                        raise ops.AkiError("perceiver stack: weights must be contiguous")
+            tb.get(rows)
+            tb.sig = sig
+        a0 = self.layers[0][0]
+        proj = self.projection
+        return ops.perceiver_stack(tb.arr, len(self.layers), x.reshape(-1, x.shape[-1]), latents.reshape(-1, latents.shape[-1]), self.norm.weight, self.norm.bias,
+                                   None if proj is None else proj.weight, None if proj is None else proj.bias, a0.heads, a0.dim_head,
+                                   self.layers[0][1][1].weight.shape[0], a0.scale, self.norm.eps)
+
     def forward(self, x):
         """x (b,T,F,v,D) -> (b,T,n,dim_inner)   (src/helpers.py:170-199)."""
         b, T, Fr, v = x.shape[:4]
@@ -140,6 +176,8 @@ class PerceiverResampler(VisionTokenizer):
             if exists(self.projection):
                 return TR.linear(latents, self.projection.weight, self.projection.bias, None)
             return latents
+        if b * T == 1 and self._can_stack(x):
+            return self._forward_stack(x, latents).view(b, T, latents.shape[2], -1)
         for attn, ff in self.layers:
             latents = attn(x, latents)                                     # attention + residual
             latents = ops.connector_mlp(latents, ff[0].weight, ff[0].bias, ff[1].weight, ff[3].weight, ff[0].eps)

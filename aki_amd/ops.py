@@ -709,6 +709,25 @@ def siglip_stack(table_arr, n_layers: int, h: torch.Tensor, fc1_out: torch.Tenso
     return out
 
 
+def perceiver_stack(table_arr, n_layers: int, x: torch.Tensor, latents: torch.Tensor, norm_w, norm_b, proj_w, proj_b, heads: int, dim_head: int, d_ff: int,
+                    scale: float, eps: float) -> torch.Tensor:
+    """The Perceiver connector for ONE (sample, image) pair in one call (aki_perceiver_stack_fwd): x [n1, D], latents [n2, D] -> [n2, D_out]."""
+    dev = _dev(x, latents, norm_w, norm_b, proj_w, proj_b)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or not latents.is_contiguous() or x.dim() != 2 or latents.dim() != 2:
+        raise AkiError("perceiver_stack: contiguous bf16 [n, D] tensors")
+    lib = L.load()
+    n1, D = x.shape
+    n2 = latents.shape[0]
+    D_out = D if proj_w is None else proj_w.shape[0]
+    out = torch.empty((n2, D_out), dtype=x.dtype, device=dev)
+    ws = _scratch(int(lib.aki_perceiver_stack_workspace_bytes(n1, n2, D, heads, dim_head, d_ff)), dev)
+    off = (-ws.data_ptr()) % 256
+    a = L.PerceiverStackArgs(table_arr, n_layers, _ptr(x), _ptr(latents), _ptr(norm_w), _ptr(norm_b), _ptr(proj_w), _ptr(proj_b), _ptr(out), n1, n2, D, heads,
+                             dim_head, d_ff, D_out, float(scale), float(eps), ws.data_ptr() + off, ws.numel() - off)
+    L.check(lib.aki_perceiver_stack_fwd(C.byref(a), _stream()), "aki_perceiver_stack_fwd")
+    return out
+
+
 # ---- fp8 (e4m3) projections: BASELINE configs[4] -------------------------------------------------------------------
 def quant_rows_fp8(x: torch.Tensor, rms_weight: Optional[torch.Tensor] = None, eps: float = 0.0):
     """bf16 rows -> (e4m3 bytes [rows, cols] as uint8, f32 scale per row).  With rms_weight the Phi-3 RMSNorm is applied on

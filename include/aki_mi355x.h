@@ -648,6 +648,45 @@ typedef struct {
 size_t aki_siglip_stack_workspace_bytes(int32_t N, int32_t L, int32_t E, int32_t heads);
 int aki_siglip_stack_fwd(const aki_siglip_stack_args* args, void* stream);
 
+/* aki_perceiver_stack_fwd: the Perceiver connector (src/helpers.py:170-199: `depth` x [PerceiverAttention + residual, FeedForward + residual],
+ * final LayerNorm, projection) for ONE (sample, image) pair - the one-sample case, where issuing its ~55 launches from Python takes longer than
+ * they run.  x [n1, D] media features, latents [n2, D] (the learned latents), out [n2, D_out] (D_out = D without a projection).  Every
+ * LayerNorm uses `eps`; the attention is softmax(scale q k^T) over the n1 + n2 keys LN_media(x) ++ LN_latents(latents).  Same launches as
+ * aki_layernorm_fwd / aki_linear_fwd / aki_attn_fwd / aki_connector_mlp_fwd / aki_connector_proj_fwd issued one by one. */
+typedef struct {
+  const void* norm_media_w;
+  const void* norm_media_b;
+  const void* norm_latents_w;
+  const void* norm_latents_b;
+  const void* w_q;   /* [heads*dim_head, D] */
+  const void* w_kv;  /* [2*heads*dim_head, D] */
+  const void* w_out; /* [D, heads*dim_head] */
+  const void* ff_ln_w;
+  const void* ff_ln_b;
+  const void* ff_w1; /* [d_ff, D] */
+  const void* ff_w2; /* [D, d_ff] */
+} aki_perceiver_layer;
+
+typedef struct {
+  const aki_perceiver_layer* layers;
+  int32_t n_layers;
+  const void* x;
+  const void* latents;
+  const void* norm_w;
+  const void* norm_b;
+  const void* proj_w; /* [D_out, D] or NULL */
+  const void* proj_b;
+  void* out;
+  int32_t n1, n2, D, heads, dim_head, d_ff, D_out;
+  float scale;
+  float eps;
+  void* workspace;
+  size_t workspace_bytes;
+} aki_perceiver_stack_args;
+
+size_t aki_perceiver_stack_workspace_bytes(int32_t n1, int32_t n2, int32_t D, int32_t heads, int32_t dim_head, int32_t d_ff);
+int aki_perceiver_stack_fwd(const aki_perceiver_stack_args* args, void* stream);
+
 /* aki_greedy_pick_embed - aki_greedy_pick + the embedding lookup of the token it picked (`DecoupledEmbedding.forward`,
  * src/helpers.py:440-492, which HF's generate loop runs at the top of the next step): next_embeds[b, :] = bf16 row `next` of embed_weight
  * [max_original_id + 1 or more rows, d], or row `next - max_original_id - 1` of additional_weight [num_additional, d] when

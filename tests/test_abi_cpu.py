@@ -44,7 +44,7 @@ STRUCTS = {"aki_mma_rect": "MmaRect", "aki_mma_attn_core_args": "MmaAttnCoreArgs
            "aki_attn_args": "AttnArgs", "aki_linear_args": "LinearArgs", "aki_splice_args": "SpliceArgs",
            "aki_attn_bwd_args": "AttnBwdArgs", "aki_decode_chain_layer": "DecodeChainLayer", "aki_decode_chain_args": "DecodeChainArgs",
            "aki_decoder_layer": "DecoderLayer", "aki_decoder_stack_args": "DecoderStackArgs", "aki_siglip_layer": "SiglipLayer",
-           "aki_siglip_stack_args": "SiglipStackArgs"}
+           "aki_siglip_stack_args": "SiglipStackArgs", "aki_perceiver_layer": "PerceiverLayer", "aki_perceiver_stack_args": "PerceiverStackArgs"}
 
 
 def header_structs():

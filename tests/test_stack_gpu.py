@@ -128,3 +128,31 @@ def test_stack_tables_follow_weight_changes():
     lm.train()
     assert lm.model._stack_table is None
     lm.eval()
+
+
+@pytest.mark.parametrize("n1,proj", [(576, True), (729, True), (100, False)])
+def test_perceiver_stack_equals_the_python_loop(n1, proj):
+    """aki_perceiver_stack_fwd (one (sample, image) pair) against PerceiverResampler's own inference loop: bit for bit, with and without the final
+    projection, LayerNorm gains / biases randomised."""
+    from aki_amd.helpers import PerceiverResampler
+    torch.manual_seed(5)
+    pr = PerceiverResampler(dim=1152, dim_inner=3072 if proj else None, num_latents=144)
+    g = torch.Generator().manual_seed(8)
+    for n_, p in pr.named_parameters():
+        if p.dim() == 1:
+            p.data.copy_((1.0 if n_.endswith("weight") else 0.0) + 0.2 * torch.randn(p.shape, generator=g))
+        elif n_ != "latents":
+            p.data.copy_(torch.randn(p.shape, generator=g) * 0.03)
+    pr = pr.to(DEV).to(torch.bfloat16).eval()
+    x = (torch.randn(1, 1, 1, n1, 1152, generator=g)).to(torch.bfloat16).to(DEV)
+    out = {}
+    for stack in (True, False):
+        pr.use_layer_stack = stack
+        with torch.no_grad():
+            out[stack] = pr(x).clone()
+    pr.use_layer_stack = True
+    assert out[True].shape == (1, 1, 144, 3072 if proj else 1152) and torch.isfinite(out[True].float()).all()
+    assert torch.equal(out[True], out[False])
+    with torch.no_grad():                                   # two pairs: the Python loop (the stack serves one pair)
+        two = pr(torch.cat([x, x], 0))
+    assert torch.equal(two[0], out[True][0]) and torch.equal(two[1], out[True][0])
