@@ -30,8 +30,9 @@ def _activate_checkpointing(module: nn.Module) -> None:
     inner = module.forward
 
     def forward(*args, **kwargs):
-        if torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in args) or (
-                torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())):
+        recording = torch.is_grad_enabled() and (any(isinstance(a, torch.Tensor) and a.requires_grad for a in args)
+                                                 or any(p.requires_grad for p in module.parameters()))
+        if recording:
             return ckpt.checkpoint(inner, *args, use_reentrant=False, **kwargs)
         return inner(*args, **kwargs)
 
