@@ -619,8 +619,9 @@ def _scratch(nbytes: int, dev) -> torch.Tensor:
 
 
 def stack_enabled() -> bool:
-    """The one-call layer loops hide the individual launches from the event tap (bench.py brackets single GEMMs): off while one is installed."""
-    return _TAP is None
+    """The one-call layer loops hide the individual launches from the event tap (bench.py brackets single GEMMs): off while one is installed.
+    Off under stream capture as well: their scratch buffer is cached across calls and must not come out of a graph's private pool."""
+    return _TAP is None and not torch.cuda.is_current_stream_capturing()
 
 
 def params_signature(tensors) -> tuple:
