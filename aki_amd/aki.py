@@ -260,10 +260,11 @@ class AKI(VLMWithLanguageStream):
             pick_e = pick if embed is None else dict(pick, embed=embed, next_embeds=nxt_emb)
             ops.greedy_pick(logits.contiguous(), ids, cache_len=cache.cache_len, advance=False, **pick_e)      # token 0, from the prefill
             t, t_ok = 1, 1                                  # tokens[:, :t_ok] are verified (token 0 comes from the prefill, not from the chain)
+            period = 8 if eos_t is not None else 32         # host synchronisations: the EOS check needs them often, the chain's verification alone does not
             while True:
                 ok = True
                 while t < max_new_tokens:
-                    if t % 8 == 0 and (eos_t is not None or chained()):
+                    if t % period == 0 and (eos_t is not None or chained()):
                         if chained() and not lm.decode_verified(cache):
                             ok = False
                             break

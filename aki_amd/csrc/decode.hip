@@ -860,9 +860,12 @@ __device__ __forceinline__ bool pick_better(float a, int ia, float b, int ib) {
   return a > b || (a == b && ia < ib);
 }
 
-__global__ __launch_bounds__(256) void greedy_pick_kernel(const PickParams p) {
-  __shared__ float s_v[4];
-  __shared__ int s_i[4];
+// One workgroup of 16 waves per row: the scan of 32 064 logits is a latency chain (load, eight compares, next load); 1024 threads walk it in 4 trips of two
+// loads each instead of 16 trips of one (19.4 -> measured in profiles/r05_decode_token_trace.txt).
+constexpr int PICK_THREADS = 1024;
+__global__ __launch_bounds__(PICK_THREADS) void greedy_pick_kernel(const PickParams p) {
+  __shared__ float s_v[PICK_THREADS / 64];
+  __shared__ int s_i[PICK_THREADS / 64];
   __shared__ int64_t s_next;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bf16_t* row = p.logits + (size_t)b * p.ld;
@@ -870,16 +873,24 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const PickParams p) {
   int bi = 0x7fffffff;
   const bool vec = ((p.ld & 7) == 0) && ((((uintptr_t)p.logits) & 15) == 0);
   const int nvec = vec ? p.V / 8 : 0;
-  for (int c = tid; c < nvec; c += 256) {
-    const u32x4 v = *(const u32x4*)(row + (size_t)c * 8);
+  for (int c0 = tid; c0 < nvec; c0 += 2 * PICK_THREADS) {
+    const int c1 = c0 + PICK_THREADS;                        // both loads go out before the first compare
+    const u32x4 v0 = *(const u32x4*)(row + (size_t)c0 * 8);
+    const u32x4 v1 = c1 < nvec ? *(const u32x4*)(row + (size_t)c1 * 8) : u32x4{0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};   // -inf: never picked
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float lo = bf16_lo(v[e]), hi = bf16_hi(v[e]);
-      if (pick_better(lo, c * 8 + 2 * e, best, bi)) { best = lo; bi = c * 8 + 2 * e; }
-      if (pick_better(hi, c * 8 + 2 * e + 1, best, bi)) { best = hi; bi = c * 8 + 2 * e + 1; }
+    for (int h = 0; h < 2; ++h) {
+      const u32x4 v = h ? v1 : v0;
+      const int c = h ? c1 : c0;
+      if (h && c1 >= nvec) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = bf16_lo(v[e]), hi = bf16_hi(v[e]);
+        if (pick_better(lo, c * 8 + 2 * e, best, bi)) { best = lo; bi = c * 8 + 2 * e; }
+        if (pick_better(hi, c * 8 + 2 * e + 1, best, bi)) { best = hi; bi = c * 8 + 2 * e + 1; }
+      }
     }
   }
-  for (int i = nvec * 8 + tid; i < p.V; i += 256) {
+  for (int i = nvec * 8 + tid; i < p.V; i += PICK_THREADS) {
     const float x = bf16_bits_to_f32(row[i]);
     if (pick_better(x, i, best, bi)) { best = x; bi = i; }
   }
@@ -893,7 +904,7 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const PickParams p) {
   __syncthreads();
   if (tid == 0) {
 #pragma unroll
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < PICK_THREADS / 64; ++w)
       if (pick_better(s_v[w], s_i[w], best, bi)) { best = s_v[w]; bi = s_i[w]; }
     const bool was_done = p.done != nullptr && p.done[b] != 0;
     const int64_t nxt = was_done ? p.pad : (int64_t)bi;
@@ -920,7 +931,7 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const PickParams p) {
     const bool extra = p.emb_extra != nullptr && nxt > p.max_original_id;
     const bf16_t* src = extra ? p.emb_extra + (size_t)(nxt - p.max_original_id - 1) * p.d : p.emb_main + (size_t)nxt * p.d;
     bf16_t* dst = p.emb_out + (size_t)b * p.d;
-    for (int c = tid; c < p.d / 8; c += 256) *(u32x4*)(dst + (size_t)c * 8) = *(const u32x4*)(src + (size_t)c * 8);
+    for (int c = tid; c < p.d / 8; c += PICK_THREADS) *(u32x4*)(dst + (size_t)c * 8) = *(const u32x4*)(src + (size_t)c * 8);
   }
 }
 
@@ -930,7 +941,7 @@ int greedy_pick_launch(const void* logits, int B, int V, int ld, const int64_t* 
   PickParams p = {(const bf16_t*)logits, B, V, ld, eos, n_eos, pad, done, ids, tokens, tokens_ld, cache_len, start_len, advance, done_at,
                   (const bf16_t*)emb_main, (const bf16_t*)emb_extra, max_original_id, d, (bf16_t*)emb_out};
   AKI_CLEAR_ERR();
-  hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(PICK_THREADS), 0, s, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }

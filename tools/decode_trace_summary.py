@@ -18,7 +18,7 @@ with open(dst + "_token_trace.txt", "w") as f:
     if len(idx) >= 3:
         a, b = idx[-3], idx[-2]
         t_prev = int(rows[a]["Start_Timestamp"])
-        f.write(f"one replayed token: {(int(rows[b]['Start_Timestamp']) - t_prev) / 1e3:.1f} us from chain start to chain start\n")
+        f.write(f"one greedy token: {(int(rows[b]['Start_Timestamp']) - t_prev) / 1e3:.1f} us from chain start to chain start\n")
         end_prev = None
         for r in rows[a:b]:
             s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
