@@ -3,7 +3,7 @@
 `generate(max_new_tokens=256)`, greedy): full AKI-4B (random-init), one 336 px image + 512-token prompt, batch 1.  Reports the time to the
 first token (vision tower + connector + splice + MMA prefill into the KV cache) and the time per generated token (one hipGraph replay
 each, the greedy pick inside it), with bf16 and with e4m3 weights.  No EOS (random weights never emit one on cue): all 256 tokens.
-    python tools/generate_bench.py [--new 256] [--fp8]"""
+    python tools/generate_bench.py [--new 256] [--fp8] [--txt 64]"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,8 +14,10 @@ def main():
     ap.add_argument("--new", type=int, default=256)
     ap.add_argument("--fp8", action="store_true")
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--txt", type=int, default=512, help="prompt tokens: 512 = the headline prompt (L = 655), 64 = BASELINE configs[0] (L = 207)")
     a = ap.parse_args()
     import bench
+    bench.N_TXT = a.txt
     from aki_amd.factory import build_aki
     dev = torch.device("cuda", 0)
     model = build_aki(dtype=torch.bfloat16, device=dev, seed=0).eval()
