@@ -133,6 +133,20 @@ def test_host_side_validation_without_gpu(lib):
     assert lib.aki_mma_attn_core_fwd(C.byref(c), None, 0, None) == -1
     assert lib.aki_mma_attn_workspace_bytes(8, 32, 655, 96, 0) >= 3 * 8 * 32 * 655 * 96 * 2
     assert lib.aki_patch_embed_workspace_bytes(8, 336, 14, 0) >= 8 * 576 * 640 * 2
+    # round 5: the one-call layer loops validate on the host before anything is launched
+    assert lib.aki_decoder_stack_fwd(C.byref(L.DecoderStackArgs()), None) == -1
+    assert lib.aki_siglip_stack_fwd(C.byref(L.SiglipStackArgs()), None) == -1
+    assert lib.aki_perceiver_stack_fwd(C.byref(L.PerceiverStackArgs()), None) == -1
+    need = lib.aki_decoder_stack_workspace_bytes(1, 32, 655, 96, 3072, 8192, 1)
+    assert need >= 655 * (2 * 3072 * 2 + 3072 * 2 + 3072 * 2 + 8192 * 2) and need % 256 == 0       # q + o + two residual streams + SwiGLU output
+    assert lib.aki_decoder_stack_workspace_bytes(1, 32, 655, 96, 3072, 8192, 0) > need                 # + k, v when no KV cache takes them
+    assert lib.aki_siglip_stack_workspace_bytes(1, 576, 1152, 16) >= 576 * 1152 * 2 * 6
+    assert lib.aki_perceiver_stack_workspace_bytes(576, 144, 1152, 8, 64, 4608) >= (576 + 144) * 1152 * 2
+    # the split-K planner: a one-sample prefill's N = 3072 GEMMs are split (a workspace is wanted), the headline batch's are not
+    assert lib.aki_linear_splitk_workspace_bytes(655, 3072, 3072) > 0 and lib.aki_linear_splitk_workspace_bytes(655, 3072, 8192) > 0
+    assert lib.aki_linear_splitk_workspace_bytes(207, 3072, 8192) > 0
+    assert lib.aki_linear_splitk_workspace_bytes(5240, 3072, 8192) == 0 and lib.aki_linear_splitk_workspace_bytes(655, 16384, 3072) == 0
+    assert lib.aki_linear_splitk_workspace_bytes(655, 3072, 1152) == 0                                # 18 K-steps: nothing to split
 
 
 def test_product_package_never_imports_the_oracle():
