@@ -28,6 +28,7 @@ def main():
     st = ops.new_stats(M, dev)
     stamps = torch.zeros(4 * 8192, dtype=torch.int64, device=dev)
     cases = {"o_proj +res+stats": lambda i: ops.linear(x[i], wo[i], residual=r[i], stats_out=st, stats_eps=1e-5, out=y),
+             "o_proj +res": lambda i: ops.linear(x[i], wo[i], residual=r[i], out=y),
              "o_proj plain": lambda i: ops.linear(x[i], wo[i], out=y),
              "down +res+stats": lambda i: ops.linear(act[i], wd[i], residual=r[i], stats_out=st, stats_eps=1e-5, out=y)}
     for name, fn in cases.items():
