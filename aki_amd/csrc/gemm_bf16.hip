@@ -1484,30 +1484,39 @@ template <int EPI, int ACT>
 static int launch_variant(GemmParams& p, int variant, int ksplit, hipStream_t stream) {
   constexpr int SKV = (EPI == EPI_PLAIN && ACT == 0) ? 1 : 0;
   p.ksplit = SKV ? ksplit : 1;
+  // Every variant exists for the plain GEMM (the one that can split K); the epilogue families that cannot (QKV + RoPE, SwiGLU, GELU) get the
+  // variants whose numbers are on record for them (EXPERIMENTS.md, round 5) - each instantiation is 2-3 s of compile time in the lab object.
+  constexpr bool ALL = EPI == EPI_PLAIN && ACT == 0, MOST = EPI != EPI_PLAIN;
   switch (variant) {
     case 0: return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 2, 0, SKV>(p, stream);
-    case 1: return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 3, 0, SKV>(p, stream);
-    case 2: return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 4, 0, SKV>(p, stream);
     case 3: return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 2, 0, SKV>(p, stream);
     case 4: return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 3, 0, SKV>(p, stream);
-    case 5: return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 3, 0, SKV>(p, stream);
     case 6: return launch_gemm<2, 4, 2, 2, EPI, ACT, false, 3, 0, SKV>(p, stream);
-    case 7: return launch_gemm<2, 2, 2, 2, EPI, ACT, false, 4, 0, SKV>(p, stream);
-    case 8: return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 2, 0, SKV>(p, stream);
-    case 9: return launch_gemm<2, 4, 2, 2, EPI, ACT, false, 4, 0, SKV>(p, stream);
-    case 10: return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
-    case 11: return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
-    case 12: return launch_gemm<8, 4, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
-    case 13: return launch_gemm<8, 4, 1, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);     // two waves, wave tile 128 features x 64 tokens
-    case 14: return launch_gemm<8, 2, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
-    case 15:
-      if constexpr (EPI != EPI_QKV_ROPE8) return launch_gemm<4, 4, 2, 4, EPI, ACT, false, 2, 1, SKV>(p, stream);
-      break;
     case 16: p.ksplit = 1; return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 2, 0, 0, 2>(p, stream);
-    case 17: p.ksplit = 1; return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 2, 0, 0, 2>(p, stream);
-    case 18: p.ksplit = 1; return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 2, 0, 0, 2>(p, stream);
-    case 19: p.ksplit = 1; return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 2, 0, 0, 3>(p, stream);
-    case 20: p.ksplit = 1; return launch_gemm<2, 2, 2, 2, EPI, ACT, false, 2, 0, 0, 4>(p, stream);
+  }
+  if constexpr (ALL || MOST) {
+    switch (variant) {
+      case 1: return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 3, 0, SKV>(p, stream);
+      case 2: return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 4, 0, SKV>(p, stream);
+      case 5: return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 3, 0, SKV>(p, stream);
+      case 7: return launch_gemm<2, 2, 2, 2, EPI, ACT, false, 4, 0, SKV>(p, stream);
+      case 8: return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 2, 0, SKV>(p, stream);
+      case 9: return launch_gemm<2, 4, 2, 2, EPI, ACT, false, 4, 0, SKV>(p, stream);
+      case 10: return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
+      case 11: return launch_gemm<4, 3, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
+      case 17: p.ksplit = 1; return launch_gemm<4, 4, 2, 2, EPI, ACT, false, 2, 0, 0, 2>(p, stream);
+    }
+  }
+  if constexpr (ALL) {
+    switch (variant) {
+      case 12: return launch_gemm<8, 4, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
+      case 13: return launch_gemm<8, 4, 1, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);     // two waves, wave tile 128 features x 64 tokens
+      case 14: return launch_gemm<8, 2, 2, 2, EPI, ACT, false, 2, 1, SKV>(p, stream);
+      case 15: return launch_gemm<4, 4, 2, 4, EPI, ACT, false, 2, 1, SKV>(p, stream);
+      case 18: p.ksplit = 1; return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 2, 0, 0, 2>(p, stream);
+      case 19: p.ksplit = 1; return launch_gemm<4, 2, 2, 2, EPI, ACT, false, 2, 0, 0, 3>(p, stream);
+      case 20: p.ksplit = 1; return launch_gemm<2, 2, 2, 2, EPI, ACT, false, 2, 0, 0, 4>(p, stream);
+    }
   }
   return AKI_ERR_UNSUPPORTED;
 }
