@@ -256,6 +256,8 @@ def load_lab() -> C.CDLL:
     lib.aki_lab_set_chain_stamps.argtypes = [C.c_void_p, C.c_int]
     lib.aki_lab_set_chain_lds.restype = None
     lib.aki_lab_set_chain_lds.argtypes = [C.c_int]
+    lib.aki_lab_set_slice_major.restype = None
+    lib.aki_lab_set_slice_major.argtypes = [C.c_int]
     lib.aki_lab_set_small_m.restype = None
     lib.aki_lab_set_small_m.argtypes = [C.c_int, C.c_int]
     lib.aki_lab_set_chain_fault.restype = None

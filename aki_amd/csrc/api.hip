@@ -49,6 +49,7 @@ int mask_to_table_launch(const int64_t* mask, int B, int L, int max_rects, aki_m
 size_t linear_splitk_plan_ws_bytes(int M, int N, int K);
 #ifdef AKI_LAB_HOOKS
 extern int g_sm_variant;
+extern int g_sk_slice_major;
 extern int g_sm_ksplit;
 extern int g_force_tile;
 extern int g_deep_ring;
@@ -117,6 +118,8 @@ void aki_lab_set_gemm_tile(int mode) {
   mode &= 255;
   aki::g_force_tile = (mode >= 1 && mode <= 5) ? mode : 0;
 }
+// split-K workgroup order: 0 = tile-major (product), 1 = slice-major
+void aki_lab_set_slice_major(int on) { aki::g_sk_slice_major = on ? 1 : 0; }
 // small-M tile variant (gemm_bf16.hip: launch_variant; -1 = the planner) and its K split, for every bf16 GEMM launch
 void aki_lab_set_small_m(int variant, int ksplit) { aki::g_sm_variant = variant; aki::g_sm_ksplit = ksplit < 1 ? 1 : ksplit; }
 // 0 = product choice, 1 = 32-row attention core (two waves per SIMD), 2 = 64-row core (one wave per SIMD)

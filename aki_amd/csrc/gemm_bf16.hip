@@ -114,6 +114,7 @@ struct GemmParams {
   int ksplit;
   float* sk_part;      // [tiles][ksplit][BN * BM] f32 partial accumulators in fragment order (16 B per lane: coalesced)
   size_t sk_bytes;     // bytes behind sk_part (host side: does the planned split fit?)
+  int sk_slice_major;  // workgroup order: every tile of slice 0, then slice 1, ... (see the kernel)
   unsigned* sk_cnt;    // [tiles] arrival tickets, zero between launches
 #ifdef AKI_LAB_HOOKS
   int probe_block;          // lab: which workgroup stamps (default 0)
@@ -182,9 +183,19 @@ __global__ __launch_bounds__(WN* WM * 64 * KG, ((NF * NT > 32 || KG > 1) ? 1 : 2
   int t = xcd_remap(blockIdx.x, gridDim.x);
   int ksp = 0, kt0 = 0;                           // split-K: this workgroup's slice of K and its first K-step
   int nk = p.K / (FP8 ? 128 : 64);
-  if constexpr (SK) {                             // the slices of a tile are neighbours in the remapped order: same XCD, same L2
-    ksp = t % p.ksplit;
-    t /= p.ksplit;
+  if constexpr (SK) {
+    // tile-major (product): the slices of a tile are neighbours in the remapped order - same XCD, same L2.  slice-major (lab): all tiles of slice 0,
+    // then slice 1, ... - an XCD then reads one or two K slices of the activation instead of all of them (for `down` at M = 655 the activation crosses
+    // the fabric 8 times: 86 MB beside 50 MB of weights).  Measured (tools/attic/slice_major_ab.py): equal at M = 655 (36.6 / 58.5 vs 37.0 / 59.2 us),
+    // 19-28 % SLOWER at M = 207 (28.5 / 48.4 vs 24.0 / 37.9): the partial tiles of a fold then come from other XCDs.
+    if (p.sk_slice_major) {
+      const int tiles = gridDim.x / p.ksplit;
+      ksp = t / tiles;
+      t -= ksp * tiles;
+    } else {
+      ksp = t % p.ksplit;
+      t /= p.ksplit;
+    }
     kt0 = ksp * nk / p.ksplit;
     nk = (ksp + 1) * nk / p.ksplit - kt0;
   }
@@ -1296,12 +1307,13 @@ __global__ __launch_bounds__(WN* WM * 64 * KG, ((NF * NT > 32 || KG > 1) ? 1 : 2
 #undef AKI_WG_STAMP
 
 #ifdef AKI_LAB_HOOKS
+int g_sk_slice_major = 0;                            // set by aki_lab_set_slice_major (lab A/B of the split-K workgroup order)
 int g_sm_variant = -1, g_sm_ksplit = 1;              // set by aki_lab_set_small_m: force a small-M tile variant (launch_variant) and its K split
 int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0;   // set by aki_lab_set_gemm_tile (lab build only); g_pipe: 0 off, 1 on, 2 on without the residual prefetch
 long long* g_clock_probe = nullptr;                  // set by aki_lab_set_clock_probe
 int g_probe_block = 0;                               // set by aki_lab_set_probe_block
 #else
-static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0, g_sm_variant = -1, g_sm_ksplit = 1;
+static constexpr int g_force_tile = 0, g_deep_ring = 1, g_pipe = 1, g_deepx = 0, g_sm_variant = -1, g_sm_ksplit = 1, g_sk_slice_major = 0;
 #endif
 
 template <int NF, int NT, int WN, int WM, int EPI, int ACT = 0, bool FP8 = false, int NST = 2, int PIPE = 0, int SK = 0, int KG = 1>
@@ -1326,6 +1338,7 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.probe_block = g_probe_block;
 #endif
   const int slices = SK ? (p.ksplit > 1 ? p.ksplit : (p.ksplit = 1)) : 1;
+  p.sk_slice_major = g_sk_slice_major;
   if (KG > 1 && (p.K / 64) % KG) return AKI_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((gemm_bf16_kernel<NF, NT, WN, WM, EPI, ACT, FP8, NST, PIPE, SK, KG>), dim3(p.tiles_m * p.tiles_n * slices), dim3(WN * WM * 64 * KG), SMEM, stream, p);
   AKI_LAUNCH_CHECK();
