@@ -868,6 +868,21 @@ __global__ __launch_bounds__(PICK_THREADS) void greedy_pick_kernel(const PickPar
   __shared__ int s_i[PICK_THREADS / 64];
   __shared__ int64_t s_next;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // What the bookkeeping needs does not depend on the argmax: thread 0 requests it BEFORE the scan, so that behind the scan only stores are
+  // left (it used to be a chain of five dependent round trips behind the reduction, about a third of the launch).
+  bool was_done = false;
+  int len0 = 0, start0 = 0;
+  int64_t eos4[4] = {-1, -1, -1, -1};                        // token ids are >= 0: -1 matches nothing
+  if (tid == 0) {
+    was_done = p.done != nullptr && p.done[b] != 0;
+    if (p.cache_len != nullptr) {
+      len0 = p.cache_len[b];
+      if (p.start_len) start0 = p.start_len[b];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < p.n_eos) eos4[i] = p.eos[i];
+  }
   const bf16_t* row = p.logits + (size_t)b * p.ld;
   float best = -INFINITY;
   int bi = 0x7fffffff;
@@ -906,19 +921,18 @@ __global__ __launch_bounds__(PICK_THREADS) void greedy_pick_kernel(const PickPar
 #pragma unroll
     for (int w = 1; w < PICK_THREADS / 64; ++w)
       if (pick_better(s_v[w], s_i[w], best, bi)) { best = s_v[w]; bi = s_i[w]; }
-    const bool was_done = p.done != nullptr && p.done[b] != 0;
     const int64_t nxt = was_done ? p.pad : (int64_t)bi;
     int t = 0;
     if (p.cache_len != nullptr) {
-      t = p.cache_len[b] + p.advance - (p.start_len ? p.start_len[b] : 0);
-      if (p.advance) p.cache_len[b] += 1;
+      t = len0 + p.advance - start0;
+      if (p.advance) p.cache_len[b] = len0 + 1;
     }
     if (p.tokens != nullptr && t >= 0 && t < p.tokens_ld) p.tokens[(size_t)b * p.tokens_ld + t] = nxt;
     p.ids[b] = nxt;
     s_next = nxt;
     if (p.done != nullptr && !was_done) {
-      bool hit = false;
-      for (int i = 0; i < p.n_eos; ++i) hit = hit || p.eos[i] == nxt;
+      bool hit = eos4[0] == nxt || eos4[1] == nxt || eos4[2] == nxt || eos4[3] == nxt;
+      for (int i = 4; i < p.n_eos; ++i) hit = hit || p.eos[i] == nxt;
       if (hit) {
         p.done[b] = 1;
         if (p.done_at) p.done_at[b] = t;

@@ -117,12 +117,14 @@ struct ChainParams {
   const bf16_t* h_in; bf16_t* h_out;
   const float* cos; const float* sin; const int* cache_len; const uint64_t* vbits; int nwords;
   int d, H, F, cap, S, T; float scale, eps;
-  unsigned* sync;         // [n_layers][CH_PHASES][CH_SYNC_WORDS], then [n_layers][H] attention tickets: zeroed by the launch function
+  unsigned* sync;         // [n_layers][CH_PHASES][CH_SYNC_WORDS], then [n_layers][H] attention tickets: all zero when the call starts (two sets)
   unsigned* attn_cnt;     // a ticket per (layer, head): nothing is re-armed inside the launch
   unsigned* head_sync;    // [n_layers][H][2 lines]: arrivals of the 96 / rows-per-workgroup x 3 qkv workgroups that produce head h's q, k, v and
                           // the head's READY flag (qkv_by_head): an attention item waits for ITS head's 18 producers, not for the phase's 576
   int qkv_by_head;        // wgs per (section, head) of the qkv phase when its workgroups are laid out head-major, else 0 (one flag for the phase)
-  unsigned* err;          // sticky error word (outside the zeroed block)
+  unsigned* err;          // sticky error word (outside the counter sets)
+  unsigned* epoch;        // calls completed on this workspace: its parity says which of the TWO counter sets this call uses (see the kernel)
+  int cnt_words;          // 4-byte words of one counter set; sync / head_sync / attn_cnt point into set 0
   bf16_t* qkv; bf16_t* attn_o; bf16_t* h1; bf16_t* act; bf16_t* hbuf;   // hand-off vectors (copy 0); hbuf = 2 x d
   int rep_stride;         // elements between the copies of a hand-off vector
   float* part;            // [H][S][CH_PSTRIDE]
@@ -181,7 +183,7 @@ __device__ __forceinline__ void chain_wait(const ChainParams& p, unsigned* sync,
 
 // Arrival of producer `idx` of `n` (wave 0, after the outputs are at the coherence point): its shard; the arriver that completes
 // a shard adds to the top counter; the one that completes the top counter raises every READY flag (32 lanes, one store each).
-__device__ __forceinline__ void chain_arrive(unsigned* sync, int idx, int n, int lane) {
+__device__ __forceinline__ unsigned chain_arrive(unsigned* sync, int idx, int n, int lane) {
   unsigned done = 0;
   if (lane == 0) {
     if (n <= 64) {     // few producers (the 32 head mergers): straight to the top counter - one memory round trip less on the edge
@@ -195,6 +197,7 @@ __device__ __forceinline__ void chain_arrive(unsigned* sync, int idx, int n, int
   }
   done = __shfl(done, 0);
   if (done && lane < CH_FLAGS) __hip_atomic_store(sync + (CH_SHARDS + 1 + lane) * 32, 1u, AKI_RLX_AGENT);
+  return done;             // 1 in the wave that completed the phase
 }
 
 // Every storing wave has drained (vmcnt(0)) before the barrier; wave 0 signals.
@@ -212,7 +215,7 @@ __device__ __forceinline__ void chain_publish(unsigned* sync, int idx, int n) {
 // ran at exactly 6.3 TB/s / 1.15 with the dependency waits switched off (tools/decode_chain_ab.py).  Batch 0 is loaded before the
 // wait; batch b+1 as soon as the dot products have released the registers of batch b, under its reduction and epilogue.
 template <int NR, int KC, bool SWIGLU, bool NORM, bool W8, int NB, int PF>
-__device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_wg, const void* w, const float* w_scale, int K, int n_out,
+__device__ __forceinline__ unsigned chain_gemv(const ChainParams& p, int wg, int n_wg, const void* w, const float* w_scale, int K, int n_out,
                                            const bf16_t* x, int x_rep, const bf16_t* norm_w, const bf16_t* residual, int res_rep, bf16_t* y,
                                            int y_reps, unsigned* wait_sync, unsigned* done_sync, unsigned code, char* sx, float* s_red,
                                            int head_per = 0, unsigned* head_sync = nullptr) {
@@ -381,15 +384,17 @@ __device__ __forceinline__ void chain_gemv(const ChainParams& p, int wg, int n_w
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chain_publish, with a stamp between the drain and the arrival
   __syncthreads();
   AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 4);
+  unsigned completed = 0;
   if (head_per > 0) {             // one counter per head: 3 x head_per arrivals, the last one raises the head's flag
     if (threadIdx.x == 0) {
       unsigned* hs = head_sync + (size_t)head_of_wg * 64;
       if (__hip_atomic_fetch_add(hs, 1u, AKI_RLX_AGENT) + 1u == (unsigned)(3 * head_per)) __hip_atomic_store(hs + 32, 1u, AKI_RLX_AGENT);
     }
   } else if (threadIdx.x < 64) {
-    chain_arrive(done_sync, wg, n_wg, threadIdx.x);
+    completed = chain_arrive(done_sync, wg, n_wg, threadIdx.x);
   }
   AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 5);
+  return completed;        // wave 0: 1 when this workgroup's arrival completed the phase
 }
 
 // ---- the attention phase: decode.hip's decode_attn_split_kernel<true>, one (head, split) item per WAVE ---------------------
@@ -639,18 +644,31 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
 #endif
 }
 
-__global__ __launch_bounds__(256) void chain_zero_kernel(u32x4* p, int n16) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n16) p[i] = u32x4{0u, 0u, 0u, 0u};
-}
-
 // KCD = d / 512, KCF = F / 512 (bf16) - the register arrays are static; W8 halves both.
 template <int KCD, int KCF, bool W8, int NBQ, int NBO, int NBG, int NBD, int PFQ = 1, int PFO = 1, int PFG = 1, int PFDN = 1, int OCC = 1>
-__global__ __launch_bounds__(256, OCC) void decode_chain_kernel(const ChainParams p) {
+__global__ __launch_bounds__(256, OCC) void decode_chain_kernel(const ChainParams p0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_red = (float*)(smem + 16384);
   char* sx = smem;
   const int bid = blockIdx.x;
+  // ---- the counters of this call: one of two sets, by the parity of the calls completed on this workspace --------------------
+  // Every polled word must be zero when a call starts.  Until round 5 a small kernel in front of the chain zeroed them (4.7-5.3 us of a
+  // 1637 us token, profiles/r05_decode_token_trace.txt).  Now call k uses set k & 1 and zeroes the OTHER set for call k + 1 (a store or two per
+  // workgroup, any time during the call: nobody polls that set now - the previous call on this workspace has ended, it is stream-ordered).  k lives
+  // in the workspace: the workgroup that completes the LAST phase writes k + 1.  Every workgroup of the launch has read k by then: the last
+  // phase completes only after every phase before it has, and a workgroup arrives at its phase's counter after all it does with k.  (After a
+  // give-up - sticky error word - the sets are in no defined state: the caller zero-fills the workspace before using it again.)  The word and
+  // the sets are read and written at agent scope or across a kernel boundary only.
+  ChainParams p = p0;
+  const unsigned ep = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p0.epoch, AKI_RLX_AGENT));
+  {
+    const size_t cur = (ep & 1u) ? (size_t)p0.cnt_words : 0;
+    p.sync = p0.sync + cur; p.head_sync = p0.head_sync + cur; p.attn_cnt = p0.attn_cnt + cur;
+    u32x4* other = (u32x4*)(p0.sync + ((size_t)p0.cnt_words - cur));
+    const int n16 = p0.cnt_words / 4, per = (n16 + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int z_end = min(n16, (bid + 1) * per);
+    for (int i = bid * per + (int)threadIdx.x; i < z_end; i += 256) other[i] = u32x4{0u, 0u, 0u, 0u};
+  }
   const int layer = bid / p.wg_layer;
   int r = bid - layer * p.wg_layer;
   const aki_decode_chain_layer& ly = p.layers[layer];
@@ -689,8 +707,9 @@ __global__ __launch_bounds__(256, OCC) void decode_chain_kernel(const ChainParam
     return;
   }
   r -= p.n_gu;
-  chain_gemv<NRF, KF, false, false, W8, NBD, PFDN>(p, r, p.n_down, ly.w_down, ly.s_down, p.F, p.d, p.act, 1, nullptr, p.h1, 1, h2, last ? 1 : CH_XREP,
-                                         sy + 3 * CH_SYNC_WORDS, sy + 4 * CH_SYNC_WORDS, code | 5u, sx, s_red);
+  const unsigned fin = chain_gemv<NRF, KF, false, false, W8, NBD, PFDN>(p, r, p.n_down, ly.w_down, ly.s_down, p.F, p.d, p.act, 1, nullptr, p.h1, 1, h2,
+                                                                         last ? 1 : CH_XREP, sy + 3 * CH_SYNC_WORDS, sy + 4 * CH_SYNC_WORDS, code | 5u, sx, s_red);
+  if (last && fin && threadIdx.x == 0) __hip_atomic_store(p.epoch, ep + 1u, AKI_RLX_AGENT);      // the call is complete: the next one takes the other set
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -712,11 +731,12 @@ static void chain_split(int H, int cap, int max_keys, int& S, int& T) {
   S = (tiles + T - 1) / T;
 }
 
-size_t decode_chain_err_offset(int n_layers, int H) { return chain_cnt_bytes(n_layers, H); }
+// workspace: counter set 0 | counter set 1 | 256 bytes: the sticky error word (+0) and the count of completed calls (+64) | hand-off vectors | partials
+size_t decode_chain_err_offset(int n_layers, int H) { return 2 * chain_cnt_bytes(n_layers, H); }
 
 size_t decode_chain_ws_bytes(int n_layers, int d, int H, int F, int cap) {
   const size_t tiles = ((size_t)cap + 63) / 64;
-  return chain_cnt_bytes(n_layers, H) + 256 /* error word */ + chain_vec_elems(d, H, F) * 2 * CH_XREP + (size_t)H * tiles * CH_PSTRIDE * 4;
+  return 2 * chain_cnt_bytes(n_layers, H) + 256 /* error word, call count */ + chain_vec_elems(d, H, F) * 2 * CH_XREP + (size_t)H * tiles * CH_PSTRIDE * 4;
 }
 
 int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
@@ -737,15 +757,17 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   p.sync = (unsigned*)ws;
   p.head_sync = p.sync + (size_t)a->n_layers * CH_PHASES * CH_SYNC_WORDS;          // 128-byte lines first, the tickets behind them
   p.attn_cnt = p.head_sync + (size_t)a->n_layers * H * 64;
-  p.err = (unsigned*)(ws + cb);
-  bf16_t* v = (bf16_t*)(ws + cb + 256);
+  p.err = (unsigned*)(ws + 2 * cb);
+  p.epoch = p.err + 16;
+  p.cnt_words = (int)(cb / 4);
+  bf16_t* v = (bf16_t*)(ws + 2 * cb + 256);
   p.rep_stride = (int)chain_vec_elems(d, H, F);
   p.qkv = v; v += 3 * H * 96;
   p.attn_o = v; v += H * 96;
   p.h1 = v; v += d;
   p.act = v; v += F;
   p.hbuf = v;
-  p.part = (float*)(ws + cb + 256 + chain_vec_elems(d, H, F) * 2 * CH_XREP);
+  p.part = (float*)(ws + 2 * cb + 256 + chain_vec_elems(d, H, F) * 2 * CH_XREP);
   const int rd = w8 ? 4 : 2, rf = w8 ? 2 : 1;     // rows per wave and batch (see the kernel)
   p.nbq = w8 ? 1 : CH_NBQ; p.nbo = w8 ? 1 : CH_NBO; p.nbg = w8 ? 1 : CH_NBG; p.nbd = w8 ? 1 : CH_NBD;
 #ifdef AKI_LAB_HOOKS
@@ -776,12 +798,12 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   if (g_chain_fault_code != 0u && g_chain_fault_skip-- == 0) { p.fault_code = g_chain_fault_code; g_chain_fault_code = 0; }     // one shot
 #endif
   AKI_CLEAR_ERR();
-  // Every polled word is zeroed by the call itself, by a KERNEL of this library.  hipMemsetAsync was used first: eager calls
-  // were fine, but as a captured memset node (ROCm 7.2, 1 MB) it left a constant non-zero word pattern in the block in some
-  // processes - every READY flag then read "set", no workgroup ever waited, and the replayed step ran at the speed of the bare
-  // weight stream (1.28 ms) with wrong logits, while the 2-layer graph test of the time happened to pass.
-  // tests/test_decode_gpu.py now compares a FULL-DEPTH graph replay with the five-launch path, and every timing tool checks logits.
-  hipLaunchKernelGGL(chain_zero_kernel, dim3((unsigned)((cb / 16 + 255) / 256)), dim3(256), 0, stream, (u32x4*)ws, (int)(cb / 16));
+  // Every polled word is zero when the kernel starts: the caller zero-fills the workspace once, and each call leaves the counter set of the NEXT
+  // call zeroed (see the top of the kernel).  History: hipMemsetAsync in front of every call was used first - eager calls were fine, but as a
+  // captured memset node (ROCm 7.2, 1 MB) it left a constant non-zero word pattern in the block in some processes: every READY flag then read
+  // "set", no workgroup ever waited, and the replayed step ran at the speed of the bare weight stream (1.28 ms) with wrong logits, while the
+  // 2-layer graph test of the time happened to pass.  tests/test_decode_gpu.py compares a FULL-DEPTH graph replay with the five-launch path,
+  // and every timing tool checks logits.  A zeroing kernel of this library in front of every call came next (4.7-5.3 us per token).
   int SMEM = 16384 + 64;                 // x (<= 8192 bf16) + the norm's partial sums; the attention phase carves 4 x 3 KiB of it
 #ifdef AKI_LAB_HOOKS
   SMEM += g_chain_lds_pad;               // lab: unused LDS that limits the workgroups resident per CU (160 KiB / SMEM)

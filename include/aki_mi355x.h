@@ -374,10 +374,12 @@ int aki_decode_linear_fwd(const aki_linear_args* args, const void* rms_weight, f
  *   cache_len     device int32 [1]: tokens cached so far = the new token's position and append index (not advanced here)
  *   max_keys      host upper bound of cache_len + 1 that sizes the attention split (0 = capacity)
  *   workspace     aki_decode_chain_workspace_bytes(...) bytes, 256-byte aligned, ZERO-FILLED ONCE by the caller before its
- *                 first use; the call re-zeroes its own arrival counters (a small kernel launched ahead of the chain).  The 32-bit
- *                 word at aki_decode_chain_error_offset(...) is sticky: 0 = every wait of every call so far was satisfied;
- *                 otherwise (layer << 8 | phase) of a wait that gave up after its bounded spin (the launch then drains and
- *                 h_out is garbage) - read it after synchronising.
+ *                 first use and owned by the calls from then on (one call in flight per workspace): it holds two sets of arrival
+ *                 counters and the count of completed calls - a call uses the set of its parity and leaves the other one zeroed
+ *                 for its successor, so a decode step is ONE launch.  The 32-bit word at aki_decode_chain_error_offset(...) is
+ *                 sticky: 0 = every wait of every call so far was satisfied; otherwise (layer << 8 | phase) of a wait that gave
+ *                 up after its bounded spin (the launch then drains and h_out is garbage) - read it after synchronising, and
+ *                 zero-fill the workspace again before any further call on it.
  * Supported: Dh = 96, d = H * 96 = 3072, F = 8192 (Phi-3.5-mini); AKI_ERR_UNSUPPORTED otherwise (use the per-layer calls). */
 typedef struct {
   const void* w_qkv;
