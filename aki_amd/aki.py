@@ -274,7 +274,7 @@ class AKI(VLMWithLanguageStream):
                     if stepper is not None:
                         stepper.step_greedy()
                     else:
-                        # One sequence on the one-launch decode chain is four launches per token (counter zeroing, chain, head, pick + embedding):
+                        # One sequence on the one-launch decode chain is three launches per token (chain, head, pick + embedding):
                         # the host runs far ahead of them and a hipGraph would only add its capture (about 12 ms per call, 7 tokens' worth).
                         # Anything else - batches, the five-launch-per-layer path - is ~165 launches per token and is captured after its first
                         # eager step.

@@ -142,6 +142,7 @@ def _stats_ws(M: int, n_out: int, dev) -> torch.Tensor:
 
 _SPLITK_WS = {}
 SPLITK_WS_MIN_BYTES = 0          # tools / tests: a floor for the split-K workspace (the lab library's forced splits need more than the planner's)
+SPLITK_MAX_M = 2048              # rows above which linear() hands no split-K workspace over (the planner splits below 1024 only; tools raise it)
 
 
 def _splitk_ws(M: int, N: int, K: int, dev) -> Optional[torch.Tensor]:
@@ -267,7 +268,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         sws = _stats_ws(M, n_out, dev)
         a.stats_rstd, a.stats_mean, a.stats_eps = _ptr(stats_out.rstd), _ptr(stats_out.mean), float(stats_eps)
         a.stats_workspace, a.stats_workspace_bytes = sws.data_ptr(), sws.numel()
-    if act == ACT_NONE and M <= 2048 and x.dtype == torch.bfloat16:
+    if act == ACT_NONE and M <= SPLITK_MAX_M and x.dtype == torch.bfloat16:
         sk = _splitk_ws(M, N, K, dev)
         if sk is not None:
             a.splitk_workspace, a.splitk_workspace_bytes = sk.data_ptr(), sk.numel()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Kernel timeline of ONE greedy token of the SHIPPED path - AKI.generate on the one-launch decode chain: counter zeroing, chain, head GEMV,
+# Kernel timeline of ONE greedy token of the SHIPPED path - AKI.generate on the one-launch decode chain: chain, head GEMV,
 # aki_greedy_pick_embed (pick + the next token's embedding row), issued eagerly - on the GPU box (run through gpurun):
 #   bash tools/profile_generate_token.sh <tag>  -> gpurun_out/<tag>_decode_token_trace.txt, gpurun_out/<tag>_decode_kernels.txt
 set -u

@@ -34,6 +34,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--M", default="655,207")
     ap.add_argument("--siglip", action="store_true")
+    ap.add_argument("--siglip-m", type=int, default=576, help="rows of the SigLIP cases: 576 = one 336 px image, 4608 = the headline batch of 8")
     ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8,9")
     ap.add_argument("--splits", default="1,2,3,4,6,8")
     ap.add_argument("--only", default="", help="substring filter on the case names")
@@ -41,6 +42,7 @@ def main():
     lib = _lib.load_lab()
     _lib._lib = lib
     ops.SPLITK_WS_MIN_BYTES = 512 << 20
+    ops.SPLITK_MAX_M = 1 << 20
     variants = [int(v) for v in a.variants.split(",")]
     splits = [int(v) for v in a.splits.split(",")]
     g = torch.Generator(device=dev).manual_seed(0)
@@ -78,7 +80,7 @@ def main():
                         (f"M{M} gate_up N16384 K3072", gateup, lambda: yg.float(), False, 2.0 * M * 2 * F * d), (f"M{M} down N3072 K8192", down, o_y, True, 2.0 * M * d * F)]
             cases += mk()
     if a.siglip:
-        M, E, I, Ip = 576, 1152, 4304, 4352
+        M, E, I, Ip = a.siglip_m, 1152, 4304, 4352
         x, r = [rnd(M, E) for _ in range(NB)], [rnd(M, E) for _ in range(NB)]
         a1 = [torch.zeros(M, Ip, device=dev, dtype=torch.bfloat16) for _ in range(NB)]
         for t_ in a1:
@@ -103,8 +105,8 @@ def main():
         def s2(i):
             ops.linear(a1[i], w2[i], bias=bE, residual=r[i], stats_out=st, stats_eps=1e-6, out=y)
         o_ys = lambda: torch.cat([y.flatten().float(), st.rstd, st.mean])
-        cases += [("siglip M576 qkv N3456 K1152", sq, lambda: y3.float(), False, 2.0 * M * 3 * E * E), ("siglip M576 out N1152 K1152", so, o_ys, True, 2.0 * M * E * E),
-                  ("siglip M576 fc1 N4304 K1152", s1, lambda: y1[:, :I].float(), False, 2.0 * M * I * E), ("siglip M576 fc2 N1152 K4352", s2, o_ys, True, 2.0 * M * E * Ip)]
+        cases += [(f"siglip M{M} qkv N3456 K1152", sq, lambda: y3.float(), False, 2.0 * M * 3 * E * E), (f"siglip M{M} out N1152 K1152", so, o_ys, True, 2.0 * M * E * E),
+                  (f"siglip M{M} fc1 N4304 K1152", s1, lambda: y1[:, :I].float(), False, 2.0 * M * I * E), (f"siglip M{M} fc2 N1152 K4352", s2, o_ys, True, 2.0 * M * E * Ip)]
     if a.only:
         cases = [c for c in cases if a.only in c[0]]
     print(f"# {torch.cuda.get_device_name(0)}; cold operands; us per launch (TF/s); '!' = output differs from the planner's beyond bf16 rounding, "
