@@ -338,11 +338,19 @@ static int launch_gemv(const GemvParams& p, hipStream_t stream) {
 // a step take the first / second 16 bytes of both operands (any k order is fine as long as A and B agree).  Partial tiles
 // of the KS waves meet in LDS; wave 0 runs the epilogue.  SWIGLU: the wave carries the gate tile and the up tile.
 // ------------------------------------------------------------------------------------------------------------
-template <int KS, bool SWIGLU, int FT>
+// NORM (M <= 8, the decode step's pre-norms): the x rows are RMS-normalised on their way into LDS - wave w takes rows w, w + KS, ... whole, with
+// the rounding points of norm_bf16_kernel<true> (HF Phi3RMSNorm: weight * (x * rstd).to(bf16)) - and the B fragments come from there instead of
+// L2; the weight loads of the first steps are requested BEFORE that prologue, so it runs under their round trip.  It replaces a 4.9 us norm launch
+// in front of the qkv and gate_up GEMMs of every layer of a batched decode step (65 of 231 launches, 9 % of the step at batch 8).
+template <int KS, bool SWIGLU, int FT, bool NORM = false>
 __global__ __launch_bounds__(KS * 64) void skinny_gemm_bf16_kernel(const GemvParams p) {
   constexpr int NS = FT * (SWIGLU ? 2 : 1);          // weight streams per wave, all fed by one x fragment
   constexpr int UN = NS >= 4 ? 2 : (NS == 2 ? 4 : 8);   // steps of 64 k whose loads are issued together (<= 20 loads in flight)
-  __shared__ float red[KS][NS][256];
+  __shared__ float red_st[NORM ? 1 : KS][NS][256];
+  extern __shared__ __attribute__((aligned(16))) char s_xn[];      // NORM: the normalised rows, (K * 2 + 16) bytes apart (the pad spreads the 16 rows over the banks)
+  // NORM: the partial tiles meet in the rows' LDS once every wave is done with them - 49 KB per workgroup instead of 57: three workgroups per CU,
+  // and the 576 of the qkv GEMM are resident at once (at two per CU the last 64 were a second round: + 3 us)
+  float (*red)[NS][256] = NORM ? (float (*)[NS][256])s_xn : red_st;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kg = lane >> 4;
   const int n_out = SWIGLU ? p.N / 2 : p.N;
   const int f0 = blockIdx.x * 16 * FT;
@@ -354,35 +362,97 @@ __global__ __launch_bounds__(KS * 64) void skinny_gemm_bf16_kernel(const GemvPar
     wp[t] = p.w + (size_t)frow * p.ldw + kbeg + 16 * kg;
     if (SWIGLU) wp[FT + t] = p.w + (size_t)(n_out + frow) * p.ldw + kbeg + 16 * kg;
   }
-  const bf16_t* xr = p.x + (size_t)min(l15, p.M - 1) * p.ldx + kbeg + 16 * kg;
+  const int xrow = min(l15, p.M - 1);
+  const bf16_t* xr = p.x + (size_t)xrow * p.ldx + kbeg + 16 * kg;
+  const int xs_pitch = p.K * 2 + 16;
+  const char* xs = s_xn + (size_t)xrow * xs_pitch + (size_t)(kbeg + 16 * kg) * 2;
   f32x4 acc[NS];
 #pragma unroll
   for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nsteps = Kw / 64;
   int it = 0;
+  auto load_w = [&](int step, u32x4 (&w2)[NS][2]) {
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+      w2[t][0] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)step * 64));
+      w2[t][1] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)step * 64 + 8));
+    }
+  };
+  auto load_x = [&](int step, u32x4 (&x2)[2]) {
+    if constexpr (NORM) {
+      x2[0] = *(const u32x4*)(xs + (size_t)step * 128);
+      x2[1] = *(const u32x4*)(xs + (size_t)step * 128 + 16);
+    } else {
+      x2[0] = *(const u32x4*)(xr + (size_t)step * 64);
+      x2[1] = *(const u32x4*)(xr + (size_t)step * 64 + 8);
+    }
+  };
+  auto mma_step = [&](const u32x4 (&w2)[NS][2], const u32x4 (&x2)[2]) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const bf16x8 xb = __builtin_bit_cast(bf16x8, x2[hh]);
+#pragma unroll
+      for (int t = 0; t < NS; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2[t][hh]), xb, acc[t], 0, 0, 0);
+    }
+  };
+  if constexpr (NORM) {
+    constexpr int UP = NS >= 2 ? 3 : 4;               // steps whose weights are requested before the prologue (more cost registers: the 576 workgroups of qkv want three per CU = 84 VGPRs)
+    u32x4 wpre[UP][NS][2];
+    const bool pre = nsteps >= UP;
+    if (pre) {
+#pragma unroll
+      for (int u = 0; u < UP; ++u) load_w(u, wpre[u]);
+    }
+    const int nchunk = p.K / 8;
+    for (int m = wave; m < p.M; m += KS) {             // a wave normalises whole rows: no cross-wave reduction
+      const bf16_t* xm = p.x + (size_t)m * p.ldx;
+      char* dst = s_xn + (size_t)m * xs_pitch;
+      float ss = 0.f;
+      for (int c = lane; c < nchunk; c += 64) {
+        const u32x4 v = *(const u32x4*)(xm + (size_t)c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = bf16_lo(v[e]), hi = bf16_hi(v[e]);
+          ss = __builtin_fmaf(lo, lo, ss);
+          ss = __builtin_fmaf(hi, hi, ss);
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+      const float r = rsqrtf(ss / (float)p.K + p.norm_eps);
+      for (int c = lane; c < nchunk; c += 64) {
+        const u32x4 v = *(const u32x4*)(xm + (size_t)c * 8);            // second read: an L1 / L2 hit
+        const u32x4 g = *(const u32x4*)(p.norm_w + (size_t)c * 8);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack_bf16x2(round_bf16(bf16_lo(v[e]) * r) * bf16_lo(g[e]), round_bf16(bf16_hi(v[e]) * r) * bf16_hi(g[e]));
+        *(u32x4*)(dst + (size_t)c * 16) = o;
+      }
+    }
+    __syncthreads();
+    if (pre) {
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        u32x4 x2[2];
+        load_x(u, x2);
+        mma_step(wpre[u], x2);
+      }
+      it = UP;
+    }
+  }
   auto run = [&](auto un_c) {
     constexpr int U = decltype(un_c)::value;
     for (; it + U <= nsteps; it += U) {
       u32x4 wa[U][NS][2], xa[U][2];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int t = 0; t < NS; ++t) {
-          wa[u][t][0] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)(it + u) * 64));
-          wa[u][t][1] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)(it + u) * 64 + 8));
-        }
-        xa[u][0] = *(const u32x4*)(xr + (size_t)(it + u) * 64);
-        xa[u][1] = *(const u32x4*)(xr + (size_t)(it + u) * 64 + 8);
+        load_w(it + u, wa[u]);
+        load_x(it + u, xa[u]);
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const bf16x8 xb = __builtin_bit_cast(bf16x8, xa[u][hh]);
-#pragma unroll
-          for (int t = 0; t < NS; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[u][t][hh]), xb, acc[t], 0, 0, 0);
-        }
+      for (int u = 0; u < U; ++u) mma_step(wa[u], xa[u]);
     }
   };
   run(std::integral_constant<int, UN>{});          // ladder: a wave's K slice can be shorter than the deepest unroll
@@ -391,6 +461,7 @@ __global__ __launch_bounds__(KS * 64) void skinny_gemm_bf16_kernel(const GemvPar
   run(std::integral_constant<int, 1>{});
   // accumulator: lane (token = l15, features 4kg..4kg+3 of each tile); fold the KS partial tiles
   if (KS > 1) {
+    if constexpr (NORM) __syncthreads();             // every wave has read its last fragment of the rows
 #pragma unroll
     for (int t = 0; t < NS; ++t)
 #pragma unroll
@@ -427,29 +498,50 @@ __global__ __launch_bounds__(KS * 64) void skinny_gemm_bf16_kernel(const GemvPar
   }
 }
 
-template <int KS, int FT>
+template <int KS, int FT, bool NORM = false>
 static int launch_skinny(const GemvParams& p, hipStream_t stream) {
   const int n_out = p.act == AKI_ACT_SWIGLU ? p.N / 2 : p.N;
   const dim3 grid((n_out + 16 * FT - 1) / (16 * FT)), block(KS * 64);
+  constexpr size_t RED = (size_t)KS * 2 * 1024;      // the partial tiles (two streams with SwiGLU) alias the rows
+  const size_t rows = (size_t)p.M * ((size_t)p.K * 2 + 16);
+  const size_t smem = NORM ? (rows > RED ? rows : RED) : 0;
+  if constexpr (NORM) {
+    static bool set_s = false, set_p = false;
+    bool& set = p.act == AKI_ACT_SWIGLU ? set_s : set_p;
+    if (!set) {
+      const void* fn = p.act == AKI_ACT_SWIGLU ? (const void*)skinny_gemm_bf16_kernel<KS, true, FT, true> : (const void*)skinny_gemm_bf16_kernel<KS, false, FT, true>;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (8192 * 2 + 16)) != hipSuccess) return AKI_ERR_LAUNCH;
+      set = true;
+    }
+  }
   AKI_CLEAR_ERR();
-  if (p.act == AKI_ACT_SWIGLU) hipLaunchKernelGGL((skinny_gemm_bf16_kernel<KS, true, FT>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((skinny_gemm_bf16_kernel<KS, false, FT>), grid, block, 0, stream, p);
+  if (p.act == AKI_ACT_SWIGLU) hipLaunchKernelGGL((skinny_gemm_bf16_kernel<KS, true, FT, NORM>), grid, block, smem, stream, p);
+  else hipLaunchKernelGGL((skinny_gemm_bf16_kernel<KS, false, FT, NORM>), grid, block, smem, stream, p);
   AKI_LAUNCH_CHECK();
   return AKI_OK;
 }
 
 // 2 <= M <= 16; n_out, ldy, ldr multiples of 4; K a multiple of 64 (per wave).  AKI_ERR_UNSUPPORTED otherwise.
-int skinny_gemm_bf16(const aki_linear_args* a, hipStream_t stream) {
+// rms_w != NULL (M <= 8, K <= 8192): the x rows are RMS-normalised (weight rms_w [K], eps) inside the launch.
+int skinny_gemm_bf16(const aki_linear_args* a, const void* rms_w, float eps, hipStream_t stream) {
   const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
   if (a->M < 2 || a->M > 16 || a->K % 64 || (a->ldx % 8) || (a->ldw % 8) || (n_out % 4) || (a->ldy % 4) || (a->residual && (a->ldr % 4)))
     return AKI_ERR_UNSUPPORTED;
   if (a->act == AKI_ACT_SWIGLU && (a->bias || (a->N & 1))) return AKI_ERR_UNSUPPORTED;
-  if (((uintptr_t)a->x & 15) || ((uintptr_t)a->w & 15) || ((uintptr_t)a->y & 7) || ((uintptr_t)a->bias & 7)) return AKI_ERR_ALIGNMENT;
+  if (rms_w && (a->M > 8 || a->K > 8192)) return AKI_ERR_UNSUPPORTED;
+  if (((uintptr_t)a->x & 15) || ((uintptr_t)a->w & 15) || ((uintptr_t)a->y & 7) || ((uintptr_t)a->bias & 7) || ((uintptr_t)rms_w & 15)) return AKI_ERR_ALIGNMENT;
   GemvParams p = {(const bf16_t*)a->x, (const bf16_t*)a->w, (const bf16_t*)a->bias, (const bf16_t*)a->residual, (bf16_t*)a->y,
-                  nullptr, 0.f, a->M, a->N, a->K, a->ldx, a->ldw, a->ldy, a->ldr, a->res_row_mod, a->act, nullptr};
+                  (const bf16_t*)rms_w, eps, a->M, a->N, a->K, a->ldx, a->ldw, a->ldy, a->ldr, a->res_row_mod, a->act, nullptr};
   // One 16-feature tile per wave and a K split that keeps >= ~4 waves per CU.  (Two tiles per wave sharing the x fragment
   // were measured: fewer x loads, but the lost wave parallelism cost more - 3.85 vs 3.30 ms per step at batch 8.)
   const int tiles = (n_out + 15) / 16;
+  if (rms_w) {
+    // every workgroup normalises the M rows for itself: fine for the 512-1024 eight- or four-wave workgroups of qkv / gate_up, not for the 2004
+    // two-wave ones of the lm_head (measured + 29 us at M = 8): wide outputs keep the norm launch (AKI_ERR_UNSUPPORTED: the caller's choice)
+    if (tiles < 768 && a->K % 512 == 0) return launch_skinny<8, 1, true>(p, stream);
+    if (tiles < 1536 && a->K % 256 == 0) return launch_skinny<4, 1, true>(p, stream);
+    return AKI_ERR_UNSUPPORTED;
+  }
   if (tiles < 768 && a->K % 512 == 0) return launch_skinny<8, 1>(p, stream);
   if (tiles < 1536 && a->K % 256 == 0) return launch_skinny<4, 1>(p, stream);
   if (a->K % 128 == 0) return launch_skinny<2, 1>(p, stream);

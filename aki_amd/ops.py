@@ -7,6 +7,7 @@ CPU tensors or a missing library raise :class:`aki_amd._lib.AkiError`.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -585,14 +586,20 @@ def greedy_pick(logits: torch.Tensor, next_ids: torch.Tensor, pad_token_id: int 
     return next_ids
 
 
+SKINNY_NORM_FUSED = os.environ.get("AKI_SKINNY_NORM", "1") != "0"      # tools: A/B of the 2-8 row norm fusion
+
+
 def decode_linear(x: torch.Tensor, w: torch.Tensor, rms_weight: torch.Tensor, eps: float, act: int = ACT_NONE,
                   bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = act(rmsnorm(x; rms_weight, eps) W^T + bias) [+ residual] for the few rows of a decode step: one weight-streaming
-    launch when x is bf16 with <= 8 rows, otherwise the norm kernel followed by linear()."""
+    launch when x is bf16 with <= 8 rows (one row: the dot-product GEMV; 2-8 rows: the skinny MFMA GEMM, the norm in its prologue),
+    otherwise the norm kernel followed by linear()."""
     x2 = _rows2d(x)
     M, K = x2.shape
-    # one row: the fused norm + GEMV launch; 2..16 rows: the norm kernel, then the skinny MFMA GEMM inside linear()
-    if x.dtype != torch.bfloat16 or M != 1 or K > 65536 or K % 8 or x2.stride(0) % 8 or w.stride(0) % 8:
+    n_tiles = ((w.shape[0] // 2 if act == ACT_SWIGLU else w.shape[0]) + 15) // 16
+    # 2-8 rows: every workgroup normalises the rows for itself - the 2004 two-wave workgroups of an lm_head-wide output keep the norm launch
+    if (x.dtype != torch.bfloat16 or M > 8 or K > (65536 if M == 1 else 8192) or K % 8 or x2.stride(0) % 8 or w.stride(0) % 8
+            or (M > 1 and (n_tiles >= 1536 or K % 256 or not SKINNY_NORM_FUSED))):
         return linear(rmsnorm(x, rms_weight, eps), w, bias=bias, residual=residual, act=act)
     dev = _dev(x, w, rms_weight, bias, residual)
     N = w.shape[0]

@@ -333,6 +333,28 @@ def test_decode_linear_fused_rmsnorm(M, act):
     check(n(fused), n(plain).astype(np.float32), dt, "fused norm+gemv vs norm kernel + gemv", scale_atol=2.0)
 
 
+@pytest.mark.parametrize("M,N,act", [(2, 32064, "none"), (5, 20000, "none"), (8, 9216, "none"), (3, 16384, "swiglu"), (8, 16384, "swiglu"), (8, 40000, "swiglu")])
+def test_batched_decode_linear_with_the_norm_in_its_prologue(M, N, act):
+    """2-8 rows: aki_decode_linear_fwd runs the skinny MFMA GEMM with the RMSNorm in its prologue (rows normalised into LDS, HF's rounding
+    points) == the norm kernel followed by the skinny GEMM - over its K splits (8 / 4 / 2 waves per 16-feature tile) and the SwiGLU pairing."""
+    from aki_amd import ops
+    rng = gen.rng_for(f"skinnynorm{M}{N}{act}")
+    K = 3072
+    x = rng.standard_normal((M, K), dtype=np.float32) * 3.0
+    x[M - 1] *= 0.01                                        # rows of very different scale: a shared / swapped rstd would show
+    g = 1.0 + 0.1 * rng.standard_normal((K,), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) * 0.05
+    dt = torch.bfloat16
+    a = ops.ACT_SWIGLU if act == "swiglu" else ops.ACT_NONE
+    xt, wt, gt = t(x, dt), t(w, dt), t(g, dt)
+    fused = ops.decode_linear(xt, wt, gt, 1e-5, act=a)
+    xn = ops.rmsnorm(xt, gt, 1e-5)
+    plain = ops.linear(xn, wt, act=a)
+    # the normalised rows are the same bf16 values up to the summation order of the variance (one ulp of rstd): compare at the fused test's bar
+    check(n(fused), n(plain).astype(np.float32), dt, "skinny GEMM with the norm in its prologue vs norm kernel + skinny GEMM", scale_atol=2.0)
+    assert torch.equal(fused, ops.decode_linear(xt, wt, gt, 1e-5, act=a))        # and reproducible
+
+
 @pytest.mark.parametrize("B,H,cap,lens", [(3, 4, 300, [17, 200, 298]), (2, 2, 5000, [4100, 63]), (8, 32, 700, [655] * 8), (1, 32, 64, [0])])
 def test_decode_attn_fused_vs_two_kernels(B, H, cap, lens):
     """RoPE + append + split-KV attention in one launch == rope_append followed by decode_attn; caches end up identical."""
