@@ -16,7 +16,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 15
+AKI_ABI_VERSION = 16
 
 
 class AkiError(RuntimeError):
@@ -135,7 +135,7 @@ class DecodeChainArgs(C.Structure):
                 ("cache_len", C.c_void_p), ("col_valid_bits", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("n_layers", C.c_int32), ("nwords", C.c_int32), ("d", C.c_int32), ("H", C.c_int32), ("Dh", C.c_int32), ("F", C.c_int32),
                 ("capacity", C.c_int32), ("max_keys", C.c_int32), ("scale", C.c_float), ("rms_eps", C.c_float), ("dtype", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("batch", C.c_int32)]
 
 
 # name -> (restype, argtypes); also the list of symbols include/aki_mi355x.h declares
@@ -172,6 +172,8 @@ SIGNATURES = {
     "aki_decode_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p, C.c_float, C.c_void_p]),
     "aki_decode_chain_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
     "aki_decode_chain_error_offset": (C.c_size_t, [C.c_int32] * 2),
+    "aki_decode_chain_batch_workspace_bytes": (C.c_size_t, [C.c_int32] * 6),
+    "aki_decode_chain_batch_error_offset": (C.c_size_t, [C.c_int32] * 3),
     "aki_decode_chain_fwd": (C.c_int, [C.POINTER(DecodeChainArgs), C.c_void_p]),
     "aki_attn_bwd_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
     "aki_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), C.c_void_p, C.c_size_t, C.c_void_p]),

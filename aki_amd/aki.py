@@ -291,13 +291,19 @@ class AKI(VLMWithLanguageStream):
                     ok = False
                 if ok:
                     break
-                # recovery (one sequence - the chain runs no batches): back to the last verified token, then on without the chain
+                # recovery: back to the last verified token, then on without the chain.  The finished flags are rebuilt from the verified tokens
+                # (a batch can hold rows that finished before that point; one sequence would have ended the loop there)
                 t = t_ok
                 cache.cache_len.copy_(start_len + (t_ok - 1))
                 cache.host_len = host_len0 + (t_ok - 1)
                 tokens[:, t_ok:] = pad_id
-                done8.zero_()                               # the loop would have ended at a verified check had the row been finished
+                done8.zero_()
                 done_at.fill_(-1)
+                if eos_t is not None:
+                    hit = (tokens[:, :t_ok, None] == eos_t[None, None, :]).any(-1)
+                    fin = hit.any(1)
+                    done8.copy_(fin.to(torch.uint8))
+                    done_at.copy_(torch.where(fin, hit.to(torch.int32).argmax(1).to(torch.int32), torch.full_like(done_at, -1)))
                 ids.copy_(tokens[:, t_ok - 1])
                 if nxt_emb is not None:
                     nxt_emb.copy_(emb_mod(ids))

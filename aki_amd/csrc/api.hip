@@ -27,6 +27,8 @@ int rope_append_launch(const void* qkv, const float* cos, const float* sin, cons
                        void* k_cache, void* v_cache, int B, int H, int Dh, int cap, int dtype, hipStream_t s);
 size_t decode_chain_ws_bytes(int n_layers, int d, int H, int F, int cap);
 size_t decode_chain_err_offset(int n_layers, int H);
+size_t decode_chain_b_ws_bytes(int n_layers, int d, int H, int F, int cap, int B);
+size_t decode_chain_b_err_offset(int n_layers, int H, int B);
 int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream);
 int decode_attn_launch(const void* q, const void* kc, const void* vc, void* o, const int* n_keys, const uint64_t* vbits, int nwords,
                        int B, int H, int Dh, int cap, float scale, int dtype, hipStream_t s);
@@ -417,6 +419,17 @@ size_t aki_decode_chain_workspace_bytes(int32_t n_layers, int32_t d, int32_t H, 
 }
 
 size_t aki_decode_chain_error_offset(int32_t n_layers, int32_t H) { return (n_layers > 0 && H > 0) ? decode_chain_err_offset(n_layers, H) : 0; }
+
+size_t aki_decode_chain_batch_workspace_bytes(int32_t n_layers, int32_t d, int32_t H, int32_t F, int32_t capacity, int32_t batch) {
+  if (batch <= 1) return aki_decode_chain_workspace_bytes(n_layers, d, H, F, capacity);
+  if (n_layers <= 0 || d <= 0 || H <= 0 || F <= 0 || capacity <= 0 || batch > 8) return 0;
+  return decode_chain_b_ws_bytes(n_layers, d, H, F, capacity, batch);
+}
+
+size_t aki_decode_chain_batch_error_offset(int32_t n_layers, int32_t H, int32_t batch) {
+  if (batch <= 1) return aki_decode_chain_error_offset(n_layers, H);
+  return (n_layers > 0 && H > 0 && batch <= 8) ? decode_chain_b_err_offset(n_layers, H, batch) : 0;
+}
 
 int aki_decode_chain_fwd(const aki_decode_chain_args* a, void* stream) {
   AKI_CLEAR_ERR();

@@ -110,6 +110,8 @@ constexpr int CH_XREP = 8;               // room for copies of every hand-off ve
 constexpr int CH_XREP_USED = 1;          // copies in use: every copy is one more write-through store per producing lane, and at the product's
                                          // 100-600 consumers per phase one copy reads fastest (1 / 2 / 4 copies: 1.66 / 1.68 / 1.71 ms per token)
 constexpr unsigned CH_SPIN_LIMIT = 200000u;
+// the batched chain's ring depths (steps of 64 k per wave held in registers; see chain_gemm): qkv, o_proj, gate_up (two streams), down (+ its x ring)
+constexpr int CH_B_RQ = 6, CH_B_RO = 6, CH_B_RG = 4, CH_B_RD = 6;         // <= 128 VGPRs: two 512-thread workgroups per CU
 
 struct ChainParams {
   const aki_decode_chain_layer* layers;
@@ -117,6 +119,7 @@ struct ChainParams {
   const bf16_t* h_in; bf16_t* h_out;
   const float* cos; const float* sin; const int* cache_len; const uint64_t* vbits; int nwords;
   int d, H, F, cap, S, T; float scale, eps;
+  int B;                  // sequences (rows) of the step: 1 for decode_chain_kernel, 2..8 for decode_chain_b_kernel (hand-off vectors are [B][n] then)
   unsigned* sync;         // [n_layers][CH_PHASES][CH_SYNC_WORDS], then [n_layers][H] attention tickets: all zero when the call starts (two sets)
   unsigned* attn_cnt;     // a ticket per (layer, head): nothing is re-armed inside the launch
   unsigned* head_sync;    // [n_layers][H][2 lines]: arrivals of the 96 / rows-per-workgroup x 3 qkv workgroups that produce head h's q, k, v and
@@ -397,10 +400,190 @@ __device__ __forceinline__ unsigned chain_gemv(const ChainParams& p, int wg, int
   return completed;        // wave 0: 1 when this workgroup's arrival completed the phase
 }
 
+// ---- one GEMM phase of the BATCHED chain (2..8 sequences; 512-thread workgroups) ---------------------------------------------------
+// = decode.hip's skinny_gemm_bf16_kernel<8, SWIGLU, 1, NORM> inside the dataflow launch: a workgroup is one 16-feature tile of
+// v_mfma_f32_16x16x32_bf16 (the rows of the step ride on the tile's columns), its EIGHT waves split K and the partial tiles are added in wave
+// order by wave 0 - the same K order, the same fold order, the same epilogue: a chained step reproduces the five-launch batched step bit for
+// bit.  Lane (row l15 of the tile, k-group kg) streams 32 contiguous bytes of ITS weight row per step of 64 k (the four k-groups of a row read
+// one 128-byte line).  A wave's KSL steps run through a register ring of R steps: the first R are requested BEFORE the dependency wait, step
+// i + R as soon as the MFMAs of step i have released its slot (R = KSL: everything is on chip when the flag rises).
+// XMODE 0: the input rows are RMS-normalised into LDS (wave m takes row m: the skinny kernel's prologue - HF's rounding points, the same
+//          summation order) and the B fragments are read from there;  1: the rows are copied into LDS as they are (K = 3072: 49 KB for eight);
+//          2: K = 8192 does not fit - the B fragments come through their own register ring of sc1 loads, R steps ahead.
+// First version (four waves, two K slices each, rings of 10 / 12 / 4 / 8 steps, 167 VGPRs): 104 us per layer at batch 8 = the five launches
+// (tools/decode_chain_edges.py --batch 8: down 20 us of ring refills, gate_up 7-15, x staging 3.4-4.8 us per phase).
+template <int KSL, bool SWIGLU, int XMODE, int R>
+__device__ __forceinline__ unsigned chain_gemm(const ChainParams& p, int wg, int n_wg, const void* w, int n_out, const bf16_t* x,
+                                               const bf16_t* norm_w, const bf16_t* residual, bf16_t* y, unsigned* wait_sync, unsigned* done_sync,
+                                               unsigned code, char* smem, int head_per = 0, unsigned* head_sync = nullptr) {
+  constexpr int K = KSL * 512, NS = SWIGLU ? 2 : 1;                    // K = 8 waves x KSL steps of 64
+  static_assert(R >= 1 && R <= KSL, "ring depth");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+  const int M = p.B;
+  int f0 = wg * 16, head_of_wg = 0;
+  if (head_per > 0) {            // qkv, head-major: the 3 x head_per tiles of one head's q, k and v are consecutive workgroups with an arrival counter of their own
+    head_of_wg = wg / (3 * head_per);
+    const int part = wg - head_of_wg * 3 * head_per, sec = part / head_per, sub = part - sec * head_per;
+    f0 = sec * (n_out / 3) + head_of_wg * 96 + sub * 16;
+  }
+  const int frow = min(f0 + l15, n_out - 1);
+  const int kw = wave * (KSL * 64) + 16 * kg;                          // this lane's first element of the wave's K slice
+  const bf16_t* w0 = (const bf16_t*)w + (size_t)frow * K + kw;
+  const bf16_t* w1 = (const bf16_t*)w + (size_t)(n_out + frow) * K + kw;      // SwiGLU: the up row of the gate row
+  u32x4 wr[R][NS][2];
+  auto issue_w = [&](int i, auto slot_c) {
+    constexpr int SL = decltype(slot_c)::value;
+    wr[SL][0][0] = __builtin_nontemporal_load(AKI_G128(w0 + i * 64));
+    wr[SL][0][1] = __builtin_nontemporal_load(AKI_G128(w0 + i * 64 + 8));
+    if constexpr (SWIGLU) {
+      wr[SL][1][0] = __builtin_nontemporal_load(AKI_G128(w1 + i * 64));
+      wr[SL][1][1] = __builtin_nontemporal_load(AKI_G128(w1 + i * 64 + 8));
+    }
+  };
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 0);
+  // (2) the weights of the first R steps before anything that depends on another workgroup
+  static_for_chain<R>([&](auto i_c) { issue_w(decltype(i_c)::value, i_c); });
+  // (3) the producer phase has published
+  chain_wait(p, wait_sync, wg, code);
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 1);
+  // (4) the input rows
+  constexpr int PITCH = K * 2 + 16;                       // LDS row pitch (XMODE 0 / 1): the pad spreads the 16 rows of a fragment read over the banks
+  const int xrow = min(l15, M - 1);
+  if constexpr (XMODE == 0) {
+    if (wave < M) {                                       // wave m normalises row m: the skinny kernel's prologue, chunk for chunk
+      const int m = wave;
+      const __amdgpu_buffer_rsrc_t rx = chain_rsrc(x + (size_t)m * K, K * 2);
+      u32x4 v[KSL], gch[KSL];
+#pragma unroll
+      for (int i = 0; i < KSL; ++i) v[i] = ld_sc1_b128(rx, (lane + 64 * i) * 16);
+#pragma unroll
+      for (int i = 0; i < KSL; ++i) gch[i] = *AKI_G128(norm_w + (size_t)(lane + 64 * i) * 8);      // the gain: an L2 hit, in flight with the row
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < KSL; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = bf16_lo(v[i][e]), hi = bf16_hi(v[i][e]);
+          ss = __builtin_fmaf(lo, lo, ss);
+          ss = __builtin_fmaf(hi, hi, ss);
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+      const float r = rsqrtf(ss / (float)K + p.eps);
+      char* dst = smem + (size_t)m * PITCH;
+#pragma unroll
+      for (int i = 0; i < KSL; ++i) {
+        __builtin_amdgcn_sched_barrier(0);                // chunk by chunk: the widened floats of one chunk at a time (this prologue sets the kernel's VGPR count)
+        u32x4 gi = gch[i], vi = v[i], o;
+        asm volatile("" : "+v"(gi), "+v"(vi));            // ... and the gain and the row are widened HERE, not kept as 96 floats from the moment they arrived
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack_bf16x2(round_bf16(bf16_lo(vi[e]) * r) * bf16_lo(gi[e]), round_bf16(bf16_hi(vi[e]) * r) * bf16_hi(gi[e]));
+        *(u32x4*)(dst + (size_t)(lane + 64 * i) * 16) = o;
+      }
+    }
+    __syncthreads();
+  } else if constexpr (XMODE == 1) {
+    const __amdgpu_buffer_rsrc_t rx = chain_rsrc(x, M * K * 2);
+    for (int c = tid; c < M * (K / 8); c += 512) {
+      const int m = c / (K / 8), cc = c - m * (K / 8);
+      *(u32x4*)(smem + (size_t)m * PITCH + (size_t)cc * 16) = ld_sc1_b128(rx, c * 16);
+    }
+    __syncthreads();
+  }
+  const char* xs = smem + (size_t)xrow * PITCH + (size_t)kw * 2;                        // XMODE 0 / 1
+  const __amdgpu_buffer_rsrc_t rxg = chain_rsrc(x + (size_t)xrow * K, K * 2);           // XMODE 2
+  u32x4 xr[XMODE == 2 ? R : 1][2];
+  auto issue_x = [&](int i, auto slot_c) {
+    constexpr int SL = decltype(slot_c)::value;
+    xr[SL][0] = ld_sc1_b128(rxg, (kw + i * 64) * 2);
+    xr[SL][1] = ld_sc1_b128(rxg, (kw + i * 64) * 2 + 16);
+  };
+  if constexpr (XMODE == 2) static_for_chain<R>([&](auto i_c) { issue_x(decltype(i_c)::value, i_c); });
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 2);
+  // (5) the steps, ring slot i % R
+  f32x4 acc[NS];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  static_for_chain<KSL>([&](auto i_c) {
+    constexpr int i = decltype(i_c)::value, SL = i % R;
+    u32x4 x2[2];
+    if constexpr (XMODE == 2) {
+      x2[0] = xr[SL][0];
+      x2[1] = xr[SL][1];
+    } else {
+      x2[0] = *(const u32x4*)(xs + (size_t)i * 128);
+      x2[1] = *(const u32x4*)(xs + (size_t)i * 128 + 16);
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const chain_bf16x8_t xb = __builtin_bit_cast(chain_bf16x8_t, x2[hh]);
+#pragma unroll
+      for (int t = 0; t < NS; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(chain_bf16x8_t, wr[SL][t][hh]), xb, acc[t], 0, 0, 0);
+    }
+    if constexpr (i + R < KSL) {
+      // the slot is free once the MFMAs above have read it; the barriers keep the scheduler from renaming the ring into KSL live steps
+      asm volatile("" : "+v"(acc[0]));
+      __builtin_amdgcn_sched_barrier(0);
+      issue_w(i + R, std::integral_constant<int, SL>{});
+      if constexpr (XMODE == 2) issue_x(i + R, std::integral_constant<int, SL>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  });
+  // (6) the eight partial tiles meet in LDS (over the rows: every wave is done with them), wave 0 adds them in wave order and runs the epilogue
+  float (*red)[NS][256] = (float (*)[NS][256])smem;
+  if constexpr (XMODE != 2) __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NS; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][t][lane * 4 + r] = acc[t][r];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int sw = 1; sw < 8; ++sw)
+#pragma unroll
+      for (int t = 0; t < NS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += red[sw][t][lane * 4 + r];
+    const int tok = l15, f = f0 + 4 * kg;
+    if (tok < M && f < n_out) {
+      unsigned long long res_bits = 0;
+      if (residual != nullptr) res_bits = __hip_atomic_load((const unsigned long long*)(residual + (size_t)tok * n_out + f), AKI_RLX_AGENT);
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = SWIGLU ? acc[NS - 1][r] * silu_fast(acc[0][r]) : acc[0][r];
+        if (residual != nullptr) v[r] += bf16_bits_to_f32((unsigned short)(res_bits >> (16 * r)));
+      }
+      const unsigned long long o = (unsigned long long)pack_bf16x2(v[0], v[1]) | ((unsigned long long)pack_bf16x2(v[2], v[3]) << 32);
+      __hip_atomic_store((unsigned long long*)(y + (size_t)tok * n_out + f), o, AKI_RLX_AGENT);
+    }
+  }
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 4);
+  unsigned completed = 0;
+  if (head_per > 0) {
+    if (threadIdx.x == 0) {
+      unsigned* hs = head_sync + (size_t)head_of_wg * 64;
+      if (__hip_atomic_fetch_add(hs, 1u, AKI_RLX_AGENT) + 1u == (unsigned)(3 * head_per)) __hip_atomic_store(hs + 32, 1u, AKI_RLX_AGENT);
+    }
+  } else if (threadIdx.x < 64) {
+    completed = chain_arrive(done_sync, wg, n_wg, threadIdx.x);
+  }
+  AKI_CHAIN_STAMP(p, (int)(code >> 8), (int)(code & 255) - 1, wg, 5);
+  return completed;
+}
+
 // ---- the attention phase: decode.hip's decode_attn_split_kernel<true>, one (head, split) item per WAVE ---------------------
 // qkv (un-rotated, handed off by phase 0) -> rotated q; the item whose key range holds the new position also rotates k, appends
 // k / v to the cache and uses them from LDS.  Partials (m, l, acc[96]) meet in the workspace; the item that arrives last at its
 // head's ticket merges, stores the head's 96 outputs write-through and adds 1 to the layer's attention counter.
+// BT (the batched chain): an item is (sequence b, head, split); the K/V caches are [B][H][cap][96], qkv / attn_o are [B][n] rows, lengths,
+// valid bits, tickets and partials are per sequence.  BT = false compiles to the one-sequence code unchanged (b = 0).
+template <bool BT = false>
 __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decode_chain_layer& ly, int layer, int wg, unsigned* wait_sync,
                                            unsigned* done_sync, unsigned code, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -409,16 +592,18 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
   bf16_t* s_k = s_q + 96;
   bf16_t* s_v = s_k + 96;
   float* s_mg = (float*)(smem + wave * 3072 + 576);
-  const int item = wg * 4 + wave;
-  const bool live = item < p.H * p.S;
-  const int h = live ? item / p.S : 0, split = live ? item - h * p.S : 0;
-  const int ln = p.cache_len[0];
+  const int item = wg * (BT ? 8 : 4) + wave;             // the batched chain runs 512-thread workgroups: eight items each
+  const int nB = BT ? p.B : 1;
+  const bool live = item < nB * p.H * p.S;
+  const int bh = live ? item / p.S : 0, split = live ? item - bh * p.S : 0;        // bh = b * H + h
+  const int b = BT ? bh / p.H : 0, h = BT ? bh - b * p.H : bh;
+  const int ln = p.cache_len[b];
   const int n = ln + 1;
   const int k_begin = split * p.T * 64;
   const int k_end = live ? min(n, k_begin + p.T * 64) : 0;
-  bf16_t* kb = (bf16_t*)ly.k_cache + (size_t)h * p.cap * 96;
-  bf16_t* vb = (bf16_t*)ly.v_cache + (size_t)h * p.cap * 96;
-  float* part = p.part + ((size_t)h * p.S + split) * CH_PSTRIDE;
+  bf16_t* kb = (bf16_t*)ly.k_cache + (size_t)bh * p.cap * 96;
+  bf16_t* vb = (bf16_t*)ly.v_cache + (size_t)bh * p.cap * 96;
+  float* part = p.part + ((size_t)bh * p.S + split) * CH_PSTRIDE;
   const int g = lane >> 4, i16 = lane & 15;
   float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
@@ -471,7 +656,7 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
   if (!live) return;                                     // no workgroup barrier below this line
   if (work) {
     if (lane < 48) {
-      const bf16_t* row = p.qkv + (size_t)(item % p.xrep) * p.rep_stride + h * 96;
+      const bf16_t* row = BT ? p.qkv + (size_t)b * 3 * p.H * 96 + h * 96 : p.qkv + (size_t)(item % p.xrep) * p.rep_stride + h * 96;
       const float c0 = p.cos[(size_t)ln * 96 + lane], c1 = p.cos[(size_t)ln * 96 + lane + 48];
       const float s0 = p.sin[(size_t)ln * 96 + lane], s1 = p.sin[(size_t)ln * 96 + lane + 48];
       const float q0 = bf16_bits_to_f32(__hip_atomic_load(row + lane, AKI_RLX_AGENT));
@@ -514,7 +699,7 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
         for (int i = 0; i < 12; ++i) kr[i] = *(const u32x4*)(s_k + i * 8);
       }
       bool ok = j < k_end;
-      if (p.vbits && (base >> 6) < p.nwords) ok = ok && ((p.vbits[base >> 6] >> lane) & 1ull);
+      if (p.vbits && (base >> 6) < p.nwords) ok = ok && ((p.vbits[(BT ? (size_t)b * p.nwords : 0) + (base >> 6)] >> lane) & 1ull);
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 12; ++i) s = cdot8(kr[i], *(const u32x4*)(s_q + i * 8), s);
@@ -559,13 +744,13 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   unsigned prev = 0;
-  if (lane == 0) prev = __hip_atomic_fetch_add(p.attn_cnt + layer * p.H + h, 1u, AKI_RLX_AGENT);
+  if (lane == 0) prev = __hip_atomic_fetch_add(p.attn_cnt + (size_t)layer * nB * p.H + bh, 1u, AKI_RLX_AGENT);
   prev = __shfl(prev, 0);
   AKI_CHAIN_STAMP(p, layer, 1, wg, 4);
   if (prev != (unsigned)(p.S - 1)) return;
   asm volatile("" ::: "memory");
   // the last arriver of head h merges the S partials (decode.hip's order: five split slots per pass, the slots then meet in LDS)
-  const float* pp = p.part + (size_t)h * p.S * CH_PSTRIDE;
+  const float* pp = p.part + (size_t)bh * p.S * CH_PSTRIDE;
   const int sl = lane / 12, ch = lane - sl * 12;
   float gm = -INFINITY, lt = 0.f, o8[8];
 #pragma unroll
@@ -632,15 +817,20 @@ __device__ __forceinline__ void chain_attn(const ChainParams& p, const aki_decod
     u32x4 ov;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ov[e] = pack_bf16x2(o8[2 * e] * inv, o8[2 * e + 1] * inv);
-    for (int rep = 0; rep < p.xrep; ++rep) {
-      const __amdgpu_buffer_rsrc_t ro = chain_rsrc(p.attn_o + (size_t)rep * p.rep_stride, p.H * 96 * 2);
+    if constexpr (BT) {
+      const __amdgpu_buffer_rsrc_t ro = chain_rsrc(p.attn_o + (size_t)b * p.H * 96, p.H * 96 * 2);
       __builtin_amdgcn_raw_buffer_store_b128(ov, ro, (h * 96 + lane * 8) * 2, 0, 16);     // sc1: write-through
+    } else {
+      for (int rep = 0; rep < p.xrep; ++rep) {
+        const __amdgpu_buffer_rsrc_t ro = chain_rsrc(p.attn_o + (size_t)rep * p.rep_stride, p.H * 96 * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(ov, ro, (h * 96 + lane * 8) * 2, 0, 16);     // sc1: write-through
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  chain_arrive(done_sync, h, p.H, lane);                 // one arrival per head
+  chain_arrive(done_sync, bh, nB * p.H, lane);           // one arrival per (sequence, head)
 #ifdef AKI_LAB_HOOKS
-  if (p.stamps && layer == p.stamp_layer && lane == 0) p.stamps[((size_t)1 * 2048 + 1024 + h) * 8 + 5] = wall_clock64();
+  if (p.stamps && layer == p.stamp_layer && lane == 0) p.stamps[((size_t)1 * 2048 + 1024 + bh) * 8 + 5] = wall_clock64();
 #endif
 }
 
@@ -691,7 +881,7 @@ __global__ __launch_bounds__(256, OCC) void decode_chain_kernel(const ChainParam
   }
   r -= p.n_qkv;
   if (r < p.n_attn) {
-    chain_attn(p, ly, layer, r, sy + 0 * CH_SYNC_WORDS, sy + 1 * CH_SYNC_WORDS, code | 2u, smem);
+    chain_attn<false>(p, ly, layer, r, sy + 0 * CH_SYNC_WORDS, sy + 1 * CH_SYNC_WORDS, code | 2u, smem);
     return;
   }
   r -= p.n_attn;
@@ -712,9 +902,64 @@ __global__ __launch_bounds__(256, OCC) void decode_chain_kernel(const ChainParam
   if (last && fin && threadIdx.x == 0) __hip_atomic_store(p.epoch, ep + 1u, AKI_RLX_AGENT);      // the call is complete: the next one takes the other set
 }
 
+// ---- the batched chain: 2..8 sequences per step ------------------------------------------------------------------------------
+// Same dataflow launch, same counters, same attention items (now per sequence); the four GEMV phases become 16-feature MFMA tiles
+// (chain_gemm).  Workgroups per layer: qkv 576 (head-major: 18 per head) | attention ceil(B * H * S / 4) | o_proj 192 | gate_up 512 | down 192.
+// RQ / RO / RG / RD: the ring depths (steps of 64 k whose operands a wave holds; the first ring-full is requested before the wait).
+template <int RQ, int RO, int RG, int RD>
+__global__ __launch_bounds__(512) void decode_chain_b_kernel(const ChainParams p0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x;
+  ChainParams p = p0;                                      // the counter set of this call: see decode_chain_kernel
+  const unsigned ep = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p0.epoch, AKI_RLX_AGENT));
+  {
+    const size_t cur = (ep & 1u) ? (size_t)p0.cnt_words : 0;
+    p.sync = p0.sync + cur; p.head_sync = p0.head_sync + cur; p.attn_cnt = p0.attn_cnt + cur;
+    u32x4* other = (u32x4*)(p0.sync + ((size_t)p0.cnt_words - cur));
+    const int n16 = p0.cnt_words / 4, per = (n16 + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int z_end = min(n16, (bid + 1) * per);
+    for (int i = bid * per + (int)threadIdx.x; i < z_end; i += 512) other[i] = u32x4{0u, 0u, 0u, 0u};
+  }
+  const int layer = bid / p.wg_layer;
+  int r = bid - layer * p.wg_layer;
+  const aki_decode_chain_layer& ly = p.layers[layer];
+  unsigned* sy = p.sync + (size_t)layer * CH_PHASES * CH_SYNC_WORDS;
+  unsigned* prev_down = layer > 0 ? sy - CH_SYNC_WORDS : nullptr;
+  const size_t rows_d = (size_t)p.B * p.d;
+  const bf16_t* h0 = layer == 0 ? p.h_in : p.hbuf + ((layer - 1) & 1) * rows_d;
+  const bool last = layer == p.n_layers - 1;
+  bf16_t* h2 = last ? p.h_out : p.hbuf + (layer & 1) * rows_d;
+  const unsigned code = ((unsigned)layer << 8);
+  if (r < p.n_qkv) {
+    chain_gemm<6, false, 0, RQ>(p, r, p.n_qkv, ly.w_qkv, 3 * p.H * 96, h0, (const bf16_t*)ly.norm1, nullptr, p.qkv, prev_down, sy + 0 * CH_SYNC_WORDS,
+                                code | 1u, smem, p.qkv_by_head, p.head_sync + (size_t)layer * p.H * 64);
+    return;
+  }
+  r -= p.n_qkv;
+  if (r < p.n_attn) {
+    chain_attn<true>(p, ly, layer, r, sy + 0 * CH_SYNC_WORDS, sy + 1 * CH_SYNC_WORDS, code | 2u, smem);
+    return;
+  }
+  r -= p.n_attn;
+  if (r < p.n_o) {
+    chain_gemm<6, false, 1, RO>(p, r, p.n_o, ly.w_o, p.d, p.attn_o, nullptr, h0, p.h1, sy + 1 * CH_SYNC_WORDS, sy + 2 * CH_SYNC_WORDS, code | 3u, smem);
+    return;
+  }
+  r -= p.n_o;
+  if (r < p.n_gu) {
+    chain_gemm<6, true, 0, RG>(p, r, p.n_gu, ly.w_gate_up, p.F, p.h1, (const bf16_t*)ly.norm2, nullptr, p.act, sy + 2 * CH_SYNC_WORDS, sy + 3 * CH_SYNC_WORDS,
+                               code | 4u, smem);
+    return;
+  }
+  r -= p.n_gu;
+  const unsigned fin = chain_gemm<16, false, 2, RD>(p, r, p.n_down, ly.w_down, p.d, p.act, nullptr, p.h1, h2, sy + 3 * CH_SYNC_WORDS, sy + 4 * CH_SYNC_WORDS,
+                                                    code | 5u, smem);
+  if (last && fin && threadIdx.x == 0) __hip_atomic_store(p.epoch, ep + 1u, AKI_RLX_AGENT);
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
-static inline size_t chain_cnt_bytes(int n_layers, int H) { return aki_align_up((size_t)n_layers * ((size_t)CH_PHASES * CH_SYNC_WORDS + H + (size_t)H * 64) * 4, 256); }
-static inline size_t chain_vec_elems(int d, int H, int F) { return aki_align_up((size_t)(3 * H * 96 + H * 96 + d + F + 2 * d) * 2 + 256, 256) / 2; }   // one copy
+static inline size_t chain_cnt_bytes(int n_layers, int H, int B = 1) { return aki_align_up((size_t)n_layers * ((size_t)CH_PHASES * CH_SYNC_WORDS + (size_t)B * H + (size_t)H * 64) * 4, 256); }
+static inline size_t chain_vec_elems(int d, int H, int F) { return aki_align_up((size_t)(3 * H * 96 + H * 96 + d + F + 2 * d) * 2 + 256, 256) / 2; }   // one copy (one row)
 
 #ifdef AKI_LAB_HOOKS
 static int g_chain_sleep = 8, g_chain_xrep = CH_XREP_USED, g_chain_nflags = CH_FLAGS, g_chain_nowait = 0, g_chain_nb = 0, g_chain_lds_pad = 0, g_chain_stamp_layer = -1, g_chain_touch = -1;
@@ -723,10 +968,10 @@ static unsigned g_chain_fault_code = 0;
 static int g_chain_fault_skip = 0;
 #endif
 
-static void chain_split(int H, int cap, int max_keys, int& S, int& T) {
+static void chain_split(int H, int cap, int max_keys, int& S, int& T, int B = 1) {
   if (max_keys <= 0 || max_keys > cap) max_keys = cap;
   const int tiles = (max_keys + 63) / 64, tiles_cap = (cap + 63) / 64;     // decode.hip's rule: T from the capacity, S from max_keys
-  T = (int)(((size_t)H * tiles_cap + AKI_DEC_ITEMS - 1) / AKI_DEC_ITEMS);
+  T = (int)(((size_t)B * H * tiles_cap + AKI_DEC_ITEMS - 1) / AKI_DEC_ITEMS);
   if (T < 1) T = 1;
   S = (tiles + T - 1) / T;
 }
@@ -734,12 +979,90 @@ static void chain_split(int H, int cap, int max_keys, int& S, int& T) {
 // workspace: counter set 0 | counter set 1 | 256 bytes: the sticky error word (+0) and the count of completed calls (+64) | hand-off vectors | partials
 size_t decode_chain_err_offset(int n_layers, int H) { return 2 * chain_cnt_bytes(n_layers, H); }
 
+// the batched chain: counters (tickets per sequence and head) x 2 | error word, call count | the hand-off rows [B][n] | partials per sequence
+size_t decode_chain_b_err_offset(int n_layers, int H, int B) { return 2 * chain_cnt_bytes(n_layers, H, B); }
+size_t decode_chain_b_ws_bytes(int n_layers, int d, int H, int F, int cap, int B) {
+  const size_t tiles = ((size_t)cap + 63) / 64;
+  return 2 * chain_cnt_bytes(n_layers, H, B) + 256 + (size_t)B * chain_vec_elems(d, H, F) * 2 + (size_t)B * H * tiles * CH_PSTRIDE * 4;
+}
+
 size_t decode_chain_ws_bytes(int n_layers, int d, int H, int F, int cap) {
   const size_t tiles = ((size_t)cap + 63) / 64;
   return 2 * chain_cnt_bytes(n_layers, H) + 256 /* error word, call count */ + chain_vec_elems(d, H, F) * 2 * CH_XREP + (size_t)H * tiles * CH_PSTRIDE * 4;
 }
 
+static int decode_chain_b_launch(const aki_decode_chain_args* a, hipStream_t stream) {
+  const int d = a->d, H = a->H, F = a->F, B = a->batch;
+  if (a->Dh != 96 || d != 3072 || H != 32 || F != 8192 || a->dtype != AKI_DT_BF16 || B < 2 || B > 8) return AKI_ERR_UNSUPPORTED;
+  if (a->workspace_bytes < decode_chain_b_ws_bytes(a->n_layers, d, H, F, a->capacity, B) || ((uintptr_t)a->workspace & 255)) return AKI_ERR_WORKSPACE;
+  ChainParams p;
+  p.layers = a->layers; p.n_layers = a->n_layers; p.B = B;
+  p.h_in = (const bf16_t*)a->h_in; p.h_out = (bf16_t*)a->h_out;
+  p.cos = a->cos; p.sin = a->sin; p.cache_len = a->cache_len; p.vbits = a->col_valid_bits; p.nwords = a->nwords;
+  p.d = d; p.H = H; p.F = F; p.cap = a->capacity; p.scale = a->scale; p.eps = a->rms_eps;
+  chain_split(H, a->capacity, a->max_keys, p.S, p.T, B);
+  char* ws = (char*)a->workspace;
+  const size_t cb = chain_cnt_bytes(a->n_layers, H, B);
+  p.sync = (unsigned*)ws;
+  p.head_sync = p.sync + (size_t)a->n_layers * CH_PHASES * CH_SYNC_WORDS;
+  p.attn_cnt = p.head_sync + (size_t)a->n_layers * H * 64;
+  p.err = (unsigned*)(ws + 2 * cb);
+  p.epoch = p.err + 16;
+  p.cnt_words = (int)(cb / 4);
+  bf16_t* v = (bf16_t*)(ws + 2 * cb + 256);
+  p.rep_stride = 0;
+  p.qkv = v; v += (size_t)B * 3 * H * 96;
+  p.attn_o = v; v += (size_t)B * H * 96;
+  p.h1 = v; v += (size_t)B * d;
+  p.act = v; v += (size_t)B * F;
+  p.hbuf = v;
+  p.part = (float*)(ws + 2 * cb + 256 + (size_t)B * chain_vec_elems(d, H, F) * 2);
+  p.nbq = p.nbo = p.nbg = p.nbd = 1;
+  p.n_qkv = 3 * H * 96 / 16;
+  p.n_attn = (B * H * p.S + 7) / 8;
+  p.n_o = d / 16;
+  p.n_gu = F / 16;
+  p.n_down = d / 16;
+  p.wg_layer = p.n_qkv + p.n_attn + p.n_o + p.n_gu + p.n_down;
+  p.qkv_by_head = 6;                      // 96 rows of a head = six 16-feature tiles: 18 workgroups produce one head's q, k and v
+  p.sleep_n = 8; p.xrep = 1; p.nflags = CH_FLAGS; p.nowait = 0; p.touch = 0;
+#ifdef AKI_LAB_HOOKS
+  p.sleep_n = g_chain_sleep; p.nowait = g_chain_nowait;
+  p.stamps = g_chain_stamps; p.stamp_layer = g_chain_stamp_layer;
+  p.fault_code = 0;
+  if (g_chain_fault_code != 0u && g_chain_fault_skip-- == 0) { p.fault_code = g_chain_fault_code; g_chain_fault_code = 0; }
+#endif
+  // LDS: the normalised / copied rows of a K = 3072 phase (49 KB at eight rows); the partial tiles (16 KB with SwiGLU) and the attention phase's
+  // per-wave scratch (12 KB) lie over them
+  int SMEM = B * (3072 * 2 + 16);
+  if (SMEM < 8 * 3072) SMEM = 8 * 3072;       // eight attention items x 3 KB; the partial tiles take 16 KB
+  const dim3 grid((unsigned)a->n_layers * (unsigned)p.wg_layer), block(512);
+  AKI_CLEAR_ERR();
+#define AKI_CHAIN_B_LAUNCH(RQ, RO, RG, RD)                                                                                                  \
+  do {                                                                                                                                      \
+    static bool attr = false;                                                                                                               \
+    if (!attr) {                                                                                                                            \
+      if (hipFuncSetAttribute((const void*)decode_chain_b_kernel<RQ, RO, RG, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (3072 * 2 + 16)) != hipSuccess) \
+        return AKI_ERR_LAUNCH;                                                                                                              \
+      attr = true;                                                                                                                          \
+    }                                                                                                                                       \
+    hipLaunchKernelGGL((decode_chain_b_kernel<RQ, RO, RG, RD>), grid, block, SMEM, stream, p);                                               \
+  } while (0)
+#ifdef AKI_LAB_HOOKS
+  if (g_chain_nb == 1) AKI_CHAIN_B_LAUNCH(6, 6, 2, 4);
+  else if (g_chain_nb == 2) AKI_CHAIN_B_LAUNCH(6, 6, 6, 8);
+  else if (g_chain_nb == 3) AKI_CHAIN_B_LAUNCH(6, 6, 4, 8);
+  else if (g_chain_nb == 4) AKI_CHAIN_B_LAUNCH(3, 3, 2, 4);
+  else
+#endif
+  AKI_CHAIN_B_LAUNCH(CH_B_RQ, CH_B_RO, CH_B_RG, CH_B_RD);
+#undef AKI_CHAIN_B_LAUNCH
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
+}
+
 int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
+  if (a->batch > 1) return decode_chain_b_launch(a, stream);
   const int d = a->d, H = a->H, F = a->F;
   if (a->Dh != 96 || d != H * 96 || d % 512 || F % 512) return AKI_ERR_UNSUPPORTED;
   const bool w8 = a->dtype == AKI_DT_W8A16;
@@ -747,7 +1070,7 @@ int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   if (!(d == 3072 && F == 8192)) return AKI_ERR_UNSUPPORTED;     // the register arrays are sized at compile time: Phi-3.5-mini
   if (a->workspace_bytes < decode_chain_ws_bytes(a->n_layers, d, H, F, a->capacity) || ((uintptr_t)a->workspace & 255)) return AKI_ERR_WORKSPACE;
   ChainParams p;
-  p.layers = a->layers; p.n_layers = a->n_layers;
+  p.layers = a->layers; p.n_layers = a->n_layers; p.B = 1;
   p.h_in = (const bf16_t*)a->h_in; p.h_out = (bf16_t*)a->h_out;
   p.cos = a->cos; p.sin = a->sin; p.cache_len = a->cache_len; p.vbits = a->col_valid_bits; p.nwords = a->nwords;
   p.d = d; p.H = H; p.F = F; p.cap = a->capacity; p.scale = a->scale; p.eps = a->rms_eps;

@@ -484,9 +484,15 @@ class DecodeChain:
 
     SUPPORTED = dict(d=3072, F=8192, Dh=96)
 
-    def __init__(self, layers, k_caches, v_caches, H: int, Dh: int, d: int, F: int, capacity: int, scale: float, eps: float, device, w8: bool):
-        """layers: per layer (w_qkv, w_o, w_gate_up, w_down, norm1, norm2, s_qkv, s_o, s_gate_up, s_down) - scales None for bf16."""
+    def __init__(self, layers, k_caches, v_caches, H: int, Dh: int, d: int, F: int, capacity: int, scale: float, eps: float, device, w8: bool,
+                 batch: int = 1):
+        """layers: per layer (w_qkv, w_o, w_gate_up, w_down, norm1, norm2, s_qkv, s_o, s_gate_up, s_down) - scales None for bf16.
+        batch 2..8 (bf16): that many sequences per step - the batched chain (16-feature MFMA tiles instead of dot-product rows), bit-identical to
+        the per-layer batched launches; k / v caches [batch, H, capacity, Dh]."""
         lib = L.load()
+        self.batch = int(batch)
+        if self.batch > 1 and (w8 or self.batch > 8 or H != 32):
+            raise AkiError("decode chain: batches of 2..8 sequences run on bf16 weights with 32 heads")
         self.n_layers = len(layers)
         rows = []
         for (wq, wo, wg, wd, n1, n2, sq, so, sg, sd), k, v in zip(layers, k_caches, v_caches):
@@ -499,29 +505,31 @@ class DecodeChain:
         self.key = tuple(r[0] for r in rows) + tuple(r[6] for r in rows)
         self.table = torch.tensor(rows, dtype=torch.int64).to(device)
         assert C.sizeof(L.DecodeChainLayer) == 12 * 8
-        nbytes = int(lib.aki_decode_chain_workspace_bytes(self.n_layers, d, H, F, capacity))
+        nbytes = int(lib.aki_decode_chain_batch_workspace_bytes(self.n_layers, d, H, F, capacity, self.batch))
         if nbytes == 0:
             raise AkiError("decode chain: bad dimensions")
         self.ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
         off = (-self.ws.data_ptr()) % 256
         self.ws_ptr = self.ws.data_ptr() + off
         self.ws_bytes = nbytes
-        self.err_index = (off + int(lib.aki_decode_chain_error_offset(self.n_layers, H))) // 4
-        self.h_out = torch.empty((1, d), dtype=torch.bfloat16, device=device)
+        self.err_index = (off + int(lib.aki_decode_chain_batch_error_offset(self.n_layers, H, self.batch))) // 4
+        self.h_out = torch.empty((self.batch, d), dtype=torch.bfloat16, device=device)
         self.dims = (H, Dh, d, F, capacity)
         self.scale, self.eps, self.w8 = float(scale), float(eps), bool(w8)
 
     def step(self, h_in: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, cache_len: torch.Tensor, col_valid_bits: Optional[torch.Tensor],
              max_keys: int) -> torch.Tensor:
         H, Dh, d, F, cap = self.dims
-        if h_in.dtype != torch.bfloat16 or h_in.numel() != d or not h_in.is_contiguous():
-            raise AkiError("decode chain: h_in must be one contiguous bf16 row")
+        if h_in.dtype != torch.bfloat16 or h_in.numel() != self.batch * d or not h_in.is_contiguous():
+            raise AkiError("decode chain: h_in must be contiguous bf16 rows [batch, d]")
+        if cache_len.numel() != self.batch or (col_valid_bits is not None and col_valid_bits.numel() != self.batch * col_valid_bits.shape[-1]):
+            raise AkiError("decode chain: cache_len / col_valid_bits are per sequence")
         if cos.shape[0] < cap or cos.shape[1] != Dh:
             raise AkiError("decode chain: cos/sin tables must cover the cache capacity")
         _dev(h_in, cos, sin, cache_len, col_valid_bits, self.table)
         a = L.DecodeChainArgs(self.table.data_ptr(), _ptr(h_in), _ptr(self.h_out), _ptr(cos), _ptr(sin), _ptr(cache_len), _ptr(col_valid_bits),
                               self.ws_ptr, self.ws_bytes, self.n_layers, 0 if col_valid_bits is None else col_valid_bits.shape[-1], d, H, Dh, F,
-                              cap, int(max_keys), self.scale, self.eps, L.AKI_DT_W8A16 if self.w8 else L.AKI_DT_BF16, 0)
+                              cap, int(max_keys), self.scale, self.eps, L.AKI_DT_W8A16 if self.w8 else L.AKI_DT_BF16, self.batch)
         end = _TAP.begin(("decode_chain", self.n_layers)) if (_TAP is not None and _TAP.want(("decode_chain",))) else None
         cur = torch.cuda.current_stream()
         with _CHAIN_LOCK:

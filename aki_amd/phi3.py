@@ -486,8 +486,8 @@ class Phi3Model(nn.Module):
         cache.grid_keys = cache.capacity if torch.cuda.is_current_stream_capturing() else min(cache.capacity, cache.host_len)
         h = inputs_embeds
         chain = self._decode_chain(h, cache)
-        if chain is not None:                       # one sequence: the 32 layers as ONE launch (decode_chain.hip)
-            h = chain.step(h.reshape(1, -1), cos, sin, cache.cache_len, cache.valid_bits, cache.grid_keys)
+        if chain is not None:                       # 1..8 sequences: the 32 layers as ONE launch (decode_chain.hip)
+            h = chain.step(h.reshape(chain.batch, -1).contiguous(), cos, sin, cache.cache_len, cache.valid_bits, cache.grid_keys)
         else:
             for layer in self.layers:
                 h = layer.decode(h, cos, sin, cache)
@@ -510,13 +510,17 @@ class Phi3Model(nn.Module):
         return super()._load_from_state_dict(*a, **kw)
 
     use_decode_chain = True                         # False: the five-launch-per-layer path (A/B and the bit-identity tests)
+    use_decode_chain_batched = False                # True: 2..8 sequences on the batched chain (bf16 weights; bit-identical to the five launches per layer,
+                                                    # measured NOT faster yet - 3.29-3.46 vs 3.27-3.34 ms per step at batch 8, EXPERIMENTS.md round 5 - so off)
     decode_chain_w8 = True                          # e4m3 weights: one batch per workgroup, 1.37 ms per token against 1.46 on five launches
                                                     # (1.55 vs 1.46 ms per token: half the bytes, the same dependency latencies)
 
     def _decode_chain(self, h, cache):
         """The one-launch decode step when it applies: one sequence, bf16 stream, Phi-3.5-mini's dimensions, every layer either
         bf16 or fully e4m3-quantised (the fp8 configuration's weight-only GEMVs).  Built once per (weights, KV cache)."""
-        if not self.use_decode_chain or cache.chain_disabled or h.shape[0] != 1 or h.dtype != torch.bfloat16 or not h.is_cuda:
+        B = h.shape[0]
+        if (not self.use_decode_chain or cache.chain_disabled or B > (8 if self.use_decode_chain_batched else 1) or h.dtype != torch.bfloat16
+                or not h.is_cuda):
             return None
         l0, ll = self.layers[0], self.layers[-1]
         chain = getattr(cache, "chain", None)
@@ -526,7 +530,7 @@ class Phi3Model(nn.Module):
         # a new quantisation - bumps `_weights_version`.  Assigning a new tensor to one middle layer's `.data` by hand is not seen:
         # build a fresh cache (a new prefill) after surgery of that kind.
         sig = (l0.self_attn.qkv_proj.weight.data_ptr(), ll.mlp.down_proj.weight.data_ptr(), self._weights_version, cache.k[0].data_ptr(),
-               cache.k[-1].data_ptr(), len(self.layers))
+               cache.k[-1].data_ptr(), len(self.layers), B)
         if chain is not None and chain.sig == sig:
             return chain
         if chain is None and getattr(cache, "chain_sig", None) == sig:
@@ -545,6 +549,8 @@ class Phi3Model(nn.Module):
             return None                             # qkv / gate_up only in e4m3: the mixed per-layer path
         if w8 and not self.decode_chain_w8:
             return None
+        if B > 1 and (w8 or at.num_heads != 32 or cache.k[0].shape[0] != B or not cache.k[0].is_contiguous()):
+            return None                             # the batched chain: bf16 weights, caches [B, H, capacity, 96]
         rows = []
         for ly in self.layers:
             a_, m_ = ly.self_attn, ly.mlp
@@ -557,7 +563,7 @@ class Phi3Model(nn.Module):
                              ly.post_attention_layernorm.weight, None, None, None, None))
         chain = cache.chain = ops.DecodeChain(rows, list(cache.k), list(cache.v), at.num_heads, at.head_dim, h.shape[-1],
                                               mlp.down_proj.weight.shape[1], cache.capacity, at.scaling, l0.input_layernorm.variance_epsilon,
-                                              h.device, w8)
+                                              h.device, w8, batch=B)
         chain.sig = sig
         return chain
 

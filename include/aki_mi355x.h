@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 15
+#define AKI_ABI_VERSION 16
 
 typedef enum {
   AKI_OK = 0,
@@ -417,11 +417,16 @@ typedef struct {
   float scale;
   float rms_eps;
   int32_t dtype;
-  int32_t reserved;
+  int32_t batch; /* 0 or 1: one sequence.  2..8 (bf16): that many sequences per step - h_in / h_out are [batch, d] rows, cache_len [batch],
+                    col_valid_bits [batch][nwords], k_cache / v_cache [batch, H, capacity, 96]; the GEMV phases become 16-feature MFMA tiles and
+                    the step reproduces the per-layer batched calls (aki_decode_linear_fwd / aki_linear_fwd at 2-8 rows,
+                    aki_decode_attn_fused_fwd) bit for bit.  Workspace: the *_batch_* functions below. */
 } aki_decode_chain_args;
 
 size_t aki_decode_chain_workspace_bytes(int32_t n_layers, int32_t d, int32_t H, int32_t F, int32_t capacity);
 size_t aki_decode_chain_error_offset(int32_t n_layers, int32_t H);
+size_t aki_decode_chain_batch_workspace_bytes(int32_t n_layers, int32_t d, int32_t H, int32_t F, int32_t capacity, int32_t batch);
+size_t aki_decode_chain_batch_error_offset(int32_t n_layers, int32_t H, int32_t batch);
 int aki_decode_chain_fwd(const aki_decode_chain_args* args, void* stream);
 
 /* ----------------------------------------------------------------------------------------------

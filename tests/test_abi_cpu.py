@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/aki_mi355x.h but not exported"
-    assert lib.aki_abi_version() == 15
+    assert lib.aki_abi_version() == 16
     exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "debug" not in exported and "aki_lab_" not in exported, "lab / debug hooks must not ship in the product library"
     assert b"aligned" in lib.aki_strerror(-3)
@@ -137,6 +137,12 @@ def test_host_side_validation_without_gpu(lib):
     assert lib.aki_decoder_stack_fwd(C.byref(L.DecoderStackArgs()), None) == -1
     assert lib.aki_siglip_stack_fwd(C.byref(L.SiglipStackArgs()), None) == -1
     assert lib.aki_perceiver_stack_fwd(C.byref(L.PerceiverStackArgs()), None) == -1
+    # the batched decode chain's workspace: grows with the batch; batch <= 1 is the one-sequence layout; more than eight sequences are refused
+    one = lib.aki_decode_chain_workspace_bytes(32, 3072, 32, 8192, 800)
+    assert lib.aki_decode_chain_batch_workspace_bytes(32, 3072, 32, 8192, 800, 1) == one and lib.aki_decode_chain_batch_workspace_bytes(32, 3072, 32, 8192, 800, 0) == one
+    assert lib.aki_decode_chain_batch_workspace_bytes(32, 3072, 32, 8192, 800, 8) > lib.aki_decode_chain_batch_workspace_bytes(32, 3072, 32, 8192, 800, 2) > 0
+    assert lib.aki_decode_chain_batch_workspace_bytes(32, 3072, 32, 8192, 800, 9) == 0
+    assert lib.aki_decode_chain_batch_error_offset(32, 32, 8) > lib.aki_decode_chain_error_offset(32, 32) > 0
     need = lib.aki_decoder_stack_workspace_bytes(1, 32, 655, 96, 3072, 8192, 1)
     assert need >= 655 * (2 * 3072 * 2 + 3072 * 2 + 3072 * 2 + 8192 * 2) and need % 256 == 0       # q + o + two residual streams + SwiGLU output
     assert lib.aki_decoder_stack_workspace_bytes(1, 32, 655, 96, 3072, 8192, 0) > need                 # + k, v when no KV cache takes them

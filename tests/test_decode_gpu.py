@@ -532,6 +532,47 @@ def test_decode_chain_is_bit_identical_to_the_per_layer_launches(prompt, steps, 
         assert torch.equal(ka, kb)
 
 
+@pytest.mark.parametrize("B,prompt,steps", [(2, 200, 5), (8, 655, 4), (5, 70, 70), (3, 4200, 3)])
+def test_batched_decode_chain_is_bit_identical_to_the_per_layer_launches(B, prompt, steps):
+    """The batched chain (2..8 sequences per step: 16-feature MFMA tiles instead of dot-product rows, attention items per sequence) against
+    the five-launch-per-layer batched path: logits of every step and the appended K/V rows bit for bit - ragged prompt lengths, a hole in
+    one prompt, across a 64-key tile boundary (70 + 70 steps), at a long context - and the error word stays 0."""
+    from aki_amd import ops
+    lm, cfg = _full_width_lm(3)
+    x = (torch.randn(B, prompt, cfg.hidden_size, generator=torch.Generator().manual_seed(1)) * 0.5).to(torch.bfloat16).to(DEV)
+    lens = [prompt - 7 * b for b in range(B)]
+    am = np.zeros((B, prompt), dtype=bool)
+    for b, n_ in enumerate(lens):
+        am[b, :n_] = True
+    am[B - 1, 3:9] = False
+    table = ops.MaskTable.from_host([[(4, 40, 40, n_ - 8)] for n_ in lens], am, lens, DEV)
+    outs = {}
+    for chained in (False, True):
+        lm.model.use_decode_chain_batched = chained
+        with torch.no_grad():
+            out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=prompt + steps + 3)
+            cache = out.past_key_values
+            ids = out.logits[:, -1].float().argmax(-1)
+            logits = []
+            for _ in range(steps):
+                lg = lm.decode_step(input_ids=ids, past_key_values=cache)
+                logits.append(lg.clone())
+                ids = lg.float().argmax(-1)
+        chain = getattr(cache, "chain", None)
+        assert (chain is not None) == chained
+        if chained:
+            assert chain.batch == B and chain.error_code() == 0
+        # the rows each sequence holds: its prompt + the appended steps (what lies beyond is unwritten cache)
+        rows = lambda c: [torch.cat([c_[b_, :, : lens[b_] + steps].reshape(-1) for b_ in range(B)]) for c_ in c]
+        outs[chained] = (torch.stack(logits), rows(cache.k), rows(cache.v), cache.cache_len.clone())
+    lm.model.use_decode_chain_batched = True
+    a, b = outs[False], outs[True]
+    assert bool(torch.isfinite(a[0].float()).all()) and torch.equal(a[3], b[3])
+    assert torch.equal(a[0], b[0]), f"{int((a[0] != b[0]).sum())} logits differ over {steps} steps"
+    for ka, kb in zip(a[1] + a[2], b[1] + b[2]):
+        assert torch.equal(ka.view(torch.int16), kb.view(torch.int16))
+
+
 def test_decode_chain_graph_replay_and_poisoned_workspace():
     """The chained step under hipGraph replay (its counter memset is a graph node) equals eager steps bit for bit, and a workspace
     whose hand-off vectors are poisoned between steps changes nothing: every byte a phase reads was written in the same step."""

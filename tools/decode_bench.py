@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--fp8", action="store_true", help="fp8 configuration: e4m3 prefill GEMMs, weight-only e4m3 GEMVs for batch 1")
+    ap.add_argument("--batched-chain", action="store_true", help="batches of 2..8: the batched chain (opt-in) instead of five launches per layer")
     ap.add_argument("--no-chain", action="store_true", help="batch 1: the five-launch-per-layer path instead of the one-launch chain")
     a = ap.parse_args()
     from aki_amd import ops
@@ -29,6 +30,7 @@ def main():
     if a.fp8:
         lm.enable_fp8()
     lm.model.use_decode_chain = not a.no_chain
+    lm.model.use_decode_chain_batched = bool(a.batched_chain)
     wbytes = sum(p.numel() * 2 for n, p in lm.named_parameters() if "embed_tokens" not in n)
     B, L = a.batch, a.prompt
     x = torch.randn(B, L, cfg.hidden_size, device=dev, dtype=torch.bfloat16) * 0.5
@@ -40,7 +42,7 @@ def main():
     # cache once per sequence (mid-run length), activations negligible.  Peak: 8 TB/s (MI355X_MICROARCH.md; ~6.3 TB/s achievable).
     kv_bytes = B * a.layers * 2 * cfg.num_attention_heads * 96 * 2 * (L + 4 + a.steps // 2)
     res = {"batch": B, "prompt": L, "steps": a.steps, "weight_bytes": wbytes, "kv_bytes": kv_bytes, "fp8": bool(a.fp8),
-           "chain": bool(B == 1 and not a.no_chain)}
+           "chain": bool(not a.no_chain and (B == 1 or (B <= 8 and not a.fp8 and a.batched_chain)))}
     with torch.no_grad():
         for mode in ("eager", "graph"):
             out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=L + 2 * a.steps + 8)

@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--layer", type=int, default=16)
     ap.add_argument("--preset", type=int, default=0)
     ap.add_argument("--dump", default=None, help="save the raw stamps [phase][workgroup][slot] (.npy)")
+    ap.add_argument("--batch", type=int, default=1, help="2..8: the batched chain")
     ap.add_argument("--fp8", action="store_true", help="e4m3 weights through the chain (the product runs them on five launches per layer)")
     a = ap.parse_args()
     from aki_amd import ops, _lib
@@ -25,8 +26,9 @@ def main():
         lm.enable_fp8()
         lm.model.decode_chain_w8 = True
     L = 655
-    x = torch.randn(1, L, cfg.hidden_size, device="cuda", dtype=torch.bfloat16) * 0.5
-    table = ops.MaskTable.from_host([[(4, 148, 4, 148)]], torch.ones(1, L, dtype=torch.bool).numpy(), [L], "cuda")
+    B = a.batch
+    x = torch.randn(B, L, cfg.hidden_size, device="cuda", dtype=torch.bfloat16) * 0.5
+    table = ops.MaskTable.from_host([[(4, 148, 4, 148)]] * B, torch.ones(B, L, dtype=torch.bool).numpy(), [L] * B, "cuda")
     names = ["qkv", "attention", "o_proj", "gate_up", "down"]
     with _lib.use_lab(0) as lab, torch.no_grad():
         lab.aki_lab_set_chain_nb(a.preset)
@@ -51,7 +53,7 @@ def main():
     for ph, nm in enumerate(names):
         st, seen, staged, done, arr = (s[ph, :1024, k] for k in (0, 1, 2, 3, 5))
         if ph == 1:
-            arr = s[1, 1024:1024 + 32, 5]            # per-head mergers
+            arr = s[1, 1024:1024 + 32 * a.batch, 5]  # per-(sequence, head) mergers
         n = int(np.isfinite(st).sum())
         r = {"workgroups": n, "first_start": round(float(np.nanmin(st)), 2), "last_start": round(float(np.nanmax(st)), 2),
              "first_flag_seen": round(float(np.nanmin(seen)), 2), "last_flag_seen": round(float(np.nanmax(seen)), 2)}
