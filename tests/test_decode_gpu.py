@@ -776,6 +776,42 @@ def test_generate_recovers_from_a_decode_chain_give_up(skip, loop):
     assert got.shape == want.shape and torch.equal(got, want), (got.tolist(), want.tolist())
 
 
+@pytest.mark.parametrize("skip", [3, 11, 17])
+def test_batched_generate_on_the_batched_chain_recovers_from_a_give_up(skip):
+    """The opt-in batched chain under `generate` (two samples, right-padded, different lengths): the same tokens as the chain-free run, and
+    after an injected give-up the unverified tokens are decoded again on the per-layer path - with the finished flags REBUILT from the
+    verified tokens: one row has hit its EOS before the fault, the other has not (the one-sequence recovery could simply clear them)."""
+    from aki_amd import _lib
+    m, vx, ids, am = _tiny_full_width_aki()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    ids2 = torch.randint(3, 32000, (1, ids.shape[1]), generator=g).to(DEV)
+    ids2[0, 0], ids2[0, 6] = 1, m.media_token_id
+    am2 = am.clone()
+    am2[0, -5:] = 0                                                              # the second sample is five tokens shorter
+    vx2 = ((torch.rand((1, 1, 1, 3, 224, 224), generator=g) - 0.5) / 0.5).to(DEV, torch.bfloat16)
+    VX, IDS, AM = torch.cat([vx, vx2]), torch.cat([ids, ids2]), torch.cat([am, am2])
+    kw = dict(max_new_tokens=24, do_sample=False)
+    lmm = m.lang_model.model
+    lmm.use_decode_chain = False
+    free = m.generate(VX, IDS, attention_mask=AM, eos_token_id=[], **kw)
+    row1 = set(free[1].tolist())
+    eos = next(int(t_) for t_ in free[0, 2:10].tolist() if int(t_) not in row1)   # row 0 finishes within its first ten tokens, row 1 never does
+    kw["eos_token_id"] = [eos]
+    want = m.generate(VX, IDS, attention_mask=AM, **kw)
+    lmm.use_decode_chain, lmm.use_decode_chain_batched = True, True
+    try:
+        with _lib.use_lab(0) as lab:
+            clean = m.generate(VX, IDS, attention_mask=AM, **kw)
+            assert torch.equal(clean, want)
+            lab.aki_lab_set_chain_fault((1 << 8) | 3, skip)
+            with pytest.warns(RuntimeWarning, match="decode chain"):
+                got = m.generate(VX, IDS, attention_mask=AM, **kw)
+            lab.aki_lab_set_chain_fault(0, 0)
+    finally:
+        lmm.use_decode_chain_batched = False
+    assert got.shape == want.shape and torch.equal(got, want), (got.tolist(), want.tolist())
+
+
 def test_forward_from_past_key_values_recovers_from_a_decode_chain_give_up():
     """The reference's `past_key_values is not None` call (src/vlm.py:463-475) runs T teacher-forced decode steps: same guarantee."""
     from aki_amd import _lib, ops
