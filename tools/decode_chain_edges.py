@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--preset", type=int, default=0)
     ap.add_argument("--dump", default=None, help="save the raw stamps [phase][workgroup][slot] (.npy)")
     ap.add_argument("--batch", type=int, default=1, help="2..8: the batched chain")
+    ap.add_argument("--nowait", action="store_true", help="no dependency waits (wrong results): the lifetimes of the workgroups of the bare stream")
     ap.add_argument("--fp8", action="store_true", help="e4m3 weights through the chain (the product runs them on five launches per layer)")
     a = ap.parse_args()
     from aki_amd import ops, _lib
@@ -32,6 +33,9 @@ def main():
     names = ["qkv", "attention", "o_proj", "gate_up", "down"]
     with _lib.use_lab(0) as lab, torch.no_grad():
         lab.aki_lab_set_chain_nb(a.preset)
+        lm.model.use_decode_chain_batched = True
+        if a.nowait:
+            lab.aki_lab_set_chain(8, 1, 32, 1)
         out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=L + 136)
         cache = out.past_key_values
         ids = out.logits[:, -1].float().argmax(-1)
@@ -42,6 +46,7 @@ def main():
         lm.decode_step(input_ids=ids, past_key_values=cache)
         torch.cuda.synchronize()
         lab.aki_lab_set_chain_stamps(None, -1)
+        lab.aki_lab_set_chain(8, 1, 32, 0)
         lab.aki_lab_set_chain_nb(0)
     s = stamps.cpu().numpy().astype(np.float64) / 100.0          # microseconds
     if a.dump:
@@ -65,6 +70,11 @@ def main():
             rope, pv, tick = (s[1, :1024, k] for k in (2, 3, 4))
             r.update(q_rotated_after_flag_med=round(float(np.nanmedian(rope - seen)), 2), scores_v_pv_med=round(float(np.nanmedian(pv - rope)), 2),
                      partial_drain_ticket_med=round(float(np.nanmedian(tick - pv)), 2), last_ticket=round(float(np.nanmax(tick)), 2))
+        life = s[ph, :1024, 5] - s[ph, :1024, 0]
+        if ph == 1:
+            life = s[1, :1024, 4] - s[1, :1024, 0]
+        r["workgroup_lifetime_med"] = round(float(np.nanmedian(life)), 2)
+        r["workgroup_lifetime_p90"] = round(float(np.nanpercentile(life[np.isfinite(life)], 90)), 2)
         r["last_arrival"] = round(float(np.nanmax(arr)), 2)
         if prev_arrive is not None:
             r["edge_last_producer_arrival_to_first_flag_seen"] = round(float(np.nanmin(seen)) - prev_arrive, 2)
