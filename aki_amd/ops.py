@@ -7,7 +7,6 @@ CPU tensors or a missing library raise :class:`aki_amd._lib.AkiError`.
 from __future__ import annotations
 
 import ctypes as C
-import os
 import threading
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -594,7 +593,7 @@ def greedy_pick(logits: torch.Tensor, next_ids: torch.Tensor, pad_token_id: int 
     return next_ids
 
 
-SKINNY_NORM_FUSED = os.environ.get("AKI_SKINNY_NORM", "1") != "0"      # tools: A/B of the 2-8 row norm fusion
+SKINNY_NORM_FUSED = True          # tools (decode_bench.py --norm-launch): False = the RMSNorm of 2-8 row decode GEMMs as a launch of its own
 
 
 def decode_linear(x: torch.Tensor, w: torch.Tensor, rms_weight: torch.Tensor, eps: float, act: int = ACT_NONE,

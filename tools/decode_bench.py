@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--fp8", action="store_true", help="fp8 configuration: e4m3 prefill GEMMs, weight-only e4m3 GEMVs for batch 1")
+    ap.add_argument("--norm-launch", action="store_true", help="batches of 2..8: the RMSNorm as a launch of its own instead of the skinny GEMM's prologue (A/B)")
     ap.add_argument("--batched-chain", action="store_true", help="batches of 2..8: the batched chain (opt-in) instead of five launches per layer")
     ap.add_argument("--no-chain", action="store_true", help="batch 1: the five-launch-per-layer path instead of the one-launch chain")
     a = ap.parse_args()
@@ -31,6 +32,7 @@ def main():
         lm.enable_fp8()
     lm.model.use_decode_chain = not a.no_chain
     lm.model.use_decode_chain_batched = bool(a.batched_chain)
+    ops.SKINNY_NORM_FUSED = not a.norm_launch
     wbytes = sum(p.numel() * 2 for n, p in lm.named_parameters() if "embed_tokens" not in n)
     B, L = a.batch, a.prompt
     x = torch.randn(B, L, cfg.hidden_size, device=dev, dtype=torch.bfloat16) * 0.5
