@@ -19,6 +19,7 @@ int attn_core_f32(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hi
 int attn_nc_bf16(const aki_attn_args* a, hipStream_t stream);
 int gemv_bf16(const aki_linear_args* a, const void* rms_w, float eps, hipStream_t stream);
 int skinny_gemm_bf16(const aki_linear_args* a, const void* rms_w, float eps, hipStream_t stream);
+int skinny_gemm_w8(const aki_linear_args* a, const void* rms_w, float eps, hipStream_t stream);
 size_t decode_attn_ws_bytes(int B, int H, int Dh, int cap);
 int decode_attn_split_launch(const void* q_or_qkv, const float* cos, const float* sin, const int* len, void* kc, void* vc, void* o,
                              const uint64_t* vbits, int nwords, int B, int H, int cap, int max_keys, float scale, bool fused,
@@ -258,7 +259,13 @@ int aki_linear_fwd(const aki_linear_args* a, void* stream) {
     return linear_bf16(a, (hipStream_t)stream);
   }
   if (a->dtype == AKI_DT_FP8_E4M3) return linear_fp8(a, (hipStream_t)stream);
-  if (a->dtype == AKI_DT_W8A16) return gemv_bf16(a, nullptr, 0.f, (hipStream_t)stream);
+  if (a->dtype == AKI_DT_W8A16) {
+    if (a->M >= 2 && a->M <= 16) {   // batched decode in the fp8 configuration: the skinny MFMA GEMM on e4m3 weights
+      const int rc = skinny_gemm_w8(a, nullptr, 0.f, (hipStream_t)stream);
+      if (rc != AKI_ERR_UNSUPPORTED) return rc;
+    }
+    return gemv_bf16(a, nullptr, 0.f, (hipStream_t)stream);
+  }
   if (a->dtype == AKI_DT_BF16) {
     if (a->M >= 2 && a->M <= 16) {  // batched decode: weight-streaming skinny MFMA GEMM
       const int rc = skinny_gemm_bf16(a, nullptr, 0.f, (hipStream_t)stream);
@@ -406,8 +413,9 @@ int aki_decode_linear_fwd(const aki_linear_args* a, const void* rms_weight, floa
   AKI_CHECK_ARG(a->act >= AKI_ACT_NONE && a->act <= AKI_ACT_SWIGLU);
   const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
   AKI_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K && a->ldy >= n_out && (!a->residual || a->ldr >= n_out));
-  if (a->dtype == AKI_DT_BF16 && a->M >= 2 && a->M <= 8) {      // batched decode: the skinny MFMA GEMM with the norm in its prologue
-    const int rc = skinny_gemm_bf16(a, rms_weight, rms_eps, (hipStream_t)stream);
+  if (a->M >= 2 && a->M <= 8) {      // batched decode: the skinny MFMA GEMM with the norm in its prologue
+    const int rc = a->dtype == AKI_DT_BF16 ? skinny_gemm_bf16(a, rms_weight, rms_eps, (hipStream_t)stream)
+                                           : skinny_gemm_w8(a, rms_weight, rms_eps, (hipStream_t)stream);
     if (rc != AKI_ERR_UNSUPPORTED) return rc;
   }
   return gemv_bf16(a, rms_weight, rms_eps, (hipStream_t)stream);

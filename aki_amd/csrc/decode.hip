@@ -548,6 +548,182 @@ int skinny_gemm_bf16(const aki_linear_args* a, const void* rms_w, float eps, hip
   return launch_skinny<1, 1>(p, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The skinny GEMM on e4m3 weights (W8A16: one f32 scale per weight row, bf16 rows) for 2 <= M <= 16 - batched decode in the fp8
+// configuration streams half the bytes.  Same tile and K split; a step is 128 k: lane (row l15, k-group kg) loads 32 bytes = 32 k of ITS
+// weight row (the four k-groups read one 128-byte line), widens them pairwise to bf16 (v_cvt_scalef32_pk_bf16_fp8, exact) and feeds four
+// MFMAs against the 64 bytes of x that carry the same k.  The row scale multiplies the finished sum, as in the one-row GEMV (gemv_bf16_kernel<W8>).
+// NORM: as in skinny_gemm_bf16_kernel.
+// ------------------------------------------------------------------------------------------------------------
+template <int KS, bool SWIGLU, bool NORM>
+__global__ __launch_bounds__(KS * 64) void skinny_gemm_w8_kernel(const GemvParams p) {
+  constexpr int NS = SWIGLU ? 2 : 1;
+  constexpr int UN = SWIGLU ? 2 : 4;                 // steps of 128 k whose loads are issued together
+  __shared__ float red_st[NORM ? 1 : KS][NS][256];
+  extern __shared__ __attribute__((aligned(16))) char s_xn[];
+  float (*red)[NS][256] = NORM ? (float (*)[NS][256])s_xn : red_st;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+  const int n_out = SWIGLU ? p.N / 2 : p.N;
+  const int f0 = blockIdx.x * 16;
+  const int Kw = p.K / KS, kbeg = wave * Kw;
+  const int frow = min(f0 + l15, n_out - 1);
+  const uint8_t* wp[NS];
+  wp[0] = (const uint8_t*)p.w + (size_t)frow * p.ldw + kbeg + 32 * kg;
+  if (SWIGLU) wp[NS - 1] = (const uint8_t*)p.w + (size_t)(n_out + frow) * p.ldw + kbeg + 32 * kg;
+  const int xrow = min(l15, p.M - 1);
+  const bf16_t* xr = p.x + (size_t)xrow * p.ldx + kbeg + 32 * kg;
+  const int xs_pitch = p.K * 2 + 16;
+  const char* xs = s_xn + (size_t)xrow * xs_pitch + (size_t)(kbeg + 32 * kg) * 2;
+  f32x4 acc[NS];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = Kw / 128;
+  if constexpr (NORM) {
+    const int nchunk = p.K / 8;
+    for (int m = wave; m < p.M; m += KS) {
+      const bf16_t* xm = p.x + (size_t)m * p.ldx;
+      char* dst = s_xn + (size_t)m * xs_pitch;
+      float ss = 0.f;
+      for (int c = lane; c < nchunk; c += 64) {
+        const u32x4 v = *(const u32x4*)(xm + (size_t)c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = bf16_lo(v[e]), hi = bf16_hi(v[e]);
+          ss = __builtin_fmaf(lo, lo, ss);
+          ss = __builtin_fmaf(hi, hi, ss);
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+      const float r = rsqrtf(ss / (float)p.K + p.norm_eps);
+      for (int c = lane; c < nchunk; c += 64) {
+        const u32x4 v = *(const u32x4*)(xm + (size_t)c * 8);
+        const u32x4 g = *(const u32x4*)(p.norm_w + (size_t)c * 8);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack_bf16x2(round_bf16(bf16_lo(v[e]) * r) * bf16_lo(g[e]), round_bf16(bf16_hi(v[e]) * r) * bf16_hi(g[e]));
+        *(u32x4*)(dst + (size_t)c * 16) = o;
+      }
+    }
+    __syncthreads();
+  }
+  int it = 0;
+  auto run = [&](auto un_c) {
+    constexpr int U = decltype(un_c)::value;
+    for (; it + U <= nsteps; it += U) {
+      u32x4 wa[U][NS][2], xa[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+          wa[u][t][0] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)(it + u) * 128));
+          wa[u][t][1] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)(it + u) * 128 + 16));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          xa[u][j] = NORM ? *(const u32x4*)(xs + (size_t)(it + u) * 256 + 16 * j) : *(const u32x4*)(xr + (size_t)(it + u) * 128 + 8 * j);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                      // k-values 8j .. 8j+7 of the lane's 32: weight bytes 8j .. 8j+7 = dwords 2j, 2j+1 of the 32 bytes
+          const bf16x8 xb = __builtin_bit_cast(bf16x8, xa[u][j]);
+#pragma unroll
+          for (int t = 0; t < NS; ++t) {
+            const unsigned d0 = wa[u][t][j >> 1][(j & 1) * 2], d1 = wa[u][t][j >> 1][(j & 1) * 2 + 1];
+            const bf16x2_t p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, 1.0f, false), p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, 1.0f, true);
+            const bf16x2_t p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, 1.0f, false), p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, 1.0f, true);
+            const u32x4 wq = u32x4{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1), __builtin_bit_cast(unsigned, p2), __builtin_bit_cast(unsigned, p3)};
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq), xb, acc[t], 0, 0, 0);
+          }
+        }
+    }
+  };
+  run(std::integral_constant<int, UN>{});
+  if constexpr (UN > 2) run(std::integral_constant<int, 2>{});
+  run(std::integral_constant<int, 1>{});
+  if (KS > 1) {
+    if constexpr (NORM) __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][t][lane * 4 + r] = acc[t][r];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < KS; ++w)
+#pragma unroll
+      for (int t = 0; t < NS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += red[w][t][lane * 4 + r];
+  }
+  const int tok = l15, f = f0 + 4 * kg;
+  if (tok >= p.M || f >= n_out) return;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (SWIGLU) {
+      v[r] = (acc[NS - 1][r] * p.w_scale[n_out + f + r]) * silu_fast(acc[0][r] * p.w_scale[f + r]);
+    } else {
+      v[r] = acc[0][r] * p.w_scale[f + r];
+      if (p.bias) v[r] += bf16_bits_to_f32(p.bias[f + r]);
+      if (p.act == AKI_ACT_GELU_ERF) v[r] = gelu_erf_fast(v[r]);
+      else if (p.act == AKI_ACT_GELU_TANH) v[r] = gelu_tanh_fast(v[r]);
+    }
+    if (p.residual) v[r] += bf16_bits_to_f32(p.residual[(size_t)(p.res_row_mod > 0 ? tok % p.res_row_mod : tok) * p.ldr + f + r]);
+  }
+  *(u32x2*)(p.y + (size_t)tok * p.ldy + f) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+}
+
+template <int KS, bool NORM>
+static int launch_skinny_w8(const GemvParams& p, hipStream_t stream) {
+  const int n_out = p.act == AKI_ACT_SWIGLU ? p.N / 2 : p.N;
+  const dim3 grid((n_out + 15) / 16), block(KS * 64);
+  constexpr size_t RED = (size_t)KS * 2 * 1024;
+  const size_t rows = (size_t)p.M * ((size_t)p.K * 2 + 16);
+  const size_t smem = NORM ? (rows > RED ? rows : RED) : 0;
+  if constexpr (NORM) {
+    static bool set_s = false, set_p = false;
+    bool& set = p.act == AKI_ACT_SWIGLU ? set_s : set_p;
+    if (!set) {
+      const void* fn = p.act == AKI_ACT_SWIGLU ? (const void*)skinny_gemm_w8_kernel<KS, true, true> : (const void*)skinny_gemm_w8_kernel<KS, false, true>;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (8192 * 2 + 16)) != hipSuccess) return AKI_ERR_LAUNCH;
+      set = true;
+    }
+  }
+  AKI_CLEAR_ERR();
+  if (p.act == AKI_ACT_SWIGLU) hipLaunchKernelGGL((skinny_gemm_w8_kernel<KS, true, NORM>), grid, block, smem, stream, p);
+  else hipLaunchKernelGGL((skinny_gemm_w8_kernel<KS, false, NORM>), grid, block, smem, stream, p);
+  AKI_LAUNCH_CHECK();
+  return AKI_OK;
+}
+
+// 2 <= M <= 16 rows on e4m3 weights; K a multiple of 128 per wave, rows of w 16-byte aligned.  AKI_ERR_UNSUPPORTED otherwise.
+int skinny_gemm_w8(const aki_linear_args* a, const void* rms_w, float eps, hipStream_t stream) {
+  const int n_out = a->act == AKI_ACT_SWIGLU ? a->N / 2 : a->N;
+  if (a->M < 2 || a->M > 16 || !a->w_scale || (a->ldx % 8) || (a->ldw % 16) || (n_out % 4) || (a->ldy % 4) || (a->residual && (a->ldr % 4)))
+    return AKI_ERR_UNSUPPORTED;
+  if (a->act == AKI_ACT_SWIGLU && (a->bias || (a->N & 1))) return AKI_ERR_UNSUPPORTED;
+  if (rms_w && (a->M > 8 || a->K > 8192)) return AKI_ERR_UNSUPPORTED;
+  if (((uintptr_t)a->x & 15) || ((uintptr_t)a->w & 15) || ((uintptr_t)a->y & 7) || ((uintptr_t)a->bias & 7) || ((uintptr_t)rms_w & 15)) return AKI_ERR_ALIGNMENT;
+  GemvParams p = {(const bf16_t*)a->x, (const bf16_t*)a->w, (const bf16_t*)a->bias, (const bf16_t*)a->residual, (bf16_t*)a->y,
+                  (const bf16_t*)rms_w, eps, a->M, a->N, a->K, a->ldx, a->ldw, a->ldy, a->ldr, a->res_row_mod, a->act, a->w_scale};
+  const int tiles = (n_out + 15) / 16;
+  // waves per tile: at least four steps of 128 k per wave, and enough waves per CU for the narrow outputs
+  const bool k8 = a->K % 1024 == 0 && a->K / 8 >= 512, k4 = a->K % 512 == 0;
+  if (rms_w) {
+    if (tiles >= 1536) return AKI_ERR_UNSUPPORTED;      // lm_head-wide outputs keep the norm launch (see skinny_gemm_bf16)
+    if (k8 && tiles < 768) return launch_skinny_w8<8, true>(p, stream);
+    if (k4) return launch_skinny_w8<4, true>(p, stream);
+    return AKI_ERR_UNSUPPORTED;
+  }
+  if (k8 && tiles < 768) return launch_skinny_w8<8, false>(p, stream);
+  if (k4 && tiles < 1536) return launch_skinny_w8<4, false>(p, stream);
+  if (a->K % 256 == 0) return launch_skinny_w8<2, false>(p, stream);
+  return AKI_ERR_UNSUPPORTED;
+}
+
 // M <= 8 rows and M*K*2 <= 128 KiB of LDS; returns AKI_ERR_UNSUPPORTED otherwise (the caller then uses the MFMA GEMM).
 // rms_w != NULL: the x rows are RMS-normalised (weight rms_w [K], eps) on the way into LDS.
 int gemv_bf16(const aki_linear_args* a, const void* rms_w, float eps, hipStream_t stream) {

@@ -831,14 +831,18 @@ def qkv_rope_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch
 def linear_w8(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias: Optional[torch.Tensor] = None,
               residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, rms_weight: Optional[torch.Tensor] = None,
               eps: float = 0.0) -> torch.Tensor:
-    """Weight-only fp8 GEMV for ONE row (single-sequence decode in the fp8 configuration): x bf16 [1, K], wq e4m3 [N, K] with one
-    scale per row; optional fused RMSNorm of x (rms_weight).  y bf16 [1, N_out]."""
+    """Weight-only fp8 (decode in the fp8 configuration): x bf16 [M <= 16, K], wq e4m3 [N, K] with one scale per row; optional fused RMSNorm of
+    x (rms_weight).  One row: the dot-product GEMV; 2-16 rows: the skinny MFMA GEMM on e4m3 weights (half the bytes of the bf16 one).
+    y bf16 [M, N_out]."""
     dev = _dev(x, wq, ws, bias, residual, rms_weight)
     x2 = _rows2d(x)
     M, K = x2.shape
-    if M != 1 or x.dtype != torch.bfloat16:
-        raise AkiError("linear_w8 serves single-row bf16 inputs")
+    if M > 16 or x.dtype != torch.bfloat16:
+        raise AkiError("linear_w8 serves up to 16 bf16 rows")
     N = wq.shape[0]
+    if M > 1 and rms_weight is not None and (M > 8 or K > 8192 or K % 512 or ((N // 2 if act == ACT_SWIGLU else N) + 15) // 16 >= 1536):
+        x2 = _rows2d(rmsnorm(x, rms_weight, eps))      # shapes whose rows the GEMM does not normalise itself (wide outputs, more than eight rows)
+        rms_weight = None
     n_out = N // 2 if act == ACT_SWIGLU else N
     out = torch.empty((*x.shape[:-1], n_out), dtype=torch.bfloat16, device=dev)
     o2 = out.view(-1, n_out)

@@ -356,8 +356,8 @@ class Phi3DecoderLayer(nn.Module):
                      "down": ops.quant_rows_fp8(mlp.down_proj.weight.detach()) if residual_writers else None}
 
     def decode(self, h, cos, sin, cache):
-        if self._fp8 is not None and self._fp8["o"] is not None and h.shape[0] == 1:
-            # fp8 configuration, one sequence: weight-only e4m3 GEMVs (half the bytes of the HBM-bound step), same 5 launches
+        if self._fp8 is not None and self._fp8["o"] is not None and h.shape[0] <= 16:
+            # fp8 configuration: weight-only e4m3 GEMVs (one sequence) / skinny MFMA GEMMs (2-16) - half the bytes of the HBM-bound step, same 5 launches
             w, at = self._fp8, self.self_attn
             n1, n2 = self.input_layernorm, self.post_attention_layernorm
             qkv = ops.linear_w8(h, *w["qkv"], rms_weight=n1.weight, eps=n1.variance_epsilon)
@@ -759,7 +759,7 @@ class Phi3ForCausalLM(nn.Module):
         """lm_head(norm(h)) for a few rows of the RAW residual stream [B, d] (a decode step; the last prompt token of a prefill): the final
         RMSNorm is applied inside the weight-streaming GEMV."""
         norm = self.model.norm
-        if getattr(self, "_fp8_head", None) is not None and h.shape[0] == 1:
+        if getattr(self, "_fp8_head", None) is not None and h.shape[0] <= 16:
             wq, ws, b, n = self._fp8_head
             return ops.linear_w8(h, wq, ws, bias=b, rms_weight=norm.weight, eps=norm.variance_epsilon)[..., :n]
         if type(self.lm_head) is nn.Linear:

@@ -44,7 +44,7 @@ typedef enum {
   AKI_DT_BF16 = 0,
   AKI_DT_F32 = 1,
   AKI_DT_FP8_E4M3 = 2, /* e4m3 x and w with per-row scales (aki_linear_args / aki_mma_attn_args) */
-  AKI_DT_W8A16 = 3     /* weight-only fp8: e4m3 w + w_scale, bf16 x; single-row decode (aki_linear_fwd / aki_decode_linear_fwd, M = 1) */
+  AKI_DT_W8A16 = 3     /* weight-only fp8: e4m3 w + w_scale, bf16 x; decode rows (aki_linear_fwd: M <= 16, aki_decode_linear_fwd: M <= 8) */
 } aki_dtype;
 
 /* Activation fused into aki_linear_fwd. */

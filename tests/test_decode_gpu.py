@@ -355,6 +355,43 @@ def test_batched_decode_linear_with_the_norm_in_its_prologue(M, N, act):
     assert torch.equal(fused, ops.decode_linear(xt, wt, gt, 1e-5, act=a))        # and reproducible
 
 
+@pytest.mark.parametrize("M", [2, 8, 16])
+@pytest.mark.parametrize("shape", ["qkv", "gate_up", "down", "head"])
+def test_skinny_gemm_on_e4m3_weights(M, shape):
+    """2-16 rows on e4m3 weights (batched decode in the fp8 configuration): y = (x . w8) * row scale [+ residual], SwiGLU pairing, the RMSNorm in
+    the prologue (2-8 rows; wide outputs and more rows through the norm launch) - against float64 arithmetic on the same e4m3 values and
+    against the one-row W8 GEMV row by row."""
+    from aki_amd import ops
+    rng = gen.rng_for(f"skinnyw8{M}{shape}")
+    N, K, act, norm, res = {"qkv": (9216, 3072, "none", True, False), "gate_up": (16384, 3072, "swiglu", True, False),
+                            "down": (3072, 8192, "none", False, True), "head": (32064, 3072, "none", True, False)}[shape]
+    dt = torch.bfloat16
+    x = t(rng.standard_normal((M, K), dtype=np.float32) * 2.0, dt)
+    x[M - 1] *= 0.05
+    g = t(1.0 + 0.1 * rng.standard_normal((K,), dtype=np.float32), dt)
+    w = t(rng.standard_normal((N, K), dtype=np.float32) * 0.05, dt)
+    wq, ws = ops.quant_rows_fp8(w)
+    n_out = N // 2 if act == "swiglu" else N
+    r = t(rng.standard_normal((M, n_out), dtype=np.float32), dt) if res else None
+    a = ops.ACT_SWIGLU if act == "swiglu" else ops.ACT_NONE
+    kw = dict(act=a, residual=r)
+    if norm:
+        kw.update(rms_weight=g, eps=1e-5)
+    got = ops.linear_w8(x, wq, ws, **kw)
+    assert got.shape == (M, n_out) and torch.equal(got, ops.linear_w8(x, wq, ws, **kw))
+    xin = ops.rmsnorm(x, g, 1e-5) if norm else x
+    wd = wq.cpu().view(torch.float8_e4m3fn).to(torch.float32).to(DEV).double()           # the e4m3 values, widened on the host
+    y = (xin.double() @ wd.T) * ws.double()[None, :]
+    if act == "swiglu":
+        y = y[:, n_out:] * torch.nn.functional.silu(y[:, :n_out])
+    if res:
+        y = y + r.double()
+    check(n(got), y.cpu().numpy().astype(np.float32), dt, f"skinny W8 GEMM {shape} M={M}", scale_atol=2.0)
+    rows = torch.cat([ops.linear_w8(x[m:m + 1], wq, ws, act=a, residual=None if r is None else r[m:m + 1],
+                                    **({"rms_weight": g, "eps": 1e-5} if norm else {})) for m in range(M)])
+    check(n(got), n(rows).astype(np.float32), dt, "skinny W8 GEMM vs the one-row W8 GEMV", scale_atol=2.0)
+
+
 @pytest.mark.parametrize("B,H,cap,lens", [(3, 4, 300, [17, 200, 298]), (2, 2, 5000, [4100, 63]), (8, 32, 700, [655] * 8), (1, 32, 64, [0])])
 def test_decode_attn_fused_vs_two_kernels(B, H, cap, lens):
     """RoPE + append + split-KV attention in one launch == rope_append followed by decode_attn; caches end up identical."""
