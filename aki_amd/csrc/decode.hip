@@ -914,9 +914,8 @@ __global__ __launch_bounds__(64) void decode_attn_split_kernel(const DecodeAttnP
       *(u32x4*)(s_q + lane * 8) = *(const u32x4*)(p.q + (size_t)bh * 96 + lane * 8);
     }
     __syncthreads();
-    u32x4 qv[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) qv[i] = *(const u32x4*)(s_q + i * 8);
+    // q is read from LDS where it is used (a broadcast): holding it (48 VGPRs) next to the K and V tiles put the kernel at 272 VGPRs = ONE wave
+    // per SIMD, 1024 single-wave items in flight for the 1536 of a batch of eight; without it two fit
     for (int t = 0; t < p.T; ++t) {
       const int base = k_begin + t * 64;
       if (base >= k_end) break;
@@ -938,7 +937,7 @@ __global__ __launch_bounds__(64) void decode_attn_split_kernel(const DecodeAttnP
       if (p.vbits && (base >> 6) < p.nwords) ok = ok && ((p.vbits[(size_t)b * p.nwords + (base >> 6)] >> lane) & 1ull);
       float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 12; ++i) s = dot8_bf16(kr[i], qv[i], s);
+      for (int i = 0; i < 12; ++i) s = dot8_bf16(kr[i], *(const u32x4*)(s_q + i * 8), s);
       s = ok ? s * p.scale : -INFINITY;
       const float mn = fmaxf(m, wave_max(s));
       if (mn == -INFINITY) continue;                                   // wave-uniform: nothing visible yet
@@ -950,10 +949,12 @@ __global__ __launch_bounds__(64) void decode_attn_split_kernel(const DecodeAttnP
 #pragma unroll
       for (int t2 = 0; t2 < 16; ++t2) {
         const float w = __shfl(pr, 4 * t2 + g);
+        u32x4 vt = vr[t2];
+        asm volatile("" : "+v"(vt));                     // widened here, row by row - not all 128 values ahead of the loop (that made it 272 VGPRs: one wave per SIMD)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc[2 * e] = __builtin_fmaf(w, bf16_lo(vr[t2][e]), acc[2 * e]);
-          acc[2 * e + 1] = __builtin_fmaf(w, bf16_hi(vr[t2][e]), acc[2 * e + 1]);
+          acc[2 * e] = __builtin_fmaf(w, bf16_lo(vt[e]), acc[2 * e]);
+          acc[2 * e + 1] = __builtin_fmaf(w, bf16_hi(vt[e]), acc[2 * e + 1]);
         }
       }
       m = mn;
