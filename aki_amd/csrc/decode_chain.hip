@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256, OCC) void decode_chain_kernel(const ChainParam
 // (chain_gemm).  Workgroups per layer: qkv 576 (head-major: 18 per head) | attention ceil(B * H * S / 4) | o_proj 192 | gate_up 512 | down 192.
 // RQ / RO / RG / RD: the ring depths (steps of 64 k whose operands a wave holds; the first ring-full is requested before the wait).
 template <int RQ, int RO, int RG, int RD>
-__global__ __launch_bounds__(512) void decode_chain_b_kernel(const ChainParams p0) {
+__global__ __launch_bounds__(512) void decode_chain_b_kernel(const ChainParams p0) {      // 144 VGPRs = ONE workgroup per CU; held to 128 (two per CU) the bare stream is faster, the step with its waits slower: EXPERIMENTS.md
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x;
   ChainParams p = p0;                                      // the counter set of this call: see decode_chain_kernel
