@@ -1,0 +1,638 @@
+// mma_attn64_bf16.hip - the long-sequence form of the span-driven modality-mutual attention core (bf16, head_dim 96).
+//
+// Same arithmetic and the same mask rule as mma_attn_bf16.hip (HF:phi3/modeling_phi3.py:145-167 under the reference's dense mask,
+// src/vlm.py:410-443); a different machine mapping, chosen for sequences where the core is MFMA-bound (BASELINE.json configs[3],
+// L = 4096: ~1000 FLOP per byte):
+//
+//   * ONE wave per SIMD (256-thread workgroup, one per CU, the whole 512-entry register file per lane) and TWO 32-row query
+//     blocks per wave, A and B.  Every K fragment (ds_read_b128) and every V^T fragment (ds_read_b64_tr_b16) read from LDS feeds
+//     two MFMAs instead of one - half the LDS bytes per FLOP of the 32-row kernel.
+//   * The two blocks run half a tile apart so that the softmax VALU of one sits in the MFMA gaps of the other:
+//         slot E(j):  MFMA  P_B V (tile j-1), K Q_B^T (tile j)      VALU  softmax of S_A(j)
+//         slot O(j):  MFMA  P_A V (tile j),   K Q_A^T (tile j+1)    VALU  softmax of S_B(j)
+//     The softmax is cut into 24 chunks, one per MFMA gap (sm_chunk); every MFMA is an inline-asm statement and
+//     __builtin_amdgcn_sched_barrier(0) pins each chunk to its gap (MI355X guide, cycle constants: an MFMA 32x32x16 holds the
+//     vector issue port for 8 of its 32 cycles; a gap hides ~5 plain VALU issues).
+//   * O (2 x 48), Q (2 x 24) and the K fragments (48) live in ACCUMULATOR registers that only this file's asm statements name
+//     (a[64:255], map below): the VALU never touches them, so the 256 architectural VGPRs are left to the scores, P, the V^T
+//     fragments and the bookkeeping.  hipcc is kept out of that range by never being given a reason to use it (<= 256 VGPRs, no
+//     "a" constraints); tools/attn64_audit.py checks the .s for compiler v_accvgpr_* and scratch after every edit.
+//   * Fragments are reloaded in place: right after the LAST MFMA that reads a fragment of tile j its LDS read for tile j+1 is
+//     issued into the same registers (an MFMA reads A/B at issue; the LDS round trip is > 64 cycles), so the reads ride in the
+//     MFMA gaps too and one counted lgkmcnt per slot is all the waiting there is.
+//   * The running maximum is only raised when a row's tile maximum exceeds it by more than THR (log2 units, 8 in the product):
+//     P <= 2^THR keeps bf16's relative precision, l and O stay in f32, and the 96-register rescale of O (an accumulator-file
+//     read-modify-write here) leaves the common path.  THR = 0 is the 32-row kernel's rule and reproduces it bit for bit
+//     (lab variant; tests/test_kernels_gpu.py compares the two).
+//
+// K/V tiles (64 keys) arrive by global_load_lds in the 32-row kernel's LDS image (K: source-side XOR swizzle; V: plain rows read
+// transposed); the ring holds three K and three V tiles, V one tile behind K: "unit" u = {K(u+1), V(u)} is what slot E(u) reads.
+// One barrier per tile: iteration j waits for its own pieces of unit j (counted vmcnt, unit j+1 stays in flight), meets the
+// other waves, and issues unit j+2.
+//
+// Work decomposition: the 32-row blocks of a (batch, head) pair are ranked by the columns they walk (as in the 32-row kernel,
+// two blocks per lane: up to 128 blocks, L <= 4096; longer sequences keep position order); rank g of a pair = ranked blocks
+// 8g .. 8g+7, two per wave; persistent workgroups snake over the ranks of their pair.
+#include "attn_mma_common.h"
+
+namespace aki {
+
+// accumulator-register map (literal names inside the asm strings)
+constexpr int A64_O = 64;     // O^T of block X, feature tile dt: a[64 + 48 X + 16 dt : +15]
+constexpr int A64_Q = 160;    // Q fragment ks of block X:        a[160 + 24 X + 4 ks : +3]
+constexpr int A64_KA = 208;   // K fragment ks, keys 0-31:        a[208 + 4 ks : +3]
+constexpr int A64_KC = 232;   //                keys 32-63:       a[232 + 4 ks : +3]
+// a[0:63] are left to hipcc: when it runs out of VGPRs outside the tile loop it parks values in the LOWEST free accumulator
+// registers (clobber lists do not keep it from doing so); tools/attn64_audit.py fails the build if it ever names a64 or above.
+
+template <int R> __device__ __forceinline__ void acc_zero() { asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"n"(R)); }
+template <int R> __device__ __forceinline__ void acc_set(unsigned x) { asm volatile("v_accvgpr_write_b32 a%c1, %0" ::"v"(x), "n"(R)); }
+template <int R> __device__ __forceinline__ float acc_get() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "n"(R));
+  return x;
+}
+// a[R .. R+3] *= alpha (four at a time so that the reads, multiplies and writes do not wait on each other)
+template <int R> __device__ __forceinline__ void acc_scale4(float alpha) {
+  float t0, t1, t2, t3;
+  asm volatile(
+      "v_accvgpr_read_b32 %0, a%c5\n\tv_accvgpr_read_b32 %1, a%c6\n\tv_accvgpr_read_b32 %2, a%c7\n\tv_accvgpr_read_b32 %3, a%c8\n\t"
+      "v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4\n\t"
+      "v_accvgpr_write_b32 a%c5, %0\n\tv_accvgpr_write_b32 a%c6, %1\n\tv_accvgpr_write_b32 a%c7, %2\n\tv_accvgpr_write_b32 a%c8, %3"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(alpha), "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
+}
+// S^T (VGPRs) = K fragment (a) * Q fragment (a) + S^T
+template <int KA, int QA> __device__ __forceinline__ void mfma_qk(f32x16& s) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
+}
+template <int KA, int QA> __device__ __forceinline__ void mfma_qk_zero(f32x16& s) {   // FULL tiles: the constant 0 as C
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
+}
+// O^T (a) += V^T fragment (VGPRs) * P fragment (VGPRs)
+template <int OA> __device__ __forceinline__ void mfma_pv(const u32x4 vv, const u32x4 pf) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vv), "v"(pf), "n"(OA), "n"(OA + 15));
+}
+template <int KA, int OFF> __device__ __forceinline__ void k_frag_read(unsigned addr) {
+  asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "n"(KA), "n"(KA + 3), "n"(OFF));
+}
+
+struct A64Blk {                 // one 32-row block of a wave
+  int wq0;                      // first row; L = the rank has no such block (the wave's half idles)
+  int jend;                     // tiles it walks
+  int touch_lo, touch_hi, full_lo, full_hi;   // wave-uniform rectangle summary
+  int row, rc0, rc1;            // per lane: its row and that row's unlock columns
+  bool exists, has_dead, row_alive, has_uniform, row_uniform;
+  float m_ref, l;               // reference maximum (log2 domain) and the row sum against it
+};
+struct A64Tmp { float mx, nm, ps; float e0[16], e1[16]; };   // e0 / e1: p = exp2(...) of the score registers, each alive for three chunks
+
+// five (four) links of the row-maximum chain in ONE asm statement: hipcc pads every asm boundary whose output the next VALU reads
+// with an s_nop, and the C form of fmaxf gets a canonicalising v_max per operand
+__device__ __forceinline__ float max3x5(float m, float a0, float b0, float a1, float b1, float a2, float b2, float a3, float b3, float a4, float b4) {
+  asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8\n\tv_max3_f32 %0, %0, %9, %10"
+      : "+v"(m) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4));
+  return m;
+}
+
+// One chunk of a block's softmax: what is issued in MFMA gap G of the other block's slot.  Chunks 1-3 the row maximum, 4 the
+// (rare) raise of the reference maximum, 5-20 two scores each through exp2 with the row sum and the bf16 packing trailing by
+// one and two chunks, 21 the rest.
+template <int THR, int OA, int G>
+__device__ __forceinline__ void sm_chunk(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], A64Blk& X, A64Tmp& t, const float c) {
+  if constexpr (G == 1) {
+    float m = max3(s0[0], s0[1], s1[0]);
+    asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8"
+        : "+v"(m) : "v"(s1[1]), "v"(s0[2]), "v"(s0[3]), "v"(s1[2]), "v"(s0[4]), "v"(s1[3]), "v"(s0[5]), "v"(s1[4]));
+    t.mx = m;
+  } else if constexpr (G == 2) {
+    t.mx = max3x5(t.mx, s0[6], s1[5], s0[7], s1[6], s0[8], s1[7], s0[9], s1[8], s0[10], s1[9]);
+  } else if constexpr (G == 3) {
+    t.mx = max3x5(t.mx, s0[11], s1[10], s0[12], s1[11], s0[13], s1[12], s0[14], s1[13], s0[15], s1[14]);
+  } else if constexpr (G == 4) {
+    float m15 = t.mx;
+    asm("v_max_f32 %0, %0, %1" : "+v"(m15) : "v"(s1[15]));
+    const float mx = halves_max(m15) * c;
+    if (__any(mx > X.m_ref + (float)THR)) {
+      const float m_new = fmaxf(X.m_ref, mx);
+      const float alpha = __builtin_amdgcn_exp2f(X.m_ref - m_new);
+      X.m_ref = m_new;
+      X.l *= alpha;
+      static_for<12>([&](auto I) { acc_scale4<OA + 4 * decltype(I)::value>(alpha); });
+    }
+    t.nm = -X.m_ref;
+    t.ps = 0.f;
+  } else if constexpr (G >= 5 && G <= 20) {
+    constexpr int r = G - 5;
+    const float a0 = __builtin_fmaf(s0[r], c, t.nm);
+    const float a1 = __builtin_fmaf(s1[r], c, t.nm);
+    t.e0[r] = __builtin_amdgcn_exp2f(a0);
+    t.e1[r] = __builtin_amdgcn_exp2f(a1);
+    if constexpr (r >= 1) t.ps += t.e0[r - 1] + t.e1[r - 1];
+    if constexpr (r >= 3 && (r & 1)) {            // s0 pair (r-3, r-2)
+      constexpr int e = r - 3;
+      pf[e >> 3][(e & 7) >> 1] = pack_bf16x2(t.e0[e], t.e0[e + 1]);
+    }
+    if constexpr (r >= 4 && !(r & 1)) {           // s1 pair (r-4, r-3)
+      constexpr int e = r - 4;
+      pf[2 + (e >> 3)][(e & 7) >> 1] = pack_bf16x2(t.e1[e], t.e1[e + 1]);
+    }
+  } else if constexpr (G == 21) {
+    t.ps += t.e0[15] + t.e1[15];
+    X.l += t.ps;
+    pf[3][2] = pack_bf16x2(t.e1[12], t.e1[13]);
+    pf[1][3] = pack_bf16x2(t.e0[14], t.e0[15]);
+    pf[3][3] = pack_bf16x2(t.e1[14], t.e1[15]);
+  }
+}
+
+template <int THR>      // THR: how far (log2 units) a row's tile maximum may exceed the reference maximum before the reference is raised
+__global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParams p) {
+  constexpr int NT = 256;
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * KTILE + NSTAGE * VTILE];
+  char* const sK = smem;
+  char* const sV = smem + NSTAGE * KTILE;
+  // the accumulator registers named in the asm strings below: declared once, ALL of them: the kernel descriptor allocates them and hipcc's VGPR-to-AGPR spilling only takes accumulator registers no instruction of the function names
+  asm volatile("" ::: "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // persistent workgroups, pair groups, splits: as in mma_attn_bf16.hip ("Persistent workgroups")
+  const int grp = blockIdx.x / (p.group_bh * p.splits);
+  const int bh0 = grp * p.group_bh;
+  const int gbh = min(p.group_bh, p.B * p.H - bh0);
+  const int within = blockIdx.x - bh0 * p.splits;
+  const int sidx = within / gbh;
+  const int bh = bh0 + within - sidx * gbh;
+  const int b = bh / p.H, head = bh - b * p.H;
+  const int L = p.L;
+  const bf16_t* qb = p.q + ((size_t)bh * L) * 96;
+  const char* kb = (const char*)(p.k + ((size_t)bh * p.kvcap) * 96);
+  const char* vb_ = (const char*)(p.v + ((size_t)bh * p.kvcap) * 96);
+  const int Lb = p.seq_lens ? min(p.seq_lens[b], L) : L;
+
+  // ---- LDS-DMA pieces: piece I of a tile = 16-B chunks I*256 + tid of its 12-KiB image (row = chunk / 12) ----------------
+  int d_kr[3], d_ko[3], d_vo[3];     // per lane and piece: tile row, byte offset inside the K row (swizzled) / V row
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int ch = i * NT + tid;
+    const int kr = ch / 12, pos = ch - kr * 12;
+    d_kr[i] = kr;
+    d_ko[i] = (pos ^ ((kr >> 2) & 3)) * 16;
+    d_vo[i] = pos * 16;
+  }
+  auto dma_k = [&](auto I, int t, int st) {
+    constexpr int i = decltype(I)::value;
+    const int row = min(t * 64 + d_kr[i], L - 1);
+    __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(kb + (size_t)(unsigned)(row * 192 + d_ko[i])), AKI_LDS_PTR(sK + st * KTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
+  };
+  auto dma_v = [&](auto I, int t, int st) {
+    constexpr int i = decltype(I)::value;
+    const int row = min(t * 64 + d_kr[i], L - 1);
+    __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(vb_ + (size_t)(unsigned)(row * 192 + d_vo[i])), AKI_LDS_PTR(sV + st * VTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
+  };
+
+  // ---- once per workgroup: valid-column words (lane i holds words i, i+64, i+128, i+192), block extents and their ranking ----
+  unsigned vw_lo[4], vw_hi[4];
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const int w = lane + 64 * q4;
+    unsigned long long vbw = 0ull;
+    if (w < p.nwords) {
+      if (p.vbits) vbw = p.vbits[(size_t)b * p.nwords + w];
+      else vbw = (w * 64 + 64 <= L) ? ~0ull : ((1ull << (L - w * 64)) - 1ull);
+    }
+    vw_lo[q4] = (unsigned)vbw;
+    vw_hi[q4] = (unsigned)(vbw >> 32);
+  }
+  auto valid_word = [&](int w) -> unsigned long long {          // wave-uniform w
+    const int wc = min(w, p.nwords - 1);
+    const int sel = wc >> 6, idx = wc & 63;
+    unsigned lo = __builtin_amdgcn_readlane(vw_lo[0], idx), hi = __builtin_amdgcn_readlane(vw_hi[0], idx);
+    if (sel == 1) { lo = __builtin_amdgcn_readlane(vw_lo[1], idx); hi = __builtin_amdgcn_readlane(vw_hi[1], idx); }
+    if (sel == 2) { lo = __builtin_amdgcn_readlane(vw_lo[2], idx); hi = __builtin_amdgcn_readlane(vw_hi[2], idx); }
+    if (sel == 3) { lo = __builtin_amdgcn_readlane(vw_lo[3], idx); hi = __builtin_amdgcn_readlane(vw_hi[3], idx); }
+    return ((unsigned long long)hi << 32) | lo;
+  };
+
+  const aki_mma_rect* const rects_b = p.rects + (size_t)b * p.max_rects;
+  auto rect_at = [&](int i) -> aki_mma_rect {       // wave-uniform: one s_load_dwordx4 through the scalar cache
+    const unsigned long long pa = (unsigned long long)(rects_b + i);
+    const unsigned long long pu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pa);
+    u32x4 r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(pu) : "memory");
+    aki_mma_rect o;
+    o.row_lo = (int)r[0]; o.row_hi = (int)r[1]; o.col_lo = (int)r[2]; o.col_hi = (int)r[3];
+    return o;
+  };
+  // columns a 32-row block starting at r0 walks (mma_attn_bf16.hip, block_extent)
+  auto block_extent = [&](int r0) -> int {
+    if (r0 >= L) return -1;
+    int ext = min(r0 + 32, L);
+    for (int i = 0; i < p.max_rects; ++i) {
+      const aki_mma_rect r = rect_at(i);
+      if (r.row_hi > r.row_lo && r.col_hi > r.col_lo && r.row_lo < r0 + 32 && r.row_hi > r0) ext = max(ext, min(r.col_hi, L));
+    }
+    if (p.dead_uniform && min(r0 + 32, L) > Lb) ext = L;
+    return ext;
+  };
+  const int nblk = (L + 31) >> 5;
+  const bool sched = nblk <= 128;                 // kernel-uniform: ranked order (lane i <-> blocks i and i + 64)
+  int ext0 = -1, ext1 = -1, rank0 = 0x7fff, rank1 = 0x7fff;
+  if (sched) {
+    ext0 = block_extent(32 * lane);
+    ext1 = block_extent(32 * (lane + 64));
+    const int key0 = ext0 < 0 ? -1 : ext0 * 256 + lane;          // unique; later block first on ties
+    const int key1 = ext1 < 0 ? -1 : ext1 * 256 + lane + 64;
+    int r0 = 0, r1 = 0;
+    for (int i = 0; i < 64; ++i) {
+      const int k0 = __builtin_amdgcn_readlane(key0, i), k1 = __builtin_amdgcn_readlane(key1, i);
+      r0 += (k0 > key0 ? 1 : 0) + (k1 > key0 ? 1 : 0);
+      r1 += (k0 > key1 ? 1 : 0) + (k1 > key1 ? 1 : 0);
+    }
+    rank0 = ext0 >= 0 ? r0 : 0x7fff;
+    rank1 = ext1 >= 0 ? r1 : 0x7fff;
+  }
+  // block with rank R of the ranked order: first row and extent (wave-uniform); no such block -> (L, 0)
+  auto ranked_block = [&](int R, int& wq0, int& ext) {
+    wq0 = L; ext = 0;
+    const unsigned long long m0 = __ballot(rank0 == R);
+    const unsigned long long m1 = __ballot(rank1 == R);
+    if (m0 != 0ull) {
+      const int l = __builtin_ctzll(m0);
+      wq0 = 32 * l; ext = __builtin_amdgcn_readlane(ext0, l);
+    } else if (m1 != 0ull) {
+      const int l = __builtin_ctzll(m1);
+      wq0 = 32 * (l + 64); ext = __builtin_amdgcn_readlane(ext1, l);
+    }
+  };
+
+  // per-lane LDS read offsets (mma_attn_bf16.hip): K rows with the XOR swizzle on the low two chunk bits - fragment ks reads
+  // chunk (2 ks + h) ^ kswz = ((2 ks) & ~3) + (((2 (ks & 1)) + h) ^ kswz): one lane address per parity of ks, the rest immediate
+  const int kswz = (l31 >> 2) & 3;
+  const int k_even = l31 * KROW + ((h ^ kswz) << 4);
+  const int k_odd = l31 * KROW + (((2 + h) ^ kswz) << 4);
+  const int voff = (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const unsigned sK_a = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)sK);
+  const unsigned sV_a = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)sV);
+  const float c = p.scale_log2;
+
+  for (int kk = 0;; ++kk) {
+  const int g = kk * p.splits + ((kk & 1) ? p.splits - 1 - sidx : sidx);   // this workgroup's next rank
+  if (g >= p.nqt) break;
+
+  // ---- which blocks: the rank's eight, this wave's two ----------------------------------------------
+  A64Blk A, B;
+  int hi_col = 0;
+  {
+    int extA = 0, extB = 0;
+    if (sched) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        int wa, ea, wb, eb;
+        ranked_block(8 * g + 2 * w, wa, ea);
+        ranked_block(8 * g + 2 * w + 1, wb, eb);
+        hi_col = max(hi_col, max(ea, eb));
+        if (w == wave) { A.wq0 = wa; extA = ea; B.wq0 = wb; extB = eb; }
+      }
+    } else {                                     // position order, late rows first; a wave's blocks are neighbours
+      const int q0 = (p.nqt - 1 - g) * 256;
+      const int e = max(block_extent(q0 + 32 * (lane & 7)), 0);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) hi_col = max(hi_col, __builtin_amdgcn_readlane(e, w));
+      A.wq0 = min(q0 + 64 * wave, L); extA = __builtin_amdgcn_readlane(e, 2 * wave);
+      B.wq0 = min(q0 + 64 * wave + 32, L); extB = __builtin_amdgcn_readlane(e, 2 * wave + 1);
+    }
+    A.wq0 = __builtin_amdgcn_readfirstlane(A.wq0); B.wq0 = __builtin_amdgcn_readfirstlane(B.wq0);
+    A.jend = __builtin_amdgcn_readfirstlane((extA + 63) >> 6); B.jend = __builtin_amdgcn_readfirstlane((extB + 63) >> 6);
+    hi_col = __builtin_amdgcn_readfirstlane(hi_col);
+  }
+  const int jend = (hi_col + 63) >> 6;            // the rank's K/V stream (workgroup-uniform)
+  const int jend_w = max(A.jend, B.jend);         // this wave's part of it
+
+  // ---- Q of both blocks first (plain loads the compiler counts), then the K/V stream: K(0), unit 0, unit 1 --------------
+  bf16x8 qa[6], qb2[6];
+  {
+    const bf16_t* ra = qb + (size_t)min(A.wq0 + l31, L - 1) * 96 + 8 * h;
+    const bf16_t* rb = qb + (size_t)min(B.wq0 + l31, L - 1) * 96 + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) { qa[ks] = *(const bf16x8*)(ra + 16 * ks); qb2[ks] = *(const bf16x8*)(rb + 16 * ks); }
+  }
+  static_for<3>([&](auto I) { dma_k(I, 0, 0); });
+  static_for<3>([&](auto I) { dma_k(I, 1, 1); });
+  static_for<3>([&](auto I) { dma_v(I, 0, 0); });
+  static_for<3>([&](auto I) { dma_k(I, 2, 2); });
+  static_for<3>([&](auto I) { dma_v(I, 1, 1); });
+
+  // ---- per block: rectangle summary, per-lane unlock range, row classes --------------------------------
+  auto setup = [&](A64Blk& X) {
+    X.exists = X.wq0 < L;
+    X.row = X.wq0 + l31;
+    X.touch_lo = 0x7fffffff; X.touch_hi = 0; X.full_lo = 0; X.full_hi = 0;
+    X.rc0 = 0; X.rc1 = 0;
+    for (int i = 0; i < p.max_rects; ++i) {
+      const aki_mma_rect r = rect_at(i);
+      if (r.row_hi > r.row_lo && r.col_hi > r.col_lo) {
+        if (r.row_lo < X.wq0 + 32 && r.row_hi > X.wq0) {
+          X.touch_lo = min(X.touch_lo, r.col_lo);
+          X.touch_hi = max(X.touch_hi, r.col_hi);
+          if (r.row_lo <= X.wq0 && r.row_hi >= X.wq0 + 32) { X.full_lo = r.col_lo; X.full_hi = r.col_hi; }
+        }
+        if (X.row >= r.row_lo && X.row < r.row_hi) { X.rc0 = r.col_lo; X.rc1 = r.col_hi; }
+      }
+    }
+    X.has_dead = min(X.wq0 + 32, L) > Lb;              // some rows of the block are beyond seq_len
+    X.row_alive = X.row < Lb;
+    X.has_uniform = p.dead_uniform && X.has_dead && X.exists;
+    X.row_uniform = p.dead_uniform && !X.row_alive && X.exists;
+    X.m_ref = -1e30f;
+    X.l = 0.f;
+  };
+  setup(A);
+  setup(B);
+  if (A.row_uniform) {   // uniform-softmax rows: score 0 on every column = an all-zero query
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) qa[ks] = bf16x8{};
+  }
+  if (B.row_uniform) {
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) qb2[ks] = bf16x8{};
+  }
+  static_for<6>([&](auto KS) {
+    constexpr int ks = decltype(KS)::value;
+    const u32x4 wa = __builtin_bit_cast(u32x4, qa[ks]), wb = __builtin_bit_cast(u32x4, qb2[ks]);
+    acc_set<A64_Q + 4 * ks + 0>(wa[0]); acc_set<A64_Q + 4 * ks + 1>(wa[1]); acc_set<A64_Q + 4 * ks + 2>(wa[2]); acc_set<A64_Q + 4 * ks + 3>(wa[3]);
+    acc_set<A64_Q + 24 + 4 * ks + 0>(wb[0]); acc_set<A64_Q + 24 + 4 * ks + 1>(wb[1]); acc_set<A64_Q + 24 + 4 * ks + 2>(wb[2]); acc_set<A64_Q + 24 + 4 * ks + 3>(wb[3]);
+  });
+  static_for<96>([&](auto R) { acc_zero<A64_O + decltype(R)::value>(); });
+
+  // ---- tile classes and the mask bias (the initial value of the score accumulators, as in the 32-row kernel) ----------
+  // FULL: every column of the tile visible to every row of the block - the first MFMA of each chain takes the constant 0.
+  auto tile_full = [&](const A64Blk& X, int j, unsigned long long vb) -> bool {
+    const int c0 = j * 64;
+    const bool causal_full = (c0 + 63 <= X.wq0);
+    const bool rect_full = (c0 >= X.full_lo && c0 + 64 <= X.full_hi);
+    return X.exists && (vb == ~0ull) && (causal_full || rect_full) && !X.has_dead;
+  };
+  // everything else: ROWWISE (one value per lane) or the per-lane visibility word expanded register by register; a tile the
+  // block sees nothing of comes out as all -inf (p = 0, the reference maximum stays)
+  auto tile_bias = [&](const A64Blk& X, int j, unsigned long long vb, f32x16& s0, f32x16& s1) {
+    const int c0 = j * 64;
+    const bool causal_none = (c0 > X.wq0 + 31);
+    const bool lane_covers = X.rc0 <= c0 && c0 + 64 <= X.rc1;
+    const bool lane_cut = !lane_covers && X.rc0 < c0 + 64 && X.rc1 > c0;
+    const bool rowwise = X.exists && causal_none && vb == ~0ull && !X.has_dead && !__any(lane_cut);
+    if (rowwise) {
+      const float lane_bias = lane_covers ? 0.f : -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = lane_bias; s1[r] = lane_bias; }
+    } else {
+      const int base = c0 + 4 * h;
+      unsigned valid;                                                       // valid columns, register order
+      if ((vb & (vb + 1ull)) == 0ull) {                                     // wave-uniform: the bits form a prefix
+        valid = low_bits(count_le(c0 + (int)__builtin_popcountll(vb) - 1 - base));
+      } else {                                                              // holes in the 1-D mask (rare)
+        const unsigned long long vbh = vb >> (4 * h);
+        valid = 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) valid |= ((unsigned)(vbh >> (8 * k)) & 0xFu) << (4 * k);
+      }
+      const unsigned alive = (low_bits(count_le(X.row - base)) | (low_bits(count_le(X.rc1 - 1 - base)) & ~low_bits(count_le(X.rc0 - 1 - base)))) & valid;
+      const unsigned uniform = low_bits(count_le(L - 1 - base));            // every column < L
+      unsigned vis = X.row_uniform ? uniform : (X.row_alive ? alive : 0u);
+      if (!X.exists) vis = 0u;
+      const int hid = (int)~vis;
+      const int ninf = 0xFF800000;
+      static_for<16>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        s0[r] = mask_bias<r>(hid, ninf);
+        s1[r] = mask_bias<r + 16>(hid, ninf);
+      });
+    }
+    asm volatile("s_nop 1" : "+v"(s0), "+v"(s1));   // VALU write -> MFMA C operand inside an asm statement: two wait states (guide 5.7 item 2)
+  };
+
+  // ---- the two halves of a slot -------------------------------------------------------------------
+  f32x16 sA0, sA1, sB0, sB1;          // score tiles S^T of the two blocks (keys 0-31 / 32-63 of the tile)
+  u32x4 pA[4], pB[4];                 // P as packed bf16: the B operand of the four 16-key steps
+  u32x2 vlo[4][3], vhi[4][3];         // V^T fragments of the current V tile (both blocks use them)
+  A64Tmp tA, tB;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { pA[i] = u32x4{0u, 0u, 0u, 0u}; pB[i] = u32x4{0u, 0u, 0u, 0u}; }
+
+  // K fragments of a tile: 12 x ds_read_b128 into a[208:255]
+  auto k_frag = [&](auto KS, auto HALF, unsigned ke, unsigned ko) {
+    constexpr int ks = decltype(KS)::value, half = decltype(HALF)::value;
+    constexpr int off = (ks >> 1) * 64 + half * 32 * KROW;
+    if constexpr (ks & 1) k_frag_read<(half ? A64_KC : A64_KA) + 4 * ks, off>(ko);
+    else k_frag_read<(half ? A64_KC : A64_KA) + 4 * ks, off>(ke);
+  };
+  auto v_frag = [&](auto KS4, auto DT, unsigned va) {
+    constexpr int ks4 = decltype(KS4)::value, dt = decltype(DT)::value;
+    constexpr int off = ks4 * 16 * VROW + dt * 64;
+    vlo[ks4][dt] = ds_read_tr<off>(va);
+    vhi[ks4][dt] = ds_read_tr<off + 8 * VROW>(va);
+  };
+  auto wait_v_frags = [&]() {        // the 24 V^T reads are older than the 12 K reads issued behind them
+    asm volatile("s_waitcnt lgkmcnt(12)"
+                 : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]), "+v"(vlo[0][2]), "+v"(vhi[0][2]),
+                   "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]), "+v"(vlo[1][2]), "+v"(vhi[1][2]),
+                   "+v"(vlo[2][0]), "+v"(vhi[2][0]), "+v"(vlo[2][1]), "+v"(vhi[2][1]), "+v"(vlo[2][2]), "+v"(vhi[2][2]),
+                   "+v"(vlo[3][0]), "+v"(vhi[3][0]), "+v"(vlo[3][1]), "+v"(vhi[3][1]), "+v"(vlo[3][2]), "+v"(vhi[3][2]));
+  };
+#define A64_PIN() __builtin_amdgcn_sched_barrier(0)
+
+  // first half of a slot: [P V of block Y] beside softmax chunks 0-11 of block X.  PV: the 12 MFMAs are issued; RELOAD: behind
+  // each MFMA the V^T fragment it was the last to read is fetched again from the V tile at va; DMA: K (E slots) or V (O slots)
+  // pieces of the unit being prefetched go into gaps 0-2.
+  auto half1 = [&](auto PV, auto RELOAD, auto YB, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, u32x4 (&py)[4], unsigned va, auto&& dma) {
+    constexpr bool pv = decltype(PV)::value, reload = decltype(RELOAD)::value;
+    constexpr int OAY = A64_O + 48 * decltype(YB)::value, OAX = A64_O + 48 * (1 - decltype(YB)::value);
+    static_for<12>([&](auto I) {
+      constexpr int i = decltype(I)::value, ks4 = i / 3, dt = i % 3;
+      if constexpr (pv) {
+        const u32x4 vv = {vlo[ks4][dt][0], vlo[ks4][dt][1], vhi[ks4][dt][0], vhi[ks4][dt][1]};
+        mfma_pv<OAY + 16 * dt>(vv, py[ks4]);
+      }
+      if constexpr (reload) v_frag(std::integral_constant<int, ks4>{}, std::integral_constant<int, dt>{}, va);
+      A64_PIN();
+      sm_chunk<THR, OAX, i>(x0, x1, px, X, tx, c);
+      if constexpr (i < 3) dma(I);
+      A64_PIN();
+    });
+  };
+  // second half: [K Q_Y^T of tile jy] beside chunks 12-23 of block X; RELOAD: behind its last reader each K fragment is fetched
+  // again from the K tile at (ke, ko)
+  auto half2 = [&](auto QK, auto RELOAD, auto YB, f32x16& y0, f32x16& y1, bool fully, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, unsigned ke, unsigned ko) {
+    constexpr bool qk = decltype(QK)::value, reload = decltype(RELOAD)::value;
+    constexpr int QAY = A64_Q + 24 * decltype(YB)::value, OAX = A64_O + 48 * (1 - decltype(YB)::value);
+    static_for<12>([&](auto I) {
+      constexpr int i = decltype(I)::value, ks = i >> 1, half = i & 1;
+      if constexpr (qk) {
+        if constexpr (ks == 0) {
+          if (fully) { if constexpr (half == 0) mfma_qk_zero<A64_KA, QAY>(y0); else mfma_qk_zero<A64_KC, QAY>(y1); }
+          else { if constexpr (half == 0) mfma_qk<A64_KA, QAY>(y0); else mfma_qk<A64_KC, QAY>(y1); }
+        } else {
+          if constexpr (half == 0) mfma_qk<A64_KA + 4 * ks, QAY + 4 * ks>(y0); else mfma_qk<A64_KC + 4 * ks, QAY + 4 * ks>(y1);
+        }
+      }
+      if constexpr (reload) k_frag(std::integral_constant<int, ks>{}, std::integral_constant<int, half>{}, ke, ko);
+      A64_PIN();
+      sm_chunk<THR, OAX, 12 + i>(x0, x1, px, X, tx, c);
+      A64_PIN();
+    });
+  };
+  auto no_dma = [](auto) {};
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  using BA = std::integral_constant<int, 0>;
+  using BB = std::integral_constant<int, 1>;
+
+  // ---- K(0) has landed (this wave's pieces: all but the 12 youngest), for everybody: fragments, then K Q_A^T of tile 0 ----
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  static_for<12>([&](auto I) { k_frag(std::integral_constant<int, decltype(I)::value / 2>{}, std::integral_constant<int, decltype(I)::value % 2>{}, sK_a + k_even, sK_a + k_odd); });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  A64_PIN();
+  if (jend_w > 0) {
+    const unsigned long long vb0 = valid_word(0);
+    const bool fa = tile_full(A, 0, vb0);
+    if (!fa) tile_bias(A, 0, vb0, sA0, sA1);
+    A64_PIN();
+    static_for<12>([&](auto I) {
+      constexpr int i = decltype(I)::value, ks = i >> 1, half = i & 1;
+      if constexpr (ks == 0) {
+        if (fa) { if constexpr (half == 0) mfma_qk_zero<A64_KA, A64_Q>(sA0); else mfma_qk_zero<A64_KC, A64_Q>(sA1); }
+        else { if constexpr (half == 0) mfma_qk<A64_KA, A64_Q>(sA0); else mfma_qk<A64_KC, A64_Q>(sA1); }
+      } else {
+        if constexpr (half == 0) mfma_qk<A64_KA + 4 * ks, A64_Q + 4 * ks>(sA0); else mfma_qk<A64_KC + 4 * ks, A64_Q + 4 * ks>(sA1);
+      }
+    });
+    A64_PIN();
+  }
+
+  int st0 = 0, st1 = 1, st2 = 2;     // ring stages of tiles j, j+1, j+2 (K and V rings alike)
+  for (int j = 0; j < jend; ++j) {
+    // unit j = {K(j+1), V(j)}: this wave's pieces are all but the 6 youngest (unit j+1); then a workgroup-wide fact
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    A64_PIN();
+    // unit j+2 = {K(j+3) -> the stage K(j) has left, V(j+2) -> the stage V(j-1) has left}
+    const int tk = j + 3, tv = j + 2;
+    auto dma_e = [&](auto I) { dma_k(I, tk, st0); };
+    auto dma_o = [&](auto I) { dma_v(I, tv, st2); };
+    if (j >= jend_w) {               // this wave's blocks are done: keep the stream and the barriers going
+      static_for<3>(dma_e);
+      static_for<3>(dma_o);
+    } else {
+      const unsigned va = sV_a + st0 * VTILE + voff;                 // V(j)
+      const unsigned ke = sK_a + st1 * KTILE + k_even, ko = sK_a + st1 * KTILE + k_odd;   // K(j+1)
+      // ---- slot E(j): P_B V (j-1), K Q_B^T (j)  beside  softmax of S_A(j) ----
+      const unsigned long long vbj = valid_word(j);
+      const bool fb = tile_full(B, j, vbj);
+      if (j > 0) half1(T_{}, T_{}, BB{}, sA0, sA1, pA, A, tA, pB, va, dma_e);
+      else half1(F_{}, T_{}, BB{}, sA0, sA1, pA, A, tA, pB, va, dma_e);
+      if (!fb) tile_bias(B, j, vbj, sB0, sB1);
+      A64_PIN();
+      half2(T_{}, T_{}, BB{}, sB0, sB1, fb, sA0, sA1, pA, A, tA, ke, ko);
+      // ---- slot O(j): P_A V (j), K Q_A^T (j+1)  beside  softmax of S_B(j) ----
+      wait_v_frags();
+      asm volatile("s_nop 1" : "+v"(pA[0]), "+v"(pA[1]), "+v"(pA[2]), "+v"(pA[3]));   // packed by the VALU just above -> MFMA operand
+      A64_PIN();
+      half1(T_{}, F_{}, BA{}, sB0, sB1, pB, B, tB, pA, va, dma_o);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // K(j+1) fragments
+      A64_PIN();
+      if (j + 1 < jend_w) {
+        const unsigned long long vbn = valid_word(j + 1);
+        const bool fa = tile_full(A, j + 1, vbn);
+        if (!fa) tile_bias(A, j + 1, vbn, sA0, sA1);
+        A64_PIN();
+        half2(T_{}, F_{}, BA{}, sA0, sA1, fa, sB0, sB1, pB, B, tB, ke, ko);
+      } else {
+        half2(F_{}, F_{}, BA{}, sA0, sA1, false, sB0, sB1, pB, B, tB, ke, ko);
+      }
+      asm volatile("s_nop 1" : "+v"(pB[0]), "+v"(pB[1]), "+v"(pB[2]), "+v"(pB[3]));
+      A64_PIN();
+    }
+    const int t_ = st0; st0 = st1; st1 = st2; st2 = t_;
+  }
+  // P_B V of the wave's last tile: its V^T fragments are still in registers
+  if (jend_w > 0) {
+    static_for<12>([&](auto I) {
+      constexpr int i = decltype(I)::value, ks4 = i / 3, dt = i % 3;
+      const u32x4 vv = {vlo[ks4][dt][0], vlo[ks4][dt][1], vhi[ks4][dt][0], vhi[ks4][dt][1]};
+      mfma_pv<A64_O + 48 + 16 * dt>(vv, pB[ks4]);
+    });
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // the last MFMA results; the prefetched units past the end have landed
+  A64_PIN();
+
+  // ---- epilogue per block: O = O^T / l through the wave's own piece of the (idle) ring, whole 192-B rows out ----------------
+  __syncthreads();                       // every wave is done reading the ring, nothing is in flight into it
+  constexpr int OROW = 208;
+  int lane_o = lane;                     // opaque per rank: the epilogue's per-lane addresses are not hoisted over the tile loop (they would be spilled)
+  asm volatile("" : "+v"(lane_o));
+  const int l31_o = lane_o & 31, h_o = lane_o >> 5;
+  auto store_block = [&](auto XB, A64Blk& X) {
+    constexpr int xb = decltype(XB)::value;
+    const float l_tot = halves_sum(X.l);
+    const bool dead = !(l_tot > 0.f);
+    char* const sO = smem + (wave * 2 + xb) * (32 * OROW);
+    const float inv = dead ? 0.f : 1.0f / l_tot;
+    static_for<12>([&](auto I) {
+      constexpr int i = decltype(I)::value, dt = i / 4, q4 = i % 4;
+      float v[4];
+      v[0] = acc_get<A64_O + 48 * xb + 16 * dt + 4 * q4 + 0>() * inv;
+      v[1] = acc_get<A64_O + 48 * xb + 16 * dt + 4 * q4 + 1>() * inv;
+      v[2] = acc_get<A64_O + 48 * xb + 16 * dt + 4 * q4 + 2>() * inv;
+      v[3] = acc_get<A64_O + 48 * xb + 16 * dt + 4 * q4 + 3>() * inv;
+      if (dead && p.dead_uniform && X.row < L) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const char* vp = vb_ + (dt * 32 + q4 * 8 + 4 * h_o) * 2;
+        for (int t2 = 0; t2 < L; ++t2) {
+          const u32x2 w2 = *(const u32x2*)(vp + (size_t)t2 * 192);
+          a0 += bf16_lo(w2[0]); a1 += bf16_hi(w2[0]); a2 += bf16_lo(w2[1]); a3 += bf16_hi(w2[1]);
+        }
+        const float il = 1.0f / (float)L;
+        v[0] = a0 * il; v[1] = a1 * il; v[2] = a2 * il; v[3] = a3 * il;
+      }
+      const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *(u32x2*)(sO + l31_o * OROW + (dt * 32 + q4 * 8 + 4 * h_o) * 2) = pk;
+    });
+    bf16_t* const obase = p.o + ((size_t)b * L * p.H + head) * 96;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int ch = it * 64 + lane_o;                 // 16-B chunk of the block's tile: row ch/12, chunk ch%12
+      const int r = ch / 12, cc = ch - r * 12;
+      const u32x4 w4 = *(const u32x4*)(sO + r * OROW + cc * 16);
+      if (X.wq0 + r < L) *(u32x4*)((char*)(obase + (size_t)(X.wq0 + r) * p.H * 96) + cc * 16) = w4;
+    }
+    if (p.lse && h_o == 0 && X.row < L) p.lse[(size_t)bh * L + X.row] = dead ? -INFINITY : (X.m_ref + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
+  };
+  store_block(BA{}, A);
+  store_block(BB{}, B);
+  __syncthreads();   // the staged output tiles live in the ring: every wave has read its tiles back before the next rank's DMA
+  }                  // next rank of this workgroup
+#undef A64_PIN
+}
+
+#ifdef AKI_LAB_HOOKS
+extern int g_attn_variant;
+#endif
+
+// host side: called by attn_core_bf16 (mma_attn_bf16.hip) with the common parameters filled in
+int attn_core64_bf16_launch(AttnParams p, int cus, hipStream_t stream, int exact_max) {
+  const int nbh = p.B * p.H;
+  p.nqt = (p.L + 255) / 256;                       // ranks of eight 32-row blocks
+  int splits = (cus + nbh - 1) / nbh;              // one workgroup per CU
+  p.splits = splits < 1 ? 1 : (splits > p.nqt ? p.nqt : splits);
+  int grp = ((cus + p.splits - 1) / p.splits + 7) & ~7;     // one round of resident slots per group
+  p.group_bh = grp > nbh ? nbh : grp;
+  if (exact_max) hipLaunchKernelGGL((mma_attn64_bf16_kernel<0>), dim3(nbh * p.splits), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((mma_attn64_bf16_kernel<8>), dim3(nbh * p.splits), dim3(256), 0, stream, p);
+  return AKI_OK;
+}
+
+}  // namespace aki

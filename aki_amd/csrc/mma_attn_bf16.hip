@@ -713,10 +713,17 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   }                  // next rank of this workgroup
 }
 
+// the long-sequence core (mma_attn64_bf16.hip): 64 rows per wave, one wave per SIMD
+int attn_core64_bf16_launch(AttnParams p, int cus, hipStream_t stream, int exact_max);
+// Sequences of at least this many rows go to it (measured crossover: profiles/r06_attn_l4096_ab.txt)
+#ifndef AKI_ATTN64_MIN_L
+#define AKI_ATTN64_MIN_L 2048
+#endif
+
 #ifdef AKI_LAB_HOOKS
 // Lab library only: structures of this core switched in for an A/B in one process (tools/attn_ab.py).  (Variant 2 was the 64-rows-per-wave core,
 // one wave per SIMD - as compiled by hipcc 1.7x SLOWER than this kernel; its source left the tree in round 5, EXPERIMENTS.md keeps the numbers.)
-int g_attn_variant = 0;   // 0 / 1 / 2 = this kernel, 3 = this kernel with the software-pipelined tile loop (lab: 6-9 % slower), 4 = 8-wave ping-pong on the software-pipelined loop, 5 = DMA behind the score MFMAs, 6 / 7 = one / three workgroups per pair, 8 = LDS arrival counters instead of the tile barrier
+int g_attn_variant = 0;   // 0 = product rule (this kernel below AKI_ATTN64_MIN_L rows, the 64-row kernel from there on), 1 / 2 = this kernel at every length, 9 = the 64-row kernel at every length, 10 = the 64-row kernel with the exact running maximum (THR 0: bit-identical to this kernel), 3 = this kernel with the software-pipelined tile loop (lab: 6-9 % slower), 4 = 8-wave ping-pong on the software-pipelined loop, 5 = DMA behind the score MFMAs, 6 / 7 = one / three workgroups per pair, 8 = LDS arrival counters instead of the tile barrier
 #endif
 
 int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -761,6 +768,26 @@ int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, h
   p.scale_log2 = a->scale * 1.44269504088896340736f;
   p.dead_uniform = a->dead_rows == AKI_DEAD_ROWS_UNIFORM;
   AKI_CLEAR_ERR();
+  {
+    bool long_core = a->L >= AKI_ATTN64_MIN_L;
+    int exact_max = 0;
+#ifdef AKI_LAB_HOOKS
+    if (g_attn_variant >= 1 && g_attn_variant <= 8) long_core = false;
+    if (g_attn_variant == 9 || g_attn_variant == 10) { long_core = true; exact_max = g_attn_variant == 10; }
+#endif
+    if (long_core) {
+      static int cus64 = 0;
+      if (cus64 == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus64 = n;
+      }
+      const int rc = attn_core64_bf16_launch(p, cus64, stream, exact_max);
+      if (rc != AKI_OK) return rc;
+      AKI_LAUNCH_CHECK();
+      return AKI_OK;
+    }
+  }
 #ifdef AKI_LAB_HOOKS
   if (g_attn_variant == 3) hipLaunchKernelGGL((mma_attn_bf16_kernel<NW, 1>), dim3(a->B * a->H * p.splits), dim3(NW * 64), 0, stream, p);
   else if (g_attn_variant == 5) hipLaunchKernelGGL((mma_attn_bf16_kernel<NW, 3>), dim3(a->B * a->H * p.splits), dim3(NW * 64), 0, stream, p);
