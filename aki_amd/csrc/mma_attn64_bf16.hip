@@ -82,76 +82,238 @@ struct A64Blk {                 // one 32-row block of a wave
   int jend;                     // tiles it walks
   int touch_lo, touch_hi, full_lo, full_hi;   // wave-uniform rectangle summary
   int row, rc0, rc1;            // per lane: its row and that row's unlock columns
-  bool exists, has_dead, row_alive, has_uniform, row_uniform;
+  bool exists, alive, has_dead, row_alive, has_uniform, row_uniform;
   float m_ref, l;               // reference maximum (log2 domain) and the row sum against it
+  float hide;                   // per lane, for the score tile in flight: 0, or -inf = this row sees nothing of the tile
+  float thr_raw;                // (m_ref + THR) / (scale log2 e): a raw score above it raises the reference maximum
+  unsigned long long fast, fullm;   // tile masks of the current window of 64 tiles (bit t <-> tile win + t): fast = FULL, HIDDEN or ROWWISE; fullm = FULL
 };
-struct A64Tmp { float mx, nm, ps; float e0[16], e1[16]; };   // e0 / e1: p = exp2(...) of the score registers, each alive for three chunks
-
-// five (four) links of the row-maximum chain in ONE asm statement: hipcc pads every asm boundary whose output the next VALU reads
-// with an s_nop, and the C form of fmaxf gets a canonicalising v_max per operand
-__device__ __forceinline__ float max3x5(float m, float a0, float b0, float a1, float b1, float a2, float b2, float a3, float b3, float a4, float b4) {
-  asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8\n\tv_max3_f32 %0, %0, %9, %10"
-      : "+v"(m) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4));
-  return m;
+// End of a softmax chunk: the values it produced are USED by an empty asm volatile statement.  asm volatile statements keep their
+// order (every MFMA is one), so the chunk's instructions cannot be sunk below the next MFMA - which is what the IR passes did with
+// sixteen chunks' exp2 work when only sched_barrier (a machine-scheduler fence) stood between the chunks.  Inputs only: an asm
+// OUTPUT read by the next VALU instruction costs an s_nop (hipcc's asm boundary pad), one per gap.
+template <class A> __device__ __forceinline__ void pin(const A& a) { asm volatile("" ::"v"(a)); }
+template <class A, class B> __device__ __forceinline__ void pin(const A& a, const B& b) { asm volatile("" ::"v"(a), "v"(b)); }
+template <class A, class B, class C> __device__ __forceinline__ void pin(const A& a, const B& b, const C& c) { asm volatile("" ::"v"(a), "v"(b), "v"(c)); }
+template <class A, class B, class C, class D> __device__ __forceinline__ void pin(const A& a, const B& b, const C& c, const D& d) { asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d)); }
+template <class A, class B, class C, class D, class E> __device__ __forceinline__ void pin(const A& a, const B& b, const C& c, const D& d, const E& e) {
+  asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d), "v"(e));
+}
+template <class A, class B, class C, class D, class E, class F> __device__ __forceinline__ void pin(const A& a, const B& b, const C& c, const D& d, const E& e, const F& f) {
+  asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f));
+}
+template <class A, class B, class C, class D, class E, class F, class G> __device__ __forceinline__ void pin(const A& a, const B& b, const C& c, const D& d, const E& e, const F& f, const G& g) {
+  asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g));
 }
 
-// One chunk of a block's softmax: what is issued in MFMA gap G of the other block's slot.  Chunks 1-3 the row maximum, 4 the
-// (rare) raise of the reference maximum, 5-20 two scores each through exp2 with the row sum and the bf16 packing trailing by
-// one and two chunks, 21 the rest.
-template <int THR, int OA, int G>
-__device__ __forceinline__ void sm_chunk(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], A64Blk& X, A64Tmp& t, const float c) {
-  if constexpr (G == 1) {
-    float m = max3(s0[0], s0[1], s1[0]);
-    asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8"
-        : "+v"(m) : "v"(s1[1]), "v"(s0[2]), "v"(s0[3]), "v"(s1[2]), "v"(s0[4]), "v"(s1[3]), "v"(s0[5]), "v"(s1[4]));
-    t.mx = m;
+struct A64Tmp {
+  float m0, m1, m2, m3;        // four independent row-maximum chains (a wave alone on its SIMD stalls on every dependent VALU pair)
+  float thr, nm, ps, T;        // raise threshold (raw score units), -m_ref + hide, running row sum, the pair sum waiting to enter it
+  float a0, a1;                // exp2 arguments of the next score pair
+  float e0[16], e1[16];        // p = exp2(...) of the score registers, each alive for three chunks
+  unsigned long long need;     // lanes whose tile maximum calls for a raise of the reference maximum
+};
+
+// One chunk of a block's softmax: what is issued in MFMA gap G of the other block's slot.  Inside a chunk no instruction depends
+// on another one of the same chunk (except the short tails of chunks 4-6 and 23): every value is consumed one chunk after it is made.
+//   0       threshold and exp2 offset of this tile (from the reference maximum as it stands)
+//   1-4     row maximum: four chains of four links
+//   5       chains merged, the two half rows merged (v_permlane32_swap), compared with the threshold
+//   6       (rare) the reference maximum is raised: l, O and the threshold follow; first exp2 arguments
+//   7-22    score pair r = G - 7: exp2 of pair r, arguments of pair r + 1, pair sum r - 1, row sum + pair sum r - 2, bf16 packing of
+//           pairs two chunks old
+//   23      the rest of the sum and of the packing
+template <int THR, int OA, int G, int ABL>
+__device__ __forceinline__ void sm_chunk(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], A64Blk& X, A64Tmp& t, const float c, const float rc) {
+  if constexpr ((ABL & 16) && G >= 1 && G <= 5) {
+    if constexpr (G == 5) t.need = 0ull;
+  } else if constexpr ((ABL & 1) && G >= 7) {
+    if constexpr (G == 7) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pf[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    }
+  } else if constexpr (G == 0) {
+    t.thr = X.hide < 0.f ? INFINITY : X.thr_raw;
+    t.nm = -X.m_ref + X.hide;       // a hidden row: exp2(-inf) = 0 on every column
+    pin(t.thr, t.nm);
+  } else if constexpr (G == 1) {
+    asm("v_max3_f32 %0, %4, %5, %6\n\tv_max3_f32 %1, %7, %8, %9\n\tv_max3_f32 %2, %10, %11, %12\n\tv_max3_f32 %3, %13, %14, %15"
+        : "=&v"(t.m0), "=&v"(t.m1), "=&v"(t.m2), "=&v"(t.m3)
+        : "v"(s0[0]), "v"(s0[1]), "v"(s1[0]), "v"(s0[4]), "v"(s0[5]), "v"(s1[4]), "v"(s0[8]), "v"(s0[9]), "v"(s1[8]), "v"(s0[12]), "v"(s0[13]), "v"(s1[12]));
+    pin(t.m0, t.m1, t.m2, t.m3);
   } else if constexpr (G == 2) {
-    t.mx = max3x5(t.mx, s0[6], s1[5], s0[7], s1[6], s0[8], s1[7], s0[9], s1[8], s0[10], s1[9]);
+    asm("v_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %8, %9\n\tv_max3_f32 %3, %3, %10, %11"
+        : "+v"(t.m0), "+v"(t.m1), "+v"(t.m2), "+v"(t.m3)
+        : "v"(s1[1]), "v"(s0[2]), "v"(s1[5]), "v"(s0[6]), "v"(s1[9]), "v"(s0[10]), "v"(s1[13]), "v"(s0[14]));
+    pin(t.m0, t.m1, t.m2, t.m3);
   } else if constexpr (G == 3) {
-    t.mx = max3x5(t.mx, s0[11], s1[10], s0[12], s1[11], s0[13], s1[12], s0[14], s1[13], s0[15], s1[14]);
+    asm("v_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %8, %9\n\tv_max3_f32 %3, %3, %10, %11"
+        : "+v"(t.m0), "+v"(t.m1), "+v"(t.m2), "+v"(t.m3)
+        : "v"(s0[3]), "v"(s1[2]), "v"(s0[7]), "v"(s1[6]), "v"(s0[11]), "v"(s1[10]), "v"(s0[15]), "v"(s1[14]));
+    pin(t.m0, t.m1, t.m2, t.m3);
   } else if constexpr (G == 4) {
-    float m15 = t.mx;
-    asm("v_max_f32 %0, %0, %1" : "+v"(m15) : "v"(s1[15]));
-    const float mx = halves_max(m15) * c;
-    if (__any(mx > X.m_ref + (float)THR)) {
+    asm("v_max_f32 %0, %0, %4\n\tv_max_f32 %1, %1, %5\n\tv_max_f32 %2, %2, %6\n\tv_max_f32 %3, %3, %7\n\tv_max3_f32 %0, %0, %1, %2"
+        : "+v"(t.m0), "+v"(t.m1), "+v"(t.m2), "+v"(t.m3)
+        : "v"(s1[3]), "v"(s1[7]), "v"(s1[11]), "v"(s1[15]));
+    pin(t.m0, t.m3);
+  } else if constexpr (G == 5) {
+    float a = t.m0, b_;
+    asm("v_max_f32 %0, %0, %2\n\tv_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "=&v"(b_) : "v"(t.m3));
+    t.m0 = a;                        // the row's maximum over the tile, raw score units, in both half rows
+    if constexpr (THR == 0) t.need = __ballot(a * c + X.hide > X.m_ref);      // the 32-row kernel's rule, bit for bit
+    else t.need = __ballot(a > t.thr);
+    pin(t.m0);
+  } else if constexpr (G == 6) {
+    if (__builtin_expect(t.need != 0ull, 0)) {
+      const float mx = t.m0 * c + X.hide;
       const float m_new = fmaxf(X.m_ref, mx);
       const float alpha = __builtin_amdgcn_exp2f(X.m_ref - m_new);
       X.m_ref = m_new;
+      X.thr_raw = (m_new + (float)THR) * rc;
       X.l *= alpha;
       static_for<12>([&](auto I) { acc_scale4<OA + 4 * decltype(I)::value>(alpha); });
+      t.nm = -m_new + X.hide;
     }
-    t.nm = -X.m_ref;
     t.ps = 0.f;
-  } else if constexpr (G >= 5 && G <= 20) {
-    constexpr int r = G - 5;
-    const float a0 = __builtin_fmaf(s0[r], c, t.nm);
-    const float a1 = __builtin_fmaf(s1[r], c, t.nm);
-    t.e0[r] = __builtin_amdgcn_exp2f(a0);
-    t.e1[r] = __builtin_amdgcn_exp2f(a1);
-    if constexpr (r >= 1) t.ps += t.e0[r - 1] + t.e1[r - 1];
-    if constexpr (r >= 3 && (r & 1)) {            // s0 pair (r-3, r-2)
-      constexpr int e = r - 3;
+    t.a0 = __builtin_fmaf(s0[0], c, t.nm);
+    t.a1 = __builtin_fmaf(s1[0], c, t.nm);
+    pin(t.a0, t.a1, t.nm, t.ps);
+  } else if constexpr (G >= 7 && G <= 22) {
+    constexpr int r = G - 7;
+    t.e0[r] = __builtin_amdgcn_exp2f(t.a0);
+    t.e1[r] = __builtin_amdgcn_exp2f(t.a1);
+    if constexpr (r < 15) {
+      t.a0 = __builtin_fmaf(s0[r + 1], c, t.nm);
+      t.a1 = __builtin_fmaf(s1[r + 1], c, t.nm);
+    }
+    if constexpr (r >= 2) t.ps += t.T;                                  // pair sum r - 2
+    if constexpr (r >= 1) t.T = t.e0[r - 1] + t.e1[r - 1];
+    if constexpr (r >= 2 && !(r & 1)) {           // s0 pair (r-2, r-1)
+      constexpr int e = r - 2;
       pf[e >> 3][(e & 7) >> 1] = pack_bf16x2(t.e0[e], t.e0[e + 1]);
     }
-    if constexpr (r >= 4 && !(r & 1)) {           // s1 pair (r-4, r-3)
-      constexpr int e = r - 4;
+    if constexpr (r >= 3 && (r & 1)) {            // s1 pair (r-3, r-2)
+      constexpr int e = r - 3;
       pf[2 + (e >> 3)][(e & 7) >> 1] = pack_bf16x2(t.e1[e], t.e1[e + 1]);
     }
-  } else if constexpr (G == 21) {
+    if constexpr (r >= 2 && !(r & 1)) pin(t.e0[r], t.e1[r], t.a0, t.a1, t.ps, t.T, pf[(r - 2) >> 3]);
+    else if constexpr (r >= 3) pin(t.e0[r], t.e1[r], t.a0, t.a1, t.ps, t.T, pf[2 + ((r - 3) >> 3)]);
+    else pin(t.e0[r], t.e1[r], t.a0, t.a1, t.ps, t.T);
+  } else if constexpr (G == 23) {
+    t.ps += t.T;                                   // pair 14
     t.ps += t.e0[15] + t.e1[15];
     X.l += t.ps;
-    pf[3][2] = pack_bf16x2(t.e1[12], t.e1[13]);
     pf[1][3] = pack_bf16x2(t.e0[14], t.e0[15]);
     pf[3][3] = pack_bf16x2(t.e1[14], t.e1[15]);
+    pin(X.l, pf[1], pf[3]);
   }
 }
 
-template <int THR>      // THR: how far (log2 units) a row's tile maximum may exceed the reference maximum before the reference is raised
+// ---- the product's softmax (THR > 0): no row maximum on the common path ---------------------------------------------
+// p = exp2(s c - m_ref) is taken against the reference maximum AS IT STANDS; whether that was admissible is read off the row sum
+// afterwards: if no score exceeded m_ref + THR every p is <= 2^THR and, conversely, a score above it alone makes the row sum
+// exceed 2^THR.  A row sum above 2^THR (inf included: the first tile of a block, whose m_ref is -1e30) sends the wave through
+// sm_redo - the exact path: row maximum, raise, rescale of l and O, this tile's p again - before anything has consumed the tile
+// (its P V MFMAs are in the next slot).  26 VALU issues per tile and block leave the common path (a slot is VALU-issue bound).
+// Gap budget: an MFMA 32x32x16 leaves 24 of its 32 cycles to the vector port = three f32 ops, or one exp2 (8) and two.
+// Score pairs r = 0..15 (registers r of both halves) go through in 8 triples of gaps:
+//     G = 3k      exp2 of pair 2k     (arguments one gap old), arguments of pair 2k + 1
+//     G = 3k + 1  exp2 of pair 2k + 1,                         arguments of pair 2k + 2
+//     G = 3k + 2  pair sums 2k, 2k + 1; row sum + the two pair sums of the previous triple; bf16 packing of pairs 2k, 2k + 1
+// i.e. 2 exp2 + 2 fma (24 cycles) or 4 add + 2 cvt (24 cycles) per gap.  sm_tail adds the last two pair sums and decides.
+template <int G, int ABL>
+__device__ __forceinline__ void sm_opt_chunk(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], const A64Blk& X, A64Tmp& t, const float c) {
+  constexpr int k = G / 3, ph = G % 3;
+  if constexpr (ABL & 1) {
+    if constexpr (G == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pf[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+      t.ps = 64.f; t.m0 = 0.f; t.m1 = 0.f;
+    }
+  } else if constexpr (ph == 0) {
+    if constexpr (k == 0) {
+      t.nm = -X.m_ref + X.hide;       // a hidden row: exp2(-inf) = 0 on every column
+      t.ps = 0.f;
+      t.a0 = __builtin_fmaf(s0[0], c, t.nm);
+      t.a1 = __builtin_fmaf(s1[0], c, t.nm);
+    }
+    constexpr int r = 2 * k;
+    t.e0[r] = __builtin_amdgcn_exp2f(t.a0);
+    t.e1[r] = __builtin_amdgcn_exp2f(t.a1);
+    t.a0 = __builtin_fmaf(s0[r + 1], c, t.nm);
+    t.a1 = __builtin_fmaf(s1[r + 1], c, t.nm);
+    pin(t.e0[r], t.e1[r], t.a0, t.a1);
+  } else if constexpr (ph == 1) {
+    constexpr int r = 2 * k + 1;
+    t.e0[r] = __builtin_amdgcn_exp2f(t.a0);
+    t.e1[r] = __builtin_amdgcn_exp2f(t.a1);
+    if constexpr (r < 15) {
+      t.a0 = __builtin_fmaf(s0[r + 1], c, t.nm);
+      t.a1 = __builtin_fmaf(s1[r + 1], c, t.nm);
+    }
+    pin(t.e0[r], t.e1[r], t.a0, t.a1);
+  } else {
+    constexpr int r = 2 * k;
+    if constexpr (k >= 1) { t.ps += t.m0; t.ps += t.m1; }        // pair sums of the previous triple, in pair order (the 32-row kernel's order)
+    t.m0 = t.e0[r] + t.e1[r];
+    t.m1 = t.e0[r + 1] + t.e1[r + 1];
+    const unsigned w0 = pack_bf16x2(t.e0[r], t.e0[r + 1]), w1 = pack_bf16x2(t.e1[r], t.e1[r + 1]);
+    pin(t.ps, t.m0, t.m1, w0, w1);      // the words, not the vectors they go into: a use of the half-built vector makes hipcc copy it
+    pf[r >> 3][(r & 7) >> 1] = w0;
+    pf[2 + (r >> 3)][(r & 7) >> 1] = w1;
+  }
+}
+// the exact path for a tile whose optimistic pass overflowed the bound (rare; cold)
+template <int THR, int OA>
+__device__ __forceinline__ void sm_redo(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], A64Blk& X, A64Tmp& t, const float c) {
+  float m = max3(s0[0], s0[1], s1[0]);
+  m = max3(m, s1[1], s0[2]);
+#pragma unroll
+  for (int r = 3; r < 16; ++r) m = max3(m, s0[r], s1[r - 1]);
+  asm("v_max_f32 %0, %0, %1" : "+v"(m) : "v"(s1[15]));
+  const float mx = halves_max(m) * c + X.hide;
+  const float m_new = fmaxf(X.m_ref, mx);
+  const float alpha = __builtin_amdgcn_exp2f(X.m_ref - m_new);
+  X.m_ref = m_new;
+  X.l *= alpha;
+  static_for<12>([&](auto I) { acc_scale4<OA + 4 * decltype(I)::value>(alpha); });
+  const float nm = -m_new + X.hide;
+  float ps = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    t.e0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, nm));
+    t.e1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, nm));
+    ps += t.e0[r] + t.e1[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    pf[r >> 3][(r & 7) >> 1] = pack_bf16x2(t.e0[r], t.e0[r + 1]);
+    pf[2 + (r >> 3)][(r & 7) >> 1] = pack_bf16x2(t.e1[r], t.e1[r + 1]);
+  }
+  t.ps = ps;
+}
+template <int THR, int OA, int ABL>
+__device__ __forceinline__ void sm_tail(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], A64Blk& X, A64Tmp& t, const float c) {
+  t.ps += t.m0;
+  t.ps += t.m1;
+  if constexpr (!(ABL & 16)) {
+    if (__builtin_expect(__any(t.ps > (float)(1 << THR)) || (ABL & 64), 0)) sm_redo<THR, OA>(s0, s1, pf, X, t, c);
+  }
+  X.l += t.ps;
+}
+
+// THR: how far (log2 units) a row's tile maximum may exceed the reference maximum before the reference is raised.
+// ABL (lab library only, timing ablations with wrong results): 1 no exp / sum / pack, 2 no LDS-DMA and no vmcnt wait, 4 no fragment
+// reloads and no lgkmcnt waits, 8 no tile barrier, 16 no row maximum, 32 every tile FULL; 64 (right results) every tile through sm_redo.
+template <int THR, int ABL>
 __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParams p) {
   constexpr int NT = 256;
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * KTILE + NSTAGE * VTILE];
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * KTILE + NSTAGE * VTILE + MAX_VB_WORDS * 8];
   char* const sK = smem;
   char* const sV = smem + NSTAGE * KTILE;
+  // the sample's valid-column words: read only on the bias path, through asm (a load hipcc can see would be given a vmcnt(0) that
+  // drains the K/V ring); in registers they were eight VGPRs of cold state that pushed hot state into spills
+  const unsigned sVB_a = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)(smem + NSTAGE * KTILE + NSTAGE * VTILE));
   // the accumulator registers named in the asm strings below: declared once, ALL of them: the kernel descriptor allocates them and hipcc's VGPR-to-AGPR spilling only takes accumulator registers no instruction of the function names
   asm volatile("" ::: "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
 
@@ -174,46 +336,56 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   const int Lb = p.seq_lens ? min(p.seq_lens[b], L) : L;
 
   // ---- LDS-DMA pieces: piece I of a tile = 16-B chunks I*256 + tid of its 12-KiB image (row = chunk / 12) ----------------
-  int d_kr[3], d_ko[3], d_vo[3];     // per lane and piece: tile row, byte offset inside the K row (swizzled) / V row
+  // Buffer addressing: descriptor = this pair's L rows of K (V), per-lane constant byte offset inside a tile's 12 KiB, tile and
+  // piece in the scalar offset - no VALU per piece.  Rows at and beyond L (the last tile of a sequence that is no multiple of 64,
+  // the prefetches past the end, unwritten rows of a KV cache) are out of the descriptor's range and arrive as ZEROS: their
+  // columns are hidden by the valid words, and P = 0 meets V = 0.
+  int d_ko[3];               // K: chunk swizzled on the source side (the LDS image is lane-linear)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int ch = i * NT + tid;
     const int kr = ch / 12, pos = ch - kr * 12;
-    d_kr[i] = kr;
-    d_ko[i] = (pos ^ ((kr >> 2) & 3)) * 16;
-    d_vo[i] = pos * 16;
+    d_ko[i] = kr * 192 + (pos ^ ((kr >> 2) & 3)) * 16;
   }
+  const int d_vo = tid * 16;  // V: the image is the tile
+  const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, L * 192, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc((void*)vb_, 0, L * 192, 0x00020000);
   auto dma_k = [&](auto I, int t, int st) {
     constexpr int i = decltype(I)::value;
-    const int row = min(t * 64 + d_kr[i], L - 1);
-    __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(kb + (size_t)(unsigned)(row * 192 + d_ko[i])), AKI_LDS_PTR(sK + st * KTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
+    if constexpr (ABL & 2) return;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, AKI_LDS_PTR(sK + st * KTILE + (i * NT + wave * 64) * 16), 16, d_ko[i], t * 12288, 0, 0);
   };
   auto dma_v = [&](auto I, int t, int st) {
     constexpr int i = decltype(I)::value;
-    const int row = min(t * 64 + d_kr[i], L - 1);
-    __builtin_amdgcn_global_load_lds(AKI_GLOBAL_PTR(vb_ + (size_t)(unsigned)(row * 192 + d_vo[i])), AKI_LDS_PTR(sV + st * VTILE + (i * NT + wave * 64) * 16), 16, 0, 0);
+    if constexpr (ABL & 2) return;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, AKI_LDS_PTR(sV + st * VTILE + (i * NT + wave * 64) * 16), 16, d_vo, t * 12288 + i * 4096, 0, 0);
   };
 
   // ---- once per workgroup: valid-column words (lane i holds words i, i+64, i+128, i+192), block extents and their ranking ----
-  unsigned vw_lo[4], vw_hi[4];
+  int first_bad = 0x7fffffff;          // valid words below this index are all ones (wave-uniform)
+  {
+    unsigned long long bad = 0ull;
+    int base = 0;
 #pragma unroll
-  for (int q4 = 0; q4 < 4; ++q4) {
-    const int w = lane + 64 * q4;
-    unsigned long long vbw = 0ull;
-    if (w < p.nwords) {
-      if (p.vbits) vbw = p.vbits[(size_t)b * p.nwords + w];
-      else vbw = (w * 64 + 64 <= L) ? ~0ull : ((1ull << (L - w * 64)) - 1ull);
+    for (int q4 = 3; q4 >= 0; --q4) {
+      const int w = lane + 64 * q4;
+      unsigned long long vbw = ~0ull;
+      if (w < p.nwords) {
+        if (p.vbits) vbw = p.vbits[(size_t)b * p.nwords + w];
+        else vbw = (w * 64 + 64 <= L) ? ~0ull : ((1ull << (L - w * 64)) - 1ull);
+        if (wave == 0) *(unsigned long long*)(smem + NSTAGE * KTILE + NSTAGE * VTILE + 8 * w) = vbw;
+      }
+      const unsigned long long m = __ballot(vbw != ~0ull);
+      if (m != 0ull) { bad = m; base = 64 * q4; }
     }
-    vw_lo[q4] = (unsigned)vbw;
-    vw_hi[q4] = (unsigned)(vbw >> 32);
+    if (bad != 0ull) first_bad = base + __builtin_ctzll(bad);
+    __syncthreads();                     // the words are in LDS for every wave (once per workgroup)
   }
-  auto valid_word = [&](int w) -> unsigned long long {          // wave-uniform w
-    const int wc = min(w, p.nwords - 1);
-    const int sel = wc >> 6, idx = wc & 63;
-    unsigned lo = __builtin_amdgcn_readlane(vw_lo[0], idx), hi = __builtin_amdgcn_readlane(vw_hi[0], idx);
-    if (sel == 1) { lo = __builtin_amdgcn_readlane(vw_lo[1], idx); hi = __builtin_amdgcn_readlane(vw_hi[1], idx); }
-    if (sel == 2) { lo = __builtin_amdgcn_readlane(vw_lo[2], idx); hi = __builtin_amdgcn_readlane(vw_hi[2], idx); }
-    if (sel == 3) { lo = __builtin_amdgcn_readlane(vw_lo[3], idx); hi = __builtin_amdgcn_readlane(vw_hi[3], idx); }
+  auto valid_word = [&](int w) -> unsigned long long {          // wave-uniform w; only called for w >= first_bad
+    const unsigned addr = sVB_a + 8u * (unsigned)min(w, p.nwords - 1);
+    u32x2 r;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr) : "memory");
+    const unsigned lo = __builtin_amdgcn_readfirstlane(r[0]), hi = __builtin_amdgcn_readfirstlane(r[1]);
     return ((unsigned long long)hi << 32) | lo;
   };
 
@@ -240,10 +412,10 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   };
   const int nblk = (L + 31) >> 5;
   const bool sched = nblk <= 128;                 // kernel-uniform: ranked order (lane i <-> blocks i and i + 64)
-  int ext0 = -1, ext1 = -1, rank0 = 0x7fff, rank1 = 0x7fff;
+  int er0 = 0xff, er1 = 0xff;        // lane i: (extent << 8) | rank of blocks i and i + 64 (rank 0xff: no such block) - cold state, kept small
   if (sched) {
-    ext0 = block_extent(32 * lane);
-    ext1 = block_extent(32 * (lane + 64));
+    const int ext0 = block_extent(32 * lane);
+    const int ext1 = block_extent(32 * (lane + 64));
     const int key0 = ext0 < 0 ? -1 : ext0 * 256 + lane;          // unique; later block first on ties
     const int key1 = ext1 < 0 ? -1 : ext1 * 256 + lane + 64;
     int r0 = 0, r1 = 0;
@@ -252,20 +424,20 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       r0 += (k0 > key0 ? 1 : 0) + (k1 > key0 ? 1 : 0);
       r1 += (k0 > key1 ? 1 : 0) + (k1 > key1 ? 1 : 0);
     }
-    rank0 = ext0 >= 0 ? r0 : 0x7fff;
-    rank1 = ext1 >= 0 ? r1 : 0x7fff;
+    er0 = ext0 >= 0 ? (ext0 << 8) | r0 : 0xff;
+    er1 = ext1 >= 0 ? (ext1 << 8) | r1 : 0xff;
   }
   // block with rank R of the ranked order: first row and extent (wave-uniform); no such block -> (L, 0)
   auto ranked_block = [&](int R, int& wq0, int& ext) {
     wq0 = L; ext = 0;
-    const unsigned long long m0 = __ballot(rank0 == R);
-    const unsigned long long m1 = __ballot(rank1 == R);
+    const unsigned long long m0 = __ballot((er0 & 0xff) == R);
+    const unsigned long long m1 = __ballot((er1 & 0xff) == R);
     if (m0 != 0ull) {
       const int l = __builtin_ctzll(m0);
-      wq0 = 32 * l; ext = __builtin_amdgcn_readlane(ext0, l);
+      wq0 = 32 * l; ext = __builtin_amdgcn_readlane(er0, l) >> 8;
     } else if (m1 != 0ull) {
       const int l = __builtin_ctzll(m1);
-      wq0 = 32 * (l + 64); ext = __builtin_amdgcn_readlane(ext1, l);
+      wq0 = 32 * (l + 64); ext = __builtin_amdgcn_readlane(er1, l) >> 8;
     }
   };
 
@@ -278,6 +450,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   const unsigned sK_a = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)sK);
   const unsigned sV_a = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)sV);
   const float c = p.scale_log2;
+  const float rc = 1.0f / c;
 
   for (int kk = 0;; ++kk) {
   const int g = kk * p.splits + ((kk & 1) ? p.splits - 1 - sidx : sidx);   // this workgroup's next rank
@@ -343,11 +516,14 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
         if (X.row >= r.row_lo && X.row < r.row_hi) { X.rc0 = r.col_lo; X.rc1 = r.col_hi; }
       }
     }
+    X.alive = X.wq0 < Lb;
+    X.hide = 0.f;
     X.has_dead = min(X.wq0 + 32, L) > Lb;              // some rows of the block are beyond seq_len
     X.row_alive = X.row < Lb;
     X.has_uniform = p.dead_uniform && X.has_dead && X.exists;
     X.row_uniform = p.dead_uniform && !X.row_alive && X.exists;
     X.m_ref = -1e30f;
+    X.thr_raw = (-1e30f + (float)THR) * rc;
     X.l = 0.f;
   };
   setup(A);
@@ -368,50 +544,70 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   });
   static_for<96>([&](auto R) { acc_zero<A64_O + decltype(R)::value>(); });
 
-  // ---- tile classes and the mask bias (the initial value of the score accumulators, as in the 32-row kernel) ----------
-  // FULL: every column of the tile visible to every row of the block - the first MFMA of each chain takes the constant 0.
-  auto tile_full = [&](const A64Blk& X, int j, unsigned long long vb) -> bool {
-    const int c0 = j * 64;
-    const bool causal_full = (c0 + 63 <= X.wq0);
-    const bool rect_full = (c0 >= X.full_lo && c0 + 64 <= X.full_hi);
-    return X.exists && (vb == ~0ull) && (causal_full || rect_full) && !X.has_dead;
-  };
-  // everything else: ROWWISE (one value per lane) or the per-lane visibility word expanded register by register; a tile the
-  // block sees nothing of comes out as all -inf (p = 0, the reference maximum stays)
-  auto tile_bias = [&](const A64Blk& X, int j, unsigned long long vb, f32x16& s0, f32x16& s1) {
-    const int c0 = j * 64;
-    const bool causal_none = (c0 > X.wq0 + 31);
-    const bool lane_covers = X.rc0 <= c0 && c0 + 64 <= X.rc1;
-    const bool lane_cut = !lane_covers && X.rc0 < c0 + 64 && X.rc1 > c0;
-    const bool rowwise = X.exists && causal_none && vb == ~0ull && !X.has_dead && !__any(lane_cut);
-    if (rowwise) {
-      const float lane_bias = lane_covers ? 0.f : -INFINITY;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s0[r] = lane_bias; s1[r] = lane_bias; }
-    } else {
-      const int base = c0 + 4 * h;
-      unsigned valid;                                                       // valid columns, register order
-      if ((vb & (vb + 1ull)) == 0ull) {                                     // wave-uniform: the bits form a prefix
-        valid = low_bits(count_le(c0 + (int)__builtin_popcountll(vb) - 1 - base));
-      } else {                                                              // holes in the 1-D mask (rare)
-        const unsigned long long vbh = vb >> (4 * h);
-        valid = 0u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) valid |= ((unsigned)(vbh >> (8 * k)) & 0xFu) << (4 * k);
+  // ---- tile classes (the 32-row kernel's, decided for 64 tiles at a time) -------------------------------------------------
+  //   FULL     every column visible to every row of the block: the first MFMA of each chain takes the constant 0 as C;
+  //   ROWWISE  right of the diagonal, every column valid, every rectangle that touches the block's rows covers the tile's columns
+  //            or misses them: a row sees the whole tile or nothing of it.  Nothing is put into the accumulators: the softmax
+  //            adds `hide` (0 or -inf per lane) to the exp2 offset, so a hidden row's p is 0 and its row sum unchanged;
+  //            HIDDEN tiles (beyond the block's extent - the other block of the wave still needs the slot) are the case
+  //            "every lane hidden";
+  //   PARTIAL  everything else (the diagonal, tiles cut by a rectangle edge, padding, blocks with dead rows): the per-lane
+  //            visibility word is expanded into a 0 / -inf bias, the initial value of the score accumulators.
+  // Lane t decides tile win + t for its block; two ballots make the masks the tile loop tests one bit of per slot.
+  auto block_masks = [&](A64Blk& X, int win) {
+    const int tl = win + lane, c0 = tl * 64;
+    const bool ok = X.exists && !X.has_dead && tl < first_bad;
+    bool rfull = false, clean = true;
+    for (int i = 0; i < p.max_rects; ++i) {
+      const aki_mma_rect r = rect_at(i);
+      if (r.row_hi > r.row_lo && r.col_hi > r.col_lo && r.row_lo < X.wq0 + 32 && r.row_hi > X.wq0) {
+        const bool inside = c0 >= r.col_lo && c0 + 64 <= r.col_hi;
+        const bool outside = c0 + 64 <= r.col_lo || c0 >= r.col_hi;
+        if (r.row_lo <= X.wq0 && r.row_hi >= X.wq0 + 32) rfull = rfull || inside;
+        clean = clean && (inside || outside);
       }
-      const unsigned alive = (low_bits(count_le(X.row - base)) | (low_bits(count_le(X.rc1 - 1 - base)) & ~low_bits(count_le(X.rc0 - 1 - base)))) & valid;
-      const unsigned uniform = low_bits(count_le(L - 1 - base));            // every column < L
-      unsigned vis = X.row_uniform ? uniform : (X.row_alive ? alive : 0u);
-      if (!X.exists) vis = 0u;
-      const int hid = (int)~vis;
-      const int ninf = 0xFF800000;
-      static_for<16>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        s0[r] = mask_bias<r>(hid, ninf);
-        s1[r] = mask_bias<r + 16>(hid, ninf);
-      });
     }
+    const bool F = ok && (c0 + 63 <= X.wq0 || rfull);
+    const bool R = ok && c0 > X.wq0 + 31 && clean;
+    X.fullm = __ballot(F);
+    X.fast = __ballot(F || R);
+    if constexpr (ABL & 32) { X.fullm = ~0ull; X.fast = ~0ull; }
+  };
+  block_masks(A, 0);
+  block_masks(B, 0);
+  // a fast tile's per-lane hide (FULL: nobody; ROWWISE / HIDDEN: the rows whose rectangle does not cover the tile)
+  auto fast_hide = [&](A64Blk& X, int jt) {
+    const int c0 = jt * 64;
+    const bool fbit = (X.fullm >> (jt & 63)) & 1ull;
+    const bool covers = X.rc0 <= c0 && c0 + 64 <= X.rc1;
+    X.hide = (fbit || covers) ? 0.f : -INFINITY;
+  };
+  auto tile_bias = [&](A64Blk& X, int j, f32x16& s0, f32x16& s1) {
+    const int c0 = j * 64;
+    const unsigned long long vb = j < first_bad ? ~0ull : valid_word(j);
+    const int base = c0 + 4 * h;
+    unsigned valid;                                                       // valid columns, register order
+    if ((vb & (vb + 1ull)) == 0ull) {                                     // wave-uniform: the bits form a prefix
+      valid = low_bits(count_le(c0 + (int)__builtin_popcountll(vb) - 1 - base));
+    } else {                                                              // holes in the 1-D mask (rare)
+      const unsigned long long vbh = vb >> (4 * h);
+      valid = 0u;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) valid |= ((unsigned)(vbh >> (8 * k)) & 0xFu) << (4 * k);
+    }
+    const unsigned alive = (low_bits(count_le(X.row - base)) | (low_bits(count_le(X.rc1 - 1 - base)) & ~low_bits(count_le(X.rc0 - 1 - base)))) & valid;
+    const unsigned uniform = low_bits(count_le(L - 1 - base));            // every column < L
+    unsigned vis = X.row_uniform ? uniform : (X.row_alive ? alive : 0u);
+    if (!X.exists) vis = 0u;
+    const int hid = (int)~vis;
+    const int ninf = 0xFF800000;
+    static_for<16>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      s0[r] = mask_bias<r>(hid, ninf);
+      s1[r] = mask_bias<r + 16>(hid, ninf);
+    });
     asm volatile("s_nop 1" : "+v"(s0), "+v"(s1));   // VALU write -> MFMA C operand inside an asm statement: two wait states (guide 5.7 item 2)
+    X.hide = 0.f;
   };
 
   // ---- the two halves of a slot -------------------------------------------------------------------
@@ -420,22 +616,29 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   u32x2 vlo[4][3], vhi[4][3];         // V^T fragments of the current V tile (both blocks use them)
   A64Tmp tA, tB;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { pA[i] = u32x4{0u, 0u, 0u, 0u}; pB[i] = u32x4{0u, 0u, 0u, 0u}; }
+  for (int i = 0; i < 4; ++i) {
+    pA[i] = u32x4{0u, 0u, 0u, 0u}; pB[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { vlo[i][d] = u32x2{0u, 0u}; vhi[i][d] = u32x2{0u, 0u}; }    // slot E(0) multiplies them by P = 0
+  }
 
   // K fragments of a tile: 12 x ds_read_b128 into a[208:255]
   auto k_frag = [&](auto KS, auto HALF, unsigned ke, unsigned ko) {
     constexpr int ks = decltype(KS)::value, half = decltype(HALF)::value;
     constexpr int off = (ks >> 1) * 64 + half * 32 * KROW;
+    if constexpr (ABL & 4) return;
     if constexpr (ks & 1) k_frag_read<(half ? A64_KC : A64_KA) + 4 * ks, off>(ko);
     else k_frag_read<(half ? A64_KC : A64_KA) + 4 * ks, off>(ke);
   };
   auto v_frag = [&](auto KS4, auto DT, unsigned va) {
     constexpr int ks4 = decltype(KS4)::value, dt = decltype(DT)::value;
     constexpr int off = ks4 * 16 * VROW + dt * 64;
+    if constexpr (ABL & 4) { vlo[ks4][dt] = u32x2{va, va}; vhi[ks4][dt] = u32x2{va, va}; return; }
     vlo[ks4][dt] = ds_read_tr<off>(va);
     vhi[ks4][dt] = ds_read_tr<off + 8 * VROW>(va);
   };
   auto wait_v_frags = [&]() {        // the 24 V^T reads are older than the 12 K reads issued behind them
+    if constexpr (ABL & 4) return;
     asm volatile("s_waitcnt lgkmcnt(12)"
                  : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]), "+v"(vlo[0][2]), "+v"(vhi[0][2]),
                    "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]), "+v"(vlo[1][2]), "+v"(vhi[1][2]),
@@ -458,21 +661,27 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       }
       if constexpr (reload) v_frag(std::integral_constant<int, ks4>{}, std::integral_constant<int, dt>{}, va);
       A64_PIN();
-      sm_chunk<THR, OAX, i>(x0, x1, px, X, tx, c);
+      // Slot O opens one MFMA behind the score MFMAs that wrote S_B (slot E ended with them), and chunk 0 of the product's softmax
+      // reads S: an MFMA result is not readable by the VALU for ~20 wait states after the instruction issued, and hipcc pads no
+      // hazard between an asm MFMA and anything (guide 5.7 item 2).  Counted: 6 (chunk 23) + 4 (tail) + 3 (waits) + 1 (this slot's
+      // first MFMA) + 4 here; slot E has the tile barrier in front.  The exact variant reads S one gap later.
+      if constexpr (THR != 0 && i == 0 && decltype(YB)::value == 0) asm volatile("s_nop 3" : "+v"(x0), "+v"(x1));
+      if constexpr (THR == 0) sm_chunk<THR, OAX, i, ABL>(x0, x1, px, X, tx, c, rc);
+      else sm_opt_chunk<i, ABL>(x0, x1, px, X, tx, c);
       if constexpr (i < 3) dma(I);
       A64_PIN();
     });
   };
   // second half: [K Q_Y^T of tile jy] beside chunks 12-23 of block X; RELOAD: behind its last reader each K fragment is fetched
   // again from the K tile at (ke, ko)
-  auto half2 = [&](auto QK, auto RELOAD, auto YB, f32x16& y0, f32x16& y1, bool fully, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, unsigned ke, unsigned ko) {
+  auto half2 = [&](auto QK, auto RELOAD, auto YB, auto FULLT, f32x16& y0, f32x16& y1, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, unsigned ke, unsigned ko) {
     constexpr bool qk = decltype(QK)::value, reload = decltype(RELOAD)::value;
     constexpr int QAY = A64_Q + 24 * decltype(YB)::value, OAX = A64_O + 48 * (1 - decltype(YB)::value);
     static_for<12>([&](auto I) {
       constexpr int i = decltype(I)::value, ks = i >> 1, half = i & 1;
       if constexpr (qk) {
         if constexpr (ks == 0) {
-          if (fully) { if constexpr (half == 0) mfma_qk_zero<A64_KA, QAY>(y0); else mfma_qk_zero<A64_KC, QAY>(y1); }
+          if constexpr (decltype(FULLT)::value) { if constexpr (half == 0) mfma_qk_zero<A64_KA, QAY>(y0); else mfma_qk_zero<A64_KC, QAY>(y1); }
           else { if constexpr (half == 0) mfma_qk<A64_KA, QAY>(y0); else mfma_qk<A64_KC, QAY>(y1); }
         } else {
           if constexpr (half == 0) mfma_qk<A64_KA + 4 * ks, QAY + 4 * ks>(y0); else mfma_qk<A64_KC + 4 * ks, QAY + 4 * ks>(y1);
@@ -480,9 +689,14 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       }
       if constexpr (reload) k_frag(std::integral_constant<int, ks>{}, std::integral_constant<int, half>{}, ke, ko);
       A64_PIN();
-      sm_chunk<THR, OAX, 12 + i>(x0, x1, px, X, tx, c);
+      if constexpr (THR == 0) sm_chunk<THR, OAX, 12 + i, ABL>(x0, x1, px, X, tx, c, rc);
+      else sm_opt_chunk<12 + i, ABL>(x0, x1, px, X, tx, c);
       A64_PIN();
     });
+    if constexpr (THR != 0) {
+      sm_tail<THR, OAX, ABL>(x0, x1, px, X, tx, c);
+      A64_PIN();
+    }
   };
   auto no_dma = [](auto) {};
   using T_ = std::true_type;
@@ -496,10 +710,9 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   static_for<12>([&](auto I) { k_frag(std::integral_constant<int, decltype(I)::value / 2>{}, std::integral_constant<int, decltype(I)::value % 2>{}, sK_a + k_even, sK_a + k_odd); });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   A64_PIN();
-  if (jend_w > 0) {
-    const unsigned long long vb0 = valid_word(0);
-    const bool fa = tile_full(A, 0, vb0);
-    if (!fa) tile_bias(A, 0, vb0, sA0, sA1);
+  {
+    const bool fa = (A.fast & 1ull) != 0ull;       // wave-uniform
+    if (fa) fast_hide(A, 0); else tile_bias(A, 0, sA0, sA1);
     A64_PIN();
     static_for<12>([&](auto I) {
       constexpr int i = decltype(I)::value, ks = i >> 1, half = i & 1;
@@ -510,52 +723,72 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
         if constexpr (half == 0) mfma_qk<A64_KA + 4 * ks, A64_Q + 4 * ks>(sA0); else mfma_qk<A64_KC + 4 * ks, A64_Q + 4 * ks>(sA1);
       }
     });
+    // hipcc takes an asm statement's outputs as ready when it ends: here it once spilled sA0[0] three instructions behind the last
+    // MFMA (v_accvgpr_write of a register the MFMA had not written yet) and restored the stale score in the tile loop.  Once per
+    // rank, 20 wait states tied to both tiles; inside the tile loop tools/attn64_hazards.py checks every build for such reads.
+    mfma_results_settle(sA0, sA1);
     A64_PIN();
   }
 
   int st0 = 0, st1 = 1, st2 = 2;     // ring stages of tiles j, j+1, j+2 (K and V rings alike)
-  for (int j = 0; j < jend; ++j) {
+  // Taken branches are not free for a wave alone on its SIMD (the instruction buffer refills): the tile loop has none but its own
+  // back edge on the common path.  Slot E(0) runs its P_B V MFMAs on P = 0 and V^T = 0 (zeroed above), slot O of the last tile
+  // computes a score tile nobody reads, and the tiles a wave only has to keep the stream going for are a second loop.
+  // one tile = slots E(j) and O(j).  FT: the score tiles produced in this iteration - block B's tile j and block A's tile j + 1 -
+  // are both fast by the masks (FULL / ROWWISE / HIDDEN): no bias, the first MFMA of each chain takes the constant 0; otherwise both
+  // go through the bias path, which is right for every class
+  auto iter = [&](auto FT, int j) {
+    constexpr bool ft = decltype(FT)::value;
     // unit j = {K(j+1), V(j)}: this wave's pieces are all but the 6 youngest (unit j+1); then a workgroup-wide fact
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
     A64_PIN();
     // unit j+2 = {K(j+3) -> the stage K(j) has left, V(j+2) -> the stage V(j-1) has left}
     const int tk = j + 3, tv = j + 2;
     auto dma_e = [&](auto I) { dma_k(I, tk, st0); };
     auto dma_o = [&](auto I) { dma_v(I, tv, st2); };
-    if (j >= jend_w) {               // this wave's blocks are done: keep the stream and the barriers going
-      static_for<3>(dma_e);
-      static_for<3>(dma_o);
+    const unsigned va = sV_a + st0 * VTILE + voff;                 // V(j)
+    const unsigned ke = sK_a + st1 * KTILE + k_even, ko = sK_a + st1 * KTILE + k_odd;   // K(j+1)
+    // ---- slot E(j): P_B V (j-1), K Q_B^T (j)  beside  softmax of S_A(j) ----
+    half1(T_{}, T_{}, BB{}, sA0, sA1, pA, A, tA, pB, va, dma_e);
+    if constexpr (ft) fast_hide(B, j); else tile_bias(B, j, sB0, sB1);
+    A64_PIN();
+    half2(T_{}, T_{}, BB{}, FT, sB0, sB1, sA0, sA1, pA, A, tA, ke, ko);
+    // ---- slot O(j): P_A V (j), K Q_A^T (j+1)  beside  softmax of S_B(j) ----
+    wait_v_frags();
+    asm volatile("s_nop 1" : "+v"(pA[0]), "+v"(pA[1]), "+v"(pA[2]), "+v"(pA[3]));   // packed by the VALU just above -> MFMA operand
+    A64_PIN();
+    half1(T_{}, F_{}, BA{}, sB0, sB1, pB, B, tB, pA, va, dma_o);
+    if constexpr (!(ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // K(j+1) fragments
+    A64_PIN();
+    if constexpr (ft) fast_hide(A, j + 1); else tile_bias(A, j + 1, sA0, sA1);
+    A64_PIN();
+    half2(T_{}, F_{}, BA{}, FT, sA0, sA1, sB0, sB1, pB, B, tB, ke, ko);
+    asm volatile("s_nop 1" : "+v"(pB[0]), "+v"(pB[1]), "+v"(pB[2]), "+v"(pB[3]));
+    A64_PIN();
+    const int t_ = st0; st0 = st1; st1 = st2; st2 = t_;
+  };
+  auto both_fast = [&](int j) -> bool {
+    const int t = j & 63;
+    return t != 63 && ((B.fast >> t) & (A.fast >> (t + 1)) & 1ull) != 0ull;      // tile j + 1 of the next window: through the bias path
+  };
+  // runs of fast tiles are an inner loop of their own: an if / else per tile would join sixteen-register score tiles defined
+  // by asm statements on two paths, and hipcc copies them through spill slots at every join
+  int j = 0;
+  while (j < jend_w) {
+    if (__builtin_expect(both_fast(j), 1)) {
+      do { iter(T_{}, j); ++j; } while (j < jend_w && both_fast(j));
     } else {
-      const unsigned va = sV_a + st0 * VTILE + voff;                 // V(j)
-      const unsigned ke = sK_a + st1 * KTILE + k_even, ko = sK_a + st1 * KTILE + k_odd;   // K(j+1)
-      // ---- slot E(j): P_B V (j-1), K Q_B^T (j)  beside  softmax of S_A(j) ----
-      const unsigned long long vbj = valid_word(j);
-      const bool fb = tile_full(B, j, vbj);
-      if (j > 0) half1(T_{}, T_{}, BB{}, sA0, sA1, pA, A, tA, pB, va, dma_e);
-      else half1(F_{}, T_{}, BB{}, sA0, sA1, pA, A, tA, pB, va, dma_e);
-      if (!fb) tile_bias(B, j, vbj, sB0, sB1);
-      A64_PIN();
-      half2(T_{}, T_{}, BB{}, sB0, sB1, fb, sA0, sA1, pA, A, tA, ke, ko);
-      // ---- slot O(j): P_A V (j), K Q_A^T (j+1)  beside  softmax of S_B(j) ----
-      wait_v_frags();
-      asm volatile("s_nop 1" : "+v"(pA[0]), "+v"(pA[1]), "+v"(pA[2]), "+v"(pA[3]));   // packed by the VALU just above -> MFMA operand
-      A64_PIN();
-      half1(T_{}, F_{}, BA{}, sB0, sB1, pB, B, tB, pA, va, dma_o);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // K(j+1) fragments
-      A64_PIN();
-      if (j + 1 < jend_w) {
-        const unsigned long long vbn = valid_word(j + 1);
-        const bool fa = tile_full(A, j + 1, vbn);
-        if (!fa) tile_bias(A, j + 1, vbn, sA0, sA1);
-        A64_PIN();
-        half2(T_{}, F_{}, BA{}, sA0, sA1, fa, sB0, sB1, pB, B, tB, ke, ko);
-      } else {
-        half2(F_{}, F_{}, BA{}, sA0, sA1, false, sB0, sB1, pB, B, tB, ke, ko);
-      }
-      asm volatile("s_nop 1" : "+v"(pB[0]), "+v"(pB[1]), "+v"(pB[2]), "+v"(pB[3]));
-      A64_PIN();
+      iter(F_{}, j); ++j;
     }
+    if ((j & 63) == 0) { block_masks(A, j); block_masks(B, j); }     // next window of 64 tiles (L > 4096)
+  }
+  for (; j < jend; ++j) {             // this wave's blocks are done: keep the stream and the barriers going
+    if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+    const int tk = j + 3, tv = j + 2;
+    static_for<3>([&](auto I) { dma_k(I, tk, st0); });
+    static_for<3>([&](auto I) { dma_v(I, tv, st2); });
     const int t_ = st0; st0 = st1; st1 = st2; st2 = t_;
   }
   // P_B V of the wave's last tile: its V^T fragments are still in registers
@@ -630,8 +863,13 @@ int attn_core64_bf16_launch(AttnParams p, int cus, hipStream_t stream, int exact
   p.splits = splits < 1 ? 1 : (splits > p.nqt ? p.nqt : splits);
   int grp = ((cus + p.splits - 1) / p.splits + 7) & ~7;     // one round of resident slots per group
   p.group_bh = grp > nbh ? nbh : grp;
-  if (exact_max) hipLaunchKernelGGL((mma_attn64_bf16_kernel<0>), dim3(nbh * p.splits), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((mma_attn64_bf16_kernel<8>), dim3(nbh * p.splits), dim3(256), 0, stream, p);
+#ifdef AKI_LAB_HOOKS
+#define A64_ABL_CASE(m) if (g_attn_variant == 100 + (m)) { hipLaunchKernelGGL((mma_attn64_bf16_kernel<8, (m)>), dim3(nbh * p.splits), dim3(256), 0, stream, p); return AKI_OK; }
+  A64_ABL_CASE(1) A64_ABL_CASE(2) A64_ABL_CASE(4) A64_ABL_CASE(8) A64_ABL_CASE(16) A64_ABL_CASE(32) A64_ABL_CASE(17) A64_ABL_CASE(14) A64_ABL_CASE(63) A64_ABL_CASE(64)
+#undef A64_ABL_CASE
+#endif
+  if (exact_max) hipLaunchKernelGGL((mma_attn64_bf16_kernel<0, 0>), dim3(nbh * p.splits), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((mma_attn64_bf16_kernel<8, 0>), dim3(nbh * p.splits), dim3(256), 0, stream, p);
   return AKI_OK;
 }
 

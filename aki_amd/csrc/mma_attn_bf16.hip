@@ -773,7 +773,7 @@ int attn_core_bf16(const aki_mma_attn_core_args* a, void* ws, size_t ws_bytes, h
     int exact_max = 0;
 #ifdef AKI_LAB_HOOKS
     if (g_attn_variant >= 1 && g_attn_variant <= 8) long_core = false;
-    if (g_attn_variant == 9 || g_attn_variant == 10) { long_core = true; exact_max = g_attn_variant == 10; }
+    if (g_attn_variant == 9 || g_attn_variant == 10 || g_attn_variant > 100) { long_core = true; exact_max = g_attn_variant == 10; }   // 100 + m: timing ablation m of the 64-row kernel
 #endif
     if (long_core) {
       static int cus64 = 0;

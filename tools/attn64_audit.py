@@ -13,16 +13,25 @@ SRC = os.path.join(ROOT, "aki_amd", "csrc", "mma_attn64_bf16.hip")
 
 
 def main():
+    rc = audit([])
+    if "--lab" in sys.argv:
+        print("-- lab build (-DAKI_LAB_HOOKS): the two kernels that must be right there too")
+        rc |= audit(["-DAKI_LAB_HOOKS"], only=("ILi0ELi0E", "ILi8ELi0E"))
+    return rc
+
+
+def audit(extra, only=None):
     keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
     d = keep or tempfile.mkdtemp(prefix="attn64_audit_")
     os.makedirs(d, exist_ok=True)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "aki_amd", "csrc"),
-           "-ffp-contract=off", "-fno-slp-vectorize", "-save-temps=obj", "-c", SRC, "-o", os.path.join(d, "a64.o")]
+           "-ffp-contract=off", "-fno-slp-vectorize", "-save-temps=obj"] + extra + ["-c", SRC, "-o", os.path.join(d, "a64.o")]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=d)
     if r.returncode != 0:
         print(r.stderr)
         return 2
-    s = open(os.path.join(d, [f for f in os.listdir(d) if f.endswith("gfx950.s")][0])).read().split("\n")
+    spath = os.path.join(d, [f for f in os.listdir(d) if f.endswith("gfx950.s")][0])
+    s = open(spath).read().split("\n")
     bad = 0
     i = 0
     while i < len(s):
@@ -31,6 +40,9 @@ def main():
             i += 1
             continue
         name = m.group(1)
+        if only and not any(o in name for o in only):
+            i += 1
+            continue
         j = i
         while not s[j].strip().startswith("s_endpgm"):
             j += 1
@@ -58,14 +70,20 @@ def main():
                         hi_acc = max(hi_acc, int(mm.group(1)))
                 if t.startswith(("v_readlane", "v_writelane")):
                     lanes += 1
-                if t.startswith(("scratch_", "buffer_store", "buffer_load")):
+                if t.startswith("scratch_"):
                     scratch += 1
                 if t.startswith("v_mov_b32"):
                     movs += 1
             if t.startswith("v_mfma"):
                 n_mfma += 1
+        hz = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "attn64_hazards.py"), spath, "--kernel", name[len("_ZN3aki22mma_attn64_bf16_kernel"):name.index("EEv")]],
+                            capture_output=True, text=True)
+        hz_line = hz.stdout.strip().split("\n")[-1] if hz.stdout.strip() else hz.stderr.strip()[-200:]
+        if hz.returncode != 0:
+            bad = 1
+            print(hz.stdout)
         print(f"{name}: {len(body)} lines, {n_mfma} MFMAs, next_free_vgpr {desc.get('next_free_vgpr')}, accum_offset {desc.get('accum_offset')}, "
-              f"private_segment {desc.get('private_segment_fixed_size')}; compiler v_accvgpr {comp_acc} (highest a{hi_acc}), lane spills {lanes}, scratch/buffer ops {scratch}, v_mov {movs}")
+              f"private_segment {desc.get('private_segment_fixed_size')}; compiler v_accvgpr {comp_acc} (highest a{hi_acc}), lane spills {lanes}, scratch ops {scratch}, v_mov {movs}; hazards: {hz_line}")
         if hi_acc >= 64 or scratch or desc.get("private_segment_fixed_size", "0") != "0":
             bad = 1
         # tile loop: the loop body between the label that precedes the first s_barrier inside a backward branch ... keep it simple:
