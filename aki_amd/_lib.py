@@ -287,6 +287,28 @@ class use_lab:
         return False
 
 
+class use_lab_attn:
+    """Context manager for tests / tools: the lab library with an attention-core variant forced (mma_attn_bf16.hip, g_attn_variant:
+    1 = the 32-row kernel at every length, 9 = the 64-row kernel at every length, 10 = the 64-row kernel with the exact running
+    maximum, 164 = the 64-row kernel with every tile sent through its exact redo path)."""
+
+    def __init__(self, variant: int):
+        self.variant = variant
+
+    def __enter__(self):
+        global _lib
+        self.saved = _lib
+        _lib = load_lab()
+        _lib.aki_lab_set_attn_variant(self.variant)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib.aki_lab_set_attn_variant(0)
+        _lib = self.saved
+        return False
+
+
 def load() -> C.CDLL:
     """Load the HIP library; raises AkiError (never falls back) when it is absent or stale."""
     global _lib
