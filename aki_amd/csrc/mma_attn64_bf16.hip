@@ -84,6 +84,7 @@ struct A64Blk {                 // one 32-row block of a wave
   int row, rc0, rc1;            // per lane: its row and that row's unlock columns
   bool exists, alive, has_dead, row_alive, has_uniform, row_uniform;
   float m_ref, l;               // reference maximum (log2 domain) and the row sum against it
+  int l_dbg;                    // lab stamps: redo count
   float hide;                   // per lane, for the score tile in flight: 0, or -inf = this row sees nothing of the tile
   float thr_raw;                // (m_ref + THR) / (scale log2 e): a raw score above it raises the reference maximum
   unsigned long long fast, fullm;   // tile masks of the current window of 64 tiles (bit t <-> tile win + t): fast = FULL, HIDDEN or ROWWISE; fullm = FULL
@@ -110,6 +111,7 @@ struct A64Tmp {
   float m0, m1, m2, m3;        // four independent row-maximum chains (a wave alone on its SIMD stalls on every dependent VALU pair)
   float thr, nm, ps, T;        // raise threshold (raw score units), -m_ref + hide, running row sum, the pair sum waiting to enter it
   float a0, a1;                // exp2 arguments of the next score pair
+  float ah0[4], ah1[4];        // product softmax: exp2 arguments of pairs 12-15, made early (the raise decision needs them at gap 20)
   float e0[16], e1[16];        // p = exp2(...) of the score registers, each alive for three chunks
   unsigned long long need;     // lanes whose tile maximum calls for a raise of the reference maximum
 };
@@ -212,7 +214,7 @@ __device__ __forceinline__ void sm_chunk(const f32x16& s0, const f32x16& s1, u32
 // ---- the product's softmax (THR > 0): no row maximum on the common path ---------------------------------------------
 // p = exp2(s c - m_ref) is taken against the reference maximum AS IT STANDS; whether that was admissible is read off the row sum
 // afterwards: if no score exceeded m_ref + THR every p is <= 2^THR and, conversely, a score above it alone makes the row sum
-// exceed 2^THR.  A row sum above 2^THR (inf included: the first tile of a block, whose m_ref is -1e30) sends the wave through
+// exceed 2^THR.  A row sum above 2^THR (inf included: the first tile of a block, whose m_ref is -1e30; see gap 20) sends the wave through
 // sm_redo - the exact path: row maximum, raise, rescale of l and O, this tile's p again - before anything has consumed the tile
 // (its P V MFMAs are in the next slot).  26 VALU issues per tile and block leave the common path (a slot is VALU-issue bound).
 // Gap budget: an MFMA 32x32x16 leaves 24 of its 32 cycles to the vector port = three f32 ops, or one exp2 (8) and two.
@@ -220,15 +222,15 @@ __device__ __forceinline__ void sm_chunk(const f32x16& s0, const f32x16& s1, u32
 //     G = 3k      exp2 of pair 2k     (arguments one gap old), arguments of pair 2k + 1
 //     G = 3k + 1  exp2 of pair 2k + 1,                         arguments of pair 2k + 2
 //     G = 3k + 2  pair sums 2k, 2k + 1; row sum + the two pair sums of the previous triple; bf16 packing of pairs 2k, 2k + 1
-// i.e. 2 exp2 + 2 fma (24 cycles) or 4 add + 2 cvt (24 cycles) per gap.  sm_tail adds the last two pair sums and decides.
-template <int G, int ABL>
+// i.e. 2 exp2 + 2 fma (24 cycles) or 4 add + 2 cvt (24 cycles) per gap; gap 23 also adds its own two pair sums.  sm_tail decides.
+template <int G, int THR, int ABL>
 __device__ __forceinline__ void sm_opt_chunk(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], const A64Blk& X, A64Tmp& t, const float c) {
   constexpr int k = G / 3, ph = G % 3;
   if constexpr (ABL & 1) {
     if constexpr (G == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) pf[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-      t.ps = 64.f; t.m0 = 0.f; t.m1 = 0.f;
+      t.ps = 64.f; t.m0 = 0.f; t.m1 = 0.f; t.need = 0ull;
     }
   } else if constexpr (ph == 0) {
     if constexpr (k == 0) {
@@ -238,26 +240,70 @@ __device__ __forceinline__ void sm_opt_chunk(const f32x16& s0, const f32x16& s1,
       t.a1 = __builtin_fmaf(s1[0], c, t.nm);
     }
     constexpr int r = 2 * k;
+    if constexpr (r >= 12) { t.a0 = t.ah0[r - 12]; t.a1 = t.ah1[r - 12]; }      // arguments made early (below)
     t.e0[r] = __builtin_amdgcn_exp2f(t.a0);
     t.e1[r] = __builtin_amdgcn_exp2f(t.a1);
-    t.a0 = __builtin_fmaf(s0[r + 1], c, t.nm);
-    t.a1 = __builtin_fmaf(s1[r + 1], c, t.nm);
+    if constexpr (r + 1 < 12) {
+      t.a0 = __builtin_fmaf(s0[r + 1], c, t.nm);
+      t.a1 = __builtin_fmaf(s1[r + 1], c, t.nm);
+    }
+    if constexpr (k == 4) {            // G = 12: arguments of pair 12, two gaps ahead of schedule
+      t.ah0[0] = __builtin_fmaf(s0[12], c, t.nm); t.ah1[0] = __builtin_fmaf(s1[12], c, t.nm);
+      pin(t.ah0[0], t.ah1[0]);
+    }
+    if constexpr (k == 5) {            // G = 15: pair 14
+      t.ah0[2] = __builtin_fmaf(s0[14], c, t.nm); t.ah1[2] = __builtin_fmaf(s1[14], c, t.nm);
+      pin(t.ah0[2], t.ah1[2]);
+    }
     pin(t.e0[r], t.e1[r], t.a0, t.a1);
   } else if constexpr (ph == 1) {
     constexpr int r = 2 * k + 1;
+    if constexpr (r >= 12) { t.a0 = t.ah0[r - 12]; t.a1 = t.ah1[r - 12]; }
     t.e0[r] = __builtin_amdgcn_exp2f(t.a0);
     t.e1[r] = __builtin_amdgcn_exp2f(t.a1);
-    if constexpr (r < 15) {
+    if constexpr (r + 1 < 12) {
       t.a0 = __builtin_fmaf(s0[r + 1], c, t.nm);
       t.a1 = __builtin_fmaf(s1[r + 1], c, t.nm);
+    }
+    if constexpr (k == 4) {            // G = 13: pair 13
+      t.ah0[1] = __builtin_fmaf(s0[13], c, t.nm); t.ah1[1] = __builtin_fmaf(s1[13], c, t.nm);
+      pin(t.ah0[1], t.ah1[1]);
+    }
+    if constexpr (k == 5) {            // G = 16: pair 15, and the largest of the eight late arguments
+      t.ah0[3] = __builtin_fmaf(s0[15], c, t.nm); t.ah1[3] = __builtin_fmaf(s1[15], c, t.nm);
+      float m = max3(t.ah0[0], t.ah1[0], t.ah0[1]);
+      asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(t.ah1[1]), "v"(t.ah0[2]));
+      t.m2 = m;
+      pin(t.ah0[3], t.ah1[3], t.m2);
     }
     pin(t.e0[r], t.e1[r], t.a0, t.a1);
   } else {
     constexpr int r = 2 * k;
     if constexpr (k >= 1) { t.ps += t.m0; t.ps += t.m1; }        // pair sums of the previous triple, in pair order (the 32-row kernel's order)
+    const float ps11 = t.ps;           // at G = 20: the sum over pairs 0-11
     t.m0 = t.e0[r] + t.e1[r];
     t.m1 = t.e0[r + 1] + t.e1[r + 1];
     const unsigned w0 = pack_bf16x2(t.e0[r], t.e0[r + 1]), w1 = pack_bf16x2(t.e1[r], t.e1[r + 1]);
+    if constexpr (k == 5) {            // G = 17: the rest of the late-argument maximum
+      float m = t.m2;
+      asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "+v"(m) : "v"(t.ah1[2]), "v"(t.ah0[3]), "v"(t.ah1[3]), "v"(t.ah1[3]));
+      t.m2 = m;
+      pin(t.m2);
+    }
+    if constexpr (k == 6) {
+      // G = 20: the raise decision.  t.ps holds pairs 0-11 here: a score above m_ref + THR among them makes it exceed 2^THR; pairs
+      // 12-15 are judged by their exp2 arguments, made early for this purpose.
+      // One vector compare straight into an SGPR pair (both conditions merged on the vector side: 2^m2 > 2^THR <=> m2 > THR), read by
+      // sm_tail's s_cmp three gaps later.  NOTE for whoever times this: builds that skip the check or the redo produce inf / NaN from
+      // the first tile on, and MFMAs on such operands draw less power - the chip then holds a higher clock and the ablated build looks
+      // 15 % faster.  With right data the check is free and a redo costs ~1.1k cycles, twice per rank (tools/attn64_ablate.py).
+      const float worst = fmaxf(ps11, __builtin_amdgcn_exp2f(t.m2));
+      unsigned long long nd;
+      const float lim = (float)(1 << THR);
+      asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(nd) : "s"(lim), "v"(worst));
+      t.need = nd;
+    }
+    if constexpr (k == 7) { t.ps += t.m0; t.ps += t.m1; }        // the last triple closes the sum under its own MFMA: sm_tail only branches
     pin(t.ps, t.m0, t.m1, w0, w1);      // the words, not the vectors they go into: a use of the half-built vector makes hipcc copy it
     pf[r >> 3][(r & 7) >> 1] = w0;
     pf[2 + (r >> 3)][(r & 7) >> 1] = w1;
@@ -294,10 +340,8 @@ __device__ __forceinline__ void sm_redo(const f32x16& s0, const f32x16& s1, u32x
 }
 template <int THR, int OA, int ABL>
 __device__ __forceinline__ void sm_tail(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], A64Blk& X, A64Tmp& t, const float c) {
-  t.ps += t.m0;
-  t.ps += t.m1;
   if constexpr (!(ABL & 16)) {
-    if (__builtin_expect(__any(t.ps > (float)(1 << THR)) || (ABL & 64), 0)) sm_redo<THR, OA>(s0, s1, pf, X, t, c);
+    if (__builtin_expect(t.need != 0ull || (ABL & 64), 0)) { sm_redo<THR, OA>(s0, s1, pf, X, t, c); if constexpr (ABL & 512) X.l_dbg += 1; }
   }
   X.l += t.ps;
 }
@@ -389,14 +433,14 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     return ((unsigned long long)hi << 32) | lo;
   };
 
-  const aki_mma_rect* const rects_b = p.rects + (size_t)b * p.max_rects;
-  auto rect_at = [&](int i) -> aki_mma_rect {       // wave-uniform: one s_load_dwordx4 through the scalar cache
-    const unsigned long long pa = (unsigned long long)(rects_b + i);
-    const unsigned long long pu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pa);
-    u32x4 r;
-    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(pu) : "memory");
+  // The sample's rectangles (at most AKI_MAX_RECTS = 8): lane i holds rectangle i, read once per workgroup; rect_at is four
+  // v_readlane.  (As scalar loads behind their own lgkmcnt(0) they were ~200 cycles each, 4 * max_rects of them per rank.)
+  u32x4 rect_reg = {0u, 0u, 0u, 0u};
+  if (lane < p.max_rects) rect_reg = *(const u32x4*)(p.rects + (size_t)b * p.max_rects + lane);
+  auto rect_at = [&](int i) -> aki_mma_rect {       // wave-uniform i
     aki_mma_rect o;
-    o.row_lo = (int)r[0]; o.row_hi = (int)r[1]; o.col_lo = (int)r[2]; o.col_hi = (int)r[3];
+    o.row_lo = (int)__builtin_amdgcn_readlane(rect_reg[0], i); o.row_hi = (int)__builtin_amdgcn_readlane(rect_reg[1], i);
+    o.col_lo = (int)__builtin_amdgcn_readlane(rect_reg[2], i); o.col_hi = (int)__builtin_amdgcn_readlane(rect_reg[3], i);
     return o;
   };
   // columns a 32-row block starting at r0 walks (mma_attn_bf16.hip, block_extent)
@@ -452,9 +496,15 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   const float c = p.scale_log2;
   const float rc = 1.0f / c;
 
+  // lab stamps (ABL & 512): shader-clock cycles of prologue / tile loops / epilogue, tiles walked, and the 100 MHz real-time
+  // counter over the whole workgroup -> lse[8 * blockIdx .. +7] (timing build: its lse output is not an lse)
+  unsigned long long st_pro = 0, st_loop = 0, st_epi = 0, st_tiles = 0, st_t = 0, st_rt0 = 0, st_redo = 0;
+  if constexpr (ABL & 512) { st_rt0 = __builtin_amdgcn_s_memrealtime(); }
+
   for (int kk = 0;; ++kk) {
   const int g = kk * p.splits + ((kk & 1) ? p.splits - 1 - sidx : sidx);   // this workgroup's next rank
   if (g >= p.nqt) break;
+  if constexpr (ABL & 512) st_t = __builtin_amdgcn_s_memtime();
 
   // ---- which blocks: the rank's eight, this wave's two ----------------------------------------------
   A64Blk A, B;
@@ -523,6 +573,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     X.has_uniform = p.dead_uniform && X.has_dead && X.exists;
     X.row_uniform = p.dead_uniform && !X.row_alive && X.exists;
     X.m_ref = -1e30f;
+    X.l_dbg = 0;
     X.thr_raw = (-1e30f + (float)THR) * rc;
     X.l = 0.f;
   };
@@ -578,9 +629,19 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   // a fast tile's per-lane hide (FULL: nobody; ROWWISE / HIDDEN: the rows whose rectangle does not cover the tile)
   auto fast_hide = [&](A64Blk& X, int jt) {
     const int c0 = jt * 64;
-    const bool fbit = (X.fullm >> (jt & 63)) & 1ull;
-    const bool covers = X.rc0 <= c0 && c0 + 64 <= X.rc1;
-    X.hide = (fbit || covers) ? 0.f : -INFINITY;
+    // wave-uniform, all scalar: -1 when the tile is FULL (nobody hidden), 0 when each lane's rectangle decides
+    const unsigned long long fm = ((X.fullm >> (jt & 63)) & 1ull) ? ~0ull : 0ull;
+    // Per lane, five VALU instructions: hide = fm ? 0 : (rc0 <= c0 && c0 + 64 <= rc1 ? 0 : -inf).  (The C form compiles to two
+    // vector compares combined on the scalar unit plus a select; no measurable difference - kept as asm for its fixed length.)
+    float hd;
+    const float ninf = -INFINITY;
+    asm("v_cmp_ge_i32_e64 vcc, %2, %3\n\t"            // c0 >= rc0
+        "v_cndmask_b32_e64 %0, %1, 0, vcc\n\t"         // ? 0 : -inf
+        "v_cmp_le_i32_e64 vcc, %4, %5\n\t"            // c0 + 64 <= rc1
+        "v_cndmask_b32_e64 %0, %1, %0, vcc\n\t"        // ? keep : -inf
+        "v_cndmask_b32_e64 %0, %0, 0, %6"              // FULL tile: 0
+        : "=&v"(hd) : "v"(ninf), "s"(c0), "v"(X.rc0), "s"(c0 + 64), "v"(X.rc1), "s"(fm) : "vcc");
+    X.hide = hd;
   };
   auto tile_bias = [&](A64Blk& X, int j, f32x16& s0, f32x16& s1) {
     const int c0 = j * 64;
@@ -667,7 +728,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       // first MFMA) + 4 here; slot E has the tile barrier in front.  The exact variant reads S one gap later.
       if constexpr (THR != 0 && i == 0 && decltype(YB)::value == 0) asm volatile("s_nop 3" : "+v"(x0), "+v"(x1));
       if constexpr (THR == 0) sm_chunk<THR, OAX, i, ABL>(x0, x1, px, X, tx, c, rc);
-      else sm_opt_chunk<i, ABL>(x0, x1, px, X, tx, c);
+      else sm_opt_chunk<i, THR, ABL>(x0, x1, px, X, tx, c);
       if constexpr (i < 3) dma(I);
       A64_PIN();
     });
@@ -690,7 +751,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       if constexpr (reload) k_frag(std::integral_constant<int, ks>{}, std::integral_constant<int, half>{}, ke, ko);
       A64_PIN();
       if constexpr (THR == 0) sm_chunk<THR, OAX, 12 + i, ABL>(x0, x1, px, X, tx, c, rc);
-      else sm_opt_chunk<12 + i, ABL>(x0, x1, px, X, tx, c);
+      else sm_opt_chunk<12 + i, THR, ABL>(x0, x1, px, X, tx, c);
       A64_PIN();
     });
     if constexpr (THR != 0) {
@@ -730,6 +791,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     A64_PIN();
   }
 
+  if constexpr (ABL & 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_pro += t_ - st_t; st_t = t_; st_tiles += jend; }
   int st0 = 0, st1 = 1, st2 = 2;     // ring stages of tiles j, j+1, j+2 (K and V rings alike)
   // Taken branches are not free for a wave alone on its SIMD (the instruction buffer refills): the tile loop has none but its own
   // back edge on the common path.  Slot E(0) runs its P_B V MFMAs on P = 0 and V^T = 0 (zeroed above), slot O of the last tile
@@ -791,6 +853,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     static_for<3>([&](auto I) { dma_v(I, tv, st2); });
     const int t_ = st0; st0 = st1; st1 = st2; st2 = t_;
   }
+  if constexpr (ABL & 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_loop += t_ - st_t; st_t = t_; st_redo += A.l_dbg + B.l_dbg; }
   // P_B V of the wave's last tile: its V^T fragments are still in registers
   if (jend_w > 0) {
     static_for<12>([&](auto I) {
@@ -842,12 +905,21 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       const u32x4 w4 = *(const u32x4*)(sO + r * OROW + cc * 16);
       if (X.wq0 + r < L) *(u32x4*)((char*)(obase + (size_t)(X.wq0 + r) * p.H * 96) + cc * 16) = w4;
     }
-    if (p.lse && h_o == 0 && X.row < L) p.lse[(size_t)bh * L + X.row] = dead ? -INFINITY : (X.m_ref + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
+    if (!(ABL & 512) && p.lse && h_o == 0 && X.row < L) p.lse[(size_t)bh * L + X.row] = dead ? -INFINITY : (X.m_ref + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
   };
   store_block(BA{}, A);
   store_block(BB{}, B);
   __syncthreads();   // the staged output tiles live in the ring: every wave has read its tiles back before the next rank's DMA
+  if constexpr (ABL & 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_epi += t_ - st_t; }
   }                  // next rank of this workgroup
+  if constexpr (ABL & 512) {
+    if (p.lse && tid == 0) {
+      float* d = p.lse + 8 * blockIdx.x;
+      d[0] = (float)st_pro; d[1] = (float)st_loop; d[2] = (float)st_epi; d[3] = (float)st_tiles;
+      d[4] = (float)(__builtin_amdgcn_s_memrealtime() - st_rt0);
+      d[5] = (float)st_redo;
+    }
+  }
 #undef A64_PIN
 }
 
@@ -865,7 +937,7 @@ int attn_core64_bf16_launch(AttnParams p, int cus, hipStream_t stream, int exact
   p.group_bh = grp > nbh ? nbh : grp;
 #ifdef AKI_LAB_HOOKS
 #define A64_ABL_CASE(m) if (g_attn_variant == 100 + (m)) { hipLaunchKernelGGL((mma_attn64_bf16_kernel<8, (m)>), dim3(nbh * p.splits), dim3(256), 0, stream, p); return AKI_OK; }
-  A64_ABL_CASE(1) A64_ABL_CASE(2) A64_ABL_CASE(4) A64_ABL_CASE(8) A64_ABL_CASE(16) A64_ABL_CASE(32) A64_ABL_CASE(17) A64_ABL_CASE(14) A64_ABL_CASE(63) A64_ABL_CASE(64)
+  A64_ABL_CASE(16) A64_ABL_CASE(17) A64_ABL_CASE(18) A64_ABL_CASE(20) A64_ABL_CASE(24) A64_ABL_CASE(48) A64_ABL_CASE(30) A64_ABL_CASE(31) A64_ABL_CASE(64) A64_ABL_CASE(512)
 #undef A64_ABL_CASE
 #endif
   if (exact_max) hipLaunchKernelGGL((mma_attn64_bf16_kernel<0, 0>), dim3(nbh * p.splits), dim3(256), 0, stream, p);

@@ -73,6 +73,7 @@ def case(name, B, H, L, rects, am=None, seq=None, dead_rows=None, spike=False):
 def timing():
     CASES = [(1, 32, 4096, [[(6, 150, 150, 4032), (900, 1044, 1044, 4032), (1800, 1944, 1944, 4032), (2700, 2844, 2844, 4032)]]),
              (4, 32, 4096, [[(6, 150, 150, 4032), (900, 1044, 1044, 4032), (1800, 1944, 1944, 4032), (2700, 2844, 2844, 4032)]] * 4),
+             (1, 32, 4096, [[(0, 0, 0, 0)]]), (4, 32, 4096, [[(0, 0, 0, 0)]] * 4),
              (1, 32, 2048, [[(6, 150, 150, 2000)]]), (4, 32, 2048, [[(6, 150, 150, 2000)]] * 4),
              (8, 32, 1024, [[(6, 150, 150, 1000)]] * 8), (8, 32, 655, [[(6, 150, 150, 638)]] * 8), (1, 32, 655, [[(6, 150, 150, 638)]])]
     res = []
@@ -88,9 +89,28 @@ def timing():
         lab.aki_lab_set_attn_variant(0)
         fl = 4.0 * 96 * pairs_of(L, rects[0]) * B * H
         tf = {v_: fl / best[v_] / 1e6 for v_ in best}
+        # product rule (variant 0) and the vendor yardstick: torch SDPA, causal only (it has no span mask: fewer visible pairs than the MMA mask)
+        lab.aki_lab_set_attn_variant(0)
+        t_prod = min(run(q, k, v, table, 10)[0] for _ in range(3))
+        import torch.nn.functional as F
+        def sdpa(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                F.scaled_dot_product_attention(q, k, v, is_causal=True)
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / n * 1e3
+        try:
+            sdpa(3)
+            t_sdpa = min(sdpa(10) for _ in range(3))
+            fl_c = 4.0 * 96 * (L * (L + 1) // 2) * B * H
+            sd = f" | torch SDPA causal {t_sdpa:7.1f} us {fl_c / t_sdpa / 1e6:5.0f} TF/s"
+        except Exception as e:      # noqa: BLE001
+            t_sdpa, sd = None, f" | torch SDPA: {type(e).__name__}"
         print(f"B{B} H{H} L{L}: 32-row {best[1]:7.1f} us {tf[1]:5.0f} TF/s ({tf[1]/2500:.3f}) | 64-row {best[9]:7.1f} us {tf[9]:5.0f} TF/s ({tf[9]/2500:.3f}) | 64-row exact {best[10]:7.1f} us "
-              f"{tf[10]:5.0f} TF/s | 64/32 time {best[9]/best[1]:.3f}", flush=True)
-        res.append({"B": B, "L": L, "us_32row": best[1], "us_64row": best[9], "us_64row_exact": best[10], "tf_32row": tf[1], "tf_64row": tf[9]})
+              f"{tf[10]:5.0f} TF/s | 64/32 time {best[9]/best[1]:.3f} | product rule {t_prod:7.1f} us ({fl/t_prod/1e6/2500:.3f})" + sd, flush=True)
+        res.append({"B": B, "L": L, "us_32row": best[1], "us_64row": best[9], "us_64row_exact": best[10], "tf_32row": tf[1], "tf_64row": tf[9], "us_product": t_prod, "us_torch_sdpa_causal": t_sdpa})
     return res
 
 
