@@ -17,6 +17,8 @@ Prints ONE JSON line (rank 0) with the contract's fields plus
   "mma_core"     the attention core alone (the op's second launch), timed live on the benchmark's own mask table and shapes
                  right after the timed region: algorithmic bytes / flops per launch against the HBM and MFMA peaks
   "cpu_baseline" the oracle (numpy port of the reference's eager path) timed on this box's host cores (N=1 only)
+  "secondary"    (N=1 only, after the headline) the other BASELINE configurations and the decode / first-token / 384-px legs, each with
+                 its own ms, steps, config.workload and roofline object - bench_legs.py
 """
 import argparse
 import json
@@ -252,6 +254,7 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8 = BASELINE configs[4]: e4m3 weights/activations for the decoder projections (use with --batch 16)")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel timing table to stderr")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (the other BASELINE configs, decode, first token, 384 px) that run after the headline at N = 1")
     args = ap.parse_args()
 
     # --gpus N outside a launcher: start the N ranks ourselves (one process per GPU) BEFORE anything touches the GPU, as a child
@@ -461,6 +464,14 @@ def main():
             res["cpu_baseline"] = cpu_baseline(model.state_dict(), model.media_token_id, thr)
             res["cpu_baseline"]["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
             res["cpu_baseline_c2_est"] = cpu_baseline_c2_est(thr)
+        # The other BASELINE configurations on the same clock, AFTER the headline's numbers exist: each leg is fenced (a failing leg
+        # reports {"error": ...}), the headline values above are final, and the line is printed once.
+        if world == 1 and not args.no_secondary and not fp8 and B == BATCH:
+            try:
+                import bench_legs
+                res["secondary"] = bench_legs.run_all(model, dev, sys.modules[__name__])
+            except Exception as e:      # noqa: BLE001
+                res["secondary"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
