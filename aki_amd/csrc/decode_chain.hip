@@ -991,6 +991,10 @@ size_t decode_chain_ws_bytes(int n_layers, int d, int H, int F, int cap) {
   return 2 * chain_cnt_bytes(n_layers, H) + 256 /* error word, call count */ + chain_vec_elems(d, H, F) * 2 * CH_XREP + (size_t)H * tiles * CH_PSTRIDE * 4;
 }
 
+// The batched chain is built, bit-identical to the five launches per layer and NOT faster (3.3-3.5 vs 3.2 ms per step at batch 8: 1664 fat
+// workgroups per layer against 512 resident ones, EXPERIMENTS.md round 5): it is compiled into the LAB library only.  The product library
+// answers batch > 1 with AKI_ERR_UNSUPPORTED and the host path keeps its five launches per layer.
+#ifdef AKI_LAB_HOOKS
 static int decode_chain_b_launch(const aki_decode_chain_args* a, hipStream_t stream) {
   const int d = a->d, H = a->H, F = a->F, B = a->batch;
   if (a->Dh != 96 || d != 3072 || H != 32 || F != 8192 || a->dtype != AKI_DT_BF16 || B < 2 || B > 8) return AKI_ERR_UNSUPPORTED;
@@ -1061,8 +1065,14 @@ static int decode_chain_b_launch(const aki_decode_chain_args* a, hipStream_t str
   return AKI_OK;
 }
 
+#endif   // AKI_LAB_HOOKS: the batched chain
+
 int decode_chain_launch(const aki_decode_chain_args* a, hipStream_t stream) {
+#ifdef AKI_LAB_HOOKS
   if (a->batch > 1) return decode_chain_b_launch(a, stream);
+#else
+  if (a->batch > 1) return AKI_ERR_UNSUPPORTED;      // lab library only (see above)
+#endif
   const int d = a->d, H = a->H, F = a->F;
   if (a->Dh != 96 || d != H * 96 || d % 512 || F % 512) return AKI_ERR_UNSUPPORTED;
   const bool w8 = a->dtype == AKI_DT_W8A16;

@@ -129,18 +129,23 @@ class PerceiverResampler(VisionTokenizer):
             return False
         eps = self.norm.eps
         for attn, ff in self.layers:
-            if (attn._forward_hooks or attn._forward_pre_hooks or attn.norm_media.eps != eps or attn.norm_latents.eps != eps or ff[0].eps != eps
+            if (attn.norm_media.eps != eps or attn.norm_latents.eps != eps or ff[0].eps != eps
                     or attn.heads != self.layers[0][0].heads or attn.dim_head != self.layers[0][0].dim_head):
                 return False
-        return True
+        return not ops.python_must_run_between(self.layers)
 
     def _forward_stack(self, x, latents):
         """= the inference loop below for one (sample, image) pair, issued by aki_perceiver_stack_fwd: same launches, same arguments."""
         tb = getattr(self, "_stack_table", None)
         if tb is None:
             tb = self._stack_table = ops.LayerTable(ops.L.PerceiverLayer)
-            tb.params = [p for p in self.layers.parameters()]
-        sig = ops.params_signature(tb.params)
+        # the LIVE parameter objects on every call (load_state_dict(assign=True) and attribute assignment replace objects: a cached list
+        # would go on signing the old ones); object identity is part of the signature
+        live = []
+        for attn, ff in self.layers:
+            live += [attn.norm_media.weight, attn.norm_media.bias, attn.norm_latents.weight, attn.norm_latents.bias, attn.to_q.weight,
+                     attn.to_kv.weight, attn.to_out.weight, ff[0].weight, ff[0].bias, ff[1].weight, ff[3].weight]
+        sig = (tuple(map(id, live)), ops.params_signature(live))
         if tb.sig != sig:
             rows = []
             for attn, ff in self.layers:

@@ -553,6 +553,18 @@ class DecodeChain:
             raise AkiError(f"decode chain: a dependency wait gave up (layer {code >> 8}, phase {code & 255}); the step's output is invalid")
 
 
+def chain_replay_on_current_stream() -> None:
+    """A hipGraph that holds a decode-chain launch is about to be replayed on the current stream: apply the same one-chain-in-flight-per-device
+    rule as DecodeChain.step does for eager launches (a replay is invisible to it otherwise) - let the stream of the previous chain launch
+    finish if it is another one, then record this stream."""
+    cur = torch.cuda.current_stream()
+    with _CHAIN_LOCK:
+        last = _CHAIN_LAST.get(cur.device_index)
+        if last is not None and last.cuda_stream != cur.cuda_stream:
+            last.synchronize()
+        _CHAIN_LAST[cur.device_index] = cur
+
+
 def greedy_pick(logits: torch.Tensor, next_ids: torch.Tensor, pad_token_id: int = 0, eos_ids: Optional[torch.Tensor] = None,
                 done: Optional[torch.Tensor] = None, tokens: Optional[torch.Tensor] = None, cache_len: Optional[torch.Tensor] = None,
                 start_len: Optional[torch.Tensor] = None, advance: bool = False, done_at: Optional[torch.Tensor] = None,
@@ -639,9 +651,22 @@ def stack_enabled() -> bool:
     return _TAP is None and not torch.cuda.is_current_stream_capturing()
 
 
+def python_must_run_between(layers) -> bool:
+    """True when something in Python has to happen inside one of `layers`: a forward (pre-)hook on the layer OR on any of its sub-modules
+    (activation capture, adapter wrappers), or an instance-level `forward` override (gradient checkpointing installs one).  The one-call
+    layer loops (csrc/stack.hip) never enter Python between layers, so they are only taken when this is False."""
+    for ly in layers:
+        for m in ly.modules():
+            if m._forward_hooks or m._forward_pre_hooks or "forward" in m.__dict__:
+                return True
+    return False
+
+
 def params_signature(tensors) -> tuple:
-    """(address, in-place version) of every tensor: changes when a parameter is re-allocated (`.to`, load_state_dict(assign=True), `.data = ...`)
-    or written in place through torch (`copy_`, an optimizer step).  Writes through raw pointers (this library's trainers) are announced by the
+    """(address, in-place version) of every tensor: changes when a parameter is re-allocated (`.to`, `.data = ...`) or written in place
+    through torch (`copy_`, an optimizer step).  It signs the OBJECTS it is given: a caller that wants load_state_dict(assign=True) or an
+    attribute assignment noticed must pass the module's live parameters (and may add their id()s), or bump a version in its load hooks
+    (Phi3Model does the latter, the SigLIP and Perceiver stacks the former).  Writes through raw pointers (this library's trainers) are announced by the
     weight epoch, which callers add themselves.  ~0.25 us per tensor: cheap enough to run before every stacked forward."""
     return tuple((t_.data_ptr(), t_._version) for t_ in tensors)
 

@@ -132,7 +132,10 @@ class DecodeGraph:
     issue cost exceeds their HBM time, so replaying removes the launch-bound gap (MI355X guide: capture launch-bound
     inner loops).  Token ids go in through a static buffer; logits come out of one.  Lengths/positions are device
     tensors advanced inside the graph, so no per-step host value is baked in - except the LongRoPE table choice, which
-    is re-captured if the sequence crosses `original_max_position_embeddings`."""
+    is re-captured if the sequence crosses `original_max_position_embeddings`.
+    Callers other than AKI.generate: a batch-1 step runs the 32 layers as one persistent launch whose dependency waits are bounded; poll
+    `decode_verified(cache)` (or `cache.chain.check()`) before trusting a run of steps, as generate does - a wait that gave up leaves
+    garbage logits and a sticky error word, nothing is raised by the step itself."""
 
     def __init__(self, lm: "Phi3ForCausalLM", cache: AkiKVCache, greedy: Optional[dict] = None):
         """greedy (optional): the arguments of ops.greedy_pick except logits / next_ids / cache_len / advance - the pick then sits INSIDE the
@@ -171,6 +174,8 @@ class DecodeGraph:
         if self.greedy is None:
             raise ops.AkiError("DecodeGraph was built without a greedy pick")
         self._ready()
+        if getattr(self.cache, "chain", None) is not None:
+            ops.chain_replay_on_current_stream()     # the replayed step holds a persistent chain launch: one in flight per device
         self.graph.replay()
         self.cache.host_len += 1
         return self.ids
@@ -190,6 +195,8 @@ class DecodeGraph:
             raise ops.AkiError("this DecodeGraph picks its own next ids: use step_greedy()")
         self._ready()
         self.ids.copy_(ids)
+        if getattr(self.cache, "chain", None) is not None:
+            ops.chain_replay_on_current_stream()
         self.graph.replay()
         self.cache.host_len += 1
         return self.logits
@@ -426,9 +433,9 @@ class Phi3Model(nn.Module):
             return False
         eps = self.norm.variance_epsilon
         for ly in self.layers:
-            if ly._forward_hooks or ly._forward_pre_hooks or ly.input_layernorm.variance_epsilon != eps or ly.post_attention_layernorm.variance_epsilon != eps:
+            if ly.input_layernorm.variance_epsilon != eps or ly.post_attention_layernorm.variance_epsilon != eps:
                 return False
-        return True
+        return not ops.python_must_run_between(self.layers)        # hooks on the layers or their sub-modules, instance-level forward overrides
 
     def _forward_stack(self, h, cos, sin, table, position_ids, cache):
         """= the loop over Phi3DecoderLayer.forward_folded, issued by aki_decoder_stack_fwd: same launches, same arguments.
@@ -510,8 +517,9 @@ class Phi3Model(nn.Module):
         return super()._load_from_state_dict(*a, **kw)
 
     use_decode_chain = True                         # False: the five-launch-per-layer path (A/B and the bit-identity tests)
-    use_decode_chain_batched = False                # True: 2..8 sequences on the batched chain (bf16 weights; bit-identical to the five launches per layer,
-                                                    # measured NOT faster yet - 3.29-3.46 vs 3.27-3.34 ms per step at batch 8, EXPERIMENTS.md round 5 - so off)
+    use_decode_chain_batched = False                # True (LAB library only: the product library does not carry the kernel and answers AKI_ERR_UNSUPPORTED):
+                                                    # 2..8 sequences on the batched chain - bit-identical to the five launches per layer, measured NOT faster
+                                                    # (3.29-3.46 vs 3.27-3.34 ms per step at batch 8, EXPERIMENTS.md round 5)
     decode_chain_w8 = True                          # e4m3 weights: one batch per workgroup, 1.37 ms per token against 1.46 on five launches
                                                     # (1.55 vs 1.46 ms per token: half the bytes, the same dependency latencies)
 
@@ -655,6 +663,10 @@ class Phi3ForCausalLM(nn.Module):
         197 MB head."""
         if past_key_values is not None:
             return self._continue(input_ids, inputs_embeds, past_key_values, labels)
+        if last_token_logits and labels is not None:
+            raise ValueError("last_token_logits=True keeps one row of logits per sample; a loss over `labels` needs all of them")
+        if last_token_logits and not use_cache:
+            raise ValueError("last_token_logits=True is the prefill of a generation: pass use_cache=True (without a cache the flag used to be ignored silently)")
         if inputs_embeds is None:
             inputs_embeds = self.model.embed_tokens(input_ids)
         B, L, _ = inputs_embeds.shape

@@ -216,10 +216,10 @@ def _siglip_can_stack(self, h) -> bool:
         return False
     l0 = self.layers[0]
     for ly in self.layers:
-        if (ly._forward_hooks or ly._forward_pre_hooks or ly.layer_norm1.eps != l0.layer_norm1.eps or ly.layer_norm2.eps != l0.layer_norm1.eps
+        if (ly.layer_norm1.eps != l0.layer_norm1.eps or ly.layer_norm2.eps != l0.layer_norm1.eps
                 or ly.mlp.act != l0.mlp.act or ly.mlp.fc1.bias is None or ly.self_attn.q_proj.bias is None):
             return False
-    return True
+    return not ops.python_must_run_between(self.layers)
 
 
 def _siglip_forward_stack(self, h):
@@ -229,13 +229,20 @@ def _siglip_forward_stack(self, h):
     tb = getattr(self, "_stack_table", None)
     if tb is None:
         tb = self._stack_table = ops.LayerTable(ops.L.SiglipLayer)
-        tb.params = [p for ly in self.layers for p in ly.parameters()]
-    ep = _epoch(tb.params)
-    sig = (ep, len(self.layers), ops.params_signature(tb.params))
+    # The LIVE parameter objects, collected on every call (a cached list would keep answering for objects that load_state_dict(assign=True)
+    # or `layer.mlp.fc1.weight = nn.Parameter(...)` have replaced: same address and version, other weights in use).  Sixteen dictionary
+    # lookups per layer, ~0.1 ms for the tower - a tenth of the preparation the signature saves.
+    live = []
+    for ly in self.layers:
+        at, mlp = ly.self_attn, ly.mlp
+        for m in (at.q_proj, at.k_proj, at.v_proj, at.out_proj, ly.layer_norm1, ly.layer_norm2, mlp.fc1, mlp.fc2):
+            pm = m._parameters
+            live.append(pm["weight"])
+            if pm.get("bias") is not None:
+                live.append(pm["bias"])
+    ep = _epoch(live)
+    sig = (ep, len(self.layers), tuple(map(id, live)), ops.params_signature(live))
     if tb.sig != sig:
-        if len(tb.params) != sum(1 for ly in self.layers for _ in ly.parameters()):
-            tb.params = [p for ly in self.layers for p in ly.parameters()]
-            sig = (ep, len(self.layers), ops.params_signature(tb.params))
         rows = []
         for ly in self.layers:
             at, mlp = ly.self_attn, ly.mlp

@@ -584,9 +584,12 @@ def test_batched_decode_chain_is_bit_identical_to_the_per_layer_launches(B, prom
     am[B - 1, 3:9] = False
     table = ops.MaskTable.from_host([[(4, 40, 40, n_ - 8)] for n_ in lens], am, lens, DEV)
     outs = {}
+    import contextlib
+    from aki_amd import _lib
     for chained in (False, True):
         lm.model.use_decode_chain_batched = chained
-        with torch.no_grad():
+        # the batched chain lives in the lab library only (round 6: built, bit-identical, not faster - out of the product)
+        with (_lib.use_lab(0) if chained else contextlib.nullcontext()), torch.no_grad():
             out = lm(inputs_embeds=x, attention_mask=table, use_cache=True, cache_capacity=prompt + steps + 3)
             cache = out.past_key_values
             ids = out.logits[:, -1].float().argmax(-1)
@@ -595,14 +598,14 @@ def test_batched_decode_chain_is_bit_identical_to_the_per_layer_launches(B, prom
                 lg = lm.decode_step(input_ids=ids, past_key_values=cache)
                 logits.append(lg.clone())
                 ids = lg.float().argmax(-1)
-        chain = getattr(cache, "chain", None)
-        assert (chain is not None) == chained
-        if chained:
-            assert chain.batch == B and chain.error_code() == 0
+            chain = getattr(cache, "chain", None)
+            assert (chain is not None) == chained
+            if chained:
+                assert chain.batch == B and chain.error_code() == 0
         # the rows each sequence holds: its prompt + the appended steps (what lies beyond is unwritten cache)
         rows = lambda c: [torch.cat([c_[b_, :, : lens[b_] + steps].reshape(-1) for b_ in range(B)]) for c_ in c]
         outs[chained] = (torch.stack(logits), rows(cache.k), rows(cache.v), cache.cache_len.clone())
-    lm.model.use_decode_chain_batched = True
+    lm.model.use_decode_chain_batched = False
     a, b = outs[False], outs[True]
     assert bool(torch.isfinite(a[0].float()).all()) and torch.equal(a[3], b[3])
     assert torch.equal(a[0], b[0]), f"{int((a[0] != b[0]).sum())} logits differ over {steps} steps"

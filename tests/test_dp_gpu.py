@@ -205,6 +205,21 @@ def test_bench_contract_two_ranks_on_one_gpu():
     tokens = 2 * 2 * 655 * 2
     assert abs(out["value"] - tokens / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 1e-3
     assert out["roofline"]["bound"] in ("mfma", "hbm") and 0.0 < out["roofline"]["frac"] < 1.0
+    # the day-one scaling table (tools/scale_report.py) from this line and a one-rank line of the same per-GPU batch
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline",
+                         "--no-secondary"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = [ln for ln in r1.stdout.splitlines() if ln.startswith("{")]
+    assert len(one) == 1
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".jsonl", delete=False) as f:
+        f.write(one[0] + "\n" + lines[0] + "\n")
+    rep = subprocess.run([sys.executable, os.path.join(root, "tools", "scale_report.py"), f.name], capture_output=True, text=True, timeout=60)
+    os.unlink(f.name)
+    assert rep.returncode == 0, rep.stderr
+    table = json.loads(rep.stdout)["forward"]
+    assert [row["n_gpus"] for row in table] == [1, 2] and table[0]["x_scaling"] == 1.0
+    assert 0.3 < table[1]["x_scaling"] < 2.2 and table[1]["rank_min_ms"] <= table[1]["rank_max_ms"]      # two ranks SHARE one GPU here: ~1x, not 2x
 
 
 def test_bench_gpus_2_starts_its_own_ranks():

@@ -130,6 +130,52 @@ def test_stack_tables_follow_weight_changes():
     lm.eval()
 
 
+def test_siglip_and_perceiver_stacks_follow_replaced_parameter_objects():
+    """load_state_dict(assign=True) and `module.weight = nn.Parameter(...)` REPLACE parameter objects; the old objects
+    stay alive with an unchanged (address, version), so a signature over a cached object list keeps the one-call loops on the old weights.
+    After each kind of replacement the stacked forward must equal the per-layer path on the new weights - and differ from before."""
+    import copy
+    from aki_amd.siglip import SiglipVisionTransformer, make_siglip_config
+    from aki_amd.helpers import PerceiverResampler
+    torch.manual_seed(11)
+    vt = SiglipVisionTransformer(make_siglip_config(num_hidden_layers=2, image_size=56, hidden_size=576, intermediate_size=1000, num_attention_heads=8))
+    vt = vt.to(DEV).to(torch.bfloat16).eval()
+    px = ((torch.rand((2, 3, 56, 56)) - 0.5) / 0.5).to(DEV, torch.bfloat16)
+
+    def tower(stack):
+        vt.encoder.use_layer_stack = stack
+        with torch.no_grad():
+            return vt(px).last_hidden_state.clone()
+
+    a = tower(True)
+    sd = {k: (v.clone() * 1.25 if v.dim() == 2 else v.clone()) for k, v in vt.state_dict().items()}
+    vt.load_state_dict(sd, assign=True)                                     # new Parameter objects around new storage
+    b_stack, b_loop = tower(True), tower(False)
+    assert torch.equal(b_stack, b_loop), "SigLIP stack kept the weights from before load_state_dict(assign=True)"
+    assert not torch.equal(b_stack, a)
+    fc1 = vt.encoder.layers[1].mlp.fc1
+    fc1.weight = torch.nn.Parameter(fc1.weight.detach() * 0.5, requires_grad=False)      # attribute assignment on a sub-module
+    c_stack, c_loop = tower(True), tower(False)
+    assert torch.equal(c_stack, c_loop) and not torch.equal(c_stack, b_stack)
+    vt.encoder.use_layer_stack = True
+
+    pr = PerceiverResampler(dim=576, dim_inner=384, depth=2, dim_head=64, heads=8, num_latents=16, ff_mult=2).to(DEV).to(torch.bfloat16).eval()
+    x = (torch.randn(1, 1, 1, 40, 576) * 0.5).to(DEV, torch.bfloat16)
+
+    def conn(stack):
+        pr.use_layer_stack = stack
+        with torch.no_grad():
+            return pr(x).clone()
+
+    a = conn(True)
+    sd = {k: (v.clone() * 1.5 if v.dim() == 2 else v.clone()) for k, v in pr.state_dict().items()}
+    pr.load_state_dict(sd, assign=True)
+    b_stack, b_loop = conn(True), conn(False)
+    assert torch.equal(b_stack, b_loop), "Perceiver stack kept the weights from before load_state_dict(assign=True)"
+    assert not torch.equal(b_stack, a)
+    pr.use_layer_stack = True
+
+
 @pytest.mark.parametrize("n1,proj", [(576, True), (729, True), (100, False)])
 def test_perceiver_stack_equals_the_python_loop(n1, proj):
     """aki_perceiver_stack_fwd (one (sample, image) pair) against PerceiverResampler's own inference loop: bit for bit, with and without the final

@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--no-chain", action="store_true", help="batch 1: the five-launch-per-layer path instead of the one-launch chain")
     a = ap.parse_args()
     from aki_amd import ops
+    if a.batched_chain:                    # the batched chain is compiled into the lab library only (round 6)
+        from aki_amd import _lib
+        _lib._lib = _lib.load_lab()
     from aki_amd.phi3 import Phi3ForCausalLM, make_phi3_config, DecodeGraph
     from aki_amd.helpers import DecoupledEmbedding, DecoupledLinear
     dev = "cuda"

@@ -33,6 +33,8 @@ def main():
     names = ["qkv", "attention", "o_proj", "gate_up", "down"]
     with _lib.use_lab(0) as lab, torch.no_grad():
         lab.aki_lab_set_chain_nb(a.preset)
+        from aki_amd import _lib
+        _lib._lib = _lib.load_lab()            # the batched chain is compiled into the lab library only (round 6)
         lm.model.use_decode_chain_batched = True
         if a.nowait:
             lab.aki_lab_set_chain(8, 1, 32, 1)
