@@ -66,12 +66,19 @@ template <int R> __device__ __forceinline__ void acc_scale4(float alpha) {
 template <int KA, int QA> __device__ __forceinline__ void mfma_qk(f32x16& s) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
 }
+template <int KA, int QA> __device__ __forceinline__ void mfma_qk_c(f32x16& s, const f32x16& cin) {   // C from another register tuple
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c2:%c3], a[%c4:%c5], %1" : "=v"(s) : "v"(cin), "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
+}
 template <int KA, int QA> __device__ __forceinline__ void mfma_qk_zero(f32x16& s) {   // FULL tiles: the constant 0 as C
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
 }
 // O^T (a) += V^T fragment (VGPRs) * P fragment (VGPRs)
 template <int OA> __device__ __forceinline__ void mfma_pv(const u32x4 vv, const u32x4 pf) {
   asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vv), "v"(pf), "n"(OA), "n"(OA + 15));
+}
+// 16 bytes of a Q row straight into accumulator registers (a load hipcc neither counts nor waits for: the rank prologue's vmcnt(0) does)
+template <int QA, int OFF> __device__ __forceinline__ void q_frag_load(const void* row) {
+  asm volatile("global_load_dwordx4 a[%c1:%c2], %0, off offset:%c3" ::"v"(row), "n"(QA), "n"(QA + 3), "n"(OFF) : "memory");
 }
 template <int KA, int OFF> __device__ __forceinline__ void k_frag_read(unsigned addr) {
   asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "n"(KA), "n"(KA + 3), "n"(OFF));
@@ -352,7 +359,10 @@ __device__ __forceinline__ void sm_tail(const f32x16& s0, const f32x16& s1, u32x
 template <int THR, int ABL>
 __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParams p) {
   constexpr int NT = 256;
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * KTILE + NSTAGE * VTILE + MAX_VB_WORDS * 8];
+  constexpr int OROW = 208;              // output staging row: 192 B + 16 (the 8-B writes of 32 rows land 2-way instead of 8-way conflicted)
+  constexpr int LDS_RING = NSTAGE * KTILE + NSTAGE * VTILE, LDS_VB = MAX_VB_WORDS * 8, LDS_OUT = 8 * 32 * OROW;
+  // ring | valid words | output staging of its own (the next rank's first tiles stream into the ring WHILE this rank's outputs are staged)
+  __shared__ __attribute__((aligned(16))) char smem[LDS_RING + LDS_VB + LDS_OUT];
   char* const sK = smem;
   char* const sV = smem + NSTAGE * KTILE;
   // the sample's valid-column words: read only on the bias path, through asm (a load hipcc can see would be given a vmcnt(0) that
@@ -498,19 +508,18 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
 
   // lab stamps (ABL & 512): shader-clock cycles of prologue / tile loops / epilogue, tiles walked, and the 100 MHz real-time
   // counter over the whole workgroup -> lse[8 * blockIdx .. +7] (timing build: its lse output is not an lse)
-  unsigned long long st_pro = 0, st_loop = 0, st_epi = 0, st_tiles = 0, st_t = 0, st_rt0 = 0, st_redo = 0;
+  unsigned long long st_pro = 0, st_loop = 0, st_epi = 0, st_tiles = 0, st_t = 0, st_rt0 = 0, st_redo = 0, st_wait = 0, st_dma = 0;
   if constexpr (ABL & 512) { st_rt0 = __builtin_amdgcn_s_memrealtime(); }
 
-  for (int kk = 0;; ++kk) {
-  const int g = kk * p.splits + ((kk & 1) ? p.splits - 1 - sidx : sidx);   // this workgroup's next rank
-  if (g >= p.nqt) break;
-  if constexpr (ABL & 512) st_t = __builtin_amdgcn_s_memtime();
-
-  // ---- which blocks: the rank's eight, this wave's two ----------------------------------------------
-  A64Blk A, B;
-  int hi_col = 0;
-  {
-    int extA = 0, extB = 0;
+  // ---- the next rank's blocks, Q rows and first K/V tiles, asked for one rank ahead ------------------------------------------
+  // Stamps of the first working build: 9-10 % of a workgroup's time went into rank prologues that waited for Q and K(0) with nothing
+  // to overlap.  Now the rank search, the Q loads and the LDS-DMA of K(0), {K(1), V(0)}, {K(2), V(1)} of rank r + 1 are issued right
+  // behind the tile loops of rank r (the ring is idle from there on - the two units the loops ask for past the rank's end are waited for first - and the
+  // outputs are staged in LDS of their own) and land under its last P V MFMAs and its epilogue.
+  struct { int wq0A, wq0B, jendA, jendB, jend; } nx = {0, 0, 0, 0, 0};
+  auto rank_of = [&](int kk) -> int { return kk * p.splits + ((kk & 1) ? p.splits - 1 - sidx : sidx); };   // the snake over the pair's ranks
+  auto prefetch_rank = [&](int g) {
+    int wq0A = L, wq0B = L, extA = 0, extB = 0, hi_col = 0;
     if (sched) {
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -518,36 +527,47 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
         ranked_block(8 * g + 2 * w, wa, ea);
         ranked_block(8 * g + 2 * w + 1, wb, eb);
         hi_col = max(hi_col, max(ea, eb));
-        if (w == wave) { A.wq0 = wa; extA = ea; B.wq0 = wb; extB = eb; }
+        if (w == wave) { wq0A = wa; extA = ea; wq0B = wb; extB = eb; }
       }
     } else {                                     // position order, late rows first; a wave's blocks are neighbours
       const int q0 = (p.nqt - 1 - g) * 256;
       const int e = max(block_extent(q0 + 32 * (lane & 7)), 0);
 #pragma unroll
       for (int w = 0; w < 8; ++w) hi_col = max(hi_col, __builtin_amdgcn_readlane(e, w));
-      A.wq0 = min(q0 + 64 * wave, L); extA = __builtin_amdgcn_readlane(e, 2 * wave);
-      B.wq0 = min(q0 + 64 * wave + 32, L); extB = __builtin_amdgcn_readlane(e, 2 * wave + 1);
+      wq0A = min(q0 + 64 * wave, L); extA = __builtin_amdgcn_readlane(e, 2 * wave);
+      wq0B = min(q0 + 64 * wave + 32, L); extB = __builtin_amdgcn_readlane(e, 2 * wave + 1);
     }
-    A.wq0 = __builtin_amdgcn_readfirstlane(A.wq0); B.wq0 = __builtin_amdgcn_readfirstlane(B.wq0);
-    A.jend = __builtin_amdgcn_readfirstlane((extA + 63) >> 6); B.jend = __builtin_amdgcn_readfirstlane((extB + 63) >> 6);
-    hi_col = __builtin_amdgcn_readfirstlane(hi_col);
-  }
-  const int jend = (hi_col + 63) >> 6;            // the rank's K/V stream (workgroup-uniform)
-  const int jend_w = max(A.jend, B.jend);         // this wave's part of it
+    nx.wq0A = __builtin_amdgcn_readfirstlane(wq0A); nx.wq0B = __builtin_amdgcn_readfirstlane(wq0B);
+    nx.jendA = __builtin_amdgcn_readfirstlane((extA + 63) >> 6); nx.jendB = __builtin_amdgcn_readfirstlane((extB + 63) >> 6);
+    nx.jend = (__builtin_amdgcn_readfirstlane(hi_col) + 63) >> 6;
+    // K/V stream first (the oldest requests), then Q of both blocks
+    static_for<3>([&](auto I) { dma_k(I, 0, 0); });
+    static_for<3>([&](auto I) { dma_k(I, 1, 1); });
+    static_for<3>([&](auto I) { dma_v(I, 0, 0); });
+    static_for<3>([&](auto I) { dma_k(I, 2, 2); });
+    static_for<3>([&](auto I) { dma_v(I, 1, 1); });
+    // the Q fragments go straight into their accumulator registers (every score MFMA of the previous rank has been issued; its last
+    // P V MFMAs and its epilogue do not name them): lane (q = l31, h) holds Q[q][16 ks + 8 h .. +7] of each block
+    const bf16_t* ra = qb + (size_t)min(nx.wq0A + l31, L - 1) * 96 + 8 * h;
+    const bf16_t* rb = qb + (size_t)min(nx.wq0B + l31, L - 1) * 96 + 8 * h;
+    static_for<6>([&](auto KS) {
+      constexpr int ks = decltype(KS)::value;
+      q_frag_load<A64_Q + 4 * ks, 32 * ks>(ra);
+      q_frag_load<A64_Q + 24 + 4 * ks, 32 * ks>(rb);
+    });
+  };
+  if (rank_of(0) < p.nqt) prefetch_rank(rank_of(0));
 
-  // ---- Q of both blocks first (plain loads the compiler counts), then the K/V stream: K(0), unit 0, unit 1 --------------
-  bf16x8 qa[6], qb2[6];
-  {
-    const bf16_t* ra = qb + (size_t)min(A.wq0 + l31, L - 1) * 96 + 8 * h;
-    const bf16_t* rb = qb + (size_t)min(B.wq0 + l31, L - 1) * 96 + 8 * h;
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) { qa[ks] = *(const bf16x8*)(ra + 16 * ks); qb2[ks] = *(const bf16x8*)(rb + 16 * ks); }
-  }
-  static_for<3>([&](auto I) { dma_k(I, 0, 0); });
-  static_for<3>([&](auto I) { dma_k(I, 1, 1); });
-  static_for<3>([&](auto I) { dma_v(I, 0, 0); });
-  static_for<3>([&](auto I) { dma_k(I, 2, 2); });
-  static_for<3>([&](auto I) { dma_v(I, 1, 1); });
+  for (int kk = 0;; ++kk) {
+  const int g = rank_of(kk);   // this workgroup's next rank
+  if (g >= p.nqt) break;
+  if constexpr (ABL & 512) st_t = __builtin_amdgcn_s_memtime();
+
+  // ---- which blocks: the rank's eight, this wave's two (found one rank ahead) ----------------------------------------------
+  A64Blk A, B;
+  A.wq0 = nx.wq0A; B.wq0 = nx.wq0B; A.jend = nx.jendA; B.jend = nx.jendB;
+  const int jend = nx.jend;                       // the rank's K/V stream (workgroup-uniform)
+  const int jend_w = max(A.jend, B.jend);         // this wave's part of it
 
   // ---- per block: rectangle summary, per-lane unlock range, row classes --------------------------------
   auto setup = [&](A64Blk& X) {
@@ -579,20 +599,6 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   };
   setup(A);
   setup(B);
-  if (A.row_uniform) {   // uniform-softmax rows: score 0 on every column = an all-zero query
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) qa[ks] = bf16x8{};
-  }
-  if (B.row_uniform) {
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) qb2[ks] = bf16x8{};
-  }
-  static_for<6>([&](auto KS) {
-    constexpr int ks = decltype(KS)::value;
-    const u32x4 wa = __builtin_bit_cast(u32x4, qa[ks]), wb = __builtin_bit_cast(u32x4, qb2[ks]);
-    acc_set<A64_Q + 4 * ks + 0>(wa[0]); acc_set<A64_Q + 4 * ks + 1>(wa[1]); acc_set<A64_Q + 4 * ks + 2>(wa[2]); acc_set<A64_Q + 4 * ks + 3>(wa[3]);
-    acc_set<A64_Q + 24 + 4 * ks + 0>(wb[0]); acc_set<A64_Q + 24 + 4 * ks + 1>(wb[1]); acc_set<A64_Q + 24 + 4 * ks + 2>(wb[2]); acc_set<A64_Q + 24 + 4 * ks + 3>(wb[3]);
-  });
   static_for<96>([&](auto R) { acc_zero<A64_O + decltype(R)::value>(); });
 
   // ---- tile classes (the 32-row kernel's, decided for 64 tiles at a time) -------------------------------------------------
@@ -676,6 +682,12 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   u32x4 pA[4], pB[4];                 // P as packed bf16: the B operand of the four 16-key steps
   u32x2 vlo[4][3], vhi[4][3];         // V^T fragments of the current V tile (both blocks use them)
   A64Tmp tA, tB;
+  f32x16 zt;                          // lab (ABL & 16384): a tuple of zeros as the C operand of the first score MFMAs
+  if constexpr (ABL & 16384) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zt[r] = 0.f;
+    asm volatile("" : "+v"(zt));
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     pA[i] = u32x4{0u, 0u, 0u, 0u}; pB[i] = u32x4{0u, 0u, 0u, 0u};
@@ -729,6 +741,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       if constexpr (THR != 0 && i == 0 && decltype(YB)::value == 0) asm volatile("s_nop 3" : "+v"(x0), "+v"(x1));
       if constexpr (THR == 0) sm_chunk<THR, OAX, i, ABL>(x0, x1, px, X, tx, c, rc);
       else sm_opt_chunk<i, THR, ABL>(x0, x1, px, X, tx, c);
+      if constexpr (ABL & 8192) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1" : "+v"(tx.m3), "+v"(tx.thr));   // lab: what do two more VALU issues per gap cost (right results)
       if constexpr (i < 3) dma(I);
       A64_PIN();
     });
@@ -742,7 +755,8 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       constexpr int i = decltype(I)::value, ks = i >> 1, half = i & 1;
       if constexpr (qk) {
         if constexpr (ks == 0) {
-          if constexpr (decltype(FULLT)::value) { if constexpr (half == 0) mfma_qk_zero<A64_KA, QAY>(y0); else mfma_qk_zero<A64_KC, QAY>(y1); }
+          if constexpr (decltype(FULLT)::value && (ABL & 16384)) { if constexpr (half == 0) mfma_qk_c<A64_KA, QAY>(y0, zt); else mfma_qk_c<A64_KC, QAY>(y1, zt); }     // lab: C from a VGPR tuple of zeros
+          else if constexpr (decltype(FULLT)::value) { if constexpr (half == 0) mfma_qk_zero<A64_KA, QAY>(y0); else mfma_qk_zero<A64_KC, QAY>(y1); }
           else { if constexpr (half == 0) mfma_qk<A64_KA, QAY>(y0); else mfma_qk<A64_KC, QAY>(y1); }
         } else {
           if constexpr (half == 0) mfma_qk<A64_KA + 4 * ks, QAY + 4 * ks>(y0); else mfma_qk<A64_KC + 4 * ks, QAY + 4 * ks>(y1);
@@ -752,6 +766,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       A64_PIN();
       if constexpr (THR == 0) sm_chunk<THR, OAX, 12 + i, ABL>(x0, x1, px, X, tx, c, rc);
       else sm_opt_chunk<12 + i, THR, ABL>(x0, x1, px, X, tx, c);
+      if constexpr (ABL & 8192) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1" : "+v"(tx.m3), "+v"(tx.thr));
       A64_PIN();
     });
     if constexpr (THR != 0) {
@@ -766,7 +781,9 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   using BB = std::integral_constant<int, 1>;
 
   // ---- K(0) has landed (this wave's pieces: all but the 12 youngest), for everybody: fragments, then K Q_A^T of tile 0 ----
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // Q, K(0) and units 0, 1 (asked for a whole epilogue ago, first rank excepted)
+  if (A.row_uniform) static_for<24>([&](auto R) { acc_zero<A64_Q + decltype(R)::value>(); });         // uniform-softmax rows: score 0 on every
+  if (B.row_uniform) static_for<24>([&](auto R) { acc_zero<A64_Q + 24 + decltype(R)::value>(); });    // column = an all-zero query (per lane)
   __builtin_amdgcn_s_barrier();
   static_for<12>([&](auto I) { k_frag(std::integral_constant<int, decltype(I)::value / 2>{}, std::integral_constant<int, decltype(I)::value % 2>{}, sK_a + k_even, sK_a + k_odd); });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -802,13 +819,17 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   auto iter = [&](auto FT, int j) {
     constexpr bool ft = decltype(FT)::value;
     // unit j = {K(j+1), V(j)}: this wave's pieces are all but the 6 youngest (unit j+1); then a workgroup-wide fact
+    unsigned long long tw0 = 0;
+    if constexpr (ABL & 512) tw0 = __builtin_amdgcn_s_memtime();
     if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (ABL & 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_dma += t_ - tw0; tw0 = t_; }
     if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+    if constexpr (ABL & 512) st_wait += __builtin_amdgcn_s_memtime() - tw0;
     A64_PIN();
     // unit j+2 = {K(j+3) -> the stage K(j) has left, V(j+2) -> the stage V(j-1) has left}
     const int tk = j + 3, tv = j + 2;
-    auto dma_e = [&](auto I) { dma_k(I, tk, st0); };
-    auto dma_o = [&](auto I) { dma_v(I, tv, st2); };
+    auto dma_e = [&](auto I) { dma_k(I, tk, st0); };      // the last two iterations ask for units past the rank's end (branch-free loop body;
+    auto dma_o = [&](auto I) { dma_v(I, tv, st2); };      // rows past L cost no traffic): they are waited for behind the loops
     const unsigned va = sV_a + st0 * VTILE + voff;                 // V(j)
     const unsigned ke = sK_a + st1 * KTILE + k_even, ko = sK_a + st1 * KTILE + k_odd;   // K(j+1)
     // ---- slot E(j): P_B V (j-1), K Q_B^T (j)  beside  softmax of S_A(j) ----
@@ -853,6 +874,11 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     static_for<3>([&](auto I) { dma_v(I, tv, st2); });
     const int t_ = st0; st0 = st1; st1 = st2; st2 = t_;
   }
+  // The two units asked for past the rank's end have landed (they were issued one and two tiles ago) and every wave has read the last
+  // tiles out of the ring: the next rank's first tiles may stream in, its Q rows be asked for.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (rank_of(kk + 1) < p.nqt) prefetch_rank(rank_of(kk + 1));
   if constexpr (ABL & 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_loop += t_ - st_t; st_t = t_; st_redo += A.l_dbg + B.l_dbg; }
   // P_B V of the wave's last tile: its V^T fragments are still in registers
   if (jend_w > 0) {
@@ -862,20 +888,21 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       mfma_pv<A64_O + 48 + 16 * dt>(vv, pB[ks4]);
     });
   }
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // the last MFMA results; the prefetched units past the end have landed
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMA results
   A64_PIN();
 
-  // ---- epilogue per block: O = O^T / l through the wave's own piece of the (idle) ring, whole 192-B rows out ----------------
-  __syncthreads();                       // every wave is done reading the ring, nothing is in flight into it
-  constexpr int OROW = 208;
+  // ---- epilogue per block: O = O^T / l through the wave's own piece of the output staging area, whole 192-B rows out -------------
   int lane_o = lane;                     // opaque per rank: the epilogue's per-lane addresses are not hoisted over the tile loop (they would be spilled)
   asm volatile("" : "+v"(lane_o));
   const int l31_o = lane_o & 31, h_o = lane_o >> 5;
+  const unsigned sO_a = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)(smem + LDS_RING + LDS_VB));
   auto store_block = [&](auto XB, A64Blk& X) {
     constexpr int xb = decltype(XB)::value;
     const float l_tot = halves_sum(X.l);
     const bool dead = !(l_tot > 0.f);
-    char* const sO = smem + (wave * 2 + xb) * (32 * OROW);
+    // wave-private staging through asm LDS accesses: an LDS access hipcc can see gets an s_waitcnt vmcnt(0) in front (it may alias an LDS-DMA
+    // in flight as far as the compiler knows) - here that would be a wait for the next rank's prefetch
+    const unsigned sO = sO_a + (unsigned)((wave * 2 + xb) * (32 * OROW));
     const float inv = dead ? 0.f : 1.0f / l_tot;
     static_for<12>([&](auto I) {
       constexpr int i = decltype(I)::value, dt = i / 4, q4 = i % 4;
@@ -895,21 +922,24 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
         v[0] = a0 * il; v[1] = a1 * il; v[2] = a2 * il; v[3] = a3 * il;
       }
       const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      *(u32x2*)(sO + l31_o * OROW + (dt * 32 + q4 * 8 + 4 * h_o) * 2) = pk;
+      const unsigned wa = sO + (unsigned)(l31_o * OROW + (dt * 32 + q4 * 8 + 4 * h_o) * 2);
+      asm volatile("ds_write_b64 %0, %1" ::"v"(wa), "v"(pk) : "memory");
     });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same-wave round trip through LDS: the writes are in before the reads go out
     bf16_t* const obase = p.o + ((size_t)b * L * p.H + head) * 96;
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
       const int ch = it * 64 + lane_o;                 // 16-B chunk of the block's tile: row ch/12, chunk ch%12
       const int r = ch / 12, cc = ch - r * 12;
-      const u32x4 w4 = *(const u32x4*)(sO + r * OROW + cc * 16);
+      u32x4 w4;
+      const unsigned ra_ = sO + (unsigned)(r * OROW + cc * 16);
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w4) : "v"(ra_) : "memory");
       if (X.wq0 + r < L) *(u32x4*)((char*)(obase + (size_t)(X.wq0 + r) * p.H * 96) + cc * 16) = w4;
     }
     if (!(ABL & 512) && p.lse && h_o == 0 && X.row < L) p.lse[(size_t)bh * L + X.row] = dead ? -INFINITY : (X.m_ref + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
   };
   store_block(BA{}, A);
   store_block(BB{}, B);
-  __syncthreads();   // the staged output tiles live in the ring: every wave has read its tiles back before the next rank's DMA
   if constexpr (ABL & 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_epi += t_ - st_t; }
   }                  // next rank of this workgroup
   if constexpr (ABL & 512) {
@@ -918,6 +948,8 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       d[0] = (float)st_pro; d[1] = (float)st_loop; d[2] = (float)st_epi; d[3] = (float)st_tiles;
       d[4] = (float)(__builtin_amdgcn_s_memrealtime() - st_rt0);
       d[5] = (float)st_redo;
+      d[6] = (float)st_dma;
+      d[7] = (float)st_wait;
     }
   }
 #undef A64_PIN
@@ -937,7 +969,7 @@ int attn_core64_bf16_launch(AttnParams p, int cus, hipStream_t stream, int exact
   p.group_bh = grp > nbh ? nbh : grp;
 #ifdef AKI_LAB_HOOKS
 #define A64_ABL_CASE(m) if (g_attn_variant == 100 + (m)) { hipLaunchKernelGGL((mma_attn64_bf16_kernel<8, (m)>), dim3(nbh * p.splits), dim3(256), 0, stream, p); return AKI_OK; }
-  A64_ABL_CASE(16) A64_ABL_CASE(17) A64_ABL_CASE(18) A64_ABL_CASE(20) A64_ABL_CASE(24) A64_ABL_CASE(48) A64_ABL_CASE(30) A64_ABL_CASE(31) A64_ABL_CASE(64) A64_ABL_CASE(512)
+  A64_ABL_CASE(16) A64_ABL_CASE(17) A64_ABL_CASE(18) A64_ABL_CASE(20) A64_ABL_CASE(24) A64_ABL_CASE(48) A64_ABL_CASE(30) A64_ABL_CASE(31) A64_ABL_CASE(64) A64_ABL_CASE(512) A64_ABL_CASE(8192) A64_ABL_CASE(8704) A64_ABL_CASE(16896)
 #undef A64_ABL_CASE
 #endif
   if (exact_max) hipLaunchKernelGGL((mma_attn64_bf16_kernel<0, 0>), dim3(nbh * p.splits), dim3(256), 0, stream, p);
