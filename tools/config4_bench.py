@@ -1,6 +1,8 @@
 """BASELINE configs[3]: AKI-4B forward at seq = 4096 with 4 interleaved 336x336 images (multi-image MMA mask), bf16, one MI355X.
-Per batch size: ms per forward, tokens/s, and a `roofline` object for the dominant kernel (gate_up + SwiGLU, bracketed live with HIP events on
-every 4th launch in a separate pass - the timed pass runs without probes) as in bench.py.   python tools/config4_bench.py > profiles/r05_config4_bench.json"""
+Per batch size: ms per forward, tokens/s, a `roofline` object for the dominant kernel (gate_up + SwiGLU, bracketed live with HIP events on
+every 4th launch in a separate pass - the timed pass runs without probes) as in bench.py, and an `mma_core` object for the attention core
+alone on the batch's own mask table (us, TF/s, fraction of the dense bf16 MFMA peak; `traffic` and `mfma_busy_frac` from the committed
+rocprofv3 --pmc passes of tools/profile_attn64.sh when they were taken on this tree).   python tools/config4_bench.py > profiles/r06_config4_bench.json"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -39,12 +41,42 @@ for B in (1, 2, 4):
             model(vx, ids, attention_mask=am)
         summ = tap.summary()
         ops.set_event_tap(None)
+        # the attention core alone: same shapes, the batch's own mask table
+        prep = model._prepare_inputs_for_forward(vision_tokens=model.vision_tokenizer(model._encode_vision_x(vx)), lang_x=ids, attention_mask=am, padding_side="right")
+        table = prep["attention_mask"]
+        gq = torch.Generator(device=dev).manual_seed(7)
+        q, k, v = (torch.randn(B, 32, L, 96, device=dev, generator=gq).to(torch.bfloat16) for _ in range(3))
+        for _ in range(5):
+            ops.mma_attn_core(q, k, v, table, 96 ** -0.5)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.mma_attn_core(q, k, v, table, 96 ** -0.5)
+        e1.record()
+        torch.cuda.synchronize()
+        core_ms = e0.elapsed_time(e1) / 20
+        del q, k, v, prep
+    pairs = L * (L + 1) // 2 + sum(NV * max(0, (L - 64) - (s_ + NV)) for s_ in (6, 900, 1800, 2700))
+    cfl = 4.0 * 96 * pairs * 32 * B
+    core = {"kernel": f"mma_attn64_bf16_kernel (64 rows per wave, one wave per SIMD) B{B} H32 L{L}, 4 images", "bound": "mfma", "us": round(core_ms * 1e3, 1),
+            "achieved": round(cfl / core_ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(cfl / core_ms / 1e9 / 2500.0, 4), "mfma_frac": round(cfl / core_ms / 1e9 / 2500.0, 4),
+            "algorithmic_flops_per_launch": cfl, "algorithmic_bytes_per_launch": int(4 * B * L * 3072 * 2), "traffic": None}
+    pf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r06_attn64_b{B}_pmc.json")
+    if os.path.exists(pf):
+        from aki_amd.build import csrc_hash
+        ent = json.load(open(pf))
+        hit = [e_ for e_ in ent if "mma_attn64" in e_.get("kernel", "")]
+        meta = [e_ for e_ in ent if e_.get("kernel") == "__meta__"]
+        if hit:
+            core.update(traffic=int(hit[0]["hbm_read_bytes_corrected_x2"] + hit[0]["hbm_write_bytes"]), traffic_unit="bytes per launch (L2<->fabric: FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache hits)",
+                        traffic_source=os.path.relpath(pf), traffic_stale=bool(not meta or meta[0].get("csrc_tree_hash") != csrc_hash()),
+                        mfma_busy_frac_of_simd_cycles=hit[0].get("mfma_busy_frac_of_simd_cycles"))
     gu = [(tag, n_, ms_) for tag, (n_, ms_) in summ.items() if tag[0] == "linear"]
     at = [(tag, n_, ms_) for tag, (n_, ms_) in summ.items() if tag[0].startswith("mma_attn")]
     (tag, _, gms), M = gu[0], B * L
     fl = 2.0 * M * 16384 * 3072
     roof = {"kernel": "gemm_bf16_kernel<8,4,2,4,SWIGLU> (gate_up + SwiGLU)", "bound": "mfma", "achieved": round(fl / gms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
             "frac": round(fl / gms / 1e9 / 2500.0, 4), "traffic": None, "avg_launch_ms": round(gms, 4), "flop_per_launch": fl}
-    res.append({"batch": B, "seq_len": L, "images_per_sample": N_IMG, "ms_per_forward": round(ms, 2), "tokens_per_s": round(B * L / ms * 1e3, 1), "roofline": roof,
+    res.append({"batch": B, "seq_len": L, "images_per_sample": N_IMG, "ms_per_forward": round(ms, 2), "tokens_per_s": round(B * L / ms * 1e3, 1), "roofline": roof, "mma_core": core,
                 "mma_attention_ms_per_launch": {str(t_[0]): round(t_[2], 4) for t_ in at}})
 print(json.dumps(res))
