@@ -42,8 +42,11 @@ constexpr int A64_O = 64;     // O^T of block X, feature tile dt: a[64 + 48 X + 
 constexpr int A64_Q = 160;    // Q fragment ks of block X:        a[160 + 24 X + 4 ks : +3]
 constexpr int A64_KA = 208;   // K fragment ks, keys 0-31:        a[208 + 4 ks : +3]
 constexpr int A64_KC = 232;   //                keys 32-63:       a[232 + 4 ks : +3]
-// a[0:63] are left to hipcc: when it runs out of VGPRs outside the tile loop it parks values in the LOWEST free accumulator
-// registers (clobber lists do not keep it from doing so); tools/attn64_audit.py fails the build if it ever names a64 or above.
+constexpr int A64_L = 56;     // row sums of block X (product build): a[56 + 4 X], register 0 of a 16x16 accumulator tile (1-3 stay zero)
+// a[0:55] are left to hipcc: when it runs out of VGPRs outside the tile loop it parks values in the LOWEST free accumulator
+// registers (clobber lists do not keep it from doing so); tools/attn64_audit.py fails the build if it ever names a56 or above (a64 in the exact build, which has no row-sum tiles).
+// (The row-sum tiles as "a"-constrained operands were tried: hipcc then copies them between register sets at loop joins with
+// v_accvgpr_mov right behind the asm MFMA that writes them - it takes asm outputs as ready - and the sums are lost.)
 
 template <int R> __device__ __forceinline__ void acc_zero() { asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"n"(R)); }
 template <int R> __device__ __forceinline__ void acc_set(unsigned x) { asm volatile("v_accvgpr_write_b32 a%c1, %0" ::"v"(x), "n"(R)); }
@@ -76,6 +79,15 @@ template <int KA, int QA> __device__ __forceinline__ void mfma_qk_zero(f32x16& s
 template <int OA> __device__ __forceinline__ void mfma_pv(const u32x4 vv, const u32x4 pf) {
   asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vv), "v"(pf), "n"(OA), "n"(OA + 15));
 }
+// Row sums on the matrix pipe (product build): l[row] += sum over the 16 keys of a P fragment.  The fragment is the B operand of the
+// 32x32x16 P V MFMAs - lane (n = lane & 31, g = lane >> 5) holds 8 keys of row n - and is handed AS IT IS to a 16x16x32 MFMA, which reads
+// the same registers as B'[k' = 8 (lane >> 4) + i][col' = lane & 15]: k' groups 0 and 2 are rows col' (first / second 8 keys), groups 1 and
+// 3 rows col' + 16.  The A operand picks the groups: output rows 0 and 8 sum groups {0, 2}, rows 4 and 12 groups {1, 3}; with the 16x16
+// result layout (col = lane & 15, row = 4 (lane >> 4) + reg) register 0 of EVERY lane then holds the sum of row lane & 31 over all 16
+// keys.  64 v_add_f32 per tile leave the vector port (a slot is VALU-issue bound) for 8 short MFMAs on a pipe with room.
+template <int LA> __device__ __forceinline__ void mfma_ones(const u32x4 sel, const u32x4 pf) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(sel), "v"(pf), "n"(LA), "n"(LA + 3));
+}
 // 16 bytes of a Q row straight into accumulator registers (a load hipcc neither counts nor waits for: the rank prologue's vmcnt(0) does)
 template <int QA, int OFF> __device__ __forceinline__ void q_frag_load(const void* row) {
   asm volatile("global_load_dwordx4 a[%c1:%c2], %0, off offset:%c3" ::"v"(row), "n"(QA), "n"(QA + 3), "n"(OFF) : "memory");
@@ -90,7 +102,7 @@ struct A64Blk {                 // one 32-row block of a wave
   int touch_lo, touch_hi, full_lo, full_hi;   // wave-uniform rectangle summary
   int row, rc0, rc1;            // per lane: its row and that row's unlock columns
   bool exists, alive, has_dead, row_alive, has_uniform, row_uniform;
-  float m_ref, l;               // reference maximum (log2 domain) and the row sum against it
+  float m_ref, l;               // reference maximum (log2 domain) and the row sum against it (exact build; product build: mfma_ones)
   int l_dbg;                    // lab stamps: redo count
   float hide;                   // per lane, for the score tile in flight: 0, or -inf = this row sees nothing of the tile
   float thr_raw;                // (m_ref + THR) / (scale log2 e): a raw score above it raises the reference maximum
@@ -218,103 +230,42 @@ __device__ __forceinline__ void sm_chunk(const f32x16& s0, const f32x16& s1, u32
   }
 }
 
-// ---- the product's softmax (THR > 0): no row maximum on the common path ---------------------------------------------
-// p = exp2(s c - m_ref) is taken against the reference maximum AS IT STANDS; whether that was admissible is read off the row sum
-// afterwards: if no score exceeded m_ref + THR every p is <= 2^THR and, conversely, a score above it alone makes the row sum
-// exceed 2^THR.  A row sum above 2^THR (inf included: the first tile of a block, whose m_ref is -1e30; see gap 20) sends the wave through
-// sm_redo - the exact path: row maximum, raise, rescale of l and O, this tile's p again - before anything has consumed the tile
-// (its P V MFMAs are in the next slot).  26 VALU issues per tile and block leave the common path (a slot is VALU-issue bound).
-// Gap budget: an MFMA 32x32x16 leaves 24 of its 32 cycles to the vector port = three f32 ops, or one exp2 (8) and two.
-// Score pairs r = 0..15 (registers r of both halves) go through in 8 triples of gaps:
-//     G = 3k      exp2 of pair 2k     (arguments one gap old), arguments of pair 2k + 1
-//     G = 3k + 1  exp2 of pair 2k + 1,                         arguments of pair 2k + 2
-//     G = 3k + 2  pair sums 2k, 2k + 1; row sum + the two pair sums of the previous triple; bf16 packing of pairs 2k, 2k + 1
-// i.e. 2 exp2 + 2 fma (24 cycles) or 4 add + 2 cvt (24 cycles) per gap; gap 23 also adds its own two pair sums.  sm_tail decides.
-template <int G, int THR, int ABL>
-__device__ __forceinline__ void sm_opt_chunk(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], const A64Blk& X, A64Tmp& t, const float c) {
-  constexpr int k = G / 3, ph = G % 3;
-  if constexpr (ABL & 1) {
+// ---- the blind softmax of the product build: no sums, no decision -------------------------------------------------------------
+// Once every row of a block has a reference maximum (its first tiles went through the checked path above), p = exp2(s c - m_ref) is
+// taken WITHOUT looking at it: bf16 has f32's exponent range, so P, the row sum (on the matrix pipe: mfma_ones) and O stay finite
+// and exact to rounding as long as no later score exceeds the reference by ~64 log2 units; whether that held is read off the row
+// sum ONCE per rank (l < 2^64, the kernel body's "verification") and a rank that fails it is walked again through the checked
+// path.  Per tile and block: 32 fma + 32 exp2 + 16 cvt over the slot's 28 MFMA gaps (16 beside P V + row sums, 12 beside K Q^T):
+// element k (score register k / 2 of half k % 2) has its exp2 in gap 1 + 26 k / 32, its argument one gap earlier, its bf16 word one
+// gap after its partner's exp2.
+struct A64Blind { float nm; float a[32]; float e[32]; };
+__host__ __device__ constexpr int bl_ge(int k) { return 1 + (k * 26) / 32; }
+template <int G, int ABL>
+__device__ __forceinline__ void sm_blind_chunk(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], const A64Blk& X, A64Blind& t, const float c) {
+  if constexpr (ABL & 1) {           // lab: no softmax VALU at all (P = 1)
     if constexpr (G == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) pf[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-      t.ps = 64.f; t.m0 = 0.f; t.m1 = 0.f; t.need = 0ull;
     }
-  } else if constexpr (ph == 0) {
-    if constexpr (k == 0) {
-      t.nm = -X.m_ref + X.hide;       // a hidden row: exp2(-inf) = 0 on every column
-      t.ps = 0.f;
-      t.a0 = __builtin_fmaf(s0[0], c, t.nm);
-      t.a1 = __builtin_fmaf(s1[0], c, t.nm);
-    }
-    constexpr int r = 2 * k;
-    if constexpr (r >= 12) { t.a0 = t.ah0[r - 12]; t.a1 = t.ah1[r - 12]; }      // arguments made early (below)
-    t.e0[r] = __builtin_amdgcn_exp2f(t.a0);
-    t.e1[r] = __builtin_amdgcn_exp2f(t.a1);
-    if constexpr (r + 1 < 12) {
-      t.a0 = __builtin_fmaf(s0[r + 1], c, t.nm);
-      t.a1 = __builtin_fmaf(s1[r + 1], c, t.nm);
-    }
-    if constexpr (k == 4) {            // G = 12: arguments of pair 12, two gaps ahead of schedule
-      t.ah0[0] = __builtin_fmaf(s0[12], c, t.nm); t.ah1[0] = __builtin_fmaf(s1[12], c, t.nm);
-      pin(t.ah0[0], t.ah1[0]);
-    }
-    if constexpr (k == 5) {            // G = 15: pair 14
-      t.ah0[2] = __builtin_fmaf(s0[14], c, t.nm); t.ah1[2] = __builtin_fmaf(s1[14], c, t.nm);
-      pin(t.ah0[2], t.ah1[2]);
-    }
-    pin(t.e0[r], t.e1[r], t.a0, t.a1);
-  } else if constexpr (ph == 1) {
-    constexpr int r = 2 * k + 1;
-    if constexpr (r >= 12) { t.a0 = t.ah0[r - 12]; t.a1 = t.ah1[r - 12]; }
-    t.e0[r] = __builtin_amdgcn_exp2f(t.a0);
-    t.e1[r] = __builtin_amdgcn_exp2f(t.a1);
-    if constexpr (r + 1 < 12) {
-      t.a0 = __builtin_fmaf(s0[r + 1], c, t.nm);
-      t.a1 = __builtin_fmaf(s1[r + 1], c, t.nm);
-    }
-    if constexpr (k == 4) {            // G = 13: pair 13
-      t.ah0[1] = __builtin_fmaf(s0[13], c, t.nm); t.ah1[1] = __builtin_fmaf(s1[13], c, t.nm);
-      pin(t.ah0[1], t.ah1[1]);
-    }
-    if constexpr (k == 5) {            // G = 16: pair 15, and the largest of the eight late arguments
-      t.ah0[3] = __builtin_fmaf(s0[15], c, t.nm); t.ah1[3] = __builtin_fmaf(s1[15], c, t.nm);
-      float m = max3(t.ah0[0], t.ah1[0], t.ah0[1]);
-      asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(t.ah1[1]), "v"(t.ah0[2]));
-      t.m2 = m;
-      pin(t.ah0[3], t.ah1[3], t.m2);
-    }
-    pin(t.e0[r], t.e1[r], t.a0, t.a1);
-  } else {
-    constexpr int r = 2 * k;
-    if constexpr (k >= 1) { t.ps += t.m0; t.ps += t.m1; }        // pair sums of the previous triple, in pair order (the 32-row kernel's order)
-    const float ps11 = t.ps;           // at G = 20: the sum over pairs 0-11
-    t.m0 = t.e0[r] + t.e1[r];
-    t.m1 = t.e0[r + 1] + t.e1[r + 1];
-    const unsigned w0 = pack_bf16x2(t.e0[r], t.e0[r + 1]), w1 = pack_bf16x2(t.e1[r], t.e1[r + 1]);
-    if constexpr (k == 5) {            // G = 17: the rest of the late-argument maximum
-      float m = t.m2;
-      asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "+v"(m) : "v"(t.ah1[2]), "v"(t.ah0[3]), "v"(t.ah1[3]), "v"(t.ah1[3]));
-      t.m2 = m;
-      pin(t.m2);
-    }
-    if constexpr (k == 6) {
-      // G = 20: the raise decision.  t.ps holds pairs 0-11 here: a score above m_ref + THR among them makes it exceed 2^THR; pairs
-      // 12-15 are judged by their exp2 arguments, made early for this purpose.
-      // One vector compare straight into an SGPR pair (both conditions merged on the vector side: 2^m2 > 2^THR <=> m2 > THR), read by
-      // sm_tail's s_cmp three gaps later.  NOTE for whoever times this: builds that skip the check or the redo produce inf / NaN from
-      // the first tile on, and MFMAs on such operands draw less power - the chip then holds a higher clock and the ablated build looks
-      // 15 % faster.  With right data the check is free and a redo costs ~1.1k cycles, twice per rank (tools/attn64_ablate.py).
-      const float worst = fmaxf(ps11, __builtin_amdgcn_exp2f(t.m2));
-      unsigned long long nd;
-      const float lim = (float)(1 << THR);
-      asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(nd) : "s"(lim), "v"(worst));
-      t.need = nd;
-    }
-    if constexpr (k == 7) { t.ps += t.m0; t.ps += t.m1; }        // the last triple closes the sum under its own MFMA: sm_tail only branches
-    pin(t.ps, t.m0, t.m1, w0, w1);      // the words, not the vectors they go into: a use of the half-built vector makes hipcc copy it
-    pf[r >> 3][(r & 7) >> 1] = w0;
-    pf[2 + (r >> 3)][(r & 7) >> 1] = w1;
+    return;
   }
+  if constexpr (G == 0) t.nm = -X.m_ref + X.hide;
+  static_for<32>([&](auto K) {
+    constexpr int k = decltype(K)::value, r = k >> 1;
+    if constexpr (bl_ge(k) == G) { t.e[k] = __builtin_amdgcn_exp2f(t.a[k]); pin(t.e[k]); }
+  });
+  static_for<32>([&](auto K) {
+    constexpr int k = decltype(K)::value, r = k >> 1;
+    if constexpr (bl_ge(k) - 1 == G) { t.a[k] = __builtin_fmaf((k & 1) ? s1[r] : s0[r], c, t.nm); pin(t.a[k]); }
+  });
+  static_for<16>([&](auto W) {          // word w: half w & 1, score registers 2 (w >> 1) and 2 (w >> 1) + 1 = elements k0 and k0 + 2
+    constexpr int w = decltype(W)::value, hf = w & 1, r = 2 * (w >> 1), k0 = 2 * r + hf;
+    if constexpr (bl_ge(k0 + 2) + 1 == G) {
+      const unsigned wd = pack_bf16x2(t.e[k0], t.e[k0 + 2]);
+      pin(wd);
+      pf[2 * hf + (r >> 3)][(r & 7) >> 1] = wd;
+    }
+  });
 }
 // the exact path for a tile whose optimistic pass overflowed the bound (rare; cold)
 template <int THR, int OA>
@@ -327,32 +278,29 @@ __device__ __forceinline__ void sm_redo(const f32x16& s0, const f32x16& s1, u32x
   const float mx = halves_max(m) * c + X.hide;
   const float m_new = fmaxf(X.m_ref, mx);
   const float alpha = __builtin_amdgcn_exp2f(X.m_ref - m_new);
+  // a rank's first tile (no row of the wave's block has a reference yet: O and the row sums are still zero) has nothing to rescale
+  const bool started = __ballot(X.m_ref > -1e29f) != 0ull;
   X.m_ref = m_new;
-  X.l *= alpha;
-  static_for<12>([&](auto I) { acc_scale4<OA + 4 * decltype(I)::value>(alpha); });
-  const float nm = -m_new + X.hide;
-  float ps = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    t.e0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, nm));
-    t.e1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, nm));
-    ps += t.e0[r] + t.e1[r];
+  if (started) {
+    {                                 // the row sum lives on the matrix pipe's side (mfma_ones); its last MFMA is a slot old
+      float lt;
+      asm volatile("v_accvgpr_read_b32 %0, a%c2\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a%c2, %0" : "=&v"(lt) : "v"(alpha), "n"(A64_L + 4 * ((OA - A64_O) / 48)));
+    }
+    static_for<12>([&](auto I) { acc_scale4<OA + 4 * decltype(I)::value>(alpha); });
   }
+  const float nm = -m_new + X.hide;
+  // two score registers of each half at a time, packed at once: four temporaries alive (the slot's whole state is - a redo that
+  // kept all 32 p made hipcc park ~60 registers in accumulator registers, up into this file's own)
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
-    pf[r >> 3][(r & 7) >> 1] = pack_bf16x2(t.e0[r], t.e0[r + 1]);
-    pf[2 + (r >> 3)][(r & 7) >> 1] = pack_bf16x2(t.e1[r], t.e1[r + 1]);
+    const float a = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, nm)), b = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r + 1], c, nm));
+    const float d = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, nm)), e = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r + 1], c, nm));
+    const unsigned w0 = pack_bf16x2(a, b), w1 = pack_bf16x2(d, e);
+    pin(w0, w1);
+    pf[r >> 3][(r & 7) >> 1] = w0;
+    pf[2 + (r >> 3)][(r & 7) >> 1] = w1;
   }
-  t.ps = ps;
 }
-template <int THR, int OA, int ABL>
-__device__ __forceinline__ void sm_tail(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], A64Blk& X, A64Tmp& t, const float c) {
-  if constexpr (!(ABL & 16)) {
-    if (__builtin_expect(t.need != 0ull || (ABL & 64), 0)) { sm_redo<THR, OA>(s0, s1, pf, X, t, c); if constexpr (ABL & 512) X.l_dbg += 1; }
-  }
-  X.l += t.ps;
-}
-
 // THR: how far (log2 units) a row's tile maximum may exceed the reference maximum before the reference is raised.
 // ABL (lab library only, timing ablations with wrong results): 1 no exp / sum / pack, 2 no LDS-DMA and no vmcnt wait, 4 no fragment
 // reloads and no lgkmcnt waits, 8 no tile barrier, 16 no row maximum, 32 every tile FULL; 64 (right results) every tile through sm_redo.
@@ -362,18 +310,29 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   constexpr int OROW = 208;              // output staging row: 192 B + 16 (the 8-B writes of 32 rows land 2-way instead of 8-way conflicted)
   constexpr int LDS_RING = NSTAGE * KTILE + NSTAGE * VTILE, LDS_VB = MAX_VB_WORDS * 8, LDS_OUT = 8 * 32 * OROW;
   // ring | valid words | output staging of its own (the next rank's first tiles stream into the ring WHILE this rank's outputs are staged)
-  __shared__ __attribute__((aligned(16))) char smem[LDS_RING + LDS_VB + LDS_OUT];
+  __shared__ __attribute__((aligned(16))) char smem[LDS_RING + LDS_VB + LDS_OUT + 16];   // + the two verification words (below)
   char* const sK = smem;
   char* const sV = smem + NSTAGE * KTILE;
   // the sample's valid-column words: read only on the bias path, through asm (a load hipcc can see would be given a vmcnt(0) that
   // drains the K/V ring); in registers they were eight VGPRs of cold state that pushed hot state into spills
   const unsigned sVB_a = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)(smem + NSTAGE * KTILE + NSTAGE * VTILE));
   // the accumulator registers named in the asm strings below: declared once, ALL of them: the kernel descriptor allocates them and hipcc's VGPR-to-AGPR spilling only takes accumulator registers no instruction of the function names
+  if constexpr (THR != 0) asm volatile("" ::: "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
   asm volatile("" ::: "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
+  // product build: the A operand of the row-sum MFMAs (mfma_ones) and the workgroup's two verification words (ranks alternate)
+  // A[row = lane & 15][k' group = lane >> 4] = 1 for (rows 0, 8; groups 0, 2) and (rows 4, 12; groups 1, 3): lanes 0 8 32 40 / 20 28 52 60
+  const unsigned ones_w = (((lane & 7) == 0 && ((lane >> 4) & 1) == 0) || ((lane & 7) == 4 && ((lane >> 4) & 1) == 1)) ? 0x3f803f80u : 0u;
+  const u32x4 sel = {ones_w, ones_w, ones_w, ones_w};
+  const unsigned sFlag_a = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)(smem + LDS_RING + LDS_VB + LDS_OUT));
+  if constexpr (THR != 0) {
+    if (tid == 0) { *(unsigned*)(smem + LDS_RING + LDS_VB + LDS_OUT) = 0u; *(unsigned*)(smem + LDS_RING + LDS_VB + LDS_OUT + 4) = 0u; }
+  }
+  bool force_checked = false;          // this rank failed its verification: walk it again through the checked path
+  int vpar = 0;
 
   // persistent workgroups, pair groups, splits: as in mma_attn_bf16.hip ("Persistent workgroups")
   const int grp = blockIdx.x / (p.group_bh * p.splits);
@@ -509,6 +468,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   // lab stamps (ABL & 512): shader-clock cycles of prologue / tile loops / epilogue, tiles walked, and the 100 MHz real-time
   // counter over the whole workgroup -> lse[8 * blockIdx .. +7] (timing build: its lse output is not an lse)
   unsigned long long st_pro = 0, st_loop = 0, st_epi = 0, st_tiles = 0, st_t = 0, st_rt0 = 0, st_redo = 0, st_wait = 0, st_dma = 0;
+  unsigned long long st_h[4] = {0, 0, 0, 0}, st_n = 0;      // ABL & 1024: the four halves of the BLIND iterations (wave 0..3 each its own), and how many
   if constexpr (ABL & 512) { st_rt0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- the next rank's blocks, Q rows and first K/V tiles, asked for one rank ahead ------------------------------------------
@@ -600,6 +560,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   setup(A);
   setup(B);
   static_for<96>([&](auto R) { acc_zero<A64_O + decltype(R)::value>(); });
+  if constexpr (THR != 0) static_for<8>([&](auto R) { acc_zero<A64_L + decltype(R)::value>(); });
 
   // ---- tile classes (the 32-row kernel's, decided for 64 tiles at a time) -------------------------------------------------
   //   FULL     every column visible to every row of the block: the first MFMA of each chain takes the constant 0 as C;
@@ -633,10 +594,11 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   block_masks(A, 0);
   block_masks(B, 0);
   // a fast tile's per-lane hide (FULL: nobody; ROWWISE / HIDDEN: the rows whose rectangle does not cover the tile)
-  auto fast_hide = [&](A64Blk& X, int jt) {
+  auto hide_val = [&](const A64Blk& X, int jt) -> float {
     const int c0 = jt * 64;
     // wave-uniform, all scalar: -1 when the tile is FULL (nobody hidden), 0 when each lane's rectangle decides
-    const unsigned long long fm = ((X.fullm >> (jt & 63)) & 1ull) ? ~0ull : 0ull;
+    const unsigned fb = __builtin_amdgcn_readfirstlane((unsigned)((X.fullm >> (jt & 63)) & 1ull));     // (the masks may sit in spilled lanes: say it is uniform)
+    const unsigned long long fm = fb ? ~0ull : 0ull;
     // Per lane, five VALU instructions: hide = fm ? 0 : (rc0 <= c0 && c0 + 64 <= rc1 ? 0 : -inf).  (The C form compiles to two
     // vector compares combined on the scalar unit plus a select; no measurable difference - kept as asm for its fixed length.)
     float hd;
@@ -647,9 +609,40 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
         "v_cndmask_b32_e64 %0, %1, %0, vcc\n\t"        // ? keep : -inf
         "v_cndmask_b32_e64 %0, %0, 0, %6"              // FULL tile: 0
         : "=&v"(hd) : "v"(ninf), "s"(c0), "v"(X.rc0), "s"(c0 + 64), "v"(X.rc1), "s"(fm) : "vcc");
-    X.hide = hd;
+    return hd;
+  };
+  auto fast_hide = [&](A64Blk& X, int jt) { X.hide = hide_val(X, jt); };
+  // for how many tiles from jt on (this window) a fast tile's hide stays what it is at jt: FULL tiles up to the first one that is
+  // not; otherwise up to the next column where a rectangle that touches the block's rows begins or ends (tiles are "clean": none
+  // straddles such a column)
+  auto const_len = [&](const A64Blk& X, int jt) -> int {
+    const unsigned long long f = X.fullm >> (jt & 63);
+    if (f & 1ull) return f == ~0ull ? 64 : (int)__builtin_ctzll(~f);
+    const int c0 = jt * 64;
+    int nb = 0x7fffffff;
+    for (int i = 0; i < p.max_rects; ++i) {
+      const aki_mma_rect r = rect_at(i);
+      if (r.row_hi > r.row_lo && r.col_hi > r.col_lo && r.row_lo < X.wq0 + 32 && r.row_hi > X.wq0) {
+        if (r.col_lo > c0) nb = min(nb, r.col_lo);
+        if (r.col_hi > c0) nb = min(nb, r.col_hi);
+      }
+    }
+    return nb == 0x7fffffff ? 64 : (nb - c0) >> 6;
   };
   auto tile_bias = [&](A64Blk& X, int j, f32x16& s0, f32x16& s1) {
+    if constexpr (THR != 0) {
+      // Product build: a bias iteration biases both tiles it makes - block B's tile j and block A's tile j + 1 - because ONE of them
+      // needs it (a block's diagonal tile, once per rank) or because the softmax mode asks for this iteration (a rank's first
+      // tile).  The other tile is fast by the masks more often than not: zeros and the per-lane hide instead of ~100 VALU issues -
+      // every wave's slow iteration is a wait at the tile barrier for the other three.
+      if ((j == 0 || (j & 63) != 0) && ((X.fast >> (j & 63)) & 1ull) != 0ull) {       // (tile j + 1 of the next window: masks not made yet)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        asm volatile("s_nop 1" : "+v"(s0), "+v"(s1));
+        X.hide = hide_val(X, j);
+        return;
+      }
+    }
     const int c0 = j * 64;
     const unsigned long long vb = j < first_bad ? ~0ull : valid_word(j);
     const int base = c0 + 4 * h;
@@ -682,6 +675,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   u32x4 pA[4], pB[4];                 // P as packed bf16: the B operand of the four 16-key steps
   u32x2 vlo[4][3], vhi[4][3];         // V^T fragments of the current V tile (both blocks use them)
   A64Tmp tA, tB;
+  A64Blind uA, uB;
   f32x16 zt;                          // lab (ABL & 16384): a tuple of zeros as the C operand of the first score MFMAs
   if constexpr (ABL & 16384) {
 #pragma unroll
@@ -723,60 +717,72 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   // first half of a slot: [P V of block Y] beside softmax chunks 0-11 of block X.  PV: the 12 MFMAs are issued; RELOAD: behind
   // each MFMA the V^T fragment it was the last to read is fetched again from the V tile at va; DMA: K (E slots) or V (O slots)
   // pieces of the unit being prefetched go into gaps 0-2.
-  auto half1 = [&](auto PV, auto RELOAD, auto YB, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, u32x4 (&py)[4], unsigned va, auto&& dma) {
-    constexpr bool pv = decltype(PV)::value, reload = decltype(RELOAD)::value;
-    constexpr int OAY = A64_O + 48 * decltype(YB)::value, OAX = A64_O + 48 * (1 - decltype(YB)::value);
-    static_for<12>([&](auto I) {
-      constexpr int i = decltype(I)::value, ks4 = i / 3, dt = i % 3;
-      if constexpr (pv) {
+  auto half1 = [&](auto SER, auto RELOAD, auto YB, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, A64Blind& ux, u32x4 (&py)[4], unsigned va, auto&& dma) {
+    constexpr bool serial = decltype(SER)::value, reload = decltype(RELOAD)::value;
+    constexpr int yb = decltype(YB)::value;
+    constexpr int OAY = A64_O + 48 * yb, OAX = A64_O + 48 * (1 - yb);
+    constexpr int NG = THR != 0 ? 16 : 12;          // product build: every fourth gap follows a row-sum MFMA of the 16 keys just multiplied
+    static_for<NG>([&](auto I) {
+      constexpr int g = decltype(I)::value;
+      constexpr int ks4 = THR != 0 ? g / 4 : g / 3, dt = THR != 0 ? g % 4 : g % 3;
+      constexpr int i = ks4 * 3 + (dt < 3 ? dt : 2);          // checked softmax: chunk i sits behind P V MFMA i
+      if constexpr (dt < 3) {
         const u32x4 vv = {vlo[ks4][dt][0], vlo[ks4][dt][1], vhi[ks4][dt][0], vhi[ks4][dt][1]};
         mfma_pv<OAY + 16 * dt>(vv, py[ks4]);
+        if constexpr (reload) v_frag(std::integral_constant<int, ks4>{}, std::integral_constant<int, dt>{}, va);
+      } else {
+        mfma_ones<A64_L + 4 * yb>(sel, py[ks4]);
       }
-      if constexpr (reload) v_frag(std::integral_constant<int, ks4>{}, std::integral_constant<int, dt>{}, va);
       A64_PIN();
       // Slot O opens one MFMA behind the score MFMAs that wrote S_B (slot E ended with them), and chunk 0 of the product's softmax
       // reads S: an MFMA result is not readable by the VALU for ~20 wait states after the instruction issued, and hipcc pads no
       // hazard between an asm MFMA and anything (guide 5.7 item 2).  Counted: 6 (chunk 23) + 4 (tail) + 3 (waits) + 1 (this slot's
       // first MFMA) + 4 here; slot E has the tile barrier in front.  The exact variant reads S one gap later.
-      if constexpr (THR != 0 && i == 0 && decltype(YB)::value == 0) asm volatile("s_nop 3" : "+v"(x0), "+v"(x1));
+      if constexpr (THR != 0 && g == 0 && yb == 0) asm volatile("s_nop 3" : "+v"(x0), "+v"(x1));
       if constexpr (THR == 0) sm_chunk<THR, OAX, i, ABL>(x0, x1, px, X, tx, c, rc);
-      else sm_opt_chunk<i, THR, ABL>(x0, x1, px, X, tx, c);
+      else if constexpr (!serial) sm_blind_chunk<g, ABL>(x0, x1, px, X, ux, c);
       if constexpr (ABL & 8192) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1" : "+v"(tx.m3), "+v"(tx.thr));   // lab: what do two more VALU issues per gap cost (right results)
-      if constexpr (i < 3) dma(I);
+      dma(I);                                  // the caller's lambda decides which gaps carry a piece
       A64_PIN();
     });
   };
   // second half: [K Q_Y^T of tile jy] beside chunks 12-23 of block X; RELOAD: behind its last reader each K fragment is fetched
   // again from the K tile at (ke, ko)
-  auto half2 = [&](auto QK, auto RELOAD, auto YB, auto FULLT, f32x16& y0, f32x16& y1, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, unsigned ke, unsigned ko) {
-    constexpr bool qk = decltype(QK)::value, reload = decltype(RELOAD)::value;
+  auto half2 = [&](auto SER, auto RELOAD, auto YB, auto FULLT, f32x16& y0, f32x16& y1, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, A64Blind& ux, unsigned ke, unsigned ko) {
+    constexpr bool serial = decltype(SER)::value, reload = decltype(RELOAD)::value;
     constexpr int QAY = A64_Q + 24 * decltype(YB)::value, OAX = A64_O + 48 * (1 - decltype(YB)::value);
     static_for<12>([&](auto I) {
       constexpr int i = decltype(I)::value, ks = i >> 1, half = i & 1;
-      if constexpr (qk) {
-        if constexpr (ks == 0) {
-          if constexpr (decltype(FULLT)::value && (ABL & 16384)) { if constexpr (half == 0) mfma_qk_c<A64_KA, QAY>(y0, zt); else mfma_qk_c<A64_KC, QAY>(y1, zt); }     // lab: C from a VGPR tuple of zeros
-          else if constexpr (decltype(FULLT)::value) { if constexpr (half == 0) mfma_qk_zero<A64_KA, QAY>(y0); else mfma_qk_zero<A64_KC, QAY>(y1); }
-          else { if constexpr (half == 0) mfma_qk<A64_KA, QAY>(y0); else mfma_qk<A64_KC, QAY>(y1); }
-        } else {
-          if constexpr (half == 0) mfma_qk<A64_KA + 4 * ks, QAY + 4 * ks>(y0); else mfma_qk<A64_KC + 4 * ks, QAY + 4 * ks>(y1);
-        }
+      if constexpr (ks == 0) {
+        if constexpr (decltype(FULLT)::value && (ABL & 16384)) { if constexpr (half == 0) mfma_qk_c<A64_KA, QAY>(y0, zt); else mfma_qk_c<A64_KC, QAY>(y1, zt); }     // lab: C from a VGPR tuple of zeros
+        else if constexpr (decltype(FULLT)::value) { if constexpr (half == 0) mfma_qk_zero<A64_KA, QAY>(y0); else mfma_qk_zero<A64_KC, QAY>(y1); }
+        else { if constexpr (half == 0) mfma_qk<A64_KA, QAY>(y0); else mfma_qk<A64_KC, QAY>(y1); }
+      } else {
+        if constexpr (half == 0) mfma_qk<A64_KA + 4 * ks, QAY + 4 * ks>(y0); else mfma_qk<A64_KC + 4 * ks, QAY + 4 * ks>(y1);
       }
       if constexpr (reload) k_frag(std::integral_constant<int, ks>{}, std::integral_constant<int, half>{}, ke, ko);
       A64_PIN();
       if constexpr (THR == 0) sm_chunk<THR, OAX, 12 + i, ABL>(x0, x1, px, X, tx, c, rc);
-      else sm_opt_chunk<12 + i, THR, ABL>(x0, x1, px, X, tx, c);
+      else if constexpr (!serial) sm_blind_chunk<16 + i, ABL>(x0, x1, px, X, ux, c);
       if constexpr (ABL & 8192) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1" : "+v"(tx.m3), "+v"(tx.thr));
       A64_PIN();
     });
-    if constexpr (THR != 0) {
-      sm_tail<THR, OAX, ABL>(x0, x1, px, X, tx, c);
+    if constexpr (serial) {
+      // the exact iteration of the product build - while a row of the wave has no reference maximum yet (the rank's first tile, as a
+      // rule) and on the second walk of a rank that failed its verification: the tile's softmax in one piece behind the slot's MFMAs
+      // (blind chunks AND this tail in one iteration would keep S and P alive together: ~60 registers over the file)
+      sm_redo<THR, OAX>(x0, x1, px, X, tx, c);
+      if constexpr (ABL & 512) X.l_dbg += 1;
       A64_PIN();
     }
   };
   auto no_dma = [](auto) {};
   using T_ = std::true_type;
   using F_ = std::false_type;
+  using M0 = std::integral_constant<int, 0>;
+  using M1 = std::integral_constant<int, 1>;
+  using M2 = std::integral_constant<int, 2>;
+  using M4 = std::integral_constant<int, 4>;
   using BA = std::integral_constant<int, 0>;
   using BB = std::integral_constant<int, 1>;
 
@@ -816,8 +822,13 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   // one tile = slots E(j) and O(j).  FT: the score tiles produced in this iteration - block B's tile j and block A's tile j + 1 -
   // are both fast by the masks (FULL / ROWWISE / HIDDEN): no bias, the first MFMA of each chain takes the constant 0; otherwise both
   // go through the bias path, which is right for every class
-  auto iter = [&](auto FT, int j) {
-    constexpr bool ft = decltype(FT)::value;
+  // MODE 0: bias path; 1: fast (per-lane hide, decided per tile); product build only: 2 - fast, inside a run that leaves both
+  // blocks' hide as it is (nothing per tile), 4 - bias path with the serial exact softmax
+  auto iter = [&](auto MODE, int j) {
+    constexpr int mode = decltype(MODE)::value;
+    constexpr bool ft = mode == 1 || mode == 2;
+    using FT = std::integral_constant<bool, ft>;
+    using BL = std::integral_constant<bool, mode == 4>;
     // unit j = {K(j+1), V(j)}: this wave's pieces are all but the 6 youngest (unit j+1); then a workgroup-wide fact
     unsigned long long tw0 = 0;
     if constexpr (ABL & 512) tw0 = __builtin_amdgcn_s_memtime();
@@ -828,25 +839,40 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     A64_PIN();
     // unit j+2 = {K(j+3) -> the stage K(j) has left, V(j+2) -> the stage V(j-1) has left}
     const int tk = j + 3, tv = j + 2;
-    auto dma_e = [&](auto I) { dma_k(I, tk, st0); };      // the last two iterations ask for units past the rank's end (branch-free loop body;
-    auto dma_o = [&](auto I) { dma_v(I, tv, st2); };      // rows past L cost no traffic): they are waited for behind the loops
+    // the last two iterations ask for units past the rank's end (branch-free loop body; rows past L cost no traffic): they are waited
+    // for behind the loops.  Product build: all six pieces ride in slot O - slot E's gaps already carry the 36 fragment reloads
+    // (stamps: a slot E gap is issue-bound, a slot O gap MFMA-bound with room).
+    auto dma_e = [&](auto I) { if constexpr (THR == 0 && decltype(I)::value < 3) dma_k(I, tk, st0); };
+    auto dma_o = [&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (THR == 0) { if constexpr (i < 3) dma_v(I, tv, st2); }
+      else if constexpr (i < 3) dma_k(I, tk, st0);
+      else if constexpr (i < 6) dma_v(std::integral_constant<int, i - 3>{}, tv, st2);
+    };
     const unsigned va = sV_a + st0 * VTILE + voff;                 // V(j)
     const unsigned ke = sK_a + st1 * KTILE + k_even, ko = sK_a + st1 * KTILE + k_odd;   // K(j+1)
     // ---- slot E(j): P_B V (j-1), K Q_B^T (j)  beside  softmax of S_A(j) ----
-    half1(T_{}, T_{}, BB{}, sA0, sA1, pA, A, tA, pB, va, dma_e);
-    if constexpr (ft) fast_hide(B, j); else tile_bias(B, j, sB0, sB1);
+    unsigned long long th_ = 0;
+    if constexpr ((ABL & 1024) && ft) th_ = __builtin_amdgcn_s_memtime();
+    half1(BL{}, T_{}, BB{}, sA0, sA1, pA, A, tA, uA, pB, va, dma_e);
+    if constexpr ((ABL & 1024) && ft) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_h[0] += t_ - th_; th_ = t_; }
+    if constexpr (mode == 1) fast_hide(B, j); else if constexpr (mode != 2) tile_bias(B, j, sB0, sB1);
     A64_PIN();
-    half2(T_{}, T_{}, BB{}, FT, sB0, sB1, sA0, sA1, pA, A, tA, ke, ko);
+    half2(BL{}, T_{}, BB{}, FT{}, sB0, sB1, sA0, sA1, pA, A, tA, uA, ke, ko);
+    if constexpr ((ABL & 1024) && ft) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_h[1] += t_ - th_; }
     // ---- slot O(j): P_A V (j), K Q_A^T (j+1)  beside  softmax of S_B(j) ----
     wait_v_frags();
     asm volatile("s_nop 1" : "+v"(pA[0]), "+v"(pA[1]), "+v"(pA[2]), "+v"(pA[3]));   // packed by the VALU just above -> MFMA operand
     A64_PIN();
-    half1(T_{}, F_{}, BA{}, sB0, sB1, pB, B, tB, pA, va, dma_o);
+    if constexpr ((ABL & 1024) && ft) th_ = __builtin_amdgcn_s_memtime();
+    half1(BL{}, F_{}, BA{}, sB0, sB1, pB, B, tB, uB, pA, va, dma_o);
+    if constexpr ((ABL & 1024) && ft) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_h[2] += t_ - th_; th_ = t_; }
     if constexpr (!(ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // K(j+1) fragments
     A64_PIN();
-    if constexpr (ft) fast_hide(A, j + 1); else tile_bias(A, j + 1, sA0, sA1);
+    if constexpr (mode == 1) fast_hide(A, j + 1); else if constexpr (mode != 2) tile_bias(A, j + 1, sA0, sA1);
     A64_PIN();
-    half2(T_{}, F_{}, BA{}, FT, sA0, sA1, sB0, sB1, pB, B, tB, ke, ko);
+    half2(BL{}, F_{}, BA{}, FT{}, sA0, sA1, sB0, sB1, pB, B, tB, uB, ke, ko);
+    if constexpr ((ABL & 1024) && ft) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_h[3] += t_ - th_; st_n += 1; }
     asm volatile("s_nop 1" : "+v"(pB[0]), "+v"(pB[1]), "+v"(pB[2]), "+v"(pB[3]));
     A64_PIN();
     const int t_ = st0; st0 = st1; st1 = st2; st2 = t_;
@@ -857,12 +883,45 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   };
   // runs of fast tiles are an inner loop of their own: an if / else per tile would join sixteen-register score tiles defined
   // by asm statements on two paths, and hipcc copies them through spill slots at every join
+  // Product build: the fast iteration is also the BLIND one (sm_blind_chunk), entered only once every row of both blocks has a
+  // reference maximum - i.e. behind the rank's first tile(s), which go through the bias path and its checked softmax - and never on
+  // the second walk of a rank that failed its verification.
+  bool settled = (THR == 0 || (ABL & 1)) && !(ABL & 64);
   int j = 0;
   while (j < jend_w) {
-    if (__builtin_expect(both_fast(j), 1)) {
-      do { iter(T_{}, j); ++j; } while (j < jend_w && both_fast(j));
+    // runs are counted once, up front: with one wave per SIMD every scalar instruction of the loop control is an issue slot of the
+    // tile, and a taken branch an instruction-buffer refill
+    const int t = j & 63;
+    // Product build: a run = tiles that are fast for both blocks AND leave each block's per-lane hide as it is (FULL runs: nobody
+    // hidden; the ROWWISE tiles of an image's edge rows between two rectangle boundaries; HIDDEN tiles): the loop body then has no
+    // per-tile mask work at all.  Tiles where the hide changes go through the single iterations below.
+    int nrun = 0;
+    if constexpr (THR != 0) {
+      if (settled) {
+        const unsigned long long mR = (B.fast & (A.fast >> 1)) >> t;
+        nrun = min(min(mR == ~0ull ? 64 : (int)__builtin_ctzll(~mR), 63 - t), jend_w - j);
+        if (nrun > 0) {
+          nrun = min(nrun, min(const_len(B, j), const_len(A, j + 1)));
+          const float hA1 = hide_val(A, j + 1);
+          if (__ballot(hA1 != A.hide) != 0ull) nrun = 0;          // block A's tile j, already in flight, was made under another hide
+          if (nrun > 0) B.hide = hide_val(B, j);
+        }
+      }
+    }
+    if (__builtin_expect(nrun > 0, 1)) {
+      do { iter(M2{}, j); ++j; } while (--nrun > 0);
+    } else if (THR == 0 && both_fast(j)) {        // the exact build's fast (per-lane hide) iteration, in runs
+      do { iter(M1{}, j); ++j; } while (j < jend_w && both_fast(j));
+    } else if (THR != 0 && settled && both_fast(j)) {      // product build: ROWWISE / HIDDEN tiles among them - per-lane hide, blind, one
+      iter(M1{}, j); ++j;                                  // at a time (a second run loop makes hipcc copy the score tiles in the first: 51 v_mov per tile)
+    } else if (THR == 0 || settled) {
+      iter(M0{}, j); ++j;
     } else {
-      iter(F_{}, j); ++j;
+      if constexpr (THR != 0) iter(M4{}, j);
+      ++j;
+      if constexpr (THR != 0) {
+        if (!settled && !force_checked && !(ABL & 64)) settled = __ballot(A.m_ref < -1e29f || B.m_ref < -1e29f) == 0ull;
+      }
     }
     if ((j & 63) == 0) { block_masks(A, j); block_masks(B, j); }     // next window of 64 tiles (L > 4096)
   }
@@ -874,20 +933,50 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     static_for<3>([&](auto I) { dma_v(I, tv, st2); });
     const int t_ = st0; st0 = st1; st1 = st2; st2 = t_;
   }
-  // The two units asked for past the rank's end have landed (they were issued one and two tiles ago) and every wave has read the last
-  // tiles out of the ring: the next rank's first tiles may stream in, its Q rows be asked for.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (rank_of(kk + 1) < p.nqt) prefetch_rank(rank_of(kk + 1));
-  if constexpr (ABL & 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_loop += t_ - st_t; st_t = t_; st_redo += A.l_dbg + B.l_dbg; }
   // P_B V of the wave's last tile: its V^T fragments are still in registers
   if (jend_w > 0) {
     static_for<12>([&](auto I) {
       constexpr int i = decltype(I)::value, ks4 = i / 3, dt = i % 3;
       const u32x4 vv = {vlo[ks4][dt][0], vlo[ks4][dt][1], vhi[ks4][dt][0], vhi[ks4][dt][1]};
       mfma_pv<A64_O + 48 + 16 * dt>(vv, pB[ks4]);
+      if constexpr (THR != 0 && dt == 2) mfma_ones<A64_L + 4>(sel, pB[ks4]);
     });
   }
+  // The two units asked for past the rank's end have landed (they were issued one and two tiles ago) and every wave has read the last
+  // tiles out of the ring: the next rank's first tiles may stream in, its Q rows be asked for.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bool walk_again = false;
+  if constexpr (THR != 0) {
+    // Verification of the blind softmax: every row sum of the rank must be below 2^64 (a score 64 log2 units above its row's
+    // reference maximum - unheard of behind a first tile that holds the row's own first keys - makes it larger; inf and NaN fail
+    // the comparison too).  One LDS word per rank parity collects the four waves' verdicts across the barrier that ends the rank
+    // anyway; a failed rank is walked again with the blind iteration switched off (the checked path raises the reference as it goes).
+    asm volatile("s_nop 15" ::: "memory");           // the last row-sum MFMAs
+    const float lA = acc_get<A64_L>(), lB = acc_get<A64_L + 4>();
+    const bool bad = !force_checked && __ballot(!(lA < 0x1p64f) || !(lB < 0x1p64f)) != 0ull;
+    const unsigned fa_ = sFlag_a + 4u * (unsigned)vpar, one = 1u, zero = 0u;
+    if (bad) asm volatile("ds_write_b32 %0, %1" ::"v"(fa_), "v"(one) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    unsigned fl;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fl) : "v"(fa_) : "memory");
+    walk_again = __builtin_amdgcn_readfirstlane(fl) != 0u;
+    // the other parity's word is cleared for the rank after this one (its writers are a whole tile loop of barriers away)
+    const unsigned fo_ = sFlag_a + 4u * (unsigned)(vpar ^ 1);
+    if (wave == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(fo_), "v"(zero) : "memory");
+    vpar ^= 1;
+  } else {
+    __builtin_amdgcn_s_barrier();
+  }
+  if (walk_again) {
+    force_checked = true;
+    prefetch_rank(g);
+    --kk;
+    continue;
+  }
+  force_checked = false;
+  if (rank_of(kk + 1) < p.nqt) prefetch_rank(rank_of(kk + 1));
+  if constexpr (ABL & 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_loop += t_ - st_t; st_t = t_; st_redo += A.l_dbg + B.l_dbg; }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMA results
   A64_PIN();
 
@@ -898,7 +987,9 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   const unsigned sO_a = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)(smem + LDS_RING + LDS_VB));
   auto store_block = [&](auto XB, A64Blk& X) {
     constexpr int xb = decltype(XB)::value;
-    const float l_tot = halves_sum(X.l);
+    float l_tot;
+    if constexpr (THR != 0) l_tot = acc_get<A64_L + 4 * xb>();       // the matrix pipe's row sum is whole (both half rows)
+    else l_tot = halves_sum(X.l);
     const bool dead = !(l_tot > 0.f);
     // wave-private staging through asm LDS accesses: an LDS access hipcc can see gets an s_waitcnt vmcnt(0) in front (it may alias an LDS-DMA
     // in flight as far as the compiler knows) - here that would be a wait for the next rank's prefetch
@@ -950,6 +1041,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       d[5] = (float)st_redo;
       d[6] = (float)st_dma;
       d[7] = (float)st_wait;
+      if constexpr (ABL & 1024) { d[0] = (float)st_h[0]; d[1] = (float)st_h[1]; d[2] = (float)st_h[2]; d[5] = (float)st_h[3]; d[3] = (float)st_n; }
     }
   }
 #undef A64_PIN
@@ -969,7 +1061,7 @@ int attn_core64_bf16_launch(AttnParams p, int cus, hipStream_t stream, int exact
   p.group_bh = grp > nbh ? nbh : grp;
 #ifdef AKI_LAB_HOOKS
 #define A64_ABL_CASE(m) if (g_attn_variant == 100 + (m)) { hipLaunchKernelGGL((mma_attn64_bf16_kernel<8, (m)>), dim3(nbh * p.splits), dim3(256), 0, stream, p); return AKI_OK; }
-  A64_ABL_CASE(16) A64_ABL_CASE(17) A64_ABL_CASE(18) A64_ABL_CASE(20) A64_ABL_CASE(24) A64_ABL_CASE(48) A64_ABL_CASE(30) A64_ABL_CASE(31) A64_ABL_CASE(64) A64_ABL_CASE(512) A64_ABL_CASE(8192) A64_ABL_CASE(8704) A64_ABL_CASE(16896)
+  A64_ABL_CASE(64) A64_ABL_CASE(512) A64_ABL_CASE(513) A64_ABL_CASE(514) A64_ABL_CASE(515) A64_ABL_CASE(520) A64_ABL_CASE(521) A64_ABL_CASE(523) A64_ABL_CASE(1536) A64_ABL_CASE(1537)
 #undef A64_ABL_CASE
 #endif
   if (exact_max) hipLaunchKernelGGL((mma_attn64_bf16_kernel<0, 0>), dim3(nbh * p.splits), dim3(256), 0, stream, p);
