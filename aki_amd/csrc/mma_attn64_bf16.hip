@@ -20,10 +20,15 @@
 //   * Fragments are reloaded in place: right after the LAST MFMA that reads a fragment of tile j its LDS read for tile j+1 is
 //     issued into the same registers (an MFMA reads A/B at issue; the LDS round trip is > 64 cycles), so the reads ride in the
 //     MFMA gaps too and one counted lgkmcnt per slot is all the waiting there is.
-//   * The running maximum is only raised when a row's tile maximum exceeds it by more than THR (log2 units, 8 in the product):
-//     P <= 2^THR keeps bf16's relative precision, l and O stay in f32, and the 96-register rescale of O (an accumulator-file
-//     read-modify-write here) leaves the common path.  THR = 0 is the 32-row kernel's rule and reproduces it bit for bit
-//     (lab variant; tests/test_kernels_gpu.py compares the two).
+//   * Product build (THR != 0): the softmax is BLIND.  A rank's first tile goes through the exact path (row maximum, p, in one
+//     piece behind the slot's MFMAs) and leaves every row a reference maximum; from there on p = exp2(s c - m_ref) is taken
+//     without looking at it - no row maximum, no sums, no decision: 32 fma + 32 exp2 + 16 cvt per block and tile in the slot's 28
+//     MFMA gaps.  bf16 has f32's exponent range, so P stays exact to rounding however far a later score exceeds m_ref; the row
+//     sums come off the matrix pipe (mfma_ones: two 16x16x32 MFMAs per 16 keys against a 0/1 operand, 8 accumulator registers) and
+//     are looked at ONCE per rank: a sum of 2^64 or more (or inf / NaN) sends the workgroup through that rank again with every tile
+//     on the exact path.  Three loop bodies: fast tiles in runs that leave both blocks' per-lane hide unchanged (nothing per tile but
+//     the softmax), bias tiles (diagonal, rectangle edges, padding) one at a time, and the exact serial iteration.
+//     THR = 0 (lab variant, tests) keeps the 32-row kernel's running maximum and reproduces it bit for bit.
 //
 // K/V tiles (64 keys) arrive by global_load_lds in the 32-row kernel's LDS image (K: source-side XOR swizzle; V: plain rows read
 // transposed); the ring holds three K and three V tiles, V one tile behind K: "unit" u = {K(u+1), V(u)} is what slot E(u) reads.
@@ -301,9 +306,12 @@ __device__ __forceinline__ void sm_redo(const f32x16& s0, const f32x16& s1, u32x
     pf[2 + (r >> 3)][(r & 7) >> 1] = w1;
   }
 }
-// THR: how far (log2 units) a row's tile maximum may exceed the reference maximum before the reference is raised.
-// ABL (lab library only, timing ablations with wrong results): 1 no exp / sum / pack, 2 no LDS-DMA and no vmcnt wait, 4 no fragment
-// reloads and no lgkmcnt waits, 8 no tile barrier, 16 no row maximum, 32 every tile FULL; 64 (right results) every tile through sm_redo.
+// THR: 0 = the exact build (running maximum per tile, the 32-row kernel's arithmetic bit for bit; lab and tests); anything else = the
+// product build (blind softmax, verified per rank - see the head of the file).
+// ABL (lab library only; the product build is instantiated with them, read in CYCLES through the stamps - tools/attn64_ablate.py):
+// timing ablations with wrong results: 1 no softmax VALU (P = 1), 2 no LDS-DMA and no vmcnt wait, 4 no fragment reloads and no
+// lgkmcnt waits, 8 no tile barrier; right results: 64 every tile through the exact serial path, 512 cycle stamps (prologue / loops /
+// epilogue / barrier wait), 1024 stamps around the four halves of the blind iteration.
 template <int THR, int ABL>
 __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParams p) {
   constexpr int NT = 256;
@@ -767,6 +775,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       if constexpr (ABL & 8192) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1" : "+v"(tx.m3), "+v"(tx.thr));
       A64_PIN();
     });
+    if constexpr (THR != 0 && !decltype(FULLT)::value) mfma_results_settle(y0, y1);      // bias iterations: hipcc copies score tiles at their joins, and takes an asm MFMA's result as ready
     if constexpr (serial) {
       // the exact iteration of the product build - while a row of the wave has no reference maximum yet (the rank's first tile, as a
       // rule) and on the second walk of a rank that failed its verification: the tile's softmax in one piece behind the slot's MFMAs
@@ -912,9 +921,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       do { iter(M2{}, j); ++j; } while (--nrun > 0);
     } else if (THR == 0 && both_fast(j)) {        // the exact build's fast (per-lane hide) iteration, in runs
       do { iter(M1{}, j); ++j; } while (j < jend_w && both_fast(j));
-    } else if (THR != 0 && settled && both_fast(j)) {      // product build: ROWWISE / HIDDEN tiles among them - per-lane hide, blind, one
-      iter(M1{}, j); ++j;                                  // at a time (a second run loop makes hipcc copy the score tiles in the first: 51 v_mov per tile)
-    } else if (THR == 0 || settled) {
+    } else if (THR == 0 || settled) {      // (product build: a fast tile where the hide changes comes here too - tile_bias has a short form for it)
       iter(M0{}, j); ++j;
     } else {
       if constexpr (THR != 0) iter(M4{}, j);

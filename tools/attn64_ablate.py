@@ -1,37 +1,17 @@
-"""Where the 64-row attention core's time goes: timing ablations (lab library, variants 100 + mask; results of ablated builds are wrong by
-construction).  Every ablation also drops the redo check (bit 16), so that garbage sums cannot send tiles through the exact path; the
-baseline is therefore variant 116.  Bits: 1 no exp / sum / pack, 2 no LDS-DMA, 4 no fragment reads, 8 no tile barrier, 32 every tile fast.
-Each variant is warmed and timed on its own (interleaving variants of very different power draw moved the clock under the next one).
-READ WITH CARE: a build whose softmax is skipped or whose redo is off produces inf / NaN from the first tile on; MFMAs on such operands
-draw less power and the chip holds a higher clock (MI355X guide, DVFS give-back), so such builds look ~15 % faster than their
-instruction streams are.  Round 6 chased a "200-cycle branch" for an hour that was this effect; tools/attn64_stamps.py (right data,
-in-kernel cycle stamps and the real-time counter) is the instrument to trust.
+"""Where the 64-row attention core's cycles go: the product build with parts taken out (lab library, variants 100 + 512 + bits), read
+through the in-kernel s_memtime stamps in CYCLES per tile - not microseconds: an ablated build draws different power and the chip
+answers with a different clock (round 6 chased a "200-cycle branch" for an hour that was a build computing NaN at a higher clock;
+later the same chip ran a perfectly balanced schedule at 1.81 GHz instead of 1.95 and lost what the balance had won).
+Bits: 1 no softmax VALU (P = 1), 2 no LDS-DMA, 8 no tile barrier (results of such builds are wrong by construction).
     python tools/attn64_ablate.py"""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from aki_amd import ops, _lib
-lab = _lib.load_lab()
-_lib._lib = lab
-dev = "cuda"
-g = torch.Generator(device=dev).manual_seed(0)
-IMG4 = [(6, 150, 150, 4032), (900, 1044, 1044, 4032), (1800, 1944, 1944, 4032), (2700, 2844, 2844, 4032)]
-VARS = [1, 9, 10, 164, 116, 117, 124, 148, 131]
-NAMES = {164: "every tile through redo (right results)", 10: "64-row exact (right results)", 1: "32-row", 9: "64-row", 116: "no redo check (garbage)", 117: "-softmax", 118: "-dma", 120: "-frag reads", 124: "-barrier", 148: "all fast", 130: "-dma-frag-barrier", 131: "MFMA only"}
-for (B, H, L, rects) in [(4, 32, 4096, [IMG4] * 4), (1, 32, 4096, [IMG4])]:
-    q, k, v = (torch.randn(B, H, L, 96, device=dev, generator=g).to(torch.bfloat16) for _ in range(3))
-    table = ops.MaskTable.from_host(rects, np.ones((B, L)), None, dev)
-    out = []
-    for var in VARS:
-        lab.aki_lab_set_attn_variant(var)
-        for _ in range(20):
-            ops.mma_attn_core(q, k, v, table, 96 ** -0.5)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(20):
-            ops.mma_attn_core(q, k, v, table, 96 ** -0.5)
-        b.record()
-        torch.cuda.synchronize()
-        out.append(f"{NAMES[var]} {a.elapsed_time(b) / 20 * 1e3:.1f}")
-    lab.aki_lab_set_attn_variant(0)
-    print(f"B{B} L{L} rects {len(rects[0]) if rects[0][0][1] else 0}: " + "  ".join(out), flush=True)
+import os, sys, subprocess
+here = os.path.dirname(os.path.abspath(__file__))
+NAMES = {612: "as shipped", 613: "- softmax VALU", 615: "- softmax VALU - DMA", 620: "- tile barrier", 621: "- softmax VALU - barrier", 623: "- softmax VALU - DMA - barrier (MFMAs, fragment reads, loop control)"}
+for var, name in NAMES.items():
+    r = subprocess.run([sys.executable, os.path.join(here, "attn64_stamps.py"), str(var)], capture_output=True, text=True)
+    line = next((l for l in r.stdout.split("\n") if l.startswith("B4 L4096 rects 4")), r.stderr[-300:])
+    cyc = line.split(" cycles per tile")[0].split(",")[-1].strip() if "cycles per tile" in line else "?"
+    clk = line.split(" us at ")[1].split(" GHz")[0] if " us at " in line else "?"
+    print(f"{name:75s} {cyc:>6s} cycles per tile (56 MFMAs = 1664 pipe cycles) at {clk} GHz", flush=True)
+print("halves of the blind iteration:")
+subprocess.run([sys.executable, os.path.join(here, "attn64_halves.py")])

@@ -16,7 +16,7 @@ def main():
     rc = audit([])
     if "--lab" in sys.argv:
         print("-- lab build (-DAKI_LAB_HOOKS): the two kernels that must be right there too")
-        rc |= audit(["-DAKI_LAB_HOOKS"], only=("ILi0ELi0E", "ILi8ELi0E"))
+        rc |= audit(["-DAKI_LAB_HOOKS"], only=("ILi0ELi0E", "ILi8ELi0E", "ILi8ELi64E"))
     return rc
 
 

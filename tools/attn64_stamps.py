@@ -1,4 +1,4 @@
-"""[optional argument: lab variant, default 612; 8804 = the same with two extra VALU issues per MFMA gap]
+"""[optional argument: lab variant, default 612; 613 / 615 / 620 / 621 / 623: with parts taken out - tools/attn64_ablate.py]
 Where a workgroup of the 64-row attention core spends its cycles (lab variant 612: s_memtime stamps around the rank prologue, the tile
 loops and the epilogue; s_memrealtime over the workgroup gives the clock the chip held).   python tools/attn64_stamps.py"""
 import os, sys
@@ -25,4 +25,4 @@ for (B, H, L, rects) in [(4, 32, 4096, [IMG4] * 4), (1, 32, 4096, [IMG4]), (4, 3
     print(f"B{B} L{L} rects {len(rects[0]) if rects[0][0][1] else 0}: per workgroup (median over {nwg}): total {np.median(tot)/1e3:.0f}k cycles = {np.median(rt)/100:.1f} us at {np.median(clk):.2f} GHz | "
           f"prologue {np.median(pro)/1e3:.1f}k ({100*np.median(pro/tot):.1f} %)  tile loops {np.median(loop)/1e3:.1f}k ({100*np.median(loop/tot):.1f} %)  epilogue {np.median(epi)/1e3:.1f}k ({100*np.median(epi/tot):.1f} %) | "
           f"waiting at the tile barrier {np.median(wait/tiles):.0f} + for the own DMA pieces {np.median(dma/tiles):.0f} cycles per tile (wave 0; both include a stamp's own ~40) | "
-          f"{np.median(tiles):.0f} tiles, {np.median(redo):.0f} redos (wave 0), {np.median(loop/tiles):.0f} cycles per tile (48 MFMAs = 1536) | slowest workgroup {rt.max()/100:.1f} us, fastest {rt.min()/100:.1f} us", flush=True)
+          f"{np.median(tiles):.0f} tiles, {np.median(redo):.0f} redos (wave 0), {np.median(loop/tiles):.0f} cycles per tile (56 MFMAs = 1664 pipe cycles) | slowest workgroup {rt.max()/100:.1f} us, fastest {rt.min()/100:.1f} us", flush=True)
