@@ -80,6 +80,14 @@ template <int KA, int QA> __device__ __forceinline__ void mfma_qk_c(f32x16& s, c
 template <int KA, int QA> __device__ __forceinline__ void mfma_qk_zero(f32x16& s) {   // FULL tiles: the constant 0 as C
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
 }
+// The same two with the result's 20 wait states INSIDE the statement (hipcc takes an asm statement's outputs as ready when it ends): for
+// MFMAs that sit under an if / else of their own - the rank prologue's first links - where hipcc copies the tile right behind them.
+template <int KA, int QA> __device__ __forceinline__ void mfma_qk_settled(f32x16& s) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0\n\ts_nop 15\n\ts_nop 3" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
+}
+template <int KA, int QA> __device__ __forceinline__ void mfma_qk_zero_settled(f32x16& s) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0\n\ts_nop 15\n\ts_nop 3" : "=v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
+}
 // O^T (a) += V^T fragment (VGPRs) * P fragment (VGPRs)
 template <int OA> __device__ __forceinline__ void mfma_pv(const u32x4 vv, const u32x4 pf) {
   asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vv), "v"(pf), "n"(OA), "n"(OA + 15));
@@ -414,6 +422,9 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   // v_readlane.  (As scalar loads behind their own lgkmcnt(0) they were ~200 cycles each, 4 * max_rects of them per rank.)
   u32x4 rect_reg = {0u, 0u, 0u, 0u};
   if (lane < p.max_rects) rect_reg = *(const u32x4*)(p.rects + (size_t)b * p.max_rects + lane);
+  // rectangles in use: up to the last non-empty one (callers pad the table to a fixed width; every scan below is per rank or per run)
+  const unsigned long long rv_ = __ballot(rect_reg[1] > rect_reg[0] && rect_reg[3] > rect_reg[2]);
+  const int nrect = rv_ == 0ull ? 0 : 64 - (int)__builtin_clzll(rv_);
   auto rect_at = [&](int i) -> aki_mma_rect {       // wave-uniform i
     aki_mma_rect o;
     o.row_lo = (int)__builtin_amdgcn_readlane(rect_reg[0], i); o.row_hi = (int)__builtin_amdgcn_readlane(rect_reg[1], i);
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   auto block_extent = [&](int r0) -> int {
     if (r0 >= L) return -1;
     int ext = min(r0 + 32, L);
-    for (int i = 0; i < p.max_rects; ++i) {
+    for (int i = 0; i < nrect; ++i) {
       const aki_mma_rect r = rect_at(i);
       if (r.row_hi > r.row_lo && r.col_hi > r.col_lo && r.row_lo < r0 + 32 && r.row_hi > r0) ext = max(ext, min(r.col_hi, L));
     }
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     X.row = X.wq0 + l31;
     X.touch_lo = 0x7fffffff; X.touch_hi = 0; X.full_lo = 0; X.full_hi = 0;
     X.rc0 = 0; X.rc1 = 0;
-    for (int i = 0; i < p.max_rects; ++i) {
+    for (int i = 0; i < nrect; ++i) {
       const aki_mma_rect r = rect_at(i);
       if (r.row_hi > r.row_lo && r.col_hi > r.col_lo) {
         if (r.row_lo < X.wq0 + 32 && r.row_hi > X.wq0) {
@@ -584,7 +595,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     const int tl = win + lane, c0 = tl * 64;
     const bool ok = X.exists && !X.has_dead && tl < first_bad;
     bool rfull = false, clean = true;
-    for (int i = 0; i < p.max_rects; ++i) {
+    for (int i = 0; i < nrect; ++i) {
       const aki_mma_rect r = rect_at(i);
       if (r.row_hi > r.row_lo && r.col_hi > r.col_lo && r.row_lo < X.wq0 + 32 && r.row_hi > X.wq0) {
         const bool inside = c0 >= r.col_lo && c0 + 64 <= r.col_hi;
@@ -628,7 +639,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     if (f & 1ull) return f == ~0ull ? 64 : (int)__builtin_ctzll(~f);
     const int c0 = jt * 64;
     int nb = 0x7fffffff;
-    for (int i = 0; i < p.max_rects; ++i) {
+    for (int i = 0; i < nrect; ++i) {
       const aki_mma_rect r = rect_at(i);
       if (r.row_hi > r.row_lo && r.col_hi > r.col_lo && r.row_lo < X.wq0 + 32 && r.row_hi > X.wq0) {
         if (r.col_lo > c0) nb = min(nb, r.col_lo);
@@ -810,8 +821,10 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     static_for<12>([&](auto I) {
       constexpr int i = decltype(I)::value, ks = i >> 1, half = i & 1;
       if constexpr (ks == 0) {
-        if (fa) { if constexpr (half == 0) mfma_qk_zero<A64_KA, A64_Q>(sA0); else mfma_qk_zero<A64_KC, A64_Q>(sA1); }
-        else { if constexpr (half == 0) mfma_qk<A64_KA, A64_Q>(sA0); else mfma_qk<A64_KC, A64_Q>(sA1); }
+        // the two forms of a chain's first MFMA meet behind this if / else: hipcc copies the tile on both sides of the join and takes an
+        // asm MFMA's result as ready (tools/attn64_hazards.py found a v_mov one wait state behind the MFMA in one build).  Once per rank.
+        if (fa) { if constexpr (half == 0) mfma_qk_zero_settled<A64_KA, A64_Q>(sA0); else mfma_qk_zero_settled<A64_KC, A64_Q>(sA1); }
+        else { if constexpr (half == 0) mfma_qk_settled<A64_KA, A64_Q>(sA0); else mfma_qk_settled<A64_KC, A64_Q>(sA1); }
       } else {
         if constexpr (half == 0) mfma_qk<A64_KA + 4 * ks, A64_Q + 4 * ks>(sA0); else mfma_qk<A64_KC + 4 * ks, A64_Q + 4 * ks>(sA1);
       }
