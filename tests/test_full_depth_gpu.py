@@ -18,7 +18,7 @@ DEV = "cuda"
 N_TXT, NV, PX = 512, 144, 336
 
 
-def _prompts(B, media_id, seed):
+def _prompts(B, media_id, seed, px=PX):
     """SURVEY 8(d) synthetic chat prompts (as bench.py); sample 1 is the padded variant (0.8 * N_txt real tokens)."""
     g = torch.Generator().manual_seed(seed)
     ids = torch.randint(3, 32000, (B, N_TXT), generator=g)
@@ -28,12 +28,16 @@ def _prompts(B, media_id, seed):
         ids[b, 0], ids[b, 6], ids[b, n - 18], ids[b, n - 17], ids[b, n - 1] = 1, media_id, 32007, 32001, 2
         ids[b, n:] = 32000
         am[b, n:] = 0
-    vx = (torch.rand((B, 1, 1, 3, PX, PX), generator=g) - 0.5) / 0.5
+    vx = (torch.rand((B, 1, 1, 3, px, px), generator=g) - 0.5) / 0.5
     return vx, ids, am
 
 
 @pytest.mark.timeout(3000)
-def test_aki4b_full_depth_bf16_logits_vs_fp32_oracle():
+@pytest.mark.parametrize("px", [336, 384])
+def test_aki4b_full_depth_bf16_logits_vs_fp32_oracle(px):
+    """px = 336: BASELINE's metric resolution (576 patches, the position table resampled bicubically); px = 384: the tower's native
+    size and the only one the reference itself runs (src/vlm.py:202-203: 729 patches, M = 729 rows per image in the 27 SigLIP layers,
+    the learned table as it is) - the workload of bench.py's `px384_forward` leg."""
     import aki_torch as OT
     from aki_amd.factory import build_aki
     B = 2
@@ -43,7 +47,7 @@ def test_aki4b_full_depth_bf16_logits_vs_fp32_oracle():
     # gains = 1, biases = 0 the folded-norm arithmetic (phi3.py forward_folded, siglip.py fold_layernorm) is the identity at depth
     n_touched = randomize_norms_and_biases(m, seed=13)
     assert n_touched >= 2 * 32 + 1 + 27 * 10
-    vx, ids, am = _prompts(B, m.media_token_id, 11)
+    vx, ids, am = _prompts(B, m.media_token_id, 11, px)
     vx16 = vx.to(torch.bfloat16)
     with torch.no_grad():
         got = m(vx16.to(DEV), ids.to(DEV), attention_mask=am.to(DEV)).logits.float().cpu()
@@ -87,15 +91,15 @@ def test_aki4b_full_depth_bf16_logits_vs_fp32_oracle():
     top_ref = ref.argmax(-1)
     stats["argmax_agreement_hip"] = float((got.argmax(-1) == top_ref)[valid].float().mean())
     stats["argmax_agreement_eager_bf16"] = float((ref16.argmax(-1) == top_ref)[valid].float().mean())
-    stats.update(max_abs_ref=mx, seconds_fp32_oracle=round(t32, 1), seconds_bf16_oracle=round(t16, 1), batch=B, L=L)
+    stats.update(max_abs_ref=mx, seconds_fp32_oracle=round(t32, 1), seconds_bf16_oracle=round(t16, 1), batch=B, L=L, image_px=px)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "parity_full_depth.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "parity_full_depth.json" if px == 336 else f"parity_full_depth_{px}px.json"), "w") as f:
         json.dump(stats, f, indent=1)
     print(json.dumps(stats))
     v = stats["valid rows"]
-    record_parity("AKI-4B 32+27 layers logits, valid rows", torch.bfloat16, v["hip_max"], v["hip_mean"], mx,
+    record_parity(f"AKI-4B 32+27 layers logits, {px} px, valid rows", torch.bfloat16, v["hip_max"], v["hip_mean"], mx,
                   "<= 1.5x mean / 2x max of the oracle's own bf16-eager error + 1e-3*max|ref|")
-    record_parity("AKI-4B 32+27 layers logits, valid rows, fold_norms=False", torch.bfloat16, v["hip_unfolded_max"], v["hip_unfolded_mean"], mx,
+    record_parity(f"AKI-4B 32+27 layers logits, {px} px, valid rows, fold_norms=False", torch.bfloat16, v["hip_unfolded_max"], v["hip_unfolded_mean"], mx,
                   "<= 1.5x mean / 2x max of the oracle's own bf16-eager error + 1e-3*max|ref|")
     assert v["hip_mean"] <= 1.5 * v["eager_bf16_mean"] + 1e-3 * mx, stats
     assert v["hip_max"] <= 2.0 * v["eager_bf16_max"] + 1e-2 * mx, stats
