@@ -245,6 +245,7 @@ def spawn_ranks(n, argv, script=None):
 
 
 def main():
+    global IMG_PX
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -254,8 +255,12 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8 = BASELINE configs[4]: e4m3 weights/activations for the decoder projections (use with --batch 16)")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel timing table to stderr")
+    ap.add_argument("--px", type=int, default=IMG_PX, choices=[336, 384],
+                    help="image side of the synthetic batch: 336 = BASELINE's metric resolution (default), 384 = the tower's native size, what the "
+                         "reference's SFT collate and demo feed (train/sft_data_utils/loader_utils.py:8, local_demo.py:20): 729 patches, M = 5832 rows in the tower at batch 8")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (the other BASELINE configs, decode, first token, 384 px) that run after the headline at N = 1")
     args = ap.parse_args()
+    IMG_PX = args.px
 
     # --gpus N outside a launcher: start the N ranks ourselves (one process per GPU) BEFORE anything touches the GPU, as a child
     # process whose exit code is ours; rank 0's JSON line goes to the inherited stdout.  Never falls back to one rank.
@@ -418,16 +423,16 @@ def main():
                         "unit": "TFLOP/s", "frac": round(r["tflops"] / peak_of(r), 4), "traffic": None,
                         "avg_launch_ms": round(r["avg_ms"], 4), "algorithmic_flops_per_launch": r["flops"]}
         res = {
-            "metric": "image+text tokens/sec forward, AKI-4B, 336px img + 512 txt",
+            "metric": f"image+text tokens/sec forward, AKI-4B, {IMG_PX}px img + 512 txt",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_step_untapped": round(ms_untapped, 3), "rccl_ranks": ranks_seen,
             # every rank's own clock around the same K steps: `ms_per_step` is the slowest rank's (what `value` uses); a straggler shows here
             "ms_per_step_rank_min": round(elapsed_min / args.steps * 1e3, 3), "ms_per_step_rank_max": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8-e4m3 projections (f32 accumulate), bf16 attention/residual" if fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": "AKI-4B (Phi-3.5-mini + SigLIP-so400m/14 + Perceiver) forward, bf16, 1x336px image + "
+            "config": {"workload": f"AKI-4B (Phi-3.5-mini + SigLIP-so400m/14 + Perceiver) forward, bf16, 1x{IMG_PX}px image + "
                                    f"512-token chat prompt per sample, batch {B} per GPU (BASELINE configs[{4 if fp8 else 1}]); random-init weights",
-                       "global_batch": B * world, "seq_len": L, "tokens_per_sample": L, "patch_plus_text_tokens": 576 + N_TXT,
+                       "global_batch": B * world, "seq_len": L, "tokens_per_sample": L, "patch_plus_text_tokens": (IMG_PX // 14) ** 2 + N_TXT,
                        "parallelism": f"dp{world}"},
             "roofline": mk(dom),
         }
@@ -459,14 +464,14 @@ def main():
                                "note": "219 FLOP/B: just on the HBM side of the ridge (312 FLOP/B); both fractions are given"}
             if src:
                 res["mma_core"].update(traffic_unit=TUNIT, traffic_source=src, traffic_stale=bool(stale))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and IMG_PX == 336:
             thr = _cpu_threads()
             res["cpu_baseline"] = cpu_baseline(model.state_dict(), model.media_token_id, thr)
             res["cpu_baseline"]["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
             res["cpu_baseline_c2_est"] = cpu_baseline_c2_est(thr)
         # The other BASELINE configurations on the same clock, AFTER the headline's numbers exist: each leg is fenced (a failing leg
         # reports {"error": ...}), the headline values above are final, and the line is printed once.
-        if world == 1 and not args.no_secondary and not fp8 and B == BATCH:
+        if world == 1 and not args.no_secondary and not fp8 and B == BATCH and IMG_PX == 336:
             try:
                 import bench_legs
                 res["secondary"] = bench_legs.run_all(model, dev, sys.modules[__name__])

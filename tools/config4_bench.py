@@ -70,6 +70,11 @@ for B in (1, 2, 4):
     fl = 2.0 * M * 16384 * 3072
     roof = {"kernel": "gemm_bf16_kernel<8,4,2,4,SWIGLU> (gate_up + SwiGLU)", "bound": "mfma", "achieved": round(fl / gms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
             "frac": round(fl / gms / 1e9 / 2500.0, 4), "traffic": None, "avg_launch_ms": round(gms, 4), "flop_per_launch": fl}
-    res.append({"batch": B, "seq_len": L, "images_per_sample": N_IMG, "ms_per_forward": round(ms, 2), "tokens_per_s": round(B * L / ms * 1e3, 1), "roofline": roof, "mma_core": core,
+    # the whole MMA op as the decoder launches it (QKV projection with the RoPE epilogue + the core), timed inside the forward on every 4th launch
+    op_ms = at[0][2] if at else None
+    op_fl = 2.0 * M * 3072 * 9216 + cfl
+    mma_op = None if not op_ms else {"kernel": "aki_mma_attn_fwd (QKV GEMM + RoPE epilogue, then the 64-row core), inside the forward", "bound": "mfma", "ms": round(op_ms, 4),
+                                     "achieved": round(op_fl / op_ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(op_fl / op_ms / 1e9 / 2500.0, 4), "flop_per_launch": op_fl}
+    res.append({"batch": B, "seq_len": L, "images_per_sample": N_IMG, "ms_per_forward": round(ms, 2), "tokens_per_s": round(B * L / ms * 1e3, 1), "roofline": roof, "mma_core": core, "mma_op": mma_op,
                 "mma_attention_ms_per_launch": {str(t_[0]): round(t_[2], 4) for t_ in at}})
 print(json.dumps(res))
