@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--bucket-mb", type=int, default=512, help="gradient bucket size; xGMI is point-to-point, few large messages")
     ap.add_argument("--exchange-when-alone", action="store_true", help="world of one: still issue the RCCL collectives")
     ap.add_argument("--first-bucket-mb", type=int, default=64, help="size of the first bucket of each segment (its gradients finish last: the exposed tail); 0 = like the others")
+    ap.add_argument("--lr-warmup", type=int, default=0, help="linear learning-rate warm-up over this many optimizer steps (the reference trains with one: train/train.py:127 "
+                    "--warmup_steps 5000, 361-366); 0 = full rate from the first step, which is what the committed loss traces ran")
     ap.add_argument("--head-chunk", type=int, default=0, help="rows per chunk of the fused lm_head + cross-entropy (0 = default 2688: two chunks at the benchmark batch)")
     a = ap.parse_args()
     import bench
@@ -93,6 +95,7 @@ def main():
         marks["b"] = ev(); marks["b"].record()
     tr.reducer.finish = timed_finish
     losses = []
+    base_lr = tr.lr
     bucket_rows = None
     torch.cuda.reset_peak_memory_stats()
     for it in range(a.warmup + a.steps):
@@ -105,6 +108,8 @@ def main():
         last_step = it == a.warmup + a.steps - 1
         if last_step and getattr(tr.reducer, "active", False) and hasattr(tr.reducer, "stamps"):
             tr.reducer.stamps = {}                     # the last timed step also stamps every bucket (two event records per bucket)
+        if a.lr_warmup > 0:
+            tr.lr = base_lr * min(1.0, (it + 1) / a.lr_warmup)
         e[0].record()
         tr.zero_grad()
         out = model(vx, ids, attention_mask=am, labels=labels)
@@ -171,7 +176,7 @@ def main():
             "exchange_ms": round(exch_ms, 3), "exchange_exposed_ms": round(parts["exchange_exposed"] / a.steps, 3),
             "overlap_frac": (round(1.0 - min(1.0, (parts["exchange_exposed"] / a.steps) / exch_ms), 3) if exch_ms > 0 else None),
             "buckets": len(tr.reducer.buckets), "bucket_timeline": bucket_rows, "exchange_bytes": int(exchange_bytes), "exchange_dtype": exchange_dtype,
-            "parts_ms": {k: round(v / a.steps, 2) for k, v in parts.items()}, "losses": [round(x, 4) for x in losses],
+            "parts_ms": {k: round(v / a.steps, 2) for k, v in parts.items()}, "losses": [round(x, 4) for x in losses], "lr_warmup_steps": a.lr_warmup,
             "trainable_params": tr.numel, "lm_mfu_vs_2500TF": round(flops / (ms * 1e-3) / 2.5e15, 4),
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1), "precision": "bf16 compute, fp32 master/moments, bf16 grads", "head_chunk_rows": getattr(model.lang_model, "head_chunk_rows", 2688)}))
     if dist.is_initialized():
