@@ -16,7 +16,7 @@ AKI_ACT_NONE, AKI_ACT_GELU_ERF, AKI_ACT_GELU_TANH, AKI_ACT_SWIGLU = 0, 1, 2, 3
 AKI_DEAD_ROWS_ZERO, AKI_DEAD_ROWS_UNIFORM = 0, 1
 AKI_MAX_RECTS = 8
 AKI_PLAN_STRIDE = 12
-AKI_ABI_VERSION = 16
+AKI_ABI_VERSION = 17
 
 
 class AkiError(RuntimeError):
@@ -69,7 +69,8 @@ class LinearArgs(C.Structure):
                 ("w2", C.c_void_p), ("w2_row0", C.c_int32), ("w2_rows", C.c_int32),
                 ("row_scale", C.c_void_p), ("row_shift", C.c_void_p), ("col_shift", C.c_void_p), ("stats_rstd", C.c_void_p),
                 ("stats_mean", C.c_void_p), ("stats_eps", C.c_float), ("stats_workspace", C.c_void_p),
-                ("stats_workspace_bytes", C.c_size_t), ("splitk_workspace", C.c_void_p), ("splitk_workspace_bytes", C.c_size_t)]
+                ("stats_workspace_bytes", C.c_size_t), ("splitk_workspace", C.c_void_p), ("splitk_workspace_bytes", C.c_size_t),
+                ("preact_out", C.c_void_p), ("ld_preact", C.c_int64)]
 
 
 class DecoderLayer(C.Structure):

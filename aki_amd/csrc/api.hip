@@ -253,6 +253,10 @@ int aki_linear_fwd(const aki_linear_args* a, void* stream) {
     if (a->dtype != AKI_DT_BF16) return AKI_ERR_UNSUPPORTED;
     return linear_bf16(a, (hipStream_t)stream);
   }
+  if (a->preact_out) {   // training forward of the gated MLP: the bf16 MFMA GEMM only (whatever M is)
+    if (a->dtype != AKI_DT_BF16 || a->act != AKI_ACT_SWIGLU) return AKI_ERR_UNSUPPORTED;
+    return linear_bf16(a, (hipStream_t)stream);
+  }
   if (a->w2) {   // two-segment weight: the bf16 MFMA GEMM only
     AKI_CHECK_ARG(a->w2_row0 > 0 && a->w2_rows > 0 && a->w2_row0 < a->N);
     if (a->dtype != AKI_DT_BF16 || a->act != AKI_ACT_NONE) return AKI_ERR_UNSUPPORTED;

@@ -84,6 +84,8 @@ struct GemmParams {
   int m_offset;  // global index of row 0 (tail launches): residual row = (m + m_offset) % res_row_mod, token index for QKV
   int act;
   int tiles_m, tiles_n;
+  bf16_t* preact;  // EPI_SWIGLU, training forward: the pre-activations g | u as bf16 [M, N] (aki_linear_args.preact_out); NULL = not kept
+  int ld_preact;
   int wide;  // 16-byte stores allowed (n_out % 8 == 0, ldy % 8 == 0, y 16-B aligned)
   int res_wide;  // 16-byte residual loads allowed (n_out % 8 == 0, ldr % 8 == 0, residual 16-B aligned)
   // QKV + RoPE
@@ -1100,6 +1102,7 @@ __global__ __launch_bounds__(WN* WM * 64 * KG, ((NF * NT > 32 || KG > 1) ? 1 : 2
       if (HR == 2 && has_res) rrow = p.residual + (size_t)(p.res_row_mod > 0 ? (mr + p.m_offset) % p.res_row_mod : mr) * p.ldr;
       const float rs = rsv[m], mu = muv[m];
       float v[NOUT][4];
+      unsigned gpk[NOUT][2], upk[NOUT][2];       // EPI_SWIGLU with preact_out: the packed pre-activations of this token row
       u32x2 rr[NOUT];
       if (HR == 1) {                                             // all of the token block's residual reads first: one wait for the lot
 #pragma unroll
@@ -1112,15 +1115,29 @@ __global__ __launch_bounds__(WN* WM * 64 * KG, ((NF * NT > 32 || KG > 1) ? 1 : 2
       for (int n = 0; n < NOUT; ++n) {
         const int f = fwave + n * 16 + 4 * kg;       // this lane's 4 features of block n
         const bool fin = FULL || f < n_out;
+        float pre_g[4], pre_u[4];                    // EPI_SWIGLU: what the activation is taken of
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (EPI == EPI_SWIGLU) {
             const float g = HSC == 0 ? acc[n][m][r] : acc[n][m][r] * rs, u = HSC == 0 ? acc[n + NF / 2][m][r] : acc[n + NF / 2][m][r] * rs;
             v[n][r] = u * silu_fast(g);
+            pre_g[r] = g; pre_u[r] = u;
           } else if (has_shift) {
             v[n][r] = (acc[n][m][r] - mu * colc4[n][r]) * rs;
           } else {
             v[n][r] = HSC == 0 ? acc[n][m][r] : acc[n][m][r] * rs;
+          }
+        }
+        if (EPI == EPI_SWIGLU) {
+          // Training forward (preact_out): the pre-activations leave as bf16 for the backward pass, and the activation is taken of
+          // THOSE values with the training kernels' own silu - the step computes what aki_linear + aki_swiglu_fwd computed, bit for
+          // bit, without the second pass over [M, 2 F].
+          if (p.preact) {
+            const unsigned g01 = pack_bf16x2(pre_g[0], pre_g[1]), g23 = pack_bf16x2(pre_g[2], pre_g[3]);
+            const unsigned u01 = pack_bf16x2(pre_u[0], pre_u[1]), u23 = pack_bf16x2(pre_u[2], pre_u[3]);
+            v[n][0] = bf16_lo(u01) * silu(bf16_lo(g01)); v[n][1] = bf16_hi(u01) * silu(bf16_hi(g01));
+            v[n][2] = bf16_lo(u23) * silu(bf16_lo(g23)); v[n][3] = bf16_hi(u23) * silu(bf16_hi(g23));
+            gpk[n][0] = g01; gpk[n][1] = g23; upk[n][0] = u01; upk[n][1] = u23;
           }
         }
         if (EPI == EPI_PLAIN) {
@@ -1145,6 +1162,27 @@ __global__ __launch_bounds__(WN* WM * 64 * KG, ((NF * NT > 32 || KG > 1) ? 1 : 2
         }
         if (has_res && fin) {
           v[n][0] += bf16_lo(rr[n][0]); v[n][1] += bf16_hi(rr[n][0]); v[n][2] += bf16_lo(rr[n][1]); v[n][3] += bf16_hi(rr[n][1]);
+        }
+      }
+      if (EPI == EPI_SWIGLU) {
+        if (p.preact) {         // the pre-activations leave like y does: 16-byte stores that pair two feature blocks where the layout allows
+          bf16_t* const prow = p.preact + (size_t)mr * p.ld_preact;
+          const bool pwide = NOUT % 2 == 0 && n_out % 8 == 0 && p.ld_preact % 8 == 0 && (((uintptr_t)p.preact) & 15) == 0;
+          if (pwide) {
+#pragma unroll
+            for (int n = 0; n + 1 < NOUT; n += 2) {
+              const u32x4 og = pair_to_wide(gpk[n][0], gpk[n][1], gpk[n + 1][0], gpk[n + 1][1]);
+              const u32x4 ou = pair_to_wide(upk[n][0], upk[n][1], upk[n + 1][0], upk[n + 1][1]);
+              const int f = fwave + (n + (kg & 1)) * 16 + 8 * (kg >> 1);
+              if (ok && (FULL || f < n_out)) { *(u32x4*)(prow + f) = og; *(u32x4*)(prow + n_out + f) = ou; }
+            }
+          } else {
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) {
+              const int f = fwave + n * 16 + 4 * kg;
+              if (ok && f < n_out) { *(u32x2*)(prow + f) = u32x2{gpk[n][0], gpk[n][1]}; *(u32x2*)(prow + n_out + f) = u32x2{upk[n][0], upk[n][1]}; }
+            }
+          }
         }
       }
       unsigned pk[NOUT][2];                                      // the values AS STORED
@@ -1586,6 +1624,7 @@ static int run_planned(GemmParams& p, int plan, hipStream_t stream) {
   b.x = (const bf16_t*)((const char*)p.x + (size_t)m_main * p.ldx * (FP8 ? 1 : 2));
   if (FP8) b.sx = p.sx + m_main;
   b.y = p.y + (size_t)m_main * p.ldy;
+  if (p.preact) b.preact = p.preact + (size_t)m_main * p.ld_preact;
   if (p.residual && p.res_row_mod <= 0) b.residual = p.residual + (size_t)m_main * p.ldr;
   if (p.row_scale) b.row_scale = p.row_scale + m_main;
   if (p.row_shift) b.row_shift = p.row_shift + m_main;
@@ -1636,6 +1675,11 @@ int linear_bf16(const aki_linear_args* a, hipStream_t stream) {
     p.st_rstd = a->stats_rstd; p.st_mean = a->stats_mean; p.st_eps = a->stats_eps;
     p.st_cnt = (unsigned*)a->stats_workspace;
     p.st_part = (float*)((char*)a->stats_workspace + linear_stats_cnt_bytes(a->M));
+  }
+  if (a->preact_out) {
+    if (a->act != AKI_ACT_SWIGLU || a->row_scale) return AKI_ERR_INVALID_ARG;
+    if ((a->ld_preact % 4) || a->ld_preact < a->N || ((uintptr_t)a->preact_out & 7)) return AKI_ERR_ALIGNMENT;
+    p.preact = (bf16_t*)a->preact_out; p.ld_preact = (int)a->ld_preact;
   }
   if (a->act == AKI_ACT_SWIGLU) {
     if (a->bias) return AKI_ERR_UNSUPPORTED;

@@ -235,8 +235,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            act: int = ACT_NONE, res_row_mod: int = 0, out: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
            w2_row0: int = 0, n_rows: Optional[int] = None, row_scale: Optional[torch.Tensor] = None,
            row_shift: Optional[torch.Tensor] = None, col_shift: Optional[torch.Tensor] = None,
-           stats_out: Optional[RowStats] = None, stats_eps: float = 0.0) -> torch.Tensor:
+           stats_out: Optional[RowStats] = None, stats_eps: float = 0.0, preact_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = act(x W^T + bias) [+ residual]; W is an nn.Linear weight [N,K] (K a multiple of 64 for bf16).
+    `preact_out` (act SWIGLU, bf16; the training forward): [M, N] buffer that receives the pre-activations g | u; y is then the
+    activation of those bf16 values - what linear + swiglu_fwd compute, in one launch.
     Two-segment weight (DecoupledLinear, src/helpers.py:594-603): with `w2`, logical weight row r is w[r] for r < w2_row0 and
     w2[r - w2_row0] beyond; `n_rows` = logical rows (output width, may include padding columns that repeat w2's last row).
     Folded normalisation (see include/aki_mi355x.h, aki_linear_args): `row_scale` / `row_shift` / `col_shift` apply the input's
@@ -268,6 +270,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         sws = _stats_ws(M, n_out, dev)
         a.stats_rstd, a.stats_mean, a.stats_eps = _ptr(stats_out.rstd), _ptr(stats_out.mean), float(stats_eps)
         a.stats_workspace, a.stats_workspace_bytes = sws.data_ptr(), sws.numel()
+    if preact_out is not None:
+        p2 = preact_out.view(-1, preact_out.shape[-1])
+        if act != ACT_SWIGLU or p2.shape != (M, N) or p2.stride(1) != 1 or p2.dtype != torch.bfloat16 or p2.device != x2.device:
+            raise AkiError("linear: preact_out must be a bf16 [M, N] buffer of an act=SWIGLU launch")
+        a.preact_out, a.ld_preact = p2.data_ptr(), p2.stride(0)
     if act == ACT_NONE and M <= SPLITK_MAX_M and x.dtype == torch.bfloat16:
         sk = _splitk_ws(M, N, K, dev)
         if sk is not None:

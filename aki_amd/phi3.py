@@ -251,6 +251,8 @@ class Phi3Attention(nn.Module):
 
 
 class Phi3MLP(nn.Module):
+    fuse_train_swiglu = True      # training forward: gate_up + SwiGLU in one launch that also keeps the pre-activations (A/B switch: tools/train_bench.py --no-fused-swiglu)
+
     def __init__(self, config):
         super().__init__()
         self.gate_up_proj = nn.Linear(config.hidden_size, 2 * config.intermediate_size, bias=False)
@@ -258,8 +260,8 @@ class Phi3MLP(nn.Module):
 
     def forward(self, x, residual):
         if _ag(x, self.gate_up_proj.weight, self.down_proj.weight):
-            # training: gate_up is kept for the SwiGLU backward, so the activation is its own (HBM-bound) kernel
-            a = T.SwigluFn.apply(T.linear(x, self.gate_up_proj.weight))
+            # training: the pre-activations are kept for the SwiGLU backward - the GEMM's epilogue writes them beside the activation
+            a = T.gate_up_swiglu(x, self.gate_up_proj.weight) if self.fuse_train_swiglu else T.SwigluFn.apply(T.linear(x, self.gate_up_proj.weight))
             return T.linear(a, self.down_proj.weight, None, residual)
         a = ops.linear(x, self.gate_up_proj.weight, act=ops.ACT_SWIGLU)
         return ops.linear(a, self.down_proj.weight, residual=residual)

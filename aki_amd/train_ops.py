@@ -427,6 +427,40 @@ class SwigluFn(torch.autograd.Function):
         return swiglu_bwd(gu, da)
 
 
+class GateUpSwigluFn(torch.autograd.Function):
+    """a = silu(g) * u with [g | u] = x W^T in ONE launch (the GEMM's SwiGLU epilogue also leaves the bf16 pre-activations for this
+    backward: aki_linear_args.preact_out) - the numbers LinearFn + SwigluFn produce, without the pass that re-read [M, 2F] to apply
+    the activation (HF:phi3/modeling_phi3.py:49-64)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _need_bf16(x, w)
+        gu = torch.empty((*x.shape[:-1], w.shape[0]), dtype=x.dtype, device=x.device)
+        a = ops.linear(x, w, act=ops.ACT_SWIGLU, preact_out=gu)
+        ctx.save_for_backward(x, gu)
+        ctx.w_ref = w
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        (x, gu), w = ctx.saved_tensors, ctx.w_ref
+        dgu = swiglu_bwd(gu, da.contiguous())
+        d2 = _rows2d(dgu)
+        N = w.shape[0]
+        if N % 64:                                         # K dimension of the dgrad GEMM must be a multiple of 64 (as LinearFn)
+            d2p = torch.zeros((d2.shape[0], _pad64(N)), dtype=d2.dtype, device=d2.device)
+            d2p[:, :N] = d2
+        else:
+            d2p = d2
+        dx = ops.linear(d2p, _weight_t(w)).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = _wgrad(ctx.w_ref, d2, _rows2d(x)) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def gate_up_swiglu(x, w):
+    return GateUpSwigluFn.apply(x, w)
+
+
 class GeluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

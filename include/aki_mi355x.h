@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AKI_ABI_VERSION 16
+#define AKI_ABI_VERSION 17
 
 typedef enum {
   AKI_OK = 0,
@@ -245,6 +245,12 @@ typedef struct {
    * at its front, put back to zero by every launch; launches sharing it must be stream-ordered).  NULL / too small: no split. */
   void* splitk_workspace;
   size_t splitk_workspace_bytes;
+  /* Training forward of the gated MLP (bf16, act SWIGLU; HF:phi3/modeling_phi3.py:49-64 under autograd): besides y = silu(g) * u the
+   * launch leaves the pre-activations [g | u] as bf16 [M, N] (row stride ld_preact elements, a multiple of 4, >= N; 8-byte aligned) for the
+   * backward pass, and takes the activation OF those bf16 values - the same numbers aki_linear_fwd (act NONE) followed by aki_swiglu_fwd
+   * produce, without the second pass over [M, N].  NULL: not kept (inference). */
+  void* preact_out;
+  int64_t ld_preact;
 } aki_linear_args;
 
 int aki_linear_fwd(const aki_linear_args* args, void* stream);

@@ -125,6 +125,31 @@ def test_swiglu_gelu_colsum():
     close(T.colsum(z), z.float().sum(0), what="colsum")
 
 
+@pytest.mark.parametrize("M,K,F_", [(5240, 3072, 8192), (655, 3072, 8192), (120, 3072, 8192), (37, 128, 96), (300, 256, 264)])
+def test_gate_up_swiglu_one_launch_equals_two(M, K, F_):
+    """Training forward of the gated MLP (HF:phi3/modeling_phi3.py:49-64): the GEMM's SwiGLU epilogue with `preact_out` must leave
+    exactly the bf16 pre-activations the plain GEMM writes and exactly the activation aki_swiglu_fwd makes of them - bit for bit, at the
+    headline's M (main launch + its 120-row tail launch), at one sample, at the tail's own M and at ragged small shapes - and the
+    autograd node built on it must return the gradients of LinearFn + SwigluFn."""
+    from aki_amd import ops, train_ops as T
+    x, w = rt(M, K, seed=M), rt(2 * F_, K, seed=M + 1, scale=K ** -0.5)
+    gu_ref = ops.linear(x, w)
+    a_ref = T.swiglu_fwd(gu_ref)
+    gu = torch.full((M, 2 * F_), float("nan"), dtype=BF, device=DEV)
+    a = ops.linear(x, w, act=ops.ACT_SWIGLU, preact_out=gu)
+    assert torch.equal(gu, gu_ref), f"pre-activations: {int((gu != gu_ref).sum())} elements differ"
+    assert torch.equal(a, a_ref), f"activation: {int((a != a_ref).sum())} elements differ"
+    da = rt(M, F_, seed=M + 2)
+    outs = []
+    for fused in (True, False):
+        xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+        y = T.gate_up_swiglu(xr, wr) if fused else T.SwigluFn.apply(T.linear(xr, wr))
+        y.backward(da)
+        outs.append((y.detach(), xr.grad, wr.grad))
+    for got, want, what in zip(outs[0], outs[1], ("y", "dx", "dw")):
+        assert torch.equal(got, want), f"{what}: {int((got != want).sum())} elements differ"
+
+
 def test_rope_backward_merge():
     from aki_amd import train_ops as T
     B, H, Lq, Dh = 2, 3, 50, 96

@@ -35,10 +35,14 @@ def main():
     ap.add_argument("--bucket-mb", type=int, default=512, help="gradient bucket size; xGMI is point-to-point, few large messages")
     ap.add_argument("--exchange-when-alone", action="store_true", help="world of one: still issue the RCCL collectives")
     ap.add_argument("--first-bucket-mb", type=int, default=64, help="size of the first bucket of each segment (its gradients finish last: the exposed tail); 0 = like the others")
+    ap.add_argument("--no-fused-swiglu", action="store_true", help="A/B: gate_up and the SwiGLU as two launches in the training forward (rounds 1-5)")
     ap.add_argument("--lr-warmup", type=int, default=0, help="linear learning-rate warm-up over this many optimizer steps (the reference trains with one: train/train.py:127 "
                     "--warmup_steps 5000, 361-366); 0 = full rate from the first step, which is what the committed loss traces ran")
     ap.add_argument("--head-chunk", type=int, default=0, help="rows per chunk of the fused lm_head + cross-entropy (0 = default 2688: two chunks at the benchmark batch)")
     a = ap.parse_args()
+    if a.no_fused_swiglu:
+        from aki_amd.phi3 import Phi3MLP
+        Phi3MLP.fuse_train_swiglu = False
     import bench
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # start the ranks ourselves, as a child process, before any GPU call
         raise SystemExit(bench.spawn_ranks(a.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
