@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/aki_mi355x.h but not exported"
-    assert lib.aki_abi_version() == 16
+    assert lib.aki_abi_version() == 17
     exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "debug" not in exported and "aki_lab_" not in exported, "lab / debug hooks must not ship in the product library"
     assert b"aligned" in lib.aki_strerror(-3)
