@@ -940,7 +940,9 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       if constexpr (THR != 0) iter(M4{}, j);
       ++j;
       if constexpr (THR != 0) {
-        if (!settled && !force_checked && !(ABL & 64)) settled = __ballot(A.m_ref < -1e29f || B.m_ref < -1e29f) == 0ull;
+        // (rows beyond seq_len under the zero convention see nothing, ever: they must not hold the wave on the exact path)
+        if (!settled && !force_checked && !(ABL & 64))
+          settled = __ballot((A.m_ref < -1e29f && (A.row_alive || A.row_uniform)) || (B.m_ref < -1e29f && (B.row_alive || B.row_uniform))) == 0ull;
       }
     }
     if ((j & 63) == 0) { block_masks(A, j); block_masks(B, j); }     // next window of 64 tiles (L > 4096)

@@ -715,9 +715,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
 
 // the long-sequence core (mma_attn64_bf16.hip): 64 rows per wave, one wave per SIMD
 int attn_core64_bf16_launch(AttnParams p, int cus, hipStream_t stream, int exact_max);
-// Sequences of at least this many rows go to it (measured crossover: profiles/r06_attn_l4096_ab.txt)
+// Sequences of at least this many rows go to it (measured crossover, tools/attn64_crossover.py -> profiles/r06_attn64_crossover.txt: the two
+// kernels tie at 1536 rows, the long one is 5 % ahead at 1792 for batch 1, 4 and 8 alike)
 #ifndef AKI_ATTN64_MIN_L
-#define AKI_ATTN64_MIN_L 2048
+#define AKI_ATTN64_MIN_L 1792
 #endif
 
 #ifdef AKI_LAB_HOOKS
