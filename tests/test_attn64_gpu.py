@@ -120,6 +120,30 @@ def test_attn64_through_the_product_library(B, H, L, rects):
     check(n(o)[:1, :, h * 96:(h + 1) * 96], want, torch.bfloat16, f"product library vs oracle, head {h}", scale_atol=4.0)
 
 
+@pytest.mark.parametrize("L", [1791, 1792, 1793])
+def test_product_rule_boundary_both_cores_agree(L):
+    """The product library switches cores at 1792 rows (AKI_ATTN64_MIN_L): one row below, at, and one row above the boundary the output and
+    the log-sum-exp must agree with the exact-f32 kernel, and the two cores with each other, on a ragged two-sample batch."""
+    ops = _ops()
+    from aki_amd import _lib
+    B, H = 2, 4
+    q, k, v = _qkv(L, B, H, L)
+    lens = [L, L - 321]
+    table = ops.MaskTable.from_host([[(6, 150, 150, L - 64)], [(6, 150, 150, L - 400)]], _ragged(B, L, lens), lens, DEV)
+    o32 = ops.mma_attn_core(q.float(), k.float(), v.float(), table, 96 ** -0.5)
+    o, lse = ops.mma_attn_core(q, k, v, table, 96 ** -0.5, return_lse=True)
+    check(n(o), n(o32), torch.bfloat16, f"product rule at L = {L}", scale_atol=4.0)
+    outs = {}
+    for var in (1, 9):
+        with _lib.use_lab_attn(var):
+            outs[var] = tuple(t.clone() for t in ops.mma_attn_core(q, k, v, table, 96 ** -0.5, return_lse=True))
+            torch.cuda.synchronize()
+    assert float((outs[1][0].float() - outs[9][0].float()).abs().max()) < 3e-2
+    fin = torch.isfinite(outs[1][1])
+    assert bool((torch.isfinite(outs[9][1]) == fin).all()) and float((outs[1][1][fin] - outs[9][1][fin]).abs().max()) < 3e-3
+    assert torch.equal(o, outs[9][0] if L >= 1792 else outs[1][0]), "the product library did not pick the core its rule names"
+
+
 def test_attn64_raised_reference_maximum():
     """cdna guide rule 26: the raise of the reference maximum is rare and data dependent, so it gets inputs that force it (a spiked key per
     tile), a full-tensor reference, and three builds that must agree to rounding: the exact one (running maximum per tile), the shipped
