@@ -931,7 +931,11 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       }
     }
     if (__builtin_expect(nrun > 0, 1)) {
-      do { iter(M2{}, j); ++j; } while (--nrun > 0);
+      // two tiles per turn: the loop control and its taken branch are issue slots of the tile (28 -> 19.5 scalar issues per tile, -1.3 % kernel
+      // time; four per turn: no further gain; three per turn with the ring stages as compile-time constants: 12 scalar issues, but the
+      // single iterations that align a run to it cost more than it saves - EXPERIMENTS.md)
+      if (nrun & 1) { iter(M2{}, j); ++j; --nrun; }
+      while (nrun > 0) { iter(M2{}, j); iter(M2{}, j + 1); j += 2; nrun -= 2; }
     } else if (THR == 0 && both_fast(j)) {        // the exact build's fast (per-lane hide) iteration, in runs
       do { iter(M1{}, j); ++j; } while (j < jend_w && both_fast(j));
     } else if (THR == 0 || settled) {      // (product build: a fast tile where the hide changes comes here too - tile_bias has a short form for it)
