@@ -252,8 +252,28 @@ __device__ __forceinline__ void sm_chunk(const f32x16& s0, const f32x16& s1, u32
 // element k (score register k / 2 of half k % 2) has its exp2 in gap 1 + 26 k / 32, its argument one gap earlier, its bf16 word one
 // gap after its partner's exp2.
 struct A64Blind { float nm; float a[32]; float e[32]; };
-__host__ __device__ constexpr int bl_ge(int k) { return 1 + (k * 26) / 32; }
-template <int G, int ABL>
+// Which gap element k's exp2 goes to.  The gaps are not equal: slot E's gaps carry fragment reloads (two V^T reads behind every P V
+// MFMA, one K read behind every K Q^T MFMA), slot O's first six carry the tile's LDS-DMA pieces, and the gap behind a row-sum MFMA is
+// 16 pipe cycles, not 32.  SLOT 0 = E, 1 = O; weights in vector-issue cycles a gap has to spare (stamps: tools/attn64_halves.py).
+template <int SLOT> __host__ __device__ constexpr int bl_weight(int g) {       // g = 0..27: 16 gaps beside P V + row sums, 12 beside K Q^T
+  if (g >= 16) return SLOT == 0 ? 15 : 20;
+  const bool ones = (g & 3) == 3;
+  if (SLOT == 0) return ones ? 7 : 9;
+  if (g < 6) return ones ? 2 : 3;            // a DMA piece rides here
+  return ones ? 6 : 14;
+}
+template <int SLOT> __host__ __device__ constexpr int bl_ge(int k) {
+  int total = 0;
+  for (int g = 1; g <= 26; ++g) total += bl_weight<SLOT>(g);
+  // element k sits where the running weight passes (k + 1/2) / 32 of the total; gaps 1..26 (gap 0 makes the first arguments, 27 the last words)
+  int run = 0;
+  for (int g = 1; g <= 26; ++g) {
+    run += bl_weight<SLOT>(g);
+    if (64 * run >= (2 * k + 1) * total) return g;
+  }
+  return 26;
+}
+template <int G, int SLOT, int ABL>
 __device__ __forceinline__ void sm_blind_chunk(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], const A64Blk& X, A64Blind& t, const float c) {
   if constexpr (ABL & 1) {           // lab: no softmax VALU at all (P = 1)
     if constexpr (G == 0) {
@@ -265,15 +285,15 @@ __device__ __forceinline__ void sm_blind_chunk(const f32x16& s0, const f32x16& s
   if constexpr (G == 0) t.nm = -X.m_ref + X.hide;
   static_for<32>([&](auto K) {
     constexpr int k = decltype(K)::value, r = k >> 1;
-    if constexpr (bl_ge(k) == G) { t.e[k] = __builtin_amdgcn_exp2f(t.a[k]); pin(t.e[k]); }
+    if constexpr (bl_ge<SLOT>(k) == G) { t.e[k] = __builtin_amdgcn_exp2f(t.a[k]); pin(t.e[k]); }
   });
   static_for<32>([&](auto K) {
     constexpr int k = decltype(K)::value, r = k >> 1;
-    if constexpr (bl_ge(k) - 1 == G) { t.a[k] = __builtin_fmaf((k & 1) ? s1[r] : s0[r], c, t.nm); pin(t.a[k]); }
+    if constexpr (bl_ge<SLOT>(k) - 1 == G) { t.a[k] = __builtin_fmaf((k & 1) ? s1[r] : s0[r], c, t.nm); pin(t.a[k]); }
   });
   static_for<16>([&](auto W) {          // word w: half w & 1, score registers 2 (w >> 1) and 2 (w >> 1) + 1 = elements k0 and k0 + 2
     constexpr int w = decltype(W)::value, hf = w & 1, r = 2 * (w >> 1), k0 = 2 * r + hf;
-    if constexpr (bl_ge(k0 + 2) + 1 == G) {
+    if constexpr (bl_ge<SLOT>(k0 + 2) + 1 == G) {
       const unsigned wd = pack_bf16x2(t.e[k0], t.e[k0 + 2]);
       pin(wd);
       pf[2 * hf + (r >> 3)][(r & 7) >> 1] = wd;
@@ -759,7 +779,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       // first MFMA) + 4 here; slot E has the tile barrier in front.  The exact variant reads S one gap later.
       if constexpr (THR != 0 && g == 0 && yb == 0) asm volatile("s_nop 3" : "+v"(x0), "+v"(x1));
       if constexpr (THR == 0) sm_chunk<THR, OAX, i, ABL>(x0, x1, px, X, tx, c, rc);
-      else if constexpr (!serial) sm_blind_chunk<g, ABL>(x0, x1, px, X, ux, c);
+      else if constexpr (!serial) sm_blind_chunk<g, 1 - yb, ABL>(x0, x1, px, X, ux, c);      // (P V of block B runs in slot E: SLOT 0)
       if constexpr (ABL & 8192) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1" : "+v"(tx.m3), "+v"(tx.thr));   // lab: what do two more VALU issues per gap cost (right results)
       dma(I);                                  // the caller's lambda decides which gaps carry a piece
       A64_PIN();
@@ -782,7 +802,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       if constexpr (reload) k_frag(std::integral_constant<int, ks>{}, std::integral_constant<int, half>{}, ke, ko);
       A64_PIN();
       if constexpr (THR == 0) sm_chunk<THR, OAX, 12 + i, ABL>(x0, x1, px, X, tx, c, rc);
-      else if constexpr (!serial) sm_blind_chunk<16 + i, ABL>(x0, x1, px, X, ux, c);
+      else if constexpr (!serial) sm_blind_chunk<16 + i, 1 - decltype(YB)::value, ABL>(x0, x1, px, X, ux, c);
       if constexpr (ABL & 8192) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1" : "+v"(tx.m3), "+v"(tx.thr));
       A64_PIN();
     });
