@@ -56,10 +56,8 @@ __device__ __forceinline__ unsigned low_bits(int n) { return n >= 32 ? ~0u : ((1
 // v_and / v_cmp / v_cndmask with hazard nops)
 template <int BIT>
 __device__ __forceinline__ float mask_bias(int hid, int ninf) {
-  int t;
-  float b;
-  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t) : "v"(hid), "n"(BIT));
-  asm("v_and_b32 %0, %1, %2" : "=v"(b) : "s"(ninf), "v"(t));
+  float b;            // ONE statement: between two dependent asm statements hipcc pads an s_nop (32 per bias tile)
+  asm("v_bfe_i32 %0, %1, %2, 1\n\tv_and_b32 %0, %3, %0" : "=&v"(b) : "v"(hid), "n"(BIT), "s"(ninf));
   return b;
 }
 

@@ -303,11 +303,18 @@ __device__ __forceinline__ void sm_blind_chunk(const f32x16& s0, const f32x16& s
 // the exact path for a tile whose optimistic pass overflowed the bound (rare; cold)
 template <int THR, int OA>
 __device__ __forceinline__ void sm_redo(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], A64Blk& X, A64Tmp& t, const float c) {
-  float m = max3(s0[0], s0[1], s1[0]);
-  m = max3(m, s1[1], s0[2]);
-#pragma unroll
-  for (int r = 3; r < 16; ++r) m = max3(m, s0[r], s1[r - 1]);
-  asm("v_max_f32 %0, %0, %1" : "+v"(m) : "v"(s1[15]));
+  // four chains of four links, two statements (between dependent asm statements hipcc pads an s_nop: sixteen in a one-statement-per-link chain)
+  float m, m1, m2, m3;
+  asm("v_max3_f32 %0, %4, %5, %6\n\tv_max3_f32 %1, %7, %8, %9\n\tv_max3_f32 %2, %10, %11, %12\n\tv_max3_f32 %3, %13, %14, %15\n\t"
+      "v_max3_f32 %0, %0, %16, %17\n\tv_max3_f32 %1, %1, %18, %19\n\tv_max3_f32 %2, %2, %20, %21\n\tv_max3_f32 %3, %3, %22, %23"
+      : "=&v"(m), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+      : "v"(s0[0]), "v"(s0[1]), "v"(s1[0]), "v"(s0[4]), "v"(s0[5]), "v"(s1[4]), "v"(s0[8]), "v"(s0[9]), "v"(s1[8]), "v"(s0[12]), "v"(s0[13]), "v"(s1[12]),
+        "v"(s1[1]), "v"(s0[2]), "v"(s1[5]), "v"(s0[6]), "v"(s1[9]), "v"(s0[10]), "v"(s1[13]), "v"(s0[14]));
+  asm("v_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %8, %9\n\tv_max3_f32 %3, %3, %10, %11\n\t"
+      "v_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %2, %2, %14, %15\n\tv_max3_f32 %0, %0, %1, %2\n\tv_max_f32 %0, %0, %3"
+      : "+v"(m), "+v"(m1), "+v"(m2), "+v"(m3)
+      : "v"(s0[3]), "v"(s1[2]), "v"(s0[7]), "v"(s1[6]), "v"(s0[11]), "v"(s1[10]), "v"(s0[15]), "v"(s1[14]),
+        "v"(s1[3]), "v"(s1[7]), "v"(s1[11]), "v"(s1[15]));
   const float mx = halves_max(m) * c + X.hide;
   const float m_new = fmaxf(X.m_ref, mx);
   const float alpha = __builtin_amdgcn_exp2f(X.m_ref - m_new);
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   // lab stamps (ABL & 512): shader-clock cycles of prologue / tile loops / epilogue, tiles walked, and the 100 MHz real-time
   // counter over the whole workgroup -> lse[8 * blockIdx .. +7] (timing build: its lse output is not an lse)
   unsigned long long st_pro = 0, st_loop = 0, st_epi = 0, st_tiles = 0, st_t = 0, st_rt0 = 0, st_redo = 0, st_wait = 0, st_dma = 0;
-  unsigned long long st_h[4] = {0, 0, 0, 0}, st_n = 0;      // ABL & 1024: the four halves of the BLIND iterations (wave 0..3 each its own), and how many
+  unsigned long long st_h[4] = {0, 0, 0, 0}, st_n = 0, st_slow = 0, st_nslow = 0;   // ... and the bias / exact iterations whole (barrier wait included)      // ABL & 1024: the four halves of the BLIND iterations (wave 0..3 each its own), and how many
   if constexpr (ABL & 512) { st_rt0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- the next rank's blocks, Q rows and first K/V tiles, asked for one rank ahead ------------------------------------------
@@ -669,36 +676,35 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     return nb == 0x7fffffff ? 64 : (nb - c0) >> 6;
   };
   auto tile_bias = [&](A64Blk& X, int j, f32x16& s0, f32x16& s1) {
-    if constexpr (THR != 0) {
-      // Product build: a bias iteration biases both tiles it makes - block B's tile j and block A's tile j + 1 - because ONE of them
-      // needs it (a block's diagonal tile, once per rank) or because the softmax mode asks for this iteration (a rank's first
-      // tile).  The other tile is fast by the masks more often than not: zeros and the per-lane hide instead of ~100 VALU issues -
-      // every wave's slow iteration is a wait at the tile barrier for the other three.
-      if ((j == 0 || (j & 63) != 0) && ((X.fast >> (j & 63)) & 1ull) != 0ull) {       // (tile j + 1 of the next window: masks not made yet)
+    // Product build: a bias iteration biases both tiles it makes - block B's tile j and block A's tile j + 1 - because ONE of them
+    // needs it (a block's diagonal tile, once per rank) or because the softmax mode asks for this iteration (a rank's first tile).
+    // The other tile is fast by the masks more often than not: its bias is all zeros and its per-lane hide the fast tile's.  Both
+    // cases write the score tiles with the SAME 64 instructions (an if / else over the tiles made hipcc copy them at the join: 64
+    // v_mov per bias iteration) - every wave's slow iteration is a wait at the tile barrier for the other three.
+    int hid = 0;
+    float hide_new = 0.f;
+    const bool short_form = THR != 0 && (j == 0 || (j & 63) != 0) && ((X.fast >> (j & 63)) & 1ull) != 0ull;       // (tile j + 1 of the next window: masks not made yet)
+    if (short_form) {
+      hide_new = hide_val(X, j);
+    } else {
+      const int c0 = j * 64;
+      const unsigned long long vb = j < first_bad ? ~0ull : valid_word(j);
+      const int base = c0 + 4 * h;
+      unsigned valid;                                                       // valid columns, register order
+      if ((vb & (vb + 1ull)) == 0ull) {                                     // wave-uniform: the bits form a prefix
+        valid = low_bits(count_le(c0 + (int)__builtin_popcountll(vb) - 1 - base));
+      } else {                                                              // holes in the 1-D mask (rare)
+        const unsigned long long vbh = vb >> (4 * h);
+        valid = 0u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-        asm volatile("s_nop 1" : "+v"(s0), "+v"(s1));
-        X.hide = hide_val(X, j);
-        return;
+        for (int k = 0; k < 8; ++k) valid |= ((unsigned)(vbh >> (8 * k)) & 0xFu) << (4 * k);
       }
+      const unsigned alive = (low_bits(count_le(X.row - base)) | (low_bits(count_le(X.rc1 - 1 - base)) & ~low_bits(count_le(X.rc0 - 1 - base)))) & valid;
+      const unsigned uniform = low_bits(count_le(L - 1 - base));            // every column < L
+      unsigned vis = X.row_uniform ? uniform : (X.row_alive ? alive : 0u);
+      if (!X.exists) vis = 0u;
+      hid = (int)~vis;
     }
-    const int c0 = j * 64;
-    const unsigned long long vb = j < first_bad ? ~0ull : valid_word(j);
-    const int base = c0 + 4 * h;
-    unsigned valid;                                                       // valid columns, register order
-    if ((vb & (vb + 1ull)) == 0ull) {                                     // wave-uniform: the bits form a prefix
-      valid = low_bits(count_le(c0 + (int)__builtin_popcountll(vb) - 1 - base));
-    } else {                                                              // holes in the 1-D mask (rare)
-      const unsigned long long vbh = vb >> (4 * h);
-      valid = 0u;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) valid |= ((unsigned)(vbh >> (8 * k)) & 0xFu) << (4 * k);
-    }
-    const unsigned alive = (low_bits(count_le(X.row - base)) | (low_bits(count_le(X.rc1 - 1 - base)) & ~low_bits(count_le(X.rc0 - 1 - base)))) & valid;
-    const unsigned uniform = low_bits(count_le(L - 1 - base));            // every column < L
-    unsigned vis = X.row_uniform ? uniform : (X.row_alive ? alive : 0u);
-    if (!X.exists) vis = 0u;
-    const int hid = (int)~vis;
     const int ninf = 0xFF800000;
     static_for<16>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
@@ -706,7 +712,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       s1[r] = mask_bias<r + 16>(hid, ninf);
     });
     asm volatile("s_nop 1" : "+v"(s0), "+v"(s1));   // VALU write -> MFMA C operand inside an asm statement: two wait states (guide 5.7 item 2)
-    X.hide = 0.f;
+    X.hide = hide_new;
   };
 
   // ---- the two halves of a slot -------------------------------------------------------------------
@@ -872,8 +878,9 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     using FT = std::integral_constant<bool, ft>;
     using BL = std::integral_constant<bool, mode == 4>;
     // unit j = {K(j+1), V(j)}: this wave's pieces are all but the 6 youngest (unit j+1); then a workgroup-wide fact
-    unsigned long long tw0 = 0;
+    unsigned long long tw0 = 0, tit0 = 0;
     if constexpr (ABL & 512) tw0 = __builtin_amdgcn_s_memtime();
+    if constexpr ((ABL & 1024) && !ft) tit0 = __builtin_amdgcn_s_memtime();
     if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if constexpr (ABL & 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_dma += t_ - tw0; tw0 = t_; }
     if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
@@ -918,6 +925,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     asm volatile("s_nop 1" : "+v"(pB[0]), "+v"(pB[1]), "+v"(pB[2]), "+v"(pB[3]));
     A64_PIN();
     const int t_ = st0; st0 = st1; st1 = st2; st2 = t_;
+    if constexpr ((ABL & 1024) && !ft) { st_slow += __builtin_amdgcn_s_memtime() - tit0; st_nslow += 1; }
   };
   auto both_fast = [&](int j) -> bool {
     const int t = j & 63;
@@ -1087,7 +1095,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       d[5] = (float)st_redo;
       d[6] = (float)st_dma;
       d[7] = (float)st_wait;
-      if constexpr (ABL & 1024) { d[0] = (float)st_h[0]; d[1] = (float)st_h[1]; d[2] = (float)st_h[2]; d[5] = (float)st_h[3]; d[3] = (float)st_n; }
+      if constexpr (ABL & 1024) { d[0] = (float)st_h[0]; d[1] = (float)st_h[1]; d[2] = (float)st_h[2]; d[5] = (float)st_h[3]; d[3] = (float)st_n; d[6] = (float)st_slow; d[7] = (float)st_nslow; }
     }
   }
 #undef A64_PIN
