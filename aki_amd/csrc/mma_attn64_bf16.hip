@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   // lab stamps (ABL & 512): shader-clock cycles of prologue / tile loops / epilogue, tiles walked, and the 100 MHz real-time
   // counter over the whole workgroup -> lse[8 * blockIdx .. +7] (timing build: its lse output is not an lse)
   unsigned long long st_pro = 0, st_loop = 0, st_epi = 0, st_tiles = 0, st_t = 0, st_rt0 = 0, st_redo = 0, st_wait = 0, st_dma = 0;
-  unsigned long long st_h[4] = {0, 0, 0, 0}, st_n = 0, st_slow = 0, st_nslow = 0;   // ... and the bias / exact iterations whole (barrier wait included)      // ABL & 1024: the four halves of the BLIND iterations (wave 0..3 each its own), and how many
+  unsigned long long st_h[4] = {0, 0, 0, 0}, st_n = 0, st_slow = 0, st_nslow = 0, st_full = 0;   // ... and the bias / exact iterations whole (barrier wait included)      // ABL & 1024: the four halves of the BLIND iterations (wave 0..3 each its own), and how many
   if constexpr (ABL & 512) { st_rt0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- the next rank's blocks, Q rows and first K/V tiles, asked for one rank ahead ------------------------------------------
@@ -812,7 +812,8 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       if constexpr (ABL & 8192) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1" : "+v"(tx.m3), "+v"(tx.thr));
       A64_PIN();
     });
-    if constexpr (THR != 0 && !decltype(FULLT)::value) mfma_results_settle(y0, y1);      // bias iterations: hipcc copies score tiles at their joins, and takes an asm MFMA's result as ready
+    // (bias iterations once ended in 20 wait states tied to both tiles: hipcc copied score tiles at their joins and takes an asm MFMA's
+    // result as ready.  With one definition of every tile per iteration there are no such copies; tools/attn64_hazards.py holds the line.)
     if constexpr (serial) {
       // the exact iteration of the product build - while a row of the wave has no reference maximum yet (the rank's first tile, as a
       // rule) and on the second walk of a rank that failed its verification: the tile's softmax in one piece behind the slot's MFMAs
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     // unit j = {K(j+1), V(j)}: this wave's pieces are all but the 6 youngest (unit j+1); then a workgroup-wide fact
     unsigned long long tw0 = 0, tit0 = 0;
     if constexpr (ABL & 512) tw0 = __builtin_amdgcn_s_memtime();
-    if constexpr ((ABL & 1024) && !ft) tit0 = __builtin_amdgcn_s_memtime();
+    if constexpr (ABL & 1024) tit0 = __builtin_amdgcn_s_memtime();
     if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if constexpr (ABL & 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_dma += t_ - tw0; tw0 = t_; }
     if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
@@ -926,6 +927,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     A64_PIN();
     const int t_ = st0; st0 = st1; st1 = st2; st2 = t_;
     if constexpr ((ABL & 1024) && !ft) { st_slow += __builtin_amdgcn_s_memtime() - tit0; st_nslow += 1; }
+    if constexpr ((ABL & 1024) && ft) st_full += __builtin_amdgcn_s_memtime() - tit0;
   };
   auto both_fast = [&](int j) -> bool {
     const int t = j & 63;
@@ -1095,7 +1097,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       d[5] = (float)st_redo;
       d[6] = (float)st_dma;
       d[7] = (float)st_wait;
-      if constexpr (ABL & 1024) { d[0] = (float)st_h[0]; d[1] = (float)st_h[1]; d[2] = (float)st_h[2]; d[5] = (float)st_h[3]; d[3] = (float)st_n; d[6] = (float)st_slow; d[7] = (float)st_nslow; }
+      if constexpr (ABL & 1024) { d[0] = (float)st_h[0]; d[1] = (float)st_h[1]; d[2] = (float)st_h[2]; d[5] = (float)st_h[3]; d[3] = (float)st_n; d[6] = (float)st_slow; d[7] = (float)st_nslow; d[4] = (float)st_full; }
     }
   }
 #undef A64_PIN

@@ -28,4 +28,4 @@ for var in ([int(a) for a in sys.argv[1:]] or [1636, 1637]):
     print(f"variant {var}: bias / exact iterations per workgroup {np.median(d[:, 7]):.0f} of {np.median(d[:, 7] + n):.0f} (wave 0), {np.median(slow):.0f} cycles each, barrier wait and one stamp included "
           f"= {100 * np.median(d[:, 6] / (d[:, 6] + d[:, 0] + d[:, 1] + d[:, 2] + d[:, 5])):.0f} % of the stamped tile time", flush=True)
     print(f"variant {var}: blind iterations per workgroup {np.median(n):.0f} (wave 0) | cycles per half (median; each includes one stamp, ~40): "
-          f"E.1 {np.median(e1):.0f} (MFMA 448)  E.2 {np.median(e2):.0f} (384)  O.1 {np.median(o1):.0f} (448)  O.2 {np.median(o2):.0f} (384) | sum {np.median(e1 + e2 + o1 + o2):.0f}", flush=True)
+          f"E.1 {np.median(e1):.0f} (MFMA 448)  E.2 {np.median(e2):.0f} (384)  O.1 {np.median(o1):.0f} (448)  O.2 {np.median(o2):.0f} (384) | sum {np.median(e1 + e2 + o1 + o2):.0f} | a whole blind iteration, barrier wait and six stamps included: {np.median(d[:, 4] / n):.0f}", flush=True)
