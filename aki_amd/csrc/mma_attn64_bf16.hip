@@ -300,6 +300,62 @@ __device__ __forceinline__ void sm_blind_chunk(const f32x16& s0, const f32x16& s
     }
   });
 }
+// ---- a rank's FIRST tile, in the gaps (product build) ----------------------------------------------------------------------------
+// Nothing has been accumulated yet (O and the row sums are zero, no row has a reference maximum), so the exact softmax of this tile is
+// the row maximum followed by the blind arithmetic against it - no rescale.  The maximum takes the gaps beside P V and the row sums
+// (four chains of max3, merged and swapped across the half rows by gap 9; gap 10 sets m_ref), the 32 elements the twelve gaps beside K Q^T
+// and the last four of the first half: two fma + two exp2 per gap, words packed one gap behind.  The serial form of this tile (sm_redo
+// behind empty gaps) cost a workgroup ~2000 cycles per rank.
+struct A64First { float m0, m1, m2, m3, nm; float a[32], e[32]; };
+template <int G>
+__device__ __forceinline__ void sm_first_chunk(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], A64Blk& X, A64First& t, const float c) {
+  if constexpr (G == 1) {
+    asm("v_max3_f32 %0, %4, %5, %6\n\tv_max3_f32 %1, %7, %8, %9\n\tv_max3_f32 %2, %10, %11, %12\n\tv_max3_f32 %3, %13, %14, %15"
+        : "=&v"(t.m0), "=&v"(t.m1), "=&v"(t.m2), "=&v"(t.m3)
+        : "v"(s0[0]), "v"(s0[1]), "v"(s1[0]), "v"(s0[4]), "v"(s0[5]), "v"(s1[4]), "v"(s0[8]), "v"(s0[9]), "v"(s1[8]), "v"(s0[12]), "v"(s0[13]), "v"(s1[12]));
+    pin(t.m0, t.m1, t.m2, t.m3);
+  } else if constexpr (G == 3) {
+    asm("v_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %8, %9\n\tv_max3_f32 %3, %3, %10, %11"
+        : "+v"(t.m0), "+v"(t.m1), "+v"(t.m2), "+v"(t.m3)
+        : "v"(s1[1]), "v"(s0[2]), "v"(s1[5]), "v"(s0[6]), "v"(s1[9]), "v"(s0[10]), "v"(s1[13]), "v"(s0[14]));
+    pin(t.m0, t.m1, t.m2, t.m3);
+  } else if constexpr (G == 5) {
+    asm("v_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %8, %9\n\tv_max3_f32 %3, %3, %10, %11"
+        : "+v"(t.m0), "+v"(t.m1), "+v"(t.m2), "+v"(t.m3)
+        : "v"(s0[3]), "v"(s1[2]), "v"(s0[7]), "v"(s1[6]), "v"(s0[11]), "v"(s1[10]), "v"(s0[15]), "v"(s1[14]));
+    pin(t.m0, t.m1, t.m2, t.m3);
+  } else if constexpr (G == 7) {
+    asm("v_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %2, %2, %6, %7\n\tv_max3_f32 %0, %0, %1, %2\n\tv_max_f32 %0, %0, %3"
+        : "+v"(t.m0), "+v"(t.m1), "+v"(t.m2), "+v"(t.m3)
+        : "v"(s1[3]), "v"(s1[7]), "v"(s1[11]), "v"(s1[15]));
+    pin(t.m0);
+  } else if constexpr (G == 9) {
+    t.m0 = halves_max(t.m0);
+    pin(t.m0);
+  } else if constexpr (G == 10) {
+    const float mx = t.m0 * c + X.hide;
+    X.m_ref = fmaxf(X.m_ref, mx);
+    t.nm = -X.m_ref + X.hide;
+    pin(t.nm, X.m_ref);
+  }
+  // element k (score register k / 2 of half k % 2): arguments in gap 11 + k / 2 (two per gap), exp2 one gap later, words one more
+  static_for<32>([&](auto K) {
+    constexpr int k = decltype(K)::value, r = k >> 1;
+    if constexpr (12 + k / 2 == G) { t.e[k] = __builtin_amdgcn_exp2f(t.a[k]); pin(t.e[k]); }
+  });
+  static_for<32>([&](auto K) {
+    constexpr int k = decltype(K)::value, r = k >> 1;
+    if constexpr (11 + k / 2 == G) { t.a[k] = __builtin_fmaf((k & 1) ? s1[r] : s0[r], c, t.nm); pin(t.a[k]); }
+  });
+  static_for<16>([&](auto W) {
+    constexpr int w = decltype(W)::value, hf = w & 1, r = 2 * (w >> 1), k0 = 2 * r + hf;
+    if constexpr (13 + (k0 + 2) / 2 == G || (G == 27 && 13 + (k0 + 2) / 2 > 27)) {
+      const unsigned wd = pack_bf16x2(t.e[k0], t.e[k0 + 2]);
+      pin(wd);
+      pf[2 * hf + (r >> 3)][(r & 7) >> 1] = wd;
+    }
+  });
+}
 // the exact path for a tile whose optimistic pass overflowed the bound (rare; cold)
 template <int THR, int OA>
 __device__ __forceinline__ void sm_redo(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], A64Blk& X, A64Tmp& t, const float c) {
@@ -721,6 +777,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   u32x2 vlo[4][3], vhi[4][3];         // V^T fragments of the current V tile (both blocks use them)
   A64Tmp tA, tB;
   A64Blind uA, uB;
+  A64First fx;                        // (a rank's first tile: one block at a time)
   f32x16 zt;                          // lab (ABL & 16384): a tuple of zeros as the C operand of the first score MFMAs
   if constexpr (ABL & 16384) {
 #pragma unroll
@@ -763,7 +820,8 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   // each MFMA the V^T fragment it was the last to read is fetched again from the V tile at va; DMA: K (E slots) or V (O slots)
   // pieces of the unit being prefetched go into gaps 0-2.
   auto half1 = [&](auto SER, auto RELOAD, auto YB, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, A64Blind& ux, u32x4 (&py)[4], unsigned va, auto&& dma) {
-    constexpr bool serial = decltype(SER)::value, reload = decltype(RELOAD)::value;
+    constexpr int kind = decltype(SER)::value;          // softmax of block X in this slot: 0 blind chunks, 1 serial exact (behind the slot), 2 first-tile chunks
+    constexpr bool serial = kind == 1, reload = decltype(RELOAD)::value;
     constexpr int yb = decltype(YB)::value;
     constexpr int OAY = A64_O + 48 * yb, OAX = A64_O + 48 * (1 - yb);
     constexpr int NG = THR != 0 ? 16 : 12;          // product build: every fourth gap follows a row-sum MFMA of the 16 keys just multiplied
@@ -785,6 +843,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       // first MFMA) + 4 here; slot E has the tile barrier in front.  The exact variant reads S one gap later.
       if constexpr (THR != 0 && g == 0 && yb == 0) asm volatile("s_nop 3" : "+v"(x0), "+v"(x1));
       if constexpr (THR == 0) sm_chunk<THR, OAX, i, ABL>(x0, x1, px, X, tx, c, rc);
+      else if constexpr (kind == 2) sm_first_chunk<g>(x0, x1, px, X, fx, c);
       else if constexpr (!serial) sm_blind_chunk<g, 1 - yb, ABL>(x0, x1, px, X, ux, c);      // (P V of block B runs in slot E: SLOT 0)
       if constexpr (ABL & 8192) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1" : "+v"(tx.m3), "+v"(tx.thr));   // lab: what do two more VALU issues per gap cost (right results)
       dma(I);                                  // the caller's lambda decides which gaps carry a piece
@@ -794,7 +853,8 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   // second half: [K Q_Y^T of tile jy] beside chunks 12-23 of block X; RELOAD: behind its last reader each K fragment is fetched
   // again from the K tile at (ke, ko)
   auto half2 = [&](auto SER, auto RELOAD, auto YB, auto FULLT, f32x16& y0, f32x16& y1, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, A64Blind& ux, unsigned ke, unsigned ko) {
-    constexpr bool serial = decltype(SER)::value, reload = decltype(RELOAD)::value;
+    constexpr int kind = decltype(SER)::value;
+    constexpr bool serial = kind == 1, reload = decltype(RELOAD)::value;
     constexpr int QAY = A64_Q + 24 * decltype(YB)::value, OAX = A64_O + 48 * (1 - decltype(YB)::value);
     static_for<12>([&](auto I) {
       constexpr int i = decltype(I)::value, ks = i >> 1, half = i & 1;
@@ -808,6 +868,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       if constexpr (reload) k_frag(std::integral_constant<int, ks>{}, std::integral_constant<int, half>{}, ke, ko);
       A64_PIN();
       if constexpr (THR == 0) sm_chunk<THR, OAX, 12 + i, ABL>(x0, x1, px, X, tx, c, rc);
+      else if constexpr (kind == 2) sm_first_chunk<16 + i>(x0, x1, px, X, fx, c);
       else if constexpr (!serial) sm_blind_chunk<16 + i, 1 - decltype(YB)::value, ABL>(x0, x1, px, X, ux, c);
       if constexpr (ABL & 8192) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1" : "+v"(tx.m3), "+v"(tx.thr));
       A64_PIN();
@@ -830,6 +891,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   using M1 = std::integral_constant<int, 1>;
   using M2 = std::integral_constant<int, 2>;
   using M4 = std::integral_constant<int, 4>;
+  using M7 = std::integral_constant<int, 7>;
   using BA = std::integral_constant<int, 0>;
   using BB = std::integral_constant<int, 1>;
 
@@ -877,7 +939,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     constexpr int mode = decltype(MODE)::value;
     constexpr bool ft = mode == 1 || mode == 2;
     using FT = std::integral_constant<bool, ft>;
-    using BL = std::integral_constant<bool, mode == 4>;
+    using BL = std::integral_constant<int, mode == 4 ? 1 : mode == 7 ? 2 : 0>;
     // unit j = {K(j+1), V(j)}: this wave's pieces are all but the 6 youngest (unit j+1); then a workgroup-wide fact
     unsigned long long tw0 = 0, tit0 = 0;
     if constexpr (ABL & 512) tw0 = __builtin_amdgcn_s_memtime();
@@ -971,7 +1033,9 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     } else if (THR == 0 || settled) {      // (product build: a fast tile where the hide changes comes here too - tile_bias has a short form for it)
       iter(M0{}, j); ++j;
     } else {
-      if constexpr (THR != 0) iter(M4{}, j);
+      // no reference maximum yet: a rank's first tile has its exact softmax in the gaps (nothing accumulated, nothing to rescale);
+      // later tiles of rows that have seen nothing so far, and every tile of a rank walked again, take the serial exact iteration
+      if constexpr (THR != 0) { if (j == 0 && !force_checked && !(ABL & 64)) iter(M7{}, j); else iter(M4{}, j); }
       ++j;
       if constexpr (THR != 0) {
         // (rows beyond seq_len under the zero convention see nothing, ever: they must not hold the wave on the exact path)
