@@ -61,6 +61,13 @@ __device__ __forceinline__ float mask_bias(int hid, int ninf) {
   return b;
 }
 
+// two columns in one ordered statement (a bias written in MFMA gaps: no pin, no pad between dependent statements)
+template <int BIT0, int BIT1>
+__device__ __forceinline__ void mask_bias2(int hid, int ninf, float& b0, float& b1) {
+  asm volatile("v_bfe_i32 %0, %2, %3, 1\n\tv_bfe_i32 %1, %2, %4, 1\n\tv_and_b32 %0, %5, %0\n\tv_and_b32 %1, %5, %1"
+               : "=&v"(b0), "=&v"(b1) : "v"(hid), "n"(BIT0), "n"(BIT1), "s"(ninf));
+}
+
 // compile-time loop (the tr-read offsets below must be immediates of an inline-asm statement)
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {

@@ -731,14 +731,11 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     }
     return nb == 0x7fffffff ? 64 : (nb - c0) >> 6;
   };
-  auto tile_bias = [&](A64Blk& X, int j, f32x16& s0, f32x16& s1) {
-    // Product build: a bias iteration biases both tiles it makes - block B's tile j and block A's tile j + 1 - because ONE of them
-    // needs it (a block's diagonal tile, once per rank) or because the softmax mode asks for this iteration (a rank's first tile).
-    // The other tile is fast by the masks more often than not: its bias is all zeros and its per-lane hide the fast tile's.  Both
-    // cases write the score tiles with the SAME 64 instructions (an if / else over the tiles made hipcc copy them at the join: 64
-    // v_mov per bias iteration) - every wave's slow iteration is a wait at the tile barrier for the other three.
-    int hid = 0;
-    float hide_new = 0.f;
+  // the per-lane part of a tile's bias: which of the lane's 32 score columns are hidden (bit r <-> score register r) and the hide the
+  // tile travels with (product build, short form: a fast tile - no column hidden by the bias, the fast tile's hide)
+  auto bias_hid = [&](const A64Blk& X, int j, int& hid, float& hide_new) {
+    hid = 0;
+    hide_new = 0.f;
     const bool short_form = THR != 0 && (j == 0 || (j & 63) != 0) && ((X.fast >> (j & 63)) & 1ull) != 0ull;       // (tile j + 1 of the next window: masks not made yet)
     if (short_form) {
       hide_new = hide_val(X, j);
@@ -761,6 +758,16 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       if (!X.exists) vis = 0u;
       hid = (int)~vis;
     }
+  };
+  auto tile_bias = [&](A64Blk& X, int j, f32x16& s0, f32x16& s1) {
+    // Product build: a bias iteration biases both tiles it makes - block B's tile j and block A's tile j + 1 - because ONE of them
+    // needs it (a block's diagonal tile, once per rank) or because the softmax mode asks for this iteration (a rank's first tile).
+    // The other tile is fast by the masks more often than not: its bias is all zeros and its per-lane hide the fast tile's.  Both
+    // cases write the score tiles with the SAME 64 instructions (an if / else over the tiles made hipcc copy them at the join: 64
+    // v_mov per bias iteration) - every wave's slow iteration is a wait at the tile barrier for the other three.
+    int hid;
+    float hide_new;
+    bias_hid(X, j, hid, hide_new);
     const int ninf = 0xFF800000;
     static_for<16>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
@@ -819,7 +826,10 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
   // first half of a slot: [P V of block Y] beside softmax chunks 0-11 of block X.  PV: the 12 MFMAs are issued; RELOAD: behind
   // each MFMA the V^T fragment it was the last to read is fetched again from the V tile at va; DMA: K (E slots) or V (O slots)
   // pieces of the unit being prefetched go into gaps 0-2.
-  auto half1 = [&](auto SER, auto RELOAD, auto YB, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, A64Blind& ux, u32x4 (&py)[4], unsigned va, auto&& dma) {
+  // BIASY (product build's bias iterations): the bias tuple of the tile the SECOND half makes (y0, y1; hidden columns hidY) is written
+  // here, two columns per gap - its registers are free while P V runs, and a bias written between the halves is ~100 vector issues the
+  // other three waves wait for at the next barrier
+  auto half1 = [&](auto SER, auto RELOAD, auto YB, auto BIASY, f32x16& y0, f32x16& y1, const int hidY, f32x16& x0, f32x16& x1, u32x4 (&px)[4], A64Blk& X, A64Tmp& tx, A64Blind& ux, u32x4 (&py)[4], unsigned va, auto&& dma) {
     constexpr int kind = decltype(SER)::value;          // softmax of block X in this slot: 0 blind chunks, 1 serial exact (behind the slot), 2 first-tile chunks
     constexpr bool serial = kind == 1, reload = decltype(RELOAD)::value;
     constexpr int yb = decltype(YB)::value;
@@ -845,7 +855,7 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
       if constexpr (THR == 0) sm_chunk<THR, OAX, i, ABL>(x0, x1, px, X, tx, c, rc);
       else if constexpr (kind == 2) sm_first_chunk<g>(x0, x1, px, X, fx, c);
       else if constexpr (!serial) sm_blind_chunk<g, 1 - yb, ABL>(x0, x1, px, X, ux, c);      // (P V of block B runs in slot E: SLOT 0)
-      if constexpr (ABL & 8192) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1" : "+v"(tx.m3), "+v"(tx.thr));   // lab: what do two more VALU issues per gap cost (right results)
+      if constexpr (decltype(BIASY)::value && g < 16) { float b0_, b1_; mask_bias2<g, g + 16>(hidY, (int)0xFF800000, b0_, b1_); y0[g] = b0_; y1[g] = b1_; }
       dma(I);                                  // the caller's lambda decides which gaps carry a piece
       A64_PIN();
     });
@@ -966,9 +976,15 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     // ---- slot E(j): P_B V (j-1), K Q_B^T (j)  beside  softmax of S_A(j) ----
     unsigned long long th_ = 0;
     if constexpr ((ABL & 1024) && ft) th_ = __builtin_amdgcn_s_memtime();
-    half1(BL{}, T_{}, BB{}, sA0, sA1, pA, A, tA, uA, pB, va, dma_e);
+    constexpr bool gap_bias = THR != 0 && (mode == 0 || mode == 4 || mode == 7);
+    using GB = std::integral_constant<bool, gap_bias>;
+    int hidY = 0;
+    float hideY = 0.f;
+    if constexpr (gap_bias) bias_hid(B, j, hidY, hideY);
+    half1(BL{}, T_{}, BB{}, GB{}, sB0, sB1, hidY, sA0, sA1, pA, A, tA, uA, pB, va, dma_e);
     if constexpr ((ABL & 1024) && ft) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_h[0] += t_ - th_; th_ = t_; }
-    if constexpr (mode == 1) fast_hide(B, j); else if constexpr (mode != 2) tile_bias(B, j, sB0, sB1);
+    if constexpr (gap_bias) { B.hide = hideY; asm volatile("s_nop 1" : "+v"(sB0), "+v"(sB1)); }
+    else if constexpr (mode == 1) fast_hide(B, j); else if constexpr (mode != 2) tile_bias(B, j, sB0, sB1);
     A64_PIN();
     half2(BL{}, T_{}, BB{}, FT{}, sB0, sB1, sA0, sA1, pA, A, tA, uA, ke, ko);
     if constexpr ((ABL & 1024) && ft) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_h[1] += t_ - th_; }
@@ -977,11 +993,13 @@ __global__ __launch_bounds__(256, 1) void mma_attn64_bf16_kernel(const AttnParam
     asm volatile("s_nop 1" : "+v"(pA[0]), "+v"(pA[1]), "+v"(pA[2]), "+v"(pA[3]));   // packed by the VALU just above -> MFMA operand
     A64_PIN();
     if constexpr ((ABL & 1024) && ft) th_ = __builtin_amdgcn_s_memtime();
-    half1(BL{}, F_{}, BA{}, sB0, sB1, pB, B, tB, uB, pA, va, dma_o);
+    if constexpr (gap_bias) bias_hid(A, j + 1, hidY, hideY);
+    half1(BL{}, F_{}, BA{}, GB{}, sA0, sA1, hidY, sB0, sB1, pB, B, tB, uB, pA, va, dma_o);
     if constexpr ((ABL & 1024) && ft) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_h[2] += t_ - th_; th_ = t_; }
     if constexpr (!(ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // K(j+1) fragments
     A64_PIN();
-    if constexpr (mode == 1) fast_hide(A, j + 1); else if constexpr (mode != 2) tile_bias(A, j + 1, sA0, sA1);
+    if constexpr (gap_bias) { A.hide = hideY; asm volatile("s_nop 1" : "+v"(sA0), "+v"(sA1)); }
+    else if constexpr (mode == 1) fast_hide(A, j + 1); else if constexpr (mode != 2) tile_bias(A, j + 1, sA0, sA1);
     A64_PIN();
     half2(BL{}, F_{}, BA{}, FT{}, sA0, sA1, sB0, sB1, pB, B, tB, uB, ke, ko);
     if constexpr ((ABL & 1024) && ft) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_h[3] += t_ - th_; st_n += 1; }
