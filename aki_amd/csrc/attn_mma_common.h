@@ -41,6 +41,23 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
   return r;
 }
 
+// The largest of a lane's 32 scores (two 16-register tiles): four chains of max3 in TWO asm statements.  (One statement per link - the
+// v_max3 helper above, chained - made hipcc pad an s_nop between every two links: asm statements that depend on each other get one.)
+__device__ __forceinline__ float tile_max32(const f32x16& s0, const f32x16& s1) {
+  float m, m1, m2, m3;
+  asm("v_max3_f32 %0, %4, %5, %6\n\tv_max3_f32 %1, %7, %8, %9\n\tv_max3_f32 %2, %10, %11, %12\n\tv_max3_f32 %3, %13, %14, %15\n\t"
+      "v_max3_f32 %0, %0, %16, %17\n\tv_max3_f32 %1, %1, %18, %19\n\tv_max3_f32 %2, %2, %20, %21\n\tv_max3_f32 %3, %3, %22, %23"
+      : "=&v"(m), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+      : "v"(s0[0]), "v"(s0[1]), "v"(s1[0]), "v"(s0[4]), "v"(s0[5]), "v"(s1[4]), "v"(s0[8]), "v"(s0[9]), "v"(s1[8]), "v"(s0[12]), "v"(s0[13]), "v"(s1[12]),
+        "v"(s1[1]), "v"(s0[2]), "v"(s1[5]), "v"(s0[6]), "v"(s1[9]), "v"(s0[10]), "v"(s1[13]), "v"(s0[14]));
+  asm("v_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %8, %9\n\tv_max3_f32 %3, %3, %10, %11\n\t"
+      "v_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %2, %2, %14, %15\n\tv_max3_f32 %0, %0, %1, %2\n\tv_max_f32 %0, %0, %3"
+      : "+v"(m), "+v"(m1), "+v"(m2), "+v"(m3)
+      : "v"(s0[3]), "v"(s1[2]), "v"(s0[7]), "v"(s1[6]), "v"(s0[11]), "v"(s1[10]), "v"(s0[15]), "v"(s1[14]),
+        "v"(s1[3]), "v"(s1[7]), "v"(s1[11]), "v"(s1[15]));
+  return m;
+}
+
 // A lane's 32 score columns of a 64-key tile, in register order i = 16*kb + r, are
 //   col(i) = c0 + 4h + (i&3) + 8*((i&15)>>2) + 32*(i>>4)      (strictly increasing in i)
 // so "col <= y" is a PREFIX of the register order.  count_le(x) = number of i with col(i) - (c0+4h) <= x.

@@ -359,18 +359,7 @@ __device__ __forceinline__ void sm_first_chunk(const f32x16& s0, const f32x16& s
 // the exact path for a tile whose optimistic pass overflowed the bound (rare; cold)
 template <int THR, int OA>
 __device__ __forceinline__ void sm_redo(const f32x16& s0, const f32x16& s1, u32x4 (&pf)[4], A64Blk& X, A64Tmp& t, const float c) {
-  // four chains of four links, two statements (between dependent asm statements hipcc pads an s_nop: sixteen in a one-statement-per-link chain)
-  float m, m1, m2, m3;
-  asm("v_max3_f32 %0, %4, %5, %6\n\tv_max3_f32 %1, %7, %8, %9\n\tv_max3_f32 %2, %10, %11, %12\n\tv_max3_f32 %3, %13, %14, %15\n\t"
-      "v_max3_f32 %0, %0, %16, %17\n\tv_max3_f32 %1, %1, %18, %19\n\tv_max3_f32 %2, %2, %20, %21\n\tv_max3_f32 %3, %3, %22, %23"
-      : "=&v"(m), "=&v"(m1), "=&v"(m2), "=&v"(m3)
-      : "v"(s0[0]), "v"(s0[1]), "v"(s1[0]), "v"(s0[4]), "v"(s0[5]), "v"(s1[4]), "v"(s0[8]), "v"(s0[9]), "v"(s1[8]), "v"(s0[12]), "v"(s0[13]), "v"(s1[12]),
-        "v"(s1[1]), "v"(s0[2]), "v"(s1[5]), "v"(s0[6]), "v"(s1[9]), "v"(s0[10]), "v"(s1[13]), "v"(s0[14]));
-  asm("v_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %8, %9\n\tv_max3_f32 %3, %3, %10, %11\n\t"
-      "v_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %2, %2, %14, %15\n\tv_max3_f32 %0, %0, %1, %2\n\tv_max_f32 %0, %0, %3"
-      : "+v"(m), "+v"(m1), "+v"(m2), "+v"(m3)
-      : "v"(s0[3]), "v"(s1[2]), "v"(s0[7]), "v"(s1[6]), "v"(s0[11]), "v"(s1[10]), "v"(s0[15]), "v"(s1[14]),
-        "v"(s1[3]), "v"(s1[7]), "v"(s1[11]), "v"(s1[15]));
+  const float m = tile_max32(s0, s1);
   const float mx = halves_max(m) * c + X.hide;
   const float m_new = fmaxf(X.m_ref, mx);
   const float alpha = __builtin_amdgcn_exp2f(X.m_ref - m_new);

@@ -395,11 +395,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
   auto softmax_tile = [&]() {      // softmax of the score tile in s0, s1 -> P (packed bf16) in pp, running max / sum, O brought to the new maximum
     __builtin_amdgcn_sched_barrier(0);
     mfma_results_settle(s0, s1);   // the max3 chain below is inline asm
-    float mx = max3(s0[0], s0[1], s1[0]);
-    mx = max3(mx, s1[1], s0[2]);
-#pragma unroll
-    for (int r = 3; r < 16; r += 1) mx = max3(mx, s0[r], s1[r - 1]);
-    mx = fmaxf(mx, s1[15]);
+    float mx = tile_max32(s0, s1);
     mx = halves_max(mx) * p.scale_log2;
     const float m_new = fmaxf(m_run, mx);
     const bool moved = m_new != m_run;
@@ -598,11 +594,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mma_attn_bf16_kernel(const AttnPar
       }
       __builtin_amdgcn_sched_barrier(0);
       mfma_results_settle(s0, s1);   // the max3 chain below is inline asm
-      float mx = max3(s0[0], s0[1], s1[0]);
-      mx = max3(mx, s1[1], s0[2]);
-#pragma unroll
-      for (int r = 3; r < 16; r += 1) mx = max3(mx, s0[r], s1[r - 1]);
-      mx = fmaxf(mx, s1[15]);
+      float mx = tile_max32(s0, s1);
       mx = halves_max(mx) * p.scale_log2;
       const float m_new = fmaxf(m_run, mx);
       const bool moved = m_new != m_run;
